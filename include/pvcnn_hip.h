@@ -1,0 +1,141 @@
+/*
+ * pvcnn_hip.h -- C ABI of libpvcnn_hip.so, the MI355X (gfx950) native backend of the PVConv
+ * hot path.  It is what the reference's Python seam `modules/functional/backend.py:_backend`
+ * (12 pybind functions, modules/functional/src/bindings.cpp:10-37) binds to on AMD hardware.
+ *
+ * Conventions (all entry points)
+ *   - plain pointers and sizes only; no torch / ATen types cross this boundary;
+ *   - every pointer is a DEVICE pointer on the current HIP device; tensors are dense,
+ *     row-major, channel-major: features (B, C, N), coords (B, 3, N), voxel grids (B, C, R^3);
+ *     data fp32, indices int32 (same as the reference, utils.hpp:7-18);
+ *   - the library NEVER allocates or frees device memory and never synchronises the host:
+ *     outputs and scratch are caller-owned, work is enqueued on `stream` (a hipStream_t,
+ *     e.g. torch.cuda.current_stream().cuda_stream; NULL = the null stream);
+ *   - every output buffer is FULLY written by the call -- the caller does not pre-zero
+ *     anything (the reference's host code zero-fills with torch::zeros first);
+ *   - return value: 0 on success; PVCNN_ERR_INVALID_ARGUMENT for a rejected argument;
+ *     otherwise the (positive) hipError_t of the failed launch.  The reference instead
+ *     prints and exit(-1)s (cuda_utils.cuh:28-37).  pvcnn_last_error_string() describes the
+ *     calling thread's most recent failure;
+ *   - re-entrant: no global mutable state except the thread-local error string.
+ *
+ * Numerics contract (what tests/ check against oracle/)
+ *   bit-exact : ind, cnt, avg_voxelize fwd `out` (deterministic, point-index summation
+ *               order), avg_voxelize bwd, devoxelize fwd outs/inds/wgts, ball_query,
+ *               grouping/gather fwd, FPS indices, 3-NN indices/weights/outputs;
+ *   <= 1e-5   : the fp32 scatter-adds (devoxelize bwd, grouping/gather bwd, 3-NN bwd), whose
+ *               order is undefined in the reference too (atomicAdd).
+ */
+#ifndef PVCNN_HIP_H_
+#define PVCNN_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* The library is built with -fvisibility=hidden; only these entry points are exported. */
+#if defined(__GNUC__)
+#define PVCNN_API __attribute__((visibility("default")))
+#else
+#define PVCNN_API
+#endif
+
+#define PVCNN_ABI_VERSION 1
+#define PVCNN_OK 0
+#define PVCNN_ERR_INVALID_ARGUMENT (-1)
+
+/* ABI version of the loaded library (== PVCNN_ABI_VERSION it was built with). */
+PVCNN_API int pvcnn_version(void);
+/* Description of the calling thread's last error ("" if none).  Never NULL. */
+PVCNN_API const char *pvcnn_last_error_string(void);
+
+/* ---- avg_voxelize -------------------------------------------------------------------------
+ * replaces avg_voxelize_forward  (voxelization/vox.cpp:17-43, kernels vox.cu:18-72)
+ *          avg_voxelize_backward (voxelization/vox.cpp:54-76, kernel  vox.cu:86-110)
+ * fwd: feat (B,C,N) f32, coords (B,3,N) i32 voxel coordinates in [0,R)
+ *      -> out (B,C,R^3) f32, ind (B,N) i32, cnt (B,R^3) i32.
+ *      out[b,c,v] = sum_{i: ind[b,i]=v} feat[b,c,i] * (1/cnt[b,v]), summed in ascending i
+ *      (deterministic; no float atomics).  `workspace` is scratch of at least
+ *      pvcnn_avg_voxelize_fwd_workspace_bytes(B,N,R) bytes, 16-byte aligned.
+ *      Out-of-range coords are clamped into the grid (the reference has no bounds check).
+ * bwd: grad_y (B,C,S) f32, ind (B,N), cnt (B,S) -> grad_x (B,C,N) f32.
+ */
+PVCNN_API size_t pvcnn_avg_voxelize_fwd_workspace_bytes(int B, int N, int R);
+PVCNN_API int pvcnn_avg_voxelize_fwd(const float *feat, const int32_t *coords, int B, int C, int N, int R,
+                           float *out, int32_t *ind, int32_t *cnt, void *workspace,
+                           size_t workspace_bytes, void *stream);
+PVCNN_API int pvcnn_avg_voxelize_bwd(const float *grad_y, const int32_t *ind, const int32_t *cnt, int B,
+                           int C, int N, int S, float *grad_x, void *stream);
+
+/* ---- trilinear_devoxelize -----------------------------------------------------------------
+ * replaces trilinear_devoxelize_forward  (interpolate/trilinear_devox.cpp:18-55, .cu:21-105)
+ *          trilinear_devoxelize_backward (interpolate/trilinear_devox.cpp:67-91, .cu:119-162)
+ * fwd: coords (B,3,N) f32 in [0,R-1], feat (B,C,R^3) -> outs (B,C,N); when is_training != 0
+ *      also inds (B,8,N) i32 and wgts (B,8,N) f32 (corner order 000..111, z fastest);
+ *      when is_training == 0 inds/wgts are not touched and may be NULL.
+ * bwd: grad_y (B,C,N), inds, wgts -> grad_x (B,C,R^3) (every element written).
+ */
+PVCNN_API int pvcnn_trilinear_devox_fwd(const float *coords, const float *feat, int B, int C, int N, int R,
+                              int is_training, int32_t *inds, float *wgts, float *outs,
+                              void *stream);
+PVCNN_API int pvcnn_trilinear_devox_bwd(const float *grad_y, const int32_t *inds, const float *wgts, int B,
+                              int C, int N, int R, float *grad_x, void *stream);
+
+/* ---- ball_query ---------------------------------------------------------------------------
+ * replaces ball_query_forward (ball_query/ball_query.cpp:6-30, kernel ball_query.cu:19-50)
+ * centers (B,3,M), points (B,3,N) -> out (B,M,U) i32: the first U points (ascending index)
+ * with d^2 < radius^2 (radius^2 evaluated in float); short rows padded with the first hit,
+ * rows without a hit are all 0.
+ */
+PVCNN_API int pvcnn_ball_query(const float *centers, const float *points, int B, int N, int M, float radius,
+                     int U, int32_t *out, void *stream);
+
+/* ---- grouping / gather --------------------------------------------------------------------
+ * replaces grouping_forward/backward        (grouping/grouping.cpp:6-44, grouping.cu:18-77)
+ *          gather_features_forward/backward (sampling/sampling.cpp:6-41, sampling.cu:17-66)
+ * grouping fwd: features (B,C,N), indices (B,M,U) -> out (B,C,M,U)
+ * grouping bwd: grad_y (B,C,M,U), indices -> grad_x (B,C,N)
+ * gather   fwd: features (B,C,N), indices (B,M)   -> out (B,C,M)
+ * gather   bwd: grad_y (B,C,M), indices -> grad_x (B,C,N)
+ * Indices must lie in [0,N).
+ */
+PVCNN_API int pvcnn_grouping_fwd(const float *features, const int32_t *indices, int B, int C, int N, int M,
+                       int U, float *out, void *stream);
+PVCNN_API int pvcnn_grouping_bwd(const float *grad_y, const int32_t *indices, int B, int C, int N, int M,
+                       int U, float *grad_x, void *stream);
+PVCNN_API int pvcnn_gather_fwd(const float *features, const int32_t *indices, int B, int C, int N, int M,
+                     float *out, void *stream);
+PVCNN_API int pvcnn_gather_bwd(const float *grad_y, const int32_t *indices, int B, int C, int N, int M,
+                     float *grad_x, void *stream);
+
+/* ---- furthest point sampling --------------------------------------------------------------
+ * replaces furthest_point_sampling_forward (sampling/sampling.cpp:43-58, sampling.cu:86-167)
+ * coords (B,3,N) -> indices (B,M) i32, starting from point 0, with the reference's tie rule
+ * (lowest (k mod 512, k) among equidistant candidates).  `distances` is optional scratch
+ * (B,N) f32: NULL is allowed for N <= PVCNN_FPS_MAX_RESIDENT_POINTS; when given it receives
+ * the final point-to-set distances (the reference's caller-visible scratch).
+ */
+#define PVCNN_FPS_MAX_RESIDENT_POINTS 16384
+PVCNN_API int pvcnn_fps(const float *coords, int B, int N, int M, float *distances, int32_t *indices,
+              void *stream);
+
+/* ---- 3-nearest-neighbour interpolation ----------------------------------------------------
+ * replaces three_nearest_neighbors_interpolate_forward/backward
+ *          (interpolate/neighbor_interpolate.cpp:6-65, neighbor_interpolate.cu:20-170)
+ * fwd: points_coords (B,3,N), centers_coords (B,3,M), centers_features (B,C,M)
+ *      -> indices (B,3,N) i32, weights (B,3,N) f32, out (B,C,N)
+ * bwd: grad_y (B,C,N), indices, weights -> grad_x (B,C,M)
+ */
+PVCNN_API int pvcnn_three_nn_interp_fwd(const float *points_coords, const float *centers_coords,
+                              const float *centers_features, int B, int C, int M, int N,
+                              int32_t *indices, float *weights, float *out, void *stream);
+PVCNN_API int pvcnn_three_nn_interp_bwd(const float *grad_y, const int32_t *indices, const float *weights,
+                              int B, int C, int N, int M, float *grad_x, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PVCNN_HIP_H_ */

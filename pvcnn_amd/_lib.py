@@ -1,0 +1,72 @@
+"""ctypes binding of libpvcnn_hip.so (C ABI: include/pvcnn_hip.h).
+
+The library is built in-tree (pvcnn_amd/csrc/libpvcnn_hip.so) by `__graft_entry__.build()` or
+`make -C pvcnn_amd/csrc`.  There is NO fallback: if it is missing or an entry point fails, the
+caller gets an exception -- the product path never degrades to a CPU / eager implementation.
+
+`import torch` happens before the dlopen on purpose: torch has already mapped its own
+libamdhip64.so.7, and the dynamic loader resolves this library's DT_NEEDED entry of the same
+soname to that copy, so kernels, streams and device pointers share ONE HIP runtime.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must be imported before the dlopen, see above)
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
+LIB_PATH = os.path.join(_CSRC, 'libpvcnn_hip.so')
+ABI_VERSION = 1
+
+_vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/pvcnn_hip.h one to one
+SIGNATURES = {
+    'pvcnn_version': (_i, []),
+    'pvcnn_last_error_string': (ctypes.c_char_p, []),
+    'pvcnn_avg_voxelize_fwd_workspace_bytes': (_sz, [_i, _i, _i]),
+    'pvcnn_avg_voxelize_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'pvcnn_avg_voxelize_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    'pvcnn_trilinear_devox_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    'pvcnn_trilinear_devox_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    'pvcnn_ball_query': (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp]),
+    'pvcnn_grouping_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    'pvcnn_grouping_bwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    'pvcnn_gather_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    'pvcnn_gather_bwd': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    'pvcnn_fps': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
+    'pvcnn_three_nn_interp_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    'pvcnn_three_nn_interp_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+}
+
+_lib = None
+
+
+class PvcnnHipError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the in-tree library (once) and attach the prototypes.  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PvcnnHipError(
+            f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            f'or `make -C {_CSRC}`.  There is no CPU fallback for the PVConv hot path.')
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)           # AttributeError if the ABI lost a symbol
+        fn.restype, fn.argtypes = res, args
+    got = lib.pvcnn_version()
+    if got != ABI_VERSION:
+        raise PvcnnHipError(f'libpvcnn_hip.so ABI version {got}, binding expects {ABI_VERSION}: rebuild')
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    """Turn a non-zero ABI return code into an exception carrying the library's message."""
+    if rc != 0:
+        msg = load().pvcnn_last_error_string().decode('utf-8', 'replace')
+        raise PvcnnHipError(f'{what} failed (code {rc}): {msg}')

@@ -1,0 +1,59 @@
+// devoxelize.hip -- trilinear_devoxelize forward / backward for gfx950.
+//
+// Reference: interpolate/trilinear_devox.cu:21-105 (forward: 8 uncoalesced global gathers per
+// point per channel from B workgroups) and :119-162 (backward: 8*C global float atomics per
+// point onto a memset grid).  Both are instances of the LDS slab kernels in slab.h:
+//   forward : gather_lds_kernel<TrilinearFromCoords>  -- a workgroup streams G channel grids
+//             (one 128 KiB grid at R = 32) into LDS, recomputes the 8 corner indices/weights
+//             of each point from its 12-byte coordinate (cheaper than re-reading 64 bytes of
+//             saved inds/wgts), and serves the 8*C random reads per point from LDS.  The
+//             workgroups of channel-slab 0 also emit inds/wgts (B,8,N) in training mode.
+//   backward: scatter_lds_kernel<SavedTaps<8>> -- the grid slab is accumulated in LDS with
+//             ds_add_f32 and written to HBM once; no memset, no global atomics.
+#include "slab.h"
+
+using namespace pvcnn;
+
+// C == 0 in training mode: no grid to read, but inds/wgts are still produced (edge case only)
+__global__ __launch_bounds__(256) void trilinear_taps_only_kernel(TrilinearFromCoords p, int N) {
+  const int b = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= N) return;
+  Taps<8> t;
+  p.load1(b, j, t);
+  p.post1(b, j, t);
+}
+
+extern "C" int pvcnn_trilinear_devox_fwd(const float *coords, const float *feat, int B, int C, int N, int R,
+                                         int is_training, int32_t *inds, float *wgts, float *outs,
+                                         void *stream) {
+  PVCNN_REQUIRE(B >= 0 && C >= 0 && N >= 0 && R > 0, "negative size");
+  PVCNN_REQUIRE((long)R * R * R <= 0x7fffffffL / 4, "resolution too large");
+  if (B == 0 || N == 0) return 0;
+  PVCNN_REQUIRE(coords && (outs || C == 0) && (feat || C == 0), "null pointer");
+  PVCNN_REQUIRE(!is_training || (inds && wgts), "training mode needs inds and wgts");
+  PVCNN_REQUIRE(B <= 65535, "batch > 65535");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  TrilinearFromCoords p{coords, is_training ? inds : nullptr, is_training ? wgts : nullptr, N, R, R * R};
+  bool vec = (N % 4 == 0) && aligned16(coords) && aligned16(outs);
+  if (is_training) vec = vec && aligned16(inds) && aligned16(wgts);
+  if (C == 0) {
+    // nothing to interpolate, but the training side outputs are still part of the contract
+    if (!is_training) return 0;
+    hipLaunchKernelGGL(trilinear_taps_only_kernel, dim3(ceil_div(N, 256), B), dim3(256), 0, s, p, N);
+    return check_launch("trilinear_taps_only");
+  }
+  return launch_gather(p, feat, outs, B, C, /*L=*/R * R * R, /*J=*/N, vec, s, "trilinear_devox_fwd");
+}
+
+extern "C" int pvcnn_trilinear_devox_bwd(const float *grad_y, const int32_t *inds, const float *wgts, int B,
+                                         int C, int N, int R, float *grad_x, void *stream) {
+  PVCNN_REQUIRE(B >= 0 && C >= 0 && N >= 0 && R > 0, "negative size");
+  PVCNN_REQUIRE((long)R * R * R <= 0x7fffffffL / 4, "resolution too large");
+  if (B == 0 || C == 0) return 0;
+  PVCNN_REQUIRE(grad_x && (N == 0 || (grad_y && inds && wgts)), "null pointer");
+  PVCNN_REQUIRE(B <= 65535, "batch > 65535");
+  SavedTaps<8> p{inds, wgts, N};
+  const bool vec = (N % 4 == 0) && aligned16(grad_y) && aligned16(inds) && aligned16(wgts);
+  return launch_scatter(p, grad_y, grad_x, B, C, /*L=*/R * R * R, /*J=*/N, vec,
+                        static_cast<hipStream_t>(stream), "trilinear_devox_bwd");
+}

@@ -1,0 +1,395 @@
+// slab.h -- the two workhorse kernels of the PVConv hot path on gfx950.
+//
+// Almost every native op of the reference is "random 4-byte access into one channel row":
+//   out[b,c,j]   = sum_k w_k(b,j) * row[b,c][idx_k(b,j)]          (gather : devoxelize fwd,
+//                  voxelize bwd, grouping/gather fwd, 3-NN interpolate fwd)
+//   row[b,c][idx_k(b,j)] += w_k(b,j) * g[b,c,j]                    (scatter: devoxelize bwd,
+//                  grouping/gather bwd, 3-NN interpolate bwd)
+// where a "row" is one channel of one cloud: a voxel grid of S = R^3 floats or a point
+// feature row of N floats.  The reference walks these with one 512-thread block per cloud
+// and uncoalesced global loads / global float atomics (e.g. trilinear_devox.cu:96-103,
+// :145-157).  Here a workgroup owns a SLAB = G consecutive channel rows of one cloud:
+//   gather : the slab is streamed HBM -> LDS once with 16-byte coalesced loads, all random
+//            reads are served by LDS (ds_read_b32), outputs leave as coalesced 16-byte stores;
+//   scatter: the slab is accumulated in LDS with ds_add_f32 and written to HBM exactly once
+//            with coalesced 16-byte stores -- no memset pass, no global atomics.
+// HBM traffic is therefore the compulsory minimum (slab once + per-element streams once).
+// An R=32 grid row is 128 KiB: it fits the 160 KiB LDS of a gfx950 CU as a single-row slab.
+// Rows that do not fit LDS (R > 34, N > 40960) take the *_direct kernels (global gathers /
+// global atomics after a memset).
+//
+// The index/weight source ("provider") is a template parameter; see the structs below.
+#pragma once
+#include "common.h"
+
+namespace pvcnn {
+
+template <int NC>
+struct Taps {
+  int32_t idx[NC];
+  float w[NC];
+};
+
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ int4 ld4(const int32_t *p) { return *reinterpret_cast<const int4 *>(p); }
+__device__ __forceinline__ void st4(float *p, float a, float b, float c, float d) {
+  *reinterpret_cast<float4 *>(p) = make_float4(a, b, c, d);
+}
+__device__ __forceinline__ void st4(int32_t *p, int a, int b, int c, int d) {
+  *reinterpret_cast<int4 *>(p) = make_int4(a, b, c, d);
+}
+
+// sum_k w_k * row[idx_k]: one multiply then a fused-multiply-add chain, left to right.  This is
+// the contraction nvcc applies to the reference's expressions (trilinear_devox.cu:98-102,
+// neighbor_interpolate.cu:112-114) and what the oracle pins with fmaf().  With NC == 1 it is a
+// single product (voxelize bwd) and with w == 1.0f an exact copy (grouping / gather).
+template <int NC, bool MAY_SKIP>
+__device__ __forceinline__ float combine(const Taps<NC> &t, const float *row) {
+  if (MAY_SKIP && t.idx[0] < 0) return 0.0f;
+  float acc = t.w[0] * row[t.idx[0]];
+#pragma unroll
+  for (int k = 1; k < NC; ++k) acc = fmaf(t.w[k], row[t.idx[k]], acc);
+  return acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Providers.  load1: taps of element j of cloud b.  load4: taps of elements j0..j0+3 using
+// 16-byte loads (only launched when J % 4 == 0 and all arrays are 16-byte aligned).
+// post1/post4: side outputs, executed by the workgroups of channel-slab 0 only.
+// ---------------------------------------------------------------------------------------------
+
+// Trilinear corner indices/weights from point coordinates: trilinear_devox.cu:41-75.
+struct TrilinearFromCoords {
+  static constexpr int NC = 8;
+  static constexpr bool kMaySkip = false;
+  const float *coords;   // (B,3,N)
+  int32_t *inds;         // (B,8,N) or nullptr
+  float *wgts;           // (B,8,N) or nullptr
+  int N, R, R2;
+
+  __device__ __forceinline__ void setup(float x, float y, float z, Taps<8> &t) const {
+    const float xl = floorf(x), yl = floorf(y), zl = floorf(z);
+    const float xd1 = x - xl, yd1 = y - yl, zd1 = z - zl;
+    const float xd0 = 1.0f - xd1, yd0 = 1.0f - yd1, zd0 = 1.0f - zd1;
+    const float w00 = xd0 * yd0, w01 = xd0 * yd1, w10 = xd1 * yd0, w11 = xd1 * yd1;
+    t.w[0] = w00 * zd0; t.w[1] = w00 * zd1; t.w[2] = w01 * zd0; t.w[3] = w01 * zd1;
+    t.w[4] = w10 * zd0; t.w[5] = w10 * zd1; t.w[6] = w11 * zd0; t.w[7] = w11 * zd1;
+    const int i000 = (int)xl * R2 + (int)yl * R + (int)zl;
+    const int zo = (zd1 > 0) ? 1 : 0;
+    const int yo = (yd1 > 0) ? R : 0;
+    const int xo = (xd1 > 0) ? R2 : 0;
+    t.idx[0] = i000;           t.idx[1] = i000 + zo;
+    t.idx[2] = i000 + yo;      t.idx[3] = i000 + yo + zo;
+    t.idx[4] = i000 + xo;      t.idx[5] = i000 + xo + zo;
+    t.idx[6] = i000 + xo + yo; t.idx[7] = i000 + xo + yo + zo;
+  }
+  __device__ __forceinline__ void load1(int b, int j, Taps<8> &t) const {
+    const float *c = coords + (size_t)b * 3 * N;
+    setup(c[j], c[j + N], c[j + 2 * N], t);
+  }
+  __device__ __forceinline__ void load4(int b, int j0, Taps<8> (&t)[4]) const {
+    const float *c = coords + (size_t)b * 3 * N;
+    const float4 x = ld4(c + j0), y = ld4(c + N + j0), z = ld4(c + 2 * N + j0);
+    setup(x.x, y.x, z.x, t[0]); setup(x.y, y.y, z.y, t[1]);
+    setup(x.z, y.z, z.z, t[2]); setup(x.w, y.w, z.w, t[3]);
+  }
+  __device__ __forceinline__ void post1(int b, int j, const Taps<8> &t) const {
+    if (!inds) return;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      inds[((size_t)b * 8 + k) * N + j] = t.idx[k];
+      wgts[((size_t)b * 8 + k) * N + j] = t.w[k];
+    }
+  }
+  __device__ __forceinline__ void post4(int b, int j0, const Taps<8> (&t)[4]) const {
+    if (!inds) return;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      st4(inds + ((size_t)b * 8 + k) * N + j0, t[0].idx[k], t[1].idx[k], t[2].idx[k], t[3].idx[k]);
+      st4(wgts + ((size_t)b * 8 + k) * N + j0, t[0].w[k], t[1].w[k], t[2].w[k], t[3].w[k]);
+    }
+  }
+};
+
+// Saved (B,NC,J) index / weight planes: devoxelize bwd (NC=8), 3-NN interpolate (NC=3).
+template <int NC_>
+struct SavedTaps {
+  static constexpr int NC = NC_;
+  static constexpr bool kMaySkip = false;
+  const int32_t *inds;   // (B,NC,J)
+  const float *wgts;     // (B,NC,J)
+  int J;
+  __device__ __forceinline__ void load1(int b, int j, Taps<NC> &t) const {
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      t.idx[k] = inds[((size_t)b * NC + k) * J + j];
+      t.w[k] = wgts[((size_t)b * NC + k) * J + j];
+    }
+  }
+  __device__ __forceinline__ void load4(int b, int j0, Taps<NC> (&t)[4]) const {
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      const int4 i = ld4(inds + ((size_t)b * NC + k) * J + j0);
+      const float4 w = ld4(wgts + ((size_t)b * NC + k) * J + j0);
+      t[0].idx[k] = i.x; t[1].idx[k] = i.y; t[2].idx[k] = i.z; t[3].idx[k] = i.w;
+      t[0].w[k] = w.x; t[1].w[k] = w.y; t[2].w[k] = w.z; t[3].w[k] = w.w;
+    }
+  }
+  __device__ __forceinline__ void post1(int, int, const Taps<NC> &) const {}
+  __device__ __forceinline__ void post4(int, int, const Taps<NC> (&)[4]) const {}
+};
+
+// One index per element, weight 1: grouping (J = M*U) and gather (J = M).
+struct IndexOnly {
+  static constexpr int NC = 1;
+  static constexpr bool kMaySkip = false;
+  const int32_t *idx;   // (B,J)
+  int J;
+  __device__ __forceinline__ void load1(int b, int j, Taps<1> &t) const {
+    t.idx[0] = idx[(size_t)b * J + j];
+    t.w[0] = 1.0f;
+  }
+  __device__ __forceinline__ void load4(int b, int j0, Taps<1> (&t)[4]) const {
+    const int4 i = ld4(idx + (size_t)b * J + j0);
+    t[0].idx[0] = i.x; t[1].idx[0] = i.y; t[2].idx[0] = i.z; t[3].idx[0] = i.w;
+    t[0].w[0] = t[1].w[0] = t[2].w[0] = t[3].w[0] = 1.0f;
+  }
+  __device__ __forceinline__ void post1(int, int, const Taps<1> &) const {}
+  __device__ __forceinline__ void post4(int, int, const Taps<1> (&)[4]) const {}
+};
+
+// Voxelize backward: idx = ind[b,j], w = 1/cnt[b,idx] (vox.cu:99-106); cnt == 0 -> output 0.
+struct VoxelMean {
+  static constexpr int NC = 1;
+  static constexpr bool kMaySkip = true;
+  const int32_t *ind;   // (B,N)
+  const int32_t *cnt;   // (B,S)
+  int N, S;
+  __device__ __forceinline__ void one(int b, int pos, Taps<1> &t) const {
+    const int c = cnt[(size_t)b * S + pos];
+    t.idx[0] = (c > 0) ? pos : -1;
+    t.w[0] = (c > 0) ? (float)(1.0 / (double)(float)c) : 0.0f;
+  }
+  __device__ __forceinline__ void load1(int b, int j, Taps<1> &t) const { one(b, ind[(size_t)b * N + j], t); }
+  __device__ __forceinline__ void load4(int b, int j0, Taps<1> (&t)[4]) const {
+    const int4 p = ld4(ind + (size_t)b * N + j0);
+    one(b, p.x, t[0]); one(b, p.y, t[1]); one(b, p.z, t[2]); one(b, p.w, t[3]);
+  }
+  __device__ __forceinline__ void post1(int, int, const Taps<1> &) const {}
+  __device__ __forceinline__ void post4(int, int, const Taps<1> (&)[4]) const {}
+};
+
+// ---------------------------------------------------------------------------------------------
+// LDS slab kernels.  grid = (ceil(C/G), B); blockIdx.x = channel slab, blockIdx.y = cloud.
+// ---------------------------------------------------------------------------------------------
+template <int THREADS>
+__device__ __forceinline__ void slab_copy(float *dst, const float *src, int total) {
+  // wave-uniform branch: 16-byte path when the slab start is aligned and a multiple of 4 floats
+  if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0 && (total & 3) == 0) {
+    for (int i = threadIdx.x * 4; i < total; i += THREADS * 4)
+      *reinterpret_cast<float4 *>(dst + i) = *reinterpret_cast<const float4 *>(src + i);
+  } else {
+    for (int i = threadIdx.x; i < total; i += THREADS) dst[i] = src[i];
+  }
+}
+
+template <class P, int VEC, int THREADS>
+__global__ __launch_bounds__(THREADS) void gather_lds_kernel(P p, const float *__restrict__ src,
+                                                             float *__restrict__ dst, int C, int L,
+                                                             int J, int G) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int NC = P::NC;
+  const int b = blockIdx.y;
+  const int c0 = blockIdx.x * G;
+  const int g = min(G, C - c0);
+  slab_copy<THREADS>(lds, src + ((size_t)b * C + c0) * L, g * L);
+  __syncthreads();
+  float *out = dst + ((size_t)b * C + c0) * J;
+  const bool side = (blockIdx.x == 0);
+  for (int j0 = threadIdx.x * VEC; j0 < J; j0 += THREADS * VEC) {
+    Taps<NC> t[VEC];
+    if constexpr (VEC == 4) {
+      p.load4(b, j0, t);
+      if (side) p.post4(b, j0, t);
+    } else {
+      p.load1(b, j0, t[0]);
+      if (side) p.post1(b, j0, t[0]);
+    }
+    for (int c = 0; c < g; ++c) {
+      const float *row = lds + c * L;
+      if constexpr (VEC == 4) {
+        const float r0 = combine<NC, P::kMaySkip>(t[0], row), r1 = combine<NC, P::kMaySkip>(t[1], row);
+        const float r2 = combine<NC, P::kMaySkip>(t[2], row), r3 = combine<NC, P::kMaySkip>(t[3], row);
+        st4(out + (size_t)c * J + j0, r0, r1, r2, r3);
+      } else {
+        out[(size_t)c * J + j0] = combine<NC, P::kMaySkip>(t[0], row);
+      }
+    }
+  }
+}
+
+template <class P, int VEC, int THREADS>
+__global__ __launch_bounds__(THREADS) void scatter_lds_kernel(P p, const float *__restrict__ src,
+                                                              float *__restrict__ dst, int C, int L,
+                                                              int J, int G) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int NC = P::NC;
+  const int b = blockIdx.y;
+  const int c0 = blockIdx.x * G;
+  const int g = min(G, C - c0);
+  const int total = g * L;
+  for (int i = threadIdx.x; i < total; i += THREADS) lds[i] = 0.0f;
+  __syncthreads();
+  const float *in = src + ((size_t)b * C + c0) * J;
+  for (int j0 = threadIdx.x * VEC; j0 < J; j0 += THREADS * VEC) {
+    Taps<NC> t[VEC];
+    if constexpr (VEC == 4) p.load4(b, j0, t); else p.load1(b, j0, t[0]);
+    for (int c = 0; c < g; ++c) {
+      float *row = lds + c * L;
+      float gv[VEC];
+      if constexpr (VEC == 4) {
+        const float4 q = ld4(in + (size_t)c * J + j0);
+        gv[0] = q.x; gv[1] = q.y; gv[2] = q.z; gv[3] = q.w;
+      } else {
+        gv[0] = in[(size_t)c * J + j0];
+      }
+#pragma unroll
+      for (int v = 0; v < VEC; ++v)
+#pragma unroll
+        for (int k = 0; k < NC; ++k) atomicAdd(row + t[v].idx[k], t[v].w[k] * gv[v]);   // ds_add_f32
+    }
+  }
+  __syncthreads();
+  slab_copy<THREADS>(dst + ((size_t)b * C + c0) * L, lds, total);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Direct (no-LDS) fallbacks for rows larger than LDS.  grid = (ceil(J/256), ceil(C/CT), B).
+// scatter_direct needs dst zeroed first (the launcher enqueues a hipMemsetAsync).
+// ---------------------------------------------------------------------------------------------
+template <class P>
+__global__ __launch_bounds__(256) void gather_direct_kernel(P p, const float *__restrict__ src,
+                                                            float *__restrict__ dst, int C, int L,
+                                                            int J, int CT) {
+  constexpr int NC = P::NC;
+  const int b = blockIdx.z;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= J) return;
+  Taps<NC> t;
+  p.load1(b, j, t);
+  if (blockIdx.y == 0) p.post1(b, j, t);
+  const int c0 = blockIdx.y * CT, c1 = min(C, c0 + CT);
+  for (int c = c0; c < c1; ++c)
+    dst[((size_t)b * C + c) * J + j] = combine<NC, P::kMaySkip>(t, src + ((size_t)b * C + c) * L);
+}
+
+template <class P>
+__global__ __launch_bounds__(256) void scatter_direct_kernel(P p, const float *__restrict__ src,
+                                                             float *__restrict__ dst, int C, int L,
+                                                             int J, int CT) {
+  constexpr int NC = P::NC;
+  const int b = blockIdx.z;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= J) return;
+  Taps<NC> t;
+  p.load1(b, j, t);
+  const int c0 = blockIdx.y * CT, c1 = min(C, c0 + CT);
+  for (int c = c0; c < c1; ++c) {
+    const float gv = src[((size_t)b * C + c) * J + j];
+    float *row = dst + ((size_t)b * C + c) * L;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) atomicAdd(row + t.idx[k], t.w[k] * gv);   // global_atomic_add_f32
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host-side launch policy.
+// ---------------------------------------------------------------------------------------------
+struct SlabPlan {
+  bool lds;       // LDS slab path possible
+  int G;          // channel rows per workgroup
+  int threads;    // 256 or 1024
+  size_t bytes;   // dynamic LDS bytes
+};
+
+// Rows per slab: keep a slab <= 64 KiB when a row allows it (>= 2 workgroups per CU so one
+// workgroup's HBM->LDS stream overlaps another's LDS phase), and keep >= ~3 workgroups per CU
+// in the grid; a row > 64 KiB (R = 32: 128 KiB) is a slab of its own with 1024 threads.
+inline SlabPlan plan_slab(int B, int C, int L) {
+  SlabPlan pl{};
+  const size_t row = (size_t)L * sizeof(float);
+  pl.lds = row <= (size_t)kLdsBytesPerCU;
+  if (!pl.lds) return pl;
+  int G = 1;
+  if (row <= 64 * 1024) {
+    G = (int)((64 * 1024) / row);
+    if (G > C) G = C;
+    while (G > 1 && (long)B * ceil_div(C, G) < 3L * kNumCU) G = (G + 1) / 2;
+  }
+  pl.G = G;
+  pl.bytes = (size_t)G * row;
+  pl.threads = (pl.bytes > 48 * 1024) ? 1024 : 256;
+  return pl;
+}
+
+template <class K>
+inline int enable_big_lds(K kernel, size_t bytes) {
+  if (bytes > 64 * 1024)
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  return 0;
+}
+
+// vec_ok: J % 4 == 0 and every per-element array (incl. src/dst rows of length J) 16-byte aligned
+template <class P>
+int launch_gather(const P &p, const float *src, float *dst, int B, int C, int L, int J, bool vec_ok,
+                  hipStream_t s, const char *what) {
+  if (B == 0 || C == 0 || J == 0) return 0;
+  const SlabPlan pl = plan_slab(B, C, L);
+  if (!pl.lds) {
+    const int CT = 16;
+    hipLaunchKernelGGL((gather_direct_kernel<P>), dim3(ceil_div(J, 256), ceil_div(C, CT), B), dim3(256), 0, s,
+                       p, src, dst, C, L, J, CT);
+    return check_launch(what);
+  }
+  const dim3 grid(ceil_div(C, pl.G), B);
+#define PVCNN_LAUNCH_GATHER(VEC, T)                                                              \
+  do {                                                                                           \
+    auto k = gather_lds_kernel<P, VEC, T>;                                                       \
+    if (int e = enable_big_lds(k, pl.bytes)) { set_error("%s: LDS attribute: %d", what, e); return e; } \
+    hipLaunchKernelGGL(k, grid, dim3(T), pl.bytes, s, p, src, dst, C, L, J, pl.G);               \
+  } while (0)
+  if (pl.threads == 1024) { if (vec_ok) PVCNN_LAUNCH_GATHER(4, 1024); else PVCNN_LAUNCH_GATHER(1, 1024); }
+  else                    { if (vec_ok) PVCNN_LAUNCH_GATHER(4, 256);  else PVCNN_LAUNCH_GATHER(1, 256); }
+#undef PVCNN_LAUNCH_GATHER
+  return check_launch(what);
+}
+
+template <class P>
+int launch_scatter(const P &p, const float *src, float *dst, int B, int C, int L, int J, bool vec_ok,
+                   hipStream_t s, const char *what) {
+  if (B == 0 || C == 0 || L == 0) return 0;
+  const SlabPlan pl = plan_slab(B, C, L);
+  if (!pl.lds) {
+    hipError_t e = hipMemsetAsync(dst, 0, (size_t)B * C * L * sizeof(float), s);
+    if (e != hipSuccess) { set_error("%s: memset: %s", what, hipGetErrorString(e)); return (int)e; }
+    if (J == 0) return 0;
+    const int CT = 16;
+    hipLaunchKernelGGL((scatter_direct_kernel<P>), dim3(ceil_div(J, 256), ceil_div(C, CT), B), dim3(256), 0, s,
+                       p, src, dst, C, L, J, CT);
+    return check_launch(what);
+  }
+  const dim3 grid(ceil_div(C, pl.G), B);
+#define PVCNN_LAUNCH_SCATTER(VEC, T)                                                             \
+  do {                                                                                           \
+    auto k = scatter_lds_kernel<P, VEC, T>;                                                      \
+    if (int e = enable_big_lds(k, pl.bytes)) { set_error("%s: LDS attribute: %d", what, e); return e; } \
+    hipLaunchKernelGGL(k, grid, dim3(T), pl.bytes, s, p, src, dst, C, L, J, pl.G);               \
+  } while (0)
+  if (pl.threads == 1024) { if (vec_ok) PVCNN_LAUNCH_SCATTER(4, 1024); else PVCNN_LAUNCH_SCATTER(1, 1024); }
+  else                    { if (vec_ok) PVCNN_LAUNCH_SCATTER(4, 256);  else PVCNN_LAUNCH_SCATTER(1, 256); }
+#undef PVCNN_LAUNCH_SCATTER
+  return check_launch(what);
+}
+
+}  // namespace pvcnn

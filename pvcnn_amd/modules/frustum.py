@@ -1,0 +1,85 @@
+"""Frustum-PointNet multi-task loss and box-corner helper (reference: modules/frustum.py:11-124).
+Pure torch on (B, <=8x3) tensors -- not on the hot path; provided so `modules.frustum` resolves
+for the reference's KITTI configs and meters."""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as tf
+
+from . import functional as PF
+
+__all__ = ['FrustumPointNetLoss', 'get_box_corners_3d']
+
+# corner sign pattern (l, h, w) of the 8 box corners, counter-clockwise, top face first
+_SX = (1, 1, -1, -1, 1, 1, -1, -1)
+_SY = (1, 1, 1, 1, -1, -1, -1, -1)
+_SZ = (1, -1, -1, 1, 1, -1, -1, 1)
+
+
+def get_box_corners_3d(centers, headings, sizes, with_flip=False):
+    """centers (N,3), headings (N,), sizes (N,3)=(l,w,h) -> corners (N,3,8) rotated about y;
+    with_flip also returns the box turned by pi."""
+    half = sizes / 2
+    sx = half.new_tensor(_SX)
+    sy = half.new_tensor(_SY)
+    sz = half.new_tensor(_SZ)
+    local = torch.stack([half[:, 0:1] * sx, half[:, 2:3] * sy, half[:, 1:2] * sz], dim=1)   # (N,3,8)
+    c, s = torch.cos(headings), torch.sin(headings)
+    o, z = torch.ones_like(headings), torch.zeros_like(headings)
+    shift = centers.unsqueeze(-1)
+    rot = torch.stack([c, z, s, z, o, z, -s, z, c], dim=1).view(-1, 3, 3)
+    if not with_flip:
+        return torch.matmul(rot, local) + shift
+    rot_flip = torch.stack([-c, z, -s, z, o, z, s, z, -c], dim=1).view(-1, 3, 3)
+    return torch.matmul(rot, local) + shift, torch.matmul(rot_flip, local) + shift
+
+
+class FrustumPointNetLoss(nn.Module):
+    def __init__(self, num_heading_angle_bins, num_size_templates, size_templates, box_loss_weight=1.0,
+                 corners_loss_weight=10.0, heading_residual_loss_weight=20.0, size_residual_loss_weight=20.0):
+        super().__init__()
+        self.box_loss_weight = box_loss_weight
+        self.corners_loss_weight = corners_loss_weight
+        self.heading_residual_loss_weight = heading_residual_loss_weight
+        self.size_residual_loss_weight = size_residual_loss_weight
+        self.num_heading_angle_bins = num_heading_angle_bins
+        self.num_size_templates = num_size_templates
+        self.register_buffer('size_templates', size_templates.view(self.num_size_templates, 3))
+        self.register_buffer('heading_angle_bin_centers',
+                             torch.arange(0, 2 * math.pi, 2 * math.pi / self.num_heading_angle_bins))
+
+    def forward(self, inputs, targets):
+        center = inputs['center']
+        rows = torch.arange(center.size(0), device=center.device)
+        h_id, s_id = targets['heading_bin_id'], targets['size_template_id']
+        h_res_t, s_res_t, center_t = targets['heading_residual'], targets['size_residual'], targets['center']
+        bin_centers, templates = self.heading_angle_bin_centers, self.size_templates
+
+        # classification / coarse regression
+        cls = (tf.cross_entropy(inputs['heading_scores'], h_id) + tf.cross_entropy(inputs['size_scores'], s_id))
+        mask_loss = tf.cross_entropy(inputs['mask_logits'], targets['mask_logits'])
+        center_loss = PF.huber_loss(torch.norm(center_t - center, dim=-1), delta=2.0)
+        center_reg_loss = PF.huber_loss(torch.norm(center_t - inputs['center_reg'], dim=-1), delta=1.0)
+
+        # normalised residuals of the target bin / template
+        h_norm_loss = PF.huber_loss(
+            inputs['heading_residuals_normalized'][rows, h_id] - h_res_t / (math.pi / self.num_heading_angle_bins),
+            delta=1.0)
+        s_norm_loss = PF.huber_loss(
+            torch.norm(s_res_t / templates[s_id] - inputs['size_residuals_normalized'][rows, s_id], dim=-1), delta=1.0)
+
+        # corner loss against the target box and its pi-flipped twin
+        heading = inputs['heading_residuals'][rows, h_id] + bin_centers[h_id]
+        size = inputs['size_residuals'][rows, s_id] + templates[s_id]
+        corners = get_box_corners_3d(centers=center, headings=heading, sizes=size, with_flip=False)
+        tgt, tgt_flip = get_box_corners_3d(centers=center_t, headings=bin_centers[h_id] + h_res_t,
+                                           sizes=templates[s_id] + s_res_t, with_flip=True)
+        corners_loss = PF.huber_loss(
+            torch.min(torch.norm(corners - tgt, dim=1), torch.norm(corners - tgt_flip, dim=1)), delta=1.0)
+
+        box = (center_loss + center_reg_loss + cls
+               + self.heading_residual_loss_weight * h_norm_loss
+               + self.size_residual_loss_weight * s_norm_loss
+               + self.corners_loss_weight * corners_loss)
+        return mask_loss + self.box_loss_weight * box

@@ -1,0 +1,256 @@
+"""The native seam: `_backend` with the reference's 12 entry points, served by libpvcnn_hip.so.
+
+Reference: modules/functional/backend.py:6-25 JIT-builds a pybind module `_pvcnn_backend`
+(src/bindings.cpp:10-37) with nvcc; every function rejects non-CUDA tensors (utils.hpp:7).
+Here the same object shape is implemented over the C ABI in include/pvcnn_hip.h:
+
+  * same names, argument order and return shapes / dtypes as the pybind functions;
+  * same input contract: device tensor, contiguous, float32 / int32 -- violations raise
+    RuntimeError like TORCH_CHECK does (plus shape checks the reference lacks);
+  * outputs are allocated here with torch.empty (the library writes every element) on the
+    inputs' device and work is enqueued on torch's current stream -- no host sync;
+  * a failed launch raises (the reference prints and exit(-1)s, cuda_utils.cuh:28-37);
+  * there is no CPU path: a CPU tensor or a missing library is an error, never a fallback.
+"""
+import ctypes
+
+import torch
+
+from ... import _lib
+
+__all__ = ['_backend']
+
+
+def _dev(t, name):
+    if not t.is_cuda:
+        raise RuntimeError(f'{name} must be a CUDA (HIP) tensor -- the PVConv hot path has no CPU implementation')
+
+
+def _f32(t, name):
+    _dev(t, name)
+    if not t.is_contiguous():
+        raise RuntimeError(f'{name} must be a contiguous tensor')
+    if t.dtype != torch.float32:
+        raise RuntimeError(f'{name} must be a float tensor')
+
+
+def _i32(t, name):
+    _dev(t, name)
+    if not t.is_contiguous():
+        raise RuntimeError(f'{name} must be a contiguous tensor')
+    if t.dtype != torch.int32:
+        raise RuntimeError(f'{name} must be an int tensor')
+
+
+def _shape(cond, msg):
+    if not cond:
+        raise RuntimeError(msg)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None and t.numel() > 0 else ctypes.c_void_p(None)
+
+
+class _Launch:
+    """Device guard + current stream of the tensor's device for one native call."""
+
+    def __init__(self, ref):
+        self.device = ref.device
+        self.guard = torch.cuda.device(self.device)
+
+    def __enter__(self):
+        self.guard.__enter__()
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def __exit__(self, *exc):
+        return self.guard.__exit__(*exc)
+
+
+class HipBackend:
+    name = 'hip-gfx950'
+
+    def __init__(self):
+        self._lib = None
+
+    @property
+    def lib(self):
+        if self._lib is None:
+            self._lib = _lib.load()
+        return self._lib
+
+    # ---- sampling.cpp:6-41 ------------------------------------------------------------------
+    def gather_features_forward(self, features, indices):
+        _f32(features, 'features'); _i32(indices, 'indices')
+        _shape(features.dim() == 3 and indices.dim() == 2 and indices.shape[0] == features.shape[0],
+               'gather: features (B,C,N), indices (B,M) expected')
+        b, c, n = features.shape
+        m = indices.shape[1]
+        out = torch.empty((b, c, m), dtype=torch.float32, device=features.device)
+        with _Launch(features) as s:
+            _lib.check(self.lib.pvcnn_gather_fwd(_p(features), _p(indices), b, c, n, m, _p(out), s), 'gather_features_forward')
+        return out
+
+    def gather_features_backward(self, grad_y, indices, n):
+        _f32(grad_y, 'grad_y'); _i32(indices, 'indices')
+        _shape(grad_y.dim() == 3 and indices.dim() == 2 and indices.shape == (grad_y.shape[0], grad_y.shape[2]),
+               'gather backward: grad_y (B,C,M), indices (B,M) expected')
+        b, c, m = grad_y.shape
+        grad_x = torch.empty((b, c, int(n)), dtype=torch.float32, device=grad_y.device)
+        with _Launch(grad_y) as s:
+            _lib.check(self.lib.pvcnn_gather_bwd(_p(grad_y), _p(indices), b, c, int(n), m, _p(grad_x), s), 'gather_features_backward')
+        return grad_x
+
+    # ---- sampling.cpp:43-58 -----------------------------------------------------------------
+    def furthest_point_sampling(self, coords, num_samples):
+        _f32(coords, 'coords')
+        _shape(coords.dim() == 3 and coords.shape[1] == 3, 'furthest_point_sampling: coords (B,3,N) expected')
+        b, _, n = coords.shape
+        m = int(num_samples)
+        indices = torch.empty((b, m), dtype=torch.int32, device=coords.device)
+        distances = None
+        if n > 16384:   # PVCNN_FPS_MAX_RESIDENT_POINTS: larger clouds need the global scratch
+            distances = torch.empty((b, n), dtype=torch.float32, device=coords.device)
+        with _Launch(coords) as s:
+            _lib.check(self.lib.pvcnn_fps(_p(coords), b, n, m, _p(distances), _p(indices), s), 'furthest_point_sampling')
+        return indices
+
+    # ---- ball_query.cpp:6-30 ----------------------------------------------------------------
+    def ball_query(self, centers_coords, points_coords, radius, num_neighbors):
+        _f32(centers_coords, 'centers_coords'); _f32(points_coords, 'points_coords')
+        _shape(centers_coords.dim() == 3 and points_coords.dim() == 3 and centers_coords.shape[1] == 3
+               and points_coords.shape[1] == 3 and centers_coords.shape[0] == points_coords.shape[0],
+               'ball_query: centers (B,3,M), points (B,3,N) expected')
+        b, _, m = centers_coords.shape
+        n = points_coords.shape[2]
+        u = int(num_neighbors)
+        out = torch.empty((b, m, u), dtype=torch.int32, device=centers_coords.device)
+        with _Launch(centers_coords) as s:
+            _lib.check(self.lib.pvcnn_ball_query(_p(centers_coords), _p(points_coords), b, n, m, float(radius), u, _p(out), s), 'ball_query')
+        return out
+
+    # ---- grouping.cpp:6-44 ------------------------------------------------------------------
+    def grouping_forward(self, features, indices):
+        _f32(features, 'features'); _i32(indices, 'indices')
+        _shape(features.dim() == 3 and indices.dim() == 3 and indices.shape[0] == features.shape[0],
+               'grouping: features (B,C,N), indices (B,M,U) expected')
+        b, c, n = features.shape
+        _, m, u = indices.shape
+        out = torch.empty((b, c, m, u), dtype=torch.float32, device=features.device)
+        with _Launch(features) as s:
+            _lib.check(self.lib.pvcnn_grouping_fwd(_p(features), _p(indices), b, c, n, m, u, _p(out), s), 'grouping_forward')
+        return out
+
+    def grouping_backward(self, grad_y, indices, n):
+        _f32(grad_y, 'grad_y'); _i32(indices, 'indices')
+        _shape(grad_y.dim() == 4 and indices.dim() == 3 and tuple(indices.shape) == (grad_y.shape[0], grad_y.shape[2], grad_y.shape[3]),
+               'grouping backward: grad_y (B,C,M,U), indices (B,M,U) expected')
+        b, c, m, u = grad_y.shape
+        grad_x = torch.empty((b, c, int(n)), dtype=torch.float32, device=grad_y.device)
+        with _Launch(grad_y) as s:
+            _lib.check(self.lib.pvcnn_grouping_bwd(_p(grad_y), _p(indices), b, c, int(n), m, u, _p(grad_x), s), 'grouping_backward')
+        return grad_x
+
+    # ---- neighbor_interpolate.cpp:6-65 ------------------------------------------------------
+    def three_nearest_neighbors_interpolate_forward(self, points_coords, centers_coords, centers_features):
+        _f32(points_coords, 'points_coords'); _f32(centers_coords, 'centers_coords'); _f32(centers_features, 'centers_features')
+        _shape(points_coords.dim() == 3 and centers_coords.dim() == 3 and centers_features.dim() == 3
+               and points_coords.shape[1] == 3 and centers_coords.shape[1] == 3
+               and centers_coords.shape[2] == centers_features.shape[2]
+               and points_coords.shape[0] == centers_coords.shape[0] == centers_features.shape[0],
+               '3-NN interpolate: points (B,3,N), centers (B,3,M), features (B,C,M) expected')
+        b, c, m = centers_features.shape
+        n = points_coords.shape[2]
+        dev = points_coords.device
+        indices = torch.empty((b, 3, n), dtype=torch.int32, device=dev)
+        weights = torch.empty((b, 3, n), dtype=torch.float32, device=dev)
+        out = torch.empty((b, c, n), dtype=torch.float32, device=dev)
+        with _Launch(points_coords) as s:
+            _lib.check(self.lib.pvcnn_three_nn_interp_fwd(_p(points_coords), _p(centers_coords), _p(centers_features),
+                                                          b, c, m, n, _p(indices), _p(weights), _p(out), s),
+                       'three_nearest_neighbors_interpolate_forward')
+        return [out, indices, weights]
+
+    def three_nearest_neighbors_interpolate_backward(self, grad_y, indices, weights, m):
+        _f32(grad_y, 'grad_y'); _i32(indices, 'indices'); _f32(weights, 'weights')
+        _shape(grad_y.dim() == 3 and tuple(indices.shape) == (grad_y.shape[0], 3, grad_y.shape[2])
+               and indices.shape == weights.shape,
+               '3-NN interpolate backward: grad_y (B,C,N), indices/weights (B,3,N) expected')
+        b, c, n = grad_y.shape
+        grad_x = torch.empty((b, c, int(m)), dtype=torch.float32, device=grad_y.device)
+        with _Launch(grad_y) as s:
+            _lib.check(self.lib.pvcnn_three_nn_interp_bwd(_p(grad_y), _p(indices), _p(weights), b, c, n, int(m), _p(grad_x), s),
+                       'three_nearest_neighbors_interpolate_backward')
+        return grad_x
+
+    # ---- trilinear_devox.cpp:18-91 (argument order: r, is_training, coords, features) ----------
+    def trilinear_devoxelize_forward(self, r, is_training, coords, features):
+        _f32(features, 'features'); _f32(coords, 'coords')
+        r = int(r)
+        _shape(features.dim() == 3 and coords.dim() == 3 and coords.shape[1] == 3
+               and coords.shape[0] == features.shape[0] and features.shape[2] == r * r * r,
+               'trilinear_devoxelize: coords (B,3,N), features (B,C,R^3) expected')
+        b, c = features.shape[:2]
+        n = coords.shape[2]
+        dev = features.device
+        outs = torch.empty((b, c, n), dtype=torch.float32, device=dev)
+        if is_training:
+            inds = torch.empty((b, 8, n), dtype=torch.int32, device=dev)
+            wgts = torch.empty((b, 8, n), dtype=torch.float32, device=dev)
+        else:   # 1-element dummies, like trilinear_devox.cpp:45-53
+            inds = torch.zeros((1,), dtype=torch.int32, device=dev)
+            wgts = torch.zeros((1,), dtype=torch.float32, device=dev)
+        with _Launch(features) as s:
+            _lib.check(self.lib.pvcnn_trilinear_devox_fwd(_p(coords), _p(features), b, c, n, r, int(bool(is_training)),
+                                                          _p(inds) if is_training else None,
+                                                          _p(wgts) if is_training else None, _p(outs), s),
+                       'trilinear_devoxelize_forward')
+        return [outs, inds, wgts]
+
+    def trilinear_devoxelize_backward(self, grad_y, indices, weights, r):
+        _f32(grad_y, 'grad_y'); _f32(weights, 'weights'); _i32(indices, 'indices')
+        _shape(grad_y.dim() == 3 and tuple(indices.shape) == (grad_y.shape[0], 8, grad_y.shape[2])
+               and indices.shape == weights.shape,
+               'trilinear_devoxelize backward: grad_y (B,C,N), indices/weights (B,8,N) expected')
+        b, c, n = grad_y.shape
+        r = int(r)
+        grad_x = torch.empty((b, c, r * r * r), dtype=torch.float32, device=grad_y.device)
+        with _Launch(grad_y) as s:
+            _lib.check(self.lib.pvcnn_trilinear_devox_bwd(_p(grad_y), _p(indices), _p(weights), b, c, n, r, _p(grad_x), s),
+                       'trilinear_devoxelize_backward')
+        return grad_x
+
+    # ---- vox.cpp:17-76 ----------------------------------------------------------------------
+    def avg_voxelize_forward(self, features, coords, resolution):
+        _f32(features, 'features'); _i32(coords, 'coords')
+        _shape(features.dim() == 3 and coords.dim() == 3 and coords.shape[1] == 3
+               and coords.shape[0] == features.shape[0] and coords.shape[2] == features.shape[2],
+               'avg_voxelize: features (B,C,N), coords (B,3,N) expected')
+        b, c, n = features.shape
+        r = int(resolution)
+        s3 = r * r * r
+        dev = features.device
+        out = torch.empty((b, c, s3), dtype=torch.float32, device=dev)
+        ind = torch.empty((b, n), dtype=torch.int32, device=dev)
+        cnt = torch.empty((b, s3), dtype=torch.int32, device=dev)
+        nbytes = int(self.lib.pvcnn_avg_voxelize_fwd_workspace_bytes(b, n, r))
+        ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=dev)
+        with _Launch(features) as s:
+            _lib.check(self.lib.pvcnn_avg_voxelize_fwd(_p(features), _p(coords), b, c, n, r, _p(out), _p(ind), _p(cnt),
+                                                       _p(ws), ws.numel(), s), 'avg_voxelize_forward')
+        return [out, ind, cnt]
+
+    def avg_voxelize_backward(self, grad_y, indices, cnt):
+        _f32(grad_y, 'grad_y'); _i32(indices, 'indices'); _i32(cnt, 'cnt')
+        _shape(grad_y.dim() == 3 and indices.dim() == 2 and tuple(cnt.shape) == (grad_y.shape[0], grad_y.shape[2])
+               and indices.shape[0] == grad_y.shape[0],
+               'avg_voxelize backward: grad_y (B,C,S), indices (B,N), cnt (B,S) expected')
+        b, c, s3 = grad_y.shape
+        n = indices.shape[1]
+        grad_x = torch.empty((b, c, n), dtype=torch.float32, device=grad_y.device)
+        with _Launch(grad_y) as s:
+            _lib.check(self.lib.pvcnn_avg_voxelize_bwd(_p(grad_y), _p(indices), _p(cnt), b, c, n, s3, _p(grad_x), s),
+                       'avg_voxelize_backward')
+        return grad_x
+
+
+_backend = HipBackend()

@@ -1,0 +1,46 @@
+"""PVConv: point-voxel convolution (reference: modules/pvconv.py:11-39).
+
+    (features (B,Cin,N), coords (B,3,N))
+        -> devoxelize( voxel_layers( voxelize(features, coords) ) ) + point_features(features)
+
+Sub-module names are the reference's, so released checkpoints load unchanged:
+  voxelization, voxel_layers.{0..5}[.6 = SE3d], point_features.layers.{0,1,2}.
+The voxel branch's scatter / gather run on the hand-written gfx950 kernels
+(avg_voxelize -> pvcnn_avg_voxelize_fwd, trilinear_devoxelize -> pvcnn_trilinear_devox_fwd).
+"""
+import torch.nn as nn
+
+from . import functional as F
+from .se import SE3d
+from .shared_mlp import SharedMLP
+from .voxelization import Voxelization
+
+__all__ = ['PVConv']
+
+
+class PVConv(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, resolution, with_se=False, normalize=True, eps=0):
+        super().__init__()
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.kernel_size = kernel_size
+        self.resolution = resolution
+
+        self.voxelization = Voxelization(resolution, normalize=normalize, eps=eps)
+        pad = kernel_size // 2
+        grid_ops = []
+        for cin in (in_channels, out_channels):
+            grid_ops += [nn.Conv3d(cin, out_channels, kernel_size, stride=1, padding=pad),
+                         nn.BatchNorm3d(out_channels, eps=1e-4),
+                         nn.LeakyReLU(0.1, True)]
+        if with_se:
+            grid_ops.append(SE3d(out_channels))
+        self.voxel_layers = nn.Sequential(*grid_ops)
+        self.point_features = SharedMLP(in_channels, out_channels)
+
+    def forward(self, inputs):
+        features, coords = inputs
+        grid, grid_coords = self.voxelization(features, coords)
+        grid = self.voxel_layers(grid)
+        from_voxels = F.trilinear_devoxelize(grid, grid_coords, self.resolution, self.training)
+        return from_voxels + self.point_features(features), coords
