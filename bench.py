@@ -1,0 +1,255 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's headline metric on MI355X.
+
+metric : point-clouds/sec, forward+backward(+Adam step), PVCNN (1xC) S3DIS, N=4096, R=32, fp32,
+         B=16 clouds per GPU (BASELINE configs[1]); weak scaling over N GPUs (one process per GPU,
+         RCCL all-reduce of gradients, launched by torch.distributed.run).
+A "step" = zero_grad -> forward -> cross-entropy -> backward (+ gradient all-reduce) -> Adam.step
+on one synthetic batch already resident in HBM.
+
+Extra objects on the JSON line:
+  roofline     : the hot path's headline kernel (trilinear_devoxelize fwd at the R=32 stage,
+                 16x64x4096 points from a 16x64x32^3 grid), timed LIVE inside the timed region with
+                 HIP events on the launch stream; achieved = algorithmic bytes / mean launch time.
+  kernels      : the same for every hand-written kernel family that ran in the step.
+  cpu_baseline : the same network on the host cores with the CPU oracle as native backend
+                 (kind "port": the reference has no CPU implementation), bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as tf
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable copy)
+
+
+# ---- algorithmic bytes per call (the figure roofline.achieved is computed from) ----
+def bytes_vox_fwd(b, c, n, s):
+    return 4 * b * (c * n + 3 * n + c * s + n + s)
+
+
+def bytes_vox_bwd(b, c, n, s):
+    return 4 * b * (c * min(n, s) + n + min(n, s) + c * n)
+
+
+def bytes_devox_fwd(b, c, n, s, training=True):
+    return 4 * b * (3 * n + c * min(s, 8 * n) + c * n) + (64 * b * n if training else 0)
+
+
+def bytes_devox_bwd(b, c, n, s):
+    return 4 * b * (c * n + 16 * n + c * s)
+
+
+class KernelClock:
+    """Times native calls with HIP events recorded on the stream they are launched on (torch's
+    current stream -- the stream handle pvcnn_amd passes through the C ABI)."""
+
+    WATCH = {
+        'avg_voxelize_forward': lambda a, out: ('avg_voxelize_fwd', bytes_vox_fwd(a[0].shape[0], a[0].shape[1], a[0].shape[2], int(a[2]) ** 3),
+                                                (a[0].shape[0], a[0].shape[1], a[0].shape[2], int(a[2]))),
+        'avg_voxelize_backward': lambda a, out: ('avg_voxelize_bwd', bytes_vox_bwd(a[0].shape[0], a[0].shape[1], a[1].shape[1], a[0].shape[2]),
+                                                 (a[0].shape[0], a[0].shape[1], a[1].shape[1], round(a[0].shape[2] ** (1 / 3)))),
+        'trilinear_devoxelize_forward': lambda a, out: ('trilinear_devoxelize_fwd',
+                                                        bytes_devox_fwd(a[3].shape[0], a[3].shape[1], a[2].shape[2], int(a[0]) ** 3, bool(a[1])),
+                                                        (a[3].shape[0], a[3].shape[1], a[2].shape[2], int(a[0]))),
+        'trilinear_devoxelize_backward': lambda a, out: ('trilinear_devoxelize_bwd',
+                                                         bytes_devox_bwd(a[0].shape[0], a[0].shape[1], a[0].shape[2], int(a[3]) ** 3),
+                                                         (a[0].shape[0], a[0].shape[1], a[0].shape[2], int(a[3]))),
+    }
+
+    def __init__(self, backend):
+        self.backend, self.records, self.enabled, self._orig = backend, [], False, {}
+
+    def install(self):
+        for name, describe in self.WATCH.items():
+            orig = getattr(self.backend, name)
+            self._orig[name] = orig
+
+            def timed(*args, _orig=orig, _describe=describe):
+                if not self.enabled:
+                    return _orig(*args)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                out = _orig(*args)
+                e1.record()
+                self.records.append((_describe(args, out), e0, e1))
+                return out
+            setattr(self.backend, name, timed)
+
+    def uninstall(self):
+        for name in self._orig:
+            try:
+                delattr(self.backend, name)      # drop the instance attribute -> class method again
+            except AttributeError:
+                pass
+
+    def summary(self):
+        agg = {}
+        for (kernel, nbytes, shape), e0, e1 in self.records:
+            k = (kernel, shape)
+            ms = e0.elapsed_time(e1)
+            a = agg.setdefault(k, [0, 0.0, nbytes])
+            a[0] += 1
+            a[1] += ms
+        out = []
+        for (kernel, shape), (calls, ms, nbytes) in sorted(agg.items()):
+            us = ms * 1e3 / calls
+            gbs = nbytes / (us * 1e-6) / 1e9
+            out.append({'kernel': kernel, 'shape_BCNR': list(shape), 'calls': calls, 'avg_us': round(us, 2),
+                        'algorithmic_MB': round(nbytes / 1e6, 3), 'achieved_GBs': round(gbs, 1),
+                        'frac_of_8TBs': round(gbs / HBM_PEAK_GBS, 4)})
+        return out
+
+
+def cpu_baseline(args, sample_batch):
+    """The same network + step on the host CPU with the oracle as native backend (kind "port")."""
+    from oracle.oracle_backend import OracleBackend          # checker / baseline only
+    from pvcnn_amd import workload
+    from pvcnn_amd.modules.functional import backend as seam
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    hip = seam._backend
+    seam._backend = OracleBackend()
+    try:
+        torch.manual_seed(workload.SEED)
+        model = workload.PVCNN(13, 6, width_multiplier=args.width).train()
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5)
+        x, y = workload.make_s3dis_batch(sample_batch, args.points)
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            loss = tf.cross_entropy(model(x), y)
+            loss.backward()
+            opt.step()
+        step()                                               # warm-up
+        t0, n = time.perf_counter(), 0
+        while True:
+            step()
+            n += 1
+            el = time.perf_counter() - t0
+            if el > 12.0 or n >= 5:
+                break
+    finally:
+        seam._backend = hip
+    return {'value': round(sample_batch * n / el, 3), 'unit': 'point-clouds/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{n} fwd+bwd+Adam steps of PVCNN {args.width}xC at B={sample_batch}, N={args.points} '
+                      f'(oracle C backend + torch-CPU conv/BN, {cores} threads; 1 warm-up step excluded)'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=16, help='clouds per GPU (BASELINE configs[1]: 16)')
+    ap.add_argument('--points', type=int, default=4096)
+    ap.add_argument('--width', type=float, default=1.0)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample-batch', type=int, default=2)
+    ap.add_argument('--bucket-mb', type=float, default=8.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU: the PVConv hot path has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)       # backend "nccl" IS RCCL on ROCm
+
+    from pvcnn_amd import workload
+    from pvcnn_amd.dp import GradBucketReducer
+    from pvcnn_amd.modules.functional import backend as seam
+    assert seam._backend.name == 'hip-gfx950'
+    seam._backend.lib                                         # dlopen now: fail loudly before timing
+
+    torch.backends.cudnn.benchmark = True                     # MIOpen find-mode for the Conv3d layers
+    torch.manual_seed(workload.SEED)
+    model = workload.PVCNN(13, 6, width_multiplier=args.width).to(dev).train()
+    reducer = GradBucketReducer(model, bucket_mb=args.bucket_mb)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5)
+    x, y = workload.make_s3dis_batch(args.batch, args.points, device=dev, seed=workload.SEED + rank)
+
+    clock = KernelClock(seam._backend)
+    clock.install()
+
+    def step():
+        reducer.zero_grad()
+        loss = tf.cross_entropy(model(x), y)
+        loss.backward()
+        reducer.finish()
+        opt.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    clock.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    clock.enabled = False
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    final_loss = float(loss)
+    kernels = clock.summary()
+    clock.uninstall()
+
+    if rank == 0:
+        global_batch = args.batch * world
+        head = next((k for k in kernels if k['kernel'] == 'trilinear_devoxelize_fwd' and k['shape_BCNR'][3] == max(
+            kk['shape_BCNR'][3] for kk in kernels if kk['kernel'] == 'trilinear_devoxelize_fwd')), None)
+        roofline = None
+        if head:
+            roofline = {'bound': 'hbm', 'kernel': 'trilinear_devoxelize_fwd (gather_lds_kernel<TrilinearFromCoords>)',
+                        'shape_BCNR': head['shape_BCNR'], 'achieved': head['achieved_GBs'], 'peak': HBM_PEAK_GBS,
+                        'unit': 'GB/s', 'frac': round(head['achieved_GBs'] / HBM_PEAK_GBS, 4),
+                        'frac_of_achievable_6300': round(head['achieved_GBs'] / 6300.0, 4),
+                        'avg_us': head['avg_us'], 'algorithmic_MB': head['algorithmic_MB'], 'traffic': None}
+        line = {
+            'metric': 'point-clouds/sec fwd+bwd, PVCNN S3DIS N=4096 R=32',
+            'value': round(global_batch * args.steps / elapsed, 2),
+            'unit': 'point-clouds/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'PVCNN ({args.width:g}xC) S3DIS fwd+bwd+Adam, B={args.batch}/GPU N={args.points} R=32/16 fp32',
+                       'global_batch': global_batch, 'points': args.points, 'parallelism': f'dp{world}',
+                       'gradient_bytes': reducer.gradient_bytes, 'final_loss': round(final_loss, 4)},
+            'roofline': roofline,
+            'kernels': kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(args, args.cpu_sample_batch)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

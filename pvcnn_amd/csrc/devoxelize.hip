@@ -8,9 +8,11 @@
 //             of each point from its 12-byte coordinate (cheaper than re-reading 64 bytes of
 //             saved inds/wgts), and serves the 8*C random reads per point from LDS.  The
 //             workgroups of channel-slab 0 also emit inds/wgts (B,8,N) in training mode.
-//   backward: scatter_lds_kernel<SavedTaps<8>> -- the grid slab is accumulated in LDS with
-//             ds_add_f32 and written to HBM once; no memset, no global atomics.
-#include "slab.h"
+//   backward: the deterministic CSR scatter of csr.h with 8 entries per point (entry id =
+//             point*8 + corner, the reference's loop order): one counting sort per cloud, then
+//             lane-owned sums over grad_y rows staged in LDS; every grid element written once;
+//             no memset, no float atomics, bit-identical to the serial oracle.
+#include "csr.h"
 
 using namespace pvcnn;
 
@@ -45,15 +47,28 @@ extern "C" int pvcnn_trilinear_devox_fwd(const float *coords, const float *feat,
   return launch_gather(p, feat, outs, B, C, /*L=*/R * R * R, /*J=*/N, vec, s, "trilinear_devox_fwd");
 }
 
+extern "C" size_t pvcnn_trilinear_devox_bwd_workspace_bytes(int B, int N, int R) {
+  if (B <= 0 || N < 0 || R <= 0) return 0;
+  const long S = (long)R * R * R;
+  if (S > 0x7fffffffL || !csr_supported((int)S, 8L * N)) return 16;   // atomic fallback: no scratch
+  return CsrWorkspace::bytes(B, (int)S, 8L * N);
+}
+
 extern "C" int pvcnn_trilinear_devox_bwd(const float *grad_y, const int32_t *inds, const float *wgts, int B,
-                                         int C, int N, int R, float *grad_x, void *stream) {
+                                         int C, int N, int R, float *grad_x, void *workspace,
+                                         size_t workspace_bytes, void *stream) {
   PVCNN_REQUIRE(B >= 0 && C >= 0 && N >= 0 && R > 0, "negative size");
   PVCNN_REQUIRE((long)R * R * R <= 0x7fffffffL / 4, "resolution too large");
   if (B == 0 || C == 0) return 0;
   PVCNN_REQUIRE(grad_x && (N == 0 || (grad_y && inds && wgts)), "null pointer");
   PVCNN_REQUIRE(B <= 65535, "batch > 65535");
-  SavedTaps<8> p{inds, wgts, N};
-  const bool vec = (N % 4 == 0) && aligned16(grad_y) && aligned16(inds) && aligned16(wgts);
-  return launch_scatter(p, grad_y, grad_x, B, C, /*L=*/R * R * R, /*J=*/N, vec,
-                        static_cast<hipStream_t>(stream), "trilinear_devox_bwd");
+  const int S = R * R * R;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (!csr_supported(S, 8L * N)) {
+    SavedTaps<8> p{inds, wgts, N};
+    return launch_scatter_direct(p, grad_y, grad_x, B, C, S, N, s, "trilinear_devox_bwd(atomic)");
+  }
+  TapEntries<8> ep{inds, wgts, N, S};
+  return launch_csr_scatter(ep, grad_y, grad_x, B, C, /*L=*/S, /*J=*/N, /*E=*/8L * N, nullptr, workspace,
+                            workspace_bytes, s, "trilinear_devox_bwd");
 }

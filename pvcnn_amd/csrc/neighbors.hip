@@ -9,10 +9,11 @@
 //              lower lanes gives each hit its slot in ascending point order -- exactly the
 //              reference's sequential "first U hits" semantics, with coalesced index writes and
 //              a wave-uniform early exit.  d^2 uses the same mul + 2 fma contraction as nvcc.
-// grouping / gather fwd+bwd, 3-NN interpolate fwd+bwd: LDS slab kernels (slab.h); a feature row
-//              of N <= 40960 floats lives in LDS, so the U-fold re-reads of grouping never touch L2.
+// grouping / gather / 3-NN interpolate forward: LDS slab gathers (slab.h); a feature row of
+//              N <= 40960 floats lives in LDS, so the U-fold re-reads of grouping never touch L2.
+// their backwards: deterministic CSR scatters (csr.h), entry id = the reference's loop order.
 // 3-NN search: one lane per query point, centres read through wave-uniform (scalar) loads.
-#include "slab.h"
+#include "csr.h"
 
 namespace pvcnn {
 
@@ -143,17 +144,29 @@ extern "C" int pvcnn_grouping_fwd(const float *features, const int32_t *indices,
   return launch_gather(p, features, out, B, C, N, J, vec, static_cast<hipStream_t>(stream), "grouping_fwd");
 }
 
+extern "C" size_t pvcnn_grouping_bwd_workspace_bytes(int B, int N, int M, int U) {
+  if (B <= 0 || N <= 0 || M < 0 || U < 0) return 0;
+  const long E = (long)M * U;
+  if (!csr_supported(N, E)) return 16;
+  return CsrWorkspace::bytes(B, N, E);
+}
+
 extern "C" int pvcnn_grouping_bwd(const float *grad_y, const int32_t *indices, int B, int C, int N, int M, int U,
-                                  float *grad_x, void *stream) {
+                                  float *grad_x, void *workspace, size_t workspace_bytes, void *stream) {
   PVCNN_REQUIRE(B >= 0 && C >= 0 && N >= 0 && M >= 0 && U >= 0, "negative size");
-  PVCNN_REQUIRE((long)M * U <= 0x7fffffffL / 4, "M*U too large");
+  PVCNN_REQUIRE((long)M * U <= 0x7fffffffL / 8, "M*U too large");
   const int J = M * U;
   if (B == 0 || C == 0 || N == 0) return 0;
   PVCNN_REQUIRE(grad_x && (J == 0 || (grad_y && indices)), "null pointer");
   PVCNN_REQUIRE(B <= 65535, "batch > 65535");
-  IndexOnly p{indices, J};
-  const bool vec = (J % 4 == 0) && aligned16(indices) && aligned16(grad_y);
-  return launch_scatter(p, grad_y, grad_x, B, C, N, J, vec, static_cast<hipStream_t>(stream), "grouping_bwd");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (!csr_supported(N, J)) {
+    IndexOnly p{indices, J};
+    return launch_scatter_direct(p, grad_y, grad_x, B, C, N, J, s, "grouping_bwd(atomic)");
+  }
+  IndexEntries ep{indices, J, N};
+  return launch_csr_scatter(ep, grad_y, grad_x, B, C, /*L=*/N, /*J=*/J, /*E=*/J, nullptr, workspace, workspace_bytes, s,
+                            "grouping_bwd");
 }
 
 extern "C" int pvcnn_gather_fwd(const float *features, const int32_t *indices, int B, int C, int N, int M,
@@ -161,9 +174,13 @@ extern "C" int pvcnn_gather_fwd(const float *features, const int32_t *indices, i
   return pvcnn_grouping_fwd(features, indices, B, C, N, M, 1, out, stream);
 }
 
+extern "C" size_t pvcnn_gather_bwd_workspace_bytes(int B, int N, int M) {
+  return pvcnn_grouping_bwd_workspace_bytes(B, N, M, 1);
+}
+
 extern "C" int pvcnn_gather_bwd(const float *grad_y, const int32_t *indices, int B, int C, int N, int M,
-                                float *grad_x, void *stream) {
-  return pvcnn_grouping_bwd(grad_y, indices, B, C, N, M, 1, grad_x, stream);
+                                float *grad_x, void *workspace, size_t workspace_bytes, void *stream) {
+  return pvcnn_grouping_bwd(grad_y, indices, B, C, N, M, 1, grad_x, workspace, workspace_bytes, stream);
 }
 
 extern "C" int pvcnn_three_nn_interp_fwd(const float *points_coords, const float *centers_coords,
@@ -185,14 +202,25 @@ extern "C" int pvcnn_three_nn_interp_fwd(const float *points_coords, const float
   return launch_gather(p, centers_features, out, B, C, /*L=*/M, /*J=*/N, vec, s, "three_nn_interp_fwd");
 }
 
+extern "C" size_t pvcnn_three_nn_interp_bwd_workspace_bytes(int B, int N, int M) {
+  if (B <= 0 || N < 0 || M <= 0) return 0;
+  if (!csr_supported(M, 3L * N)) return 16;
+  return CsrWorkspace::bytes(B, M, 3L * N);
+}
+
 extern "C" int pvcnn_three_nn_interp_bwd(const float *grad_y, const int32_t *indices, const float *weights, int B,
-                                         int C, int N, int M, float *grad_x, void *stream) {
+                                         int C, int N, int M, float *grad_x, void *workspace,
+                                         size_t workspace_bytes, void *stream) {
   PVCNN_REQUIRE(B >= 0 && C >= 0 && N >= 0 && M >= 0, "negative size");
   if (B == 0 || C == 0 || M == 0) return 0;
   PVCNN_REQUIRE(grad_x && (N == 0 || (grad_y && indices && weights)), "null pointer");
   PVCNN_REQUIRE(B <= 65535, "batch > 65535");
-  SavedTaps<3> p{indices, weights, N};
-  const bool vec = (N % 4 == 0) && aligned16(indices) && aligned16(weights) && aligned16(grad_y);
-  return launch_scatter(p, grad_y, grad_x, B, C, /*L=*/M, /*J=*/N, vec, static_cast<hipStream_t>(stream),
-                        "three_nn_interp_bwd");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (!csr_supported(M, 3L * N)) {
+    SavedTaps<3> p{indices, weights, N};
+    return launch_scatter_direct(p, grad_y, grad_x, B, C, M, N, s, "three_nn_interp_bwd(atomic)");
+  }
+  TapEntries<3> ep{indices, weights, N, M};
+  return launch_csr_scatter(ep, grad_y, grad_x, B, C, /*L=*/M, /*J=*/N, /*E=*/3L * N, nullptr, workspace,
+                            workspace_bytes, s, "three_nn_interp_bwd");
 }

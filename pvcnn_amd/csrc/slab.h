@@ -11,8 +11,8 @@
 // :145-157).  Here a workgroup owns a SLAB = G consecutive channel rows of one cloud:
 //   gather : the slab is streamed HBM -> LDS once with 16-byte coalesced loads, all random
 //            reads are served by LDS (ds_read_b32), outputs leave as coalesced 16-byte stores;
-//   scatter: the slab is accumulated in LDS with ds_add_f32 and written to HBM exactly once
-//            with coalesced 16-byte stores -- no memset pass, no global atomics.
+//   scatter: see csr.h -- float atomics (LDS or global) are far too slow on gfx950, so scatters
+//            are a per-cloud counting sort + lane-owned segmented sums instead.
 // HBM traffic is therefore the compulsory minimum (slab once + per-element streams once).
 // An R=32 grid row is 128 KiB: it fits the 160 KiB LDS of a gfx950 CU as a single-row slab.
 // Rows that do not fit LDS (R > 34, N > 40960) take the *_direct kernels (global gathers /
@@ -228,41 +228,6 @@ __global__ __launch_bounds__(THREADS) void gather_lds_kernel(P p, const float *_
   }
 }
 
-template <class P, int VEC, int THREADS>
-__global__ __launch_bounds__(THREADS) void scatter_lds_kernel(P p, const float *__restrict__ src,
-                                                              float *__restrict__ dst, int C, int L,
-                                                              int J, int G) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int NC = P::NC;
-  const int b = blockIdx.y;
-  const int c0 = blockIdx.x * G;
-  const int g = min(G, C - c0);
-  const int total = g * L;
-  for (int i = threadIdx.x; i < total; i += THREADS) lds[i] = 0.0f;
-  __syncthreads();
-  const float *in = src + ((size_t)b * C + c0) * J;
-  for (int j0 = threadIdx.x * VEC; j0 < J; j0 += THREADS * VEC) {
-    Taps<NC> t[VEC];
-    if constexpr (VEC == 4) p.load4(b, j0, t); else p.load1(b, j0, t[0]);
-    for (int c = 0; c < g; ++c) {
-      float *row = lds + c * L;
-      float gv[VEC];
-      if constexpr (VEC == 4) {
-        const float4 q = ld4(in + (size_t)c * J + j0);
-        gv[0] = q.x; gv[1] = q.y; gv[2] = q.z; gv[3] = q.w;
-      } else {
-        gv[0] = in[(size_t)c * J + j0];
-      }
-#pragma unroll
-      for (int v = 0; v < VEC; ++v)
-#pragma unroll
-        for (int k = 0; k < NC; ++k) atomicAdd(row + t[v].idx[k], t[v].w[k] * gv[v]);   // ds_add_f32
-    }
-  }
-  __syncthreads();
-  slab_copy<THREADS>(dst + ((size_t)b * C + c0) * L, lds, total);
-}
-
 // ---------------------------------------------------------------------------------------------
 // Direct (no-LDS) fallbacks for rows larger than LDS.  grid = (ceil(J/256), ceil(C/CT), B).
 // scatter_direct needs dst zeroed first (the launcher enqueues a hipMemsetAsync).
@@ -365,30 +330,18 @@ int launch_gather(const P &p, const float *src, float *dst, int B, int C, int L,
   return check_launch(what);
 }
 
+// Atomic fallback for scatters whose target row does not fit the CSR histogram in LDS
+// (csr.h, L > kCsrMaxTargets): memset + global_atomic_add_f32, like the reference.
 template <class P>
-int launch_scatter(const P &p, const float *src, float *dst, int B, int C, int L, int J, bool vec_ok,
-                   hipStream_t s, const char *what) {
+int launch_scatter_direct(const P &p, const float *src, float *dst, int B, int C, int L, int J, hipStream_t s,
+                          const char *what) {
   if (B == 0 || C == 0 || L == 0) return 0;
-  const SlabPlan pl = plan_slab(B, C, L);
-  if (!pl.lds) {
-    hipError_t e = hipMemsetAsync(dst, 0, (size_t)B * C * L * sizeof(float), s);
-    if (e != hipSuccess) { set_error("%s: memset: %s", what, hipGetErrorString(e)); return (int)e; }
-    if (J == 0) return 0;
-    const int CT = 16;
-    hipLaunchKernelGGL((scatter_direct_kernel<P>), dim3(ceil_div(J, 256), ceil_div(C, CT), B), dim3(256), 0, s,
-                       p, src, dst, C, L, J, CT);
-    return check_launch(what);
-  }
-  const dim3 grid(ceil_div(C, pl.G), B);
-#define PVCNN_LAUNCH_SCATTER(VEC, T)                                                             \
-  do {                                                                                           \
-    auto k = scatter_lds_kernel<P, VEC, T>;                                                      \
-    if (int e = enable_big_lds(k, pl.bytes)) { set_error("%s: LDS attribute: %d", what, e); return e; } \
-    hipLaunchKernelGGL(k, grid, dim3(T), pl.bytes, s, p, src, dst, C, L, J, pl.G);               \
-  } while (0)
-  if (pl.threads == 1024) { if (vec_ok) PVCNN_LAUNCH_SCATTER(4, 1024); else PVCNN_LAUNCH_SCATTER(1, 1024); }
-  else                    { if (vec_ok) PVCNN_LAUNCH_SCATTER(4, 256);  else PVCNN_LAUNCH_SCATTER(1, 256); }
-#undef PVCNN_LAUNCH_SCATTER
+  hipError_t e = hipMemsetAsync(dst, 0, (size_t)B * C * L * sizeof(float), s);
+  if (e != hipSuccess) { set_error("%s: memset: %s", what, hipGetErrorString(e)); return (int)e; }
+  if (J == 0) return 0;
+  const int CT = 16;
+  hipLaunchKernelGGL((scatter_direct_kernel<P>), dim3(ceil_div(J, 256), ceil_div(C, CT), B), dim3(256), 0, s,
+                     p, src, dst, C, L, J, CT);
   return check_launch(what);
 }
 

@@ -1,0 +1,67 @@
+"""The C-ABI library loads and exports exactly what include/pvcnn_hip.h declares (no GPU needed:
+no compute call is made here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+HEADER = os.path.join(ROOT, 'include', 'pvcnn_hip.h')
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'PVCNN_API\s+[\w\s\*]+?\b(pvcnn_\w+)\s*\(', text)))
+
+
+def test_header_declares_the_boundary():
+    syms = declared_symbols()
+    # one entry point per reference native function (bindings.cpp:10-37) + version/error/workspace
+    for name in ['pvcnn_avg_voxelize_fwd', 'pvcnn_avg_voxelize_bwd', 'pvcnn_trilinear_devox_fwd',
+                 'pvcnn_trilinear_devox_bwd', 'pvcnn_ball_query', 'pvcnn_grouping_fwd', 'pvcnn_grouping_bwd',
+                 'pvcnn_gather_fwd', 'pvcnn_gather_bwd', 'pvcnn_fps', 'pvcnn_three_nn_interp_fwd',
+                 'pvcnn_three_nn_interp_bwd', 'pvcnn_version', 'pvcnn_last_error_string',
+                 'pvcnn_avg_voxelize_fwd_workspace_bytes']:
+        assert name in syms
+
+
+def test_library_exports_every_declared_symbol():
+    from pvcnn_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH), 'libpvcnn_hip.so not built (run __graft_entry__.build())'
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared_symbols():
+        assert hasattr(lib, name), f'{name} declared in pvcnn_hip.h but not exported'
+
+
+def test_binding_table_matches_header():
+    from pvcnn_amd import _lib
+    assert sorted(_lib.SIGNATURES) == declared_symbols()
+    lib = _lib.load()
+    assert lib.pvcnn_version() == _lib.ABI_VERSION
+    assert lib.pvcnn_last_error_string() is not None
+    assert lib.pvcnn_avg_voxelize_fwd_workspace_bytes(16, 4096, 32) >= 16 * 32768 * 4 + 2 * 16 * 4096 * 4
+
+
+def test_product_path_refuses_cpu_tensors():
+    """No CPU fallback: the product backend raises instead of computing on the host."""
+    import torch
+    from pvcnn_amd.modules.functional.backend import HipBackend
+    b = HipBackend()
+    with pytest.raises(RuntimeError, match='no CPU implementation'):
+        b.avg_voxelize_forward(torch.rand(1, 2, 8), torch.zeros(1, 3, 8, dtype=torch.int32), 2)
+    with pytest.raises(RuntimeError):
+        b.trilinear_devoxelize_forward(2, True, torch.rand(1, 3, 8), torch.rand(1, 2, 8))
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under pvcnn_amd/ may reference it."""
+    pkg = os.path.join(ROOT, 'pvcnn_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h')):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle', src, flags=re.M), f'{f} imports the oracle'
+                assert 'libpvcnn_oracle' not in src, f'{f} references the oracle library'

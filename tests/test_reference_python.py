@@ -1,0 +1,128 @@
+"""Cross-checks against the reference's OWN Python layers, executed here.
+
+/root/reference's `modules/*.py` and `models/**` import fine once the native extension is
+replaced at its seam (`modules.functional.backend._backend`).  With the
+CPU oracle plugged into BOTH stacks, the reference's Python glue and pvcnn_amd's must agree
+exactly: same state_dict keys/shapes, same forward outputs, same gradients.  These tests only
+run where the reference tree is mounted (this build container); the GPU box relies on the
+golden vectors in tests/golden/ that gen_golden.py produced from the same reference run.
+"""
+import importlib
+import os
+import sys
+import types
+
+import pytest
+import torch
+
+REF = '/root/reference'
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, 'modules')), reason='reference tree not mounted')
+
+
+@pytest.fixture()
+def ref(oracle, oracle_seam):
+    """Import the reference's `modules` / `models` with the oracle as their native backend."""
+    saved = {k: v for k, v in sys.modules.items() if k == 'modules' or k.startswith('modules.') or k == 'models' or k.startswith('models.')}
+    for k in saved:
+        del sys.modules[k]
+    fake = types.ModuleType('modules.functional.backend')
+    fake._backend = oracle
+    sys.modules['modules.functional.backend'] = fake
+    sys.path.insert(0, REF)
+    try:
+        mods = importlib.import_module('modules')
+        models = importlib.import_module('models.s3dis')
+        yield types.SimpleNamespace(modules=mods, models=models, F=importlib.import_module('modules.functional'))
+    finally:
+        sys.path.remove(REF)
+        for k in [k for k in sys.modules if k == 'modules' or k.startswith('modules.') or k == 'models' or k.startswith('models.')]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+
+
+def _same_state(a, b):
+    sa, sb = a.state_dict(), b.state_dict()
+    assert list(sa.keys()) == list(sb.keys())
+    for k in sa:
+        assert sa[k].shape == sb[k].shape, k
+
+
+def test_pvconv_matches_reference(ref):
+    from pvcnn_amd.modules import PVConv
+    for kw in [dict(with_se=False, normalize=True), dict(with_se=True, normalize=False)]:
+        torch.manual_seed(0)
+        theirs = ref.modules.PVConv(9, 16, 3, 8, **kw)
+        mine = PVConv(9, 16, 3, 8, **kw)
+        _same_state(theirs, mine)
+        mine.load_state_dict(theirs.state_dict())
+        x = torch.rand(2, 9, 300)
+        xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+        ya, ca = theirs((xa, xa[:, :3, :] if kw['normalize'] else xa[:, :3, :] - 0.5))
+        yb, cb = mine((xb, xb[:, :3, :] if kw['normalize'] else xb[:, :3, :] - 0.5))
+        assert torch.equal(ya, yb)
+        ya.square().sum().backward(); yb.square().sum().backward()
+        assert torch.equal(xa.grad, xb.grad)
+        for (n1, p1), (n2, p2) in zip(theirs.named_parameters(), mine.named_parameters()):
+            assert n1 == n2 and torch.equal(p1.grad, p2.grad), n1
+
+
+def test_pointnet_modules_match_reference(ref):
+    from pvcnn_amd.modules import PointNetSAModule, PointNetFPModule, PointNetAModule, BallQuery
+    torch.manual_seed(1)
+    feats, coords = torch.rand(2, 6, 256), torch.rand(2, 3, 256)
+    a = ref.modules.PointNetSAModule(32, [0.2, 0.4], [8, 16], 6, [[8, 16], [8, 32]])
+    b = PointNetSAModule(32, [0.2, 0.4], [8, 16], 6, [[8, 16], [8, 32]])
+    _same_state(a, b); b.load_state_dict(a.state_dict())
+    (fa, ca), (fb, cb) = a((feats, coords)), b((feats, coords))
+    assert torch.equal(fa, fb) and torch.equal(ca, cb) and a.out_channels == b.out_channels
+    a = ref.modules.PointNetFPModule(48 + 6, (32, 16)); b = PointNetFPModule(48 + 6, (32, 16))
+    _same_state(a, b); b.load_state_dict(a.state_dict())
+    assert torch.equal(a((coords, ca, fa, feats))[0], b((coords, cb, fb, feats))[0])
+    a = ref.modules.PointNetAModule(6, [16, 32]); b = PointNetAModule(6, [16, 32])
+    _same_state(a, b); b.load_state_dict(a.state_dict())
+    assert torch.equal(a((feats, coords))[0], b((feats, coords))[0])
+    assert torch.equal(ref.modules.BallQuery(0.3, 8)(coords, ca, feats), BallQuery(0.3, 8)(coords, cb, feats))
+
+
+@pytest.mark.parametrize('name,n', [('PVCNN', 512), ('PVCNN2', 1024)])
+def test_s3dis_networks_match_reference(ref, name, n):
+    from pvcnn_amd import workload
+    torch.manual_seed(2)
+    theirs = getattr(ref.models, name)(13, 6, width_multiplier=0.125)
+    mine = getattr(workload, name)(13, 6, width_multiplier=0.125)
+    _same_state(theirs, mine)
+    mine.load_state_dict(theirs.state_dict())
+    theirs.eval(); mine.eval()
+    x, _ = workload.make_s3dis_batch(2, n)
+    with torch.no_grad():
+        assert torch.equal(theirs(x), mine(x))
+
+
+def test_full_width_parameter_counts(ref):
+    # PVCNN 1xC 2,572,493 parameters; PVCNN++ 13,709,837
+    from pvcnn_amd import workload
+    assert sum(p.numel() for p in workload.PVCNN(13, 6, 1).parameters()) == 2572493
+    assert sum(p.numel() for p in workload.PVCNN2(13, 6, 1).parameters()) == 13709837
+
+
+def test_reference_models_run_unchanged_on_the_dropin(oracle_seam):
+    """`install_dropin()` makes the reference's unmodified models/ import pvcnn_amd.modules."""
+    import pvcnn_amd
+    saved = {k: v for k, v in sys.modules.items() if k.split('.')[0] in ('modules', 'models')}
+    for k in saved:
+        del sys.modules[k]
+    sys.path.insert(0, REF)
+    try:
+        impl = pvcnn_amd.install_dropin()
+        models = importlib.import_module('models.s3dis')
+        import modules
+        assert modules is impl and modules.PVConv.__module__.startswith('pvcnn_amd.')
+        net = models.PVCNN(13, 6, width_multiplier=0.125).eval()
+        assert isinstance(net.point_features[0], impl.PVConv)
+        with torch.no_grad():
+            assert net(torch.rand(1, 9, 256)).shape == (1, 13, 256)
+    finally:
+        sys.path.remove(REF)
+        for k in [k for k in sys.modules if k.split('.')[0] in ('modules', 'models')]:
+            del sys.modules[k]
+        sys.modules.update(saved)
