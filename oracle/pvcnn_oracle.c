@@ -14,8 +14,14 @@
  * Restatement rules:
  *   - loops run in POINT-INDEX order: this defines the canonical fp32 summation order for
  *     every kernel the reference implements with fp32 atomicAdd (order undefined there);
- *   - nvcc's default -fmad=true contraction is pinned with explicit fmaf();
- *     this file must be compiled with -ffp-contract=off so nothing else is contracted;
+ *   - floating-point contraction (nvcc's default -fmad=true) is pinned with explicit fmaf()
+ *     following the rule LLVM/NVVM and GCC both apply to a left-associated sum of products:
+ *     the FIRST addition fuses its LEFT product and rounds the right one,
+ *         a*b + c*d        ->  fma(a, b, c*d)
+ *     and every later "+ e*f" fuses too:  -> fma(e, f, acc).
+ *     This was established against oracle/_ref (the reference's own .cu sources built with
+ *     -ffp-contract=fast): the opposite association fma(c, d, a*b) does NOT reproduce it.
+ *     This file must be compiled with -ffp-contract=off so nothing else is contracted;
  *   - all index tensors are int32, all data fp32, layout channel-major (B, C, N).
  *
  * Every function cites the reference file:line it follows (paths relative to
@@ -107,8 +113,8 @@ ORC_API void orc_avg_voxelize_bwd(const float *grad_y, const int32_t *ind, const
  * trilinear_devoxelize forward: interpolate/trilinear_devox.cu:21-105.
  * Corner order 000,001,010,011,100,101,110,111 (bits x,y,z; z fastest).  Hi offsets are
  * applied only where the fractional part is > 0 (:64-75), so p in [0, r-1] never reads
- * out of bounds.  The 8-term sum (:98-102) is evaluated left to right; nvcc contracts
- * it to mul + 7 fma, pinned here with fmaf().  inds/wgts are written only in training.
+ * out of bounds.  The 8-term sum (:98-102) is evaluated left to right and contracted to
+ * fma(w0,f0, w1*f1) followed by 6 more fma (see the header).  inds/wgts only in training.
  * ---------------------------------------------------------------------------------- */
 static inline void trilinear_setup(float x, float y, float z, int r, int r2, int32_t idx[8],
                                    float w[8]) {
@@ -158,8 +164,8 @@ ORC_API void orc_trilinear_devox_fwd(const float *coords, const float *feat, int
       }
       for (int j = 0; j < c; ++j) {
         const float *fj = f + (size_t)j * r3;
-        float acc = w[0] * fj[idx[0]];
-        for (int k = 1; k < 8; ++k) acc = fmaf(w[k], fj[idx[k]], acc);
+        float acc = fmaf(w[0], fj[idx[0]], w[1] * fj[idx[1]]);
+        for (int k = 2; k < 8; ++k) acc = fmaf(w[k], fj[idx[k]], acc);
         o[(size_t)j * n + i] = acc;
       }
     }
@@ -226,8 +232,8 @@ ORC_API void orc_trilinear_devox_bwd_f64(const float *grad_y, const int32_t *ind
 
 /* ------------------------------------------------------------------------------------
  * ball_query: ball_query/ball_query.cu:19-50; r2 = radius*radius in float on the host
- * (ball_query.cpp:24).  Output zero on entry (ball_query.cpp:20-22).  d2 is nvcc-contracted:
- * dx*dx, then fma(dy,dy,.), then fma(dz,dz,.).  Strict '<'.  First hit fills all u slots.
+ * (ball_query.cpp:24).  Output zero on entry (ball_query.cpp:20-22).  d2 is contracted:
+ * fma(dz,dz, fma(dx,dx, dy*dy)).  Strict '<'.  First hit fills all u slots.
  * ---------------------------------------------------------------------------------- */
 ORC_API void orc_ball_query(const float *centers, const float *points, int b, int n, int m,
                             float r2, int u, int32_t *out) {
@@ -240,7 +246,7 @@ ORC_API void orc_ball_query(const float *centers, const float *points, int b, in
       const float cx = cc[j], cy = cc[j + m], cz = cc[j + m + m];
       for (int k = 0, cnt = 0; k < n && cnt < u; ++k) {
         const float dx = cx - pc[k], dy = cy - pc[k + n], dz = cz - pc[k + n + n];
-        const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+        const float d2 = fmaf(dz, dz, fmaf(dx, dx, dy * dy));
         if (d2 < r2) {
           if (cnt == 0)
             for (int v = 0; v < u; ++v) ni[(size_t)j * u + v] = k;
@@ -334,7 +340,7 @@ ORC_API void orc_fps(const float *coords, int b, int n, int m, float *distances,
         for (int k = t; k < n; k += FPS_SLOTS) {
           const float td = dist[k];
           const float ex = co[k] - x1, ey = co[k + n] - y1, ez = co[k + n + n] - z1;
-          const float d = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
+          const float d = fmaf(ez, ez, fmaf(ex, ex, ey * ey));
           const float d2 = fminf(d, td);
           if (d2 != td) dist[k] = d2;
           if (d2 > best) {
@@ -363,7 +369,7 @@ ORC_API void orc_fps(const float *coords, int b, int n, int m, float *distances,
  * 3-NN inverse-squared-distance interpolation:
  * interpolate/neighbor_interpolate.cu:20-75 (neighbour search, running minima kept as
  * double, init 1e40, strict '<'), :61-72 (clamp to [1e-10, 1e10] and product-form
- * weights), :90-116 (interpolation, nvcc-contracted mul + 2 fma), :145-170 (backward).
+ * weights), :90-116 (interpolation: fma(f3,w3, fma(f1,w1, f2*w2))), :145-170 (backward).
  * ---------------------------------------------------------------------------------- */
 ORC_API void orc_three_nn_interp_fwd(const float *points_coords, const float *centers_coords,
                                      const float *centers_features, int b, int c, int m, int n,
@@ -380,7 +386,7 @@ ORC_API void orc_three_nn_interp_fwd(const float *points_coords, const float *ce
       int besti0 = 0, besti1 = 0, besti2 = 0;
       for (int k = 0; k < m; ++k) {
         const float ex = ux - cc[k], ey = uy - cc[k + m], ez = uz - cc[k + m + m];
-        const float d = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
+        const float d = fmaf(ez, ez, fmaf(ex, ex, ey * ey));
         if (d < best2) {
           best2 = d;
           besti2 = k;
@@ -418,7 +424,7 @@ ORC_API void orc_three_nn_interp_fwd(const float *points_coords, const float *ce
       for (int j = 0; j < n; ++j) {
         const float *cfl = cf + (size_t)l * m;
         o[(size_t)l * n + j] =
-            fmaf(cfl[id[j + n + n]], w[j + n + n], fmaf(cfl[id[j + n]], w[j + n], cfl[id[j]] * w[j]));
+            fmaf(cfl[id[j + n + n]], w[j + n + n], fmaf(cfl[id[j]], w[j], cfl[id[j + n]] * w[j + n]));
       }
   }
 }

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(const float *__restrict__ 
 #pragma unroll
     for (int q = 0; q < PPT; ++q) {
       const float ex = x[q] - x1, ey = y[q] - y1, ez = z[q] - z1;
-      const float d = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
+      const float d = fmaf(ez, ez, fmaf(ex, ex, ey * ey));
       const float d2 = fminf(d, dist[q]);
       dist[q] = d2;
       const int k = tid + q * THREADS;
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(1024) void fps_global_kernel(const float *__restric
     unsigned long long best = 0ull;
     for (int k = tid; k < N; k += 1024) {
       const float ex = coords[k] - x1, ey = coords[k + N] - y1, ez = coords[k + 2 * N] - z1;
-      const float d = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
+      const float d = fmaf(ez, ez, fmaf(ex, ex, ey * ey));
       const float d2 = fminf(d, distances[k]);
       distances[k] = d2;
       const unsigned long long cand =

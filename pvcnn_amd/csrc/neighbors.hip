@@ -8,7 +8,7 @@
 //              points per step (coalesced 256-byte coordinate rows), __ballot + popcount of the
 //              lower lanes gives each hit its slot in ascending point order -- exactly the
 //              reference's sequential "first U hits" semantics, with coalesced index writes and
-//              a wave-uniform early exit.  d^2 uses the same mul + 2 fma contraction as nvcc.
+//              a wave-uniform early exit.  d^2 uses the reference's contraction fma(dz,dz,fma(dx,dx,dy*dy)).
 // grouping / gather / 3-NN interpolate forward: LDS slab gathers (slab.h); a feature row of
 //              N <= 40960 floats lives in LDS, so the U-fold re-reads of grouping never touch L2.
 // their backwards: deterministic CSR scatters (csr.h), entry id = the reference's loop order.
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const float *__restrict
     for (int q = 0; q < kCPW; ++q) {
       if (cnt[q] < U) {   // wave-uniform
         const float dx = cx[q] - px, dy = cy[q] - py, dz = cz[q] - pz;
-        const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+        const float d2 = fmaf(dz, dz, fmaf(dx, dx, dy * dy));   // = dx*dx + dy*dy + dz*dz as contracted
         const bool hit = valid && (d2 < r2);
         const unsigned long long mask = __ballot(hit);
         if (mask) {
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void three_nn_kernel(const float *__restrict__
   for (int k = 0; k < M; ++k) {
     const float x = cc[k], y = cc[k + M], z = cc[k + 2 * M];   // wave-uniform -> scalar loads
     const float ex = ux - x, ey = uy - y, ez = uz - z;
-    const float d = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
+    const float d = fmaf(ez, ez, fmaf(ex, ex, ey * ey));
     if (d < b2) {
       if (d < b1) {
         b2 = b1; i2 = i1;

@@ -39,17 +39,23 @@ __device__ __forceinline__ void st4(int32_t *p, int a, int b, int c, int d) {
   *reinterpret_cast<int4 *>(p) = make_int4(a, b, c, d);
 }
 
-// sum_k w_k * row[idx_k]: one multiply then a fused-multiply-add chain, left to right.  This is
-// the contraction nvcc applies to the reference's expressions (trilinear_devox.cu:98-102,
-// neighbor_interpolate.cu:112-114) and what the oracle pins with fmaf().  With NC == 1 it is a
-// single product (voxelize bwd) and with w == 1.0f an exact copy (grouping / gather).
+// sum_k w_k * row[idx_k], left to right, with the floating-point contraction the reference's
+// expressions (trilinear_devox.cu:98-102, neighbor_interpolate.cu:112-114) receive from
+// LLVM/NVVM and GCC alike: the first addition fuses its LEFT product, w0*f0 + w1*f1 ->
+// fma(w0, f0, w1*f1), and every further term is an fma onto the running sum (verified against the
+// reference's own sources, oracle/_ref).  With NC == 1 it is a single product (voxelize bwd) and
+// with w == 1.0f an exact copy (grouping / gather).
 template <int NC, bool MAY_SKIP>
 __device__ __forceinline__ float combine(const Taps<NC> &t, const float *row) {
   if (MAY_SKIP && t.idx[0] < 0) return 0.0f;
-  float acc = t.w[0] * row[t.idx[0]];
+  if constexpr (NC == 1) {
+    return t.w[0] * row[t.idx[0]];
+  } else {
+    float acc = fmaf(t.w[0], row[t.idx[0]], t.w[1] * row[t.idx[1]]);
 #pragma unroll
-  for (int k = 1; k < NC; ++k) acc = fmaf(t.w[k], row[t.idx[k]], acc);
-  return acc;
+    for (int k = 2; k < NC; ++k) acc = fmaf(t.w[k], row[t.idx[k]], acc);
+    return acc;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1,0 +1,101 @@
+"""Data-parallel harness on CPU: 2 processes, gloo backend, the same GradBucketReducer that runs
+over RCCL on the GPUs.  Property: the all-reduced, averaged gradients of the per-rank micro-batches
+equal the gradients of one process computing the mean loss over the concatenated batch
+(SURVEY.md 8e), for any bucket size; and parameters / buffers start identical on every rank."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+from pvcnn_amd.dp import GradBucketReducer, shard_batch
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _net():
+    # BatchNorm-free so that shard means compose exactly (BN statistics are per replica by design)
+    return nn.Sequential(nn.Conv1d(6, 16, 1), nn.ReLU(), nn.Conv1d(16, 16, 1), nn.ReLU(), nn.Conv1d(16, 5, 1))
+
+
+def _worker(rank, world, port, bucket_mb, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.manual_seed(100 + rank)                 # different initial weights per rank ...
+        model = _net()
+        reducer = GradBucketReducer(model, bucket_mb=bucket_mb)   # ... made identical by the rank-0 broadcast
+        g = torch.Generator().manual_seed(7)
+        x = torch.randn(8, 6, 32, generator=g)
+        y = torch.randint(0, 5, (8, 32), generator=g)
+        sl = shard_batch(8, world, rank)
+        grads = []
+        for _ in range(2):                            # two steps: buckets must reset correctly
+            reducer.zero_grad()
+            loss = nn.functional.cross_entropy(model(x[sl]), y[sl])
+            loss.backward()
+            reducer.finish()
+            grads.append([p.grad.clone() for p in model.parameters()])
+        q.put((rank, [p.detach().clone() for p in model.parameters()], grads, len(reducer.buckets)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('bucket_mb', [8.0, 0.0005])
+def test_two_rank_gradients_equal_big_batch(bucket_mb):
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, bucket_mb, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, params0, grads0, nb0), (_, params1, grads1, nb1) = results
+    assert nb0 == nb1 and (nb0 > 1 if bucket_mb < 0.01 else nb0 == 1)
+    for a, b in zip(params0, params1):
+        assert torch.equal(a, b)                      # broadcast from rank 0
+    # single-process reference: same weights, whole batch, mean loss
+    model = _net()
+    with torch.no_grad():
+        for p, src in zip(model.parameters(), params0):
+            p.copy_(src)
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(8, 6, 32, generator=g)
+    y = torch.randint(0, 5, (8, 32), generator=g)
+    nn.functional.cross_entropy(model(x), y).backward()
+    for step in range(2):
+        for p, ga, gb in zip(model.parameters(), grads0[step], grads1[step]):
+            assert torch.equal(ga, gb)                # every rank holds the same reduced gradient
+            assert torch.allclose(ga, p.grad, atol=1e-6, rtol=1e-5)
+
+
+def test_single_process_reducer_is_transparent():
+    model = _net()
+    reducer = GradBucketReducer(model)                # no process group: world = 1, no collective
+    x = torch.randn(4, 6, 16)
+    reducer.zero_grad()
+    model(x).square().mean().backward()
+    reducer.finish()
+    ref = [p.grad.clone() for p in model.parameters()]
+    model2 = _net()
+    model2.load_state_dict(model.state_dict())
+    model2(x).square().mean().backward()
+    for a, p in zip(ref, model2.parameters()):
+        assert torch.equal(a, p.grad)
+    assert reducer.gradient_bytes == sum(p.numel() for p in model.parameters()) * 4
+
+
+def test_shard_batch_requires_equal_shards():
+    assert shard_batch(16, 4, 1) == slice(4, 8)
+    with pytest.raises(ValueError):
+        shard_batch(10, 4, 0)
