@@ -177,7 +177,9 @@ def main():
     assert seam._backend.name == 'hip-gfx950'
     seam._backend.lib                                         # dlopen now: fail loudly before timing
 
-    torch.backends.cudnn.benchmark = True                     # MIOpen find-mode for the Conv3d layers
+    # No MIOpen find-mode: the 3-D convolutions run on pvcnn_amd's own MFMA kernels, and an exhaustive
+    # search for the remaining 1x1 convolutions would cost minutes of start-up for nothing.
+    torch.backends.cudnn.benchmark = False
     torch.manual_seed(workload.SEED)
     model = workload.PVCNN(13, 6, width_multiplier=args.width).to(dev).train()
     reducer = GradBucketReducer(model, bucket_mb=args.bucket_mb)

@@ -146,6 +146,27 @@ PVCNN_API int pvcnn_three_nn_interp_bwd(const float *grad_y, const int32_t *indi
                               int B, int C, int N, int M, float *grad_x, void *workspace,
                               size_t workspace_bytes, void *stream);
 
+/* ---- 3x3x3 voxel convolution (PVConv.voxel_layers) -------------------------------------------
+ * replaces the nn.Conv3d(k=3, stride 1, padding 1) calls of modules/pvconv.py:20-27 (cuDNN in the
+ * reference) with an fp32-MFMA implicit GEMM.  x (B,Ci,R,R,R), y (B,Co,R,R,R), channel-major.
+ * weight_transform: w (Co,Ci,3,3,3) -> wt, the layout the kernels consume:
+ *     for_bwd_data = 0 : wt (Ci,27,Co)                      [forward: y = conv(x, w) + bias]
+ *     for_bwd_data = 1 : wt (Co,27,Ci), taps reversed       [grad_x = conv3d_fwd(grad_y, wt) with
+ *                                                            Ci and Co exchanged, bias = NULL]
+ * fp32 in / fp32 accumulate (v_mfma_f32_32x32x2_f32); results agree with an fp64 evaluation to
+ * fp32 round-off (summation order differs from cuDNN / MIOpen / torch-CPU, as theirs do).
+ */
+PVCNN_API int pvcnn_conv3d_weight_transform(const float *w, int Co, int Ci, int for_bwd_data, float *wt,
+                                            void *stream);
+PVCNN_API int pvcnn_conv3d_fwd(const float *x, const float *wt, const float *bias, int B, int Ci, int Co,
+                               int R, float *y, void *stream);
+/* grad_w (Co,Ci,3,3,3) = sum over batch and voxels of grad_y (B,Co,R^3) x shifted x (B,Ci,R^3);
+ * every element written.  `workspace`: >= pvcnn_conv3d_bwd_weight_workspace_bytes(...) bytes of
+ * 16-byte aligned scratch (per-partition partial sums; no float atomics). */
+PVCNN_API size_t pvcnn_conv3d_bwd_weight_workspace_bytes(int B, int Ci, int Co, int R);
+PVCNN_API int pvcnn_conv3d_bwd_weight(const float *x, const float *grad_y, int B, int Ci, int Co, int R,
+                                      float *grad_w, void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

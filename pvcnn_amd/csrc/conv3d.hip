@@ -1,0 +1,482 @@
+// conv3d.hip -- the dense 3x3x3 voxel convolutions of PVConv.voxel_layers on gfx950 matrix cores.
+//
+// Reference: modules/pvconv.py:20-27 -- nn.Conv3d(k=3, stride 1, pad 1) on (B, C, R, R, R) fp32
+// grids, executed by cuDNN there.  This is the one genuinely dense contraction of the hot path
+// (67-96 % of the model FLOPs), so it is the one place MFMA is used:
+//     Y[b, co, v] = bias[co] + sum_{ci, tap} W[co, ci, tap] * X[b, ci, v + off(tap)]
+// as an implicit GEMM  D[co][voxel] += A[co][k] * B[k][voxel],  k = (ci, tap), on
+// v_mfma_f32_32x32x2_f32 (exact fp32 in / fp32 accumulate; 157 TFLOP/s peak; no TF32 on gfx950).
+//
+// Mapping (wave64, one workgroup = 4 waves = 256 output voxels x 64 output channels):
+//   * M = output channels, N = voxels: the MFMA C/D layout then puts 32 CONSECUTIVE-z voxels of
+//     one channel in the 32 lanes of a half-wave, so results leave as full 128-byte rows of the
+//     channel-major (B, C, R^3) tensor -- no transpose on the way out;
+//   * per chunk of CIC input channels the workgroup stages in LDS
+//       xs[CIC][(TX+2)(TY+2)(TZ+2)]  the input tile WITH its halo (zero-filled outside the grid)
+//       ws[CIC][27][64]              the weights, pre-transposed on device to (Ci, 27, Co)
+//     and all 27 taps are served from LDS (27-fold reuse of every staged input element);
+//   * each wave owns 64 voxels x 64 channels = 2 x 2 MFMA tiles (64 accumulator VGPRs); per
+//     (tap, channel pair) it issues 2 + 2 ds_read_b32 (conflict-free: consecutive z / consecutive
+//     co) and 4 MFMAs;
+//   * ~41 KiB of LDS per workgroup -> 3 workgroups per CU: one workgroup's global->LDS staging
+//     overlaps the others' MFMA phases without explicit double buffering.
+// Backward-data is the same kernel on the flipped, channel-transposed weights (one tiny transform
+// kernel).  Backward-weight is the transposed problem (K = voxels) -- conv3d_wgrad_kernel below.
+#include <algorithm>
+
+#include "common.h"
+
+namespace pvcnn {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int kCoTile = 64;
+
+// (Co, Ci, 27) -> (Ci, 27, Co)                      [forward]
+// (Co, Ci, 27) -> (Co, 27, Ci) with taps reversed   [backward-data: a conv with Ci' = Co, Co' = Ci]
+__global__ __launch_bounds__(256) void conv3d_weight_transform_kernel(const float *__restrict__ w, int Co, int Ci,
+                                                                      int for_bwd_data, float *__restrict__ wt) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= Co * Ci * 27) return;
+  const int tap = e % 27, ci = (e / 27) % Ci, co = e / (27 * Ci);
+  if (!for_bwd_data) wt[((size_t)ci * 27 + tap) * Co + co] = w[e];
+  else               wt[((size_t)co * 27 + (26 - tap)) * Ci + ci] = w[e];
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Tile staging (global -> registers -> LDS).  Staging is latency-bound unless many loads are in
+// flight per thread, so both paths first issue ALL of a thread's loads into a register array and
+// only then touch LDS.
+//   VEC path (R == TZ: every z-row of the tile is one full, 16-byte aligned row of the grid and the
+//   z halo is always outside the grid): one float4 per (row, quad);
+//   scalar path (any R): element-wise with bounds checks, 8 loads per batch.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 ld4g(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+
+template <int TX, int TY, int TZ, int NCH, bool VEC>
+__device__ __forceinline__ void stage_halo_tile(float *xs, const float *xb, int c0, int Ci, int R, int x0, int y0, int z0,
+                                                int tid) {
+  constexpr int HX = TX + 2, HY = TY + 2, HZ = TZ + 2, HS = HX * HY * HZ;
+  const size_t RR = (size_t)R * R, S = RR * R;
+  if constexpr (VEC) {
+    constexpr int QPR = TZ / 4, ROWS = NCH * HX * HY, NQ = ROWS * QPR, ITER = (NQ + 255) / 256;
+    float4 v[ITER];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int q = tid + it * 256;
+      const int row = q / QPR, qi = q - row * QPR;
+      const int c = row / (HX * HY), hx = (row / HY) % HX, hy = row % HY;
+      const int gx = x0 + hx - 1, gy = y0 + hy - 1;
+      v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (q < NQ && c0 + c < Ci && (unsigned)gx < (unsigned)R && (unsigned)gy < (unsigned)R)
+        v[it] = ld4g(xb + (size_t)(c0 + c) * S + (size_t)gx * RR + (size_t)gy * R + qi * 4);
+    }
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int q = tid + it * 256;
+      if (q < NQ) {
+        const int row = q / QPR, qi = q - row * QPR;
+        float *d = xs + row * HZ + 1 + qi * 4;     // row = (c*HX + hx)*HY + hy  ->  c*HS + (hx*HY+hy)*HZ
+        d[0] = v[it].x; d[1] = v[it].y; d[2] = v[it].z; d[3] = v[it].w;
+      }
+    }
+    for (int r = tid; r < ROWS * 2; r += 256) xs[(r >> 1) * HZ + ((r & 1) ? HZ - 1 : 0)] = 0.0f;   // z halo
+  } else {
+    constexpr int N = NCH * HS;
+    for (int e0 = 0; e0 < N; e0 += 256 * 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + u * 256 + tid;
+        const int c = e / HS, r = e - c * HS;
+        const int hx = r / (HY * HZ), hy = (r / HZ) % HY, hz = r % HZ;
+        const int gx = x0 + hx - 1, gy = y0 + hy - 1, gz = z0 + hz - 1;
+        v[u] = 0.0f;
+        if (e < N && c0 + c < Ci && (unsigned)gx < (unsigned)R && (unsigned)gy < (unsigned)R && (unsigned)gz < (unsigned)R)
+          v[u] = xb[(size_t)(c0 + c) * S + (size_t)gx * RR + (size_t)gy * R + gz];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + u * 256 + tid;
+        if (e < N) xs[e] = v[u];
+      }
+    }
+  }
+}
+
+template <int TX, int TY, int TZ, int CIC, bool VEC>
+__global__ __launch_bounds__(256) void conv3d_igemm_kernel(const float *__restrict__ x, const float *__restrict__ wt,
+                                                           const float *__restrict__ bias, float *__restrict__ y,
+                                                           int Ci, int Co, int R, int tiles_x, int tiles_y, int tiles_z) {
+  static_assert(TX * TY * TZ == 256, "a workgroup tile is 256 voxels");
+  static_assert(CIC % 2 == 0, "channels are consumed in pairs (MFMA K = 2)");
+  constexpr int HX = TX + 2, HY = TY + 2, HZ = TZ + 2, HS = HX * HY * HZ;
+  constexpr int WS = 27 * kCoTile;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *xs = lds;
+  float *ws = lds + CIC * HS;
+
+  int bid = blockIdx.x;
+  const int tzi = bid % tiles_z; bid /= tiles_z;
+  const int tyi = bid % tiles_y; bid /= tiles_y;
+  const int txi = bid % tiles_x; bid /= tiles_x;
+  const int b = bid;
+  const int co0 = blockIdx.y * kCoTile;
+  const int x0 = txi * TX, y0 = tyi * TY, z0 = tzi * TZ;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, kh = lane >> 5;
+  const size_t RR = (size_t)R * R;
+
+  int hb[2];   // LDS offset of this lane's voxel (N-block 0/1) incl. the k-half channel offset
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    const int m = wave * 64 + nb * 32 + j;
+    const int zt = m % TZ, yt = (m / TZ) % TY, xt = m / (TZ * TY);
+    hb[nb] = (xt * HY + yt) * HZ + zt + kh * HS;
+  }
+  const int a_off = kh * WS + j;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.0f;
+
+  const float *xb = x + (size_t)b * Ci * R * RR;
+  for (int c0 = 0; c0 < Ci; c0 += CIC) {
+    __syncthreads();
+    stage_halo_tile<TX, TY, TZ, CIC, VEC>(xs, xb, c0, Ci, R, x0, y0, z0, tid);
+    // ---- weights of this channel chunk: wt is (Ci, 27, Co) -> ws[c][tap][64] ----
+    if (VEC) {   // Co % 4 == 0 and the 64-wide co tile lies inside Co: whole 16-byte quads
+      constexpr int NQ = CIC * 27 * (kCoTile / 4), ITER = (NQ + 255) / 256;
+      float4 v[ITER];
+#pragma unroll
+      for (int it = 0; it < ITER; ++it) {
+        const int q = tid + it * 256;
+        const int rowi = q / (kCoTile / 4), qi = q - rowi * (kCoTile / 4);   // rowi = c*27 + tap
+        v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q < NQ && c0 + rowi / 27 < Ci) v[it] = ld4g(wt + ((size_t)c0 * 27 + rowi) * Co + co0 + qi * 4);
+      }
+#pragma unroll
+      for (int it = 0; it < ITER; ++it) {
+        const int q = tid + it * 256;
+        if (q < NQ) *reinterpret_cast<float4 *>(ws + q * 4) = v[it];
+      }
+    } else {
+      for (int e0 = 0; e0 < CIC * WS; e0 += 256 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int e = e0 + u * 256 + tid;
+          const int c = e / WS, r = e - c * WS;
+          const int tap = r / kCoTile, co = r % kCoTile;
+          v[u] = 0.0f;
+          if (e < CIC * WS && c0 + c < Ci && co0 + co < Co) v[u] = wt[((size_t)(c0 + c) * 27 + tap) * Co + co0 + co];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int e = e0 + u * 256 + tid;
+          if (e < CIC * WS) ws[e] = v[u];
+        }
+      }
+    }
+    __syncthreads();
+    // ---- 27 taps x CIC/2 channel pairs x (2x2) MFMA tiles ----
+#pragma unroll 1
+    for (int dxy = 0; dxy < 9; ++dxy) {
+      const int dx = dxy / 3, dy = dxy - dx * 3;
+      const int toff_xy = (dx * HY + dy) * HZ;
+#pragma unroll
+      for (int dz = 0; dz < 3; ++dz) {
+        const int tap = dxy * 3 + dz;
+#pragma unroll
+        for (int cc = 0; cc < CIC; cc += 2) {
+          const float a0 = ws[cc * WS + tap * kCoTile + a_off];
+          const float a1 = ws[cc * WS + tap * kCoTile + a_off + 32];
+          const float b0 = xs[cc * HS + hb[0] + toff_xy + dz];
+          const float b1 = xs[cc * HS + hb[1] + toff_xy + dz];
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+          acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+          acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: D[i = co][j = voxel]; lane -> voxel j, register r -> co row ----
+  float *yb = y + (size_t)b * Co * R * RR;
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    const int m = wave * 64 + nb * 32 + j;
+    const int zt = m % TZ, yt = (m / TZ) % TY, xt = m / (TZ * TY);
+    const int gx = x0 + xt, gy = y0 + yt, gz = z0 + zt;
+    const bool vok = gx < R && gy < R && gz < R;
+    const size_t voff = (size_t)gx * RR + (size_t)gy * R + gz;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (vok && co < Co) yb[(size_t)co * R * RR + voff] = acc[mb][nb][r] + (bias ? bias[co] : 0.0f);
+      }
+  }
+}
+
+template <int TX, int TY, int TZ, int CIC, bool VEC>
+static int launch_igemm_v(const float *x, const float *wt, const float *bias, float *y, int B, int Ci, int Co, int R,
+                          hipStream_t s) {
+  constexpr int HS = (TX + 2) * (TY + 2) * (TZ + 2);
+  const size_t lds = (size_t)(CIC * HS + CIC * 27 * kCoTile) * sizeof(float);
+  const int tx = ceil_div(R, TX), ty = ceil_div(R, TY), tz = ceil_div(R, TZ);
+  auto k = conv3d_igemm_kernel<TX, TY, TZ, CIC, VEC>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error("conv3d: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
+  }
+  hipLaunchKernelGGL(k, dim3((unsigned)((long)B * tx * ty * tz), ceil_div(Co, kCoTile)), dim3(256), lds, s, x, wt, bias,
+                     y, Ci, Co, R, tx, ty, tz);
+  return check_launch("conv3d_igemm");
+}
+
+template <int TX, int TY, int TZ, int CIC>
+static int launch_igemm(const float *x, const float *wt, const float *bias, float *y, int B, int Ci, int Co, int R,
+                        hipStream_t s) {
+  // vector staging needs full aligned z-rows (R == TZ) and whole 64-wide, 16-byte aligned co tiles
+  const bool vec = (R == TZ) && (Co % kCoTile == 0) && aligned16(x) && aligned16(wt);
+  return vec ? launch_igemm_v<TX, TY, TZ, CIC, true>(x, wt, bias, y, B, Ci, Co, R, s)
+             : launch_igemm_v<TX, TY, TZ, CIC, false>(x, wt, bias, y, B, Ci, Co, R, s);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Backward-weight:  gw[co][ci][tap] = sum_{b, v} gy[b,co,v] * x[b,ci,v + off(tap)]
+// as the GEMM  D[co][n] += A[co][k] * B[k][n]  with  n = (ci, tap)  and  K = voxels.
+//   * one workgroup owns a (64 co) x (CIC = 8 input channels x 27 taps = 216 -> 224 columns) slab
+//     of gw and walks a strided subset of the spatial tiles, accumulating in registers; its 7
+//     column blocks are spread over the 4 waves (2,2,2,1), each wave holding 2 x 2 MFMA tiles;
+//   * per tile it stages gy[64][256 voxels] (row stride 257: conflict-free A reads) and the input
+//     halo tile xs[8][(TX+2)(TY+2)(TZ+2)]; B reads gather xs at (channel, tap) offsets fixed per lane;
+//   * the partial slab goes to workspace[p] with plain coalesced stores; conv3d_wgrad_reduce_kernel
+//     sums the P partials (float atomics would cost more than the whole GEMM on this chip).
+// ---------------------------------------------------------------------------------------------
+constexpr int kWgCic = 8;
+constexpr int kWgN = kWgCic * 27;          // 216 real columns
+constexpr int kGyStride = 257;
+
+template <int TX, int TY, int TZ, bool VEC>
+__global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ gy,
+                                                           float *__restrict__ part, int B, int Ci, int Co, int R,
+                                                           int tiles_x, int tiles_y, int tiles_z, int P) {
+  static_assert(TX * TY * TZ == 256, "a workgroup tile is 256 voxels");
+  constexpr int HX = TX + 2, HY = TY + 2, HZ = TZ + 2, HS = HX * HY * HZ;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *gys = lds;                          // [64][257]
+  float *xs = lds + kCoTile * kGyStride;     // [8][HS]
+
+  const int chunk = blockIdx.x, p = blockIdx.y;
+  const int co0 = blockIdx.z * kCoTile, c0 = chunk * kWgCic;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, kh = lane >> 5;
+  const size_t RR = (size_t)R * R, S = RR * R;
+
+  // this lane's B-operand columns: n = nb*32 + j for nb in {wave, wave + 4}
+  int boff[2];
+  bool bval[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int n = (wave + 4 * q) * 32 + j;
+    const int cl = n / 27, tap = n - cl * 27;
+    const int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
+    bval[q] = (wave + 4 * q) < 7 && n < kWgN && c0 + cl < Ci;
+    boff[q] = bval[q] ? cl * HS + (dx * HY + dy) * HZ + dz : 0;
+  }
+  const bool second = (wave + 4) < 7;        // wave 3 owns a single column block
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mb][q][r] = 0.0f;
+
+  const int tiles_per_cloud = tiles_x * tiles_y * tiles_z;
+  const int tiles_total = B * tiles_per_cloud;
+  for (int t = p; t < tiles_total; t += P) {
+    int tt = t;
+    const int tzi = tt % tiles_z; tt /= tiles_z;
+    const int tyi = tt % tiles_y; tt /= tiles_y;
+    const int txi = tt % tiles_x; tt /= tiles_x;
+    const int b = tt;
+    const int x0 = txi * TX, y0 = tyi * TY, z0 = tzi * TZ;
+    __syncthreads();
+    // ---- stage gy[co][voxel of the tile] (zero outside the grid / beyond Co) ----
+    const float *gyb = gy + (size_t)b * Co * S;
+    if constexpr (VEC) {
+      constexpr int QPR = TZ / 4, NQ = kCoTile * 256 / 4, ITER = NQ / 256;   // 16 float4 per thread
+      float4 v[ITER];
+#pragma unroll
+      for (int it = 0; it < ITER; ++it) {
+        const int q = tid + it * 256;
+        const int co = q / (256 / 4), mq = q - co * (256 / 4);       // mq = quad index inside the 256-voxel tile
+        const int zrow = mq / QPR, qi = mq - zrow * QPR;
+        const int yt = zrow % TY, xt = zrow / TY;
+        const int gx = x0 + xt, gyy = y0 + yt;
+        v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (co0 + co < Co && gx < R && gyy < R) v[it] = ld4g(gyb + (size_t)(co0 + co) * S + (size_t)gx * RR + (size_t)gyy * R + qi * 4);
+      }
+#pragma unroll
+      for (int it = 0; it < ITER; ++it) {
+        const int q = tid + it * 256;
+        const int co = q / (256 / 4), mq = q - co * (256 / 4);
+        float *d = gys + co * kGyStride + mq * 4;
+        d[0] = v[it].x; d[1] = v[it].y; d[2] = v[it].z; d[3] = v[it].w;
+      }
+    } else {
+      for (int e0 = 0; e0 < kCoTile * 256; e0 += 256 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int e = e0 + u * 256 + tid;
+          const int co = e >> 8, m = e & 255;
+          const int zt = m % TZ, yt = (m / TZ) % TY, xt = m / (TZ * TY);
+          const int gx = x0 + xt, gyy = y0 + yt, gz = z0 + zt;
+          v[u] = 0.0f;
+          if (co0 + co < Co && gx < R && gyy < R && gz < R) v[u] = gyb[(size_t)(co0 + co) * S + (size_t)gx * RR + (size_t)gyy * R + gz];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int e = e0 + u * 256 + tid;
+          gys[(e >> 8) * kGyStride + (e & 255)] = v[u];
+        }
+      }
+    }
+    // ---- stage the input halo tile of the 8 channels ----
+    stage_halo_tile<TX, TY, TZ, kWgCic, VEC>(xs, x + (size_t)b * Ci * S, c0, Ci, R, x0, y0, z0, tid);
+    __syncthreads();
+    // ---- K loop over the tile's 256 voxels, two per MFMA ----
+#pragma unroll 4
+    for (int ks = 0; ks < 128; ++ks) {
+      const int v = 2 * ks + kh;
+      const int zt = v % TZ, yt = (v / TZ) % TY, xt = v / (TZ * TY);
+      const int h = (xt * HY + yt) * HZ + zt;
+      const float a0 = gys[j * kGyStride + v];
+      const float a1 = gys[(32 + j) * kGyStride + v];
+      const float b0 = bval[0] ? xs[boff[0] + h] : 0.0f;
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      if (second) {   // wave-uniform
+        const float b1 = bval[1] ? xs[boff[1] + h] : 0.0f;
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      }
+    }
+  }
+  // ---- partial slab -> workspace[p][co][ci*27 + tap]: lanes = consecutive columns ----
+  float *out = part + (size_t)p * Co * Ci * 27;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    if (!bval[q]) continue;
+    const int n = (wave + 4 * q) * 32 + j;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (co < Co) out[(size_t)co * Ci * 27 + (size_t)c0 * 27 + n] = acc[mb][q][r];
+      }
+  }
+}
+
+__global__ __launch_bounds__(256) void conv3d_wgrad_reduce_kernel(const float *__restrict__ part, int n, int P,
+                                                                  float *__restrict__ gw) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  float s = 0.0f;
+  for (int p = 0; p < P; ++p) s += part[(size_t)p * n + e];
+  gw[e] = s;
+}
+
+inline int wgrad_partitions(int B, int Ci, int Co, int tiles_per_cloud) {
+  const int tiles_total = B * tiles_per_cloud;
+  const int slabs = ceil_div(Ci, kWgCic) * ceil_div(Co, kCoTile);
+  int P = std::max(1, (3 * kNumCU) / slabs);          // ~3 workgroups per CU in the grid
+  P = std::min(P, tiles_total);
+  while (P > 1 && tiles_total % P) --P;               // equal work per partition
+  return P;
+}
+
+template <int TX, int TY, int TZ>
+static int launch_wgrad(const float *x, const float *gy, float *gw, float *part, int B, int Ci, int Co, int R, int P,
+                        hipStream_t s) {
+  constexpr int HS = (TX + 2) * (TY + 2) * (TZ + 2);
+  const size_t lds = (size_t)(kCoTile * kGyStride + kWgCic * HS) * sizeof(float);
+  const int tx = ceil_div(R, TX), ty = ceil_div(R, TY), tz = ceil_div(R, TZ);
+  const bool vec = (R == TZ) && aligned16(x) && aligned16(gy);
+  auto k = vec ? conv3d_wgrad_kernel<TX, TY, TZ, true> : conv3d_wgrad_kernel<TX, TY, TZ, false>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) { set_error("conv3d_wgrad: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
+  hipLaunchKernelGGL(k, dim3(ceil_div(Ci, kWgCic), P, ceil_div(Co, kCoTile)), dim3(256), lds, s, x, gy, part, B, Ci, Co, R,
+                     tx, ty, tz, P);
+  if (int rc = check_launch("conv3d_wgrad")) return rc;
+  const int n = Co * Ci * 27;
+  hipLaunchKernelGGL(conv3d_wgrad_reduce_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, part, n, P, gw);
+  return check_launch("conv3d_wgrad_reduce");
+}
+
+inline void wgrad_tiles(int R, int &tpc) {
+  if (R > 16) tpc = ceil_div(R, 2) * ceil_div(R, 4) * ceil_div(R, 32);
+  else if (R > 8) tpc = ceil_div(R, 4) * ceil_div(R, 4) * ceil_div(R, 16);
+  else tpc = ceil_div(R, 4) * ceil_div(R, 8) * ceil_div(R, 8);
+}
+
+}  // namespace pvcnn
+
+using namespace pvcnn;
+
+extern "C" int pvcnn_conv3d_weight_transform(const float *w, int Co, int Ci, int for_bwd_data, float *wt, void *stream) {
+  PVCNN_REQUIRE(Co > 0 && Ci > 0 && w && wt, "bad argument");
+  hipLaunchKernelGGL(conv3d_weight_transform_kernel, dim3(ceil_div(Co * Ci * 27, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), w, Co, Ci, for_bwd_data, wt);
+  return check_launch("conv3d_weight_transform");
+}
+
+extern "C" int pvcnn_conv3d_fwd(const float *x, const float *wt, const float *bias, int B, int Ci, int Co, int R,
+                                float *y, void *stream) {
+  PVCNN_REQUIRE(B >= 0 && Ci > 0 && Co > 0 && R > 0, "bad size");
+  if (B == 0) return 0;
+  PVCNN_REQUIRE(x && wt && y, "null pointer");
+  PVCNN_REQUIRE((long)R * R * R * (long)std::max(Ci, Co) <= 0x7fffffffL, "grid too large");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (R > 16) return launch_igemm<2, 4, 32, 4>(x, wt, bias, y, B, Ci, Co, R, s);
+  if (R > 8)  return launch_igemm<4, 4, 16, 4>(x, wt, bias, y, B, Ci, Co, R, s);
+  return launch_igemm<4, 8, 8, 4>(x, wt, bias, y, B, Ci, Co, R, s);
+}
+
+extern "C" size_t pvcnn_conv3d_bwd_weight_workspace_bytes(int B, int Ci, int Co, int R) {
+  if (B <= 0 || Ci <= 0 || Co <= 0 || R <= 0) return 0;
+  int tpc;
+  wgrad_tiles(R, tpc);
+  return (size_t)wgrad_partitions(B, Ci, Co, tpc) * Co * Ci * 27 * sizeof(float) + 16;
+}
+
+extern "C" int pvcnn_conv3d_bwd_weight(const float *x, const float *grad_y, int B, int Ci, int Co, int R, float *grad_w,
+                                       void *workspace, size_t workspace_bytes, void *stream) {
+  PVCNN_REQUIRE(B >= 0 && Ci > 0 && Co > 0 && R > 0, "bad size");
+  PVCNN_REQUIRE(grad_w, "null pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (B == 0) { PVCNN_HIP_TRY(hipMemsetAsync(grad_w, 0, (size_t)Co * Ci * 27 * sizeof(float), s)); return 0; }
+  PVCNN_REQUIRE(x && grad_y, "null pointer");
+  PVCNN_REQUIRE((long)R * R * R * (long)std::max(Ci, Co) <= 0x7fffffffL, "grid too large");
+  PVCNN_REQUIRE(workspace && aligned16(workspace) && workspace_bytes >= pvcnn_conv3d_bwd_weight_workspace_bytes(B, Ci, Co, R),
+                "workspace missing, misaligned or too small (see pvcnn_conv3d_bwd_weight_workspace_bytes)");
+  int tpc;
+  wgrad_tiles(R, tpc);
+  const int P = wgrad_partitions(B, Ci, Co, tpc);
+  float *part = static_cast<float *>(workspace);
+  if (R > 16) return launch_wgrad<2, 4, 32>(x, grad_y, grad_w, part, B, Ci, Co, R, P, s);
+  if (R > 8)  return launch_wgrad<4, 4, 16>(x, grad_y, grad_w, part, B, Ci, Co, R, P, s);
+  return launch_wgrad<4, 8, 8>(x, grad_y, grad_w, part, B, Ci, Co, R, P, s);
+}

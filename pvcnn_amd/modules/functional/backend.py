@@ -265,4 +265,49 @@ class HipBackend:
         return grad_x
 
 
+    # ---- voxel_layers Conv3d (k=3, stride 1, pad 1): modules/pvconv.py:20-27 (cuDNN in the reference) ----
+    has_conv3d = True
+
+    def _conv_wt(self, weight, for_bwd_data):
+        co, ci = weight.shape[0], weight.shape[1]
+        wt = torch.empty((ci * 27 * co,), dtype=torch.float32, device=weight.device)
+        with _Launch(weight) as s:
+            _lib.check(self.lib.pvcnn_conv3d_weight_transform(_p(weight), co, ci, int(for_bwd_data), _p(wt), s), 'conv3d_weight_transform')
+        return wt
+
+    def conv3d_forward(self, x, weight, bias):
+        _f32(x, 'x'); _f32(weight, 'weight')
+        _shape(x.dim() == 5 and weight.dim() == 5 and tuple(weight.shape[2:]) == (3, 3, 3) and weight.shape[1] == x.shape[1]
+               and x.shape[2] == x.shape[3] == x.shape[4], 'conv3d: x (B,Ci,R,R,R), weight (Co,Ci,3,3,3) expected')
+        if bias is not None:
+            _f32(bias, 'bias')
+        b, ci, r = x.shape[0], x.shape[1], x.shape[2]
+        co = weight.shape[0]
+        wt = self._conv_wt(weight, False)
+        y = torch.empty((b, co, r, r, r), dtype=torch.float32, device=x.device)
+        with _Launch(x) as s:
+            _lib.check(self.lib.pvcnn_conv3d_fwd(_p(x), _p(wt), _p(bias) if bias is not None else None, b, ci, co, r, _p(y), s), 'conv3d_forward')
+        return y
+
+    def conv3d_backward_data(self, grad_y, weight):
+        _f32(grad_y, 'grad_y'); _f32(weight, 'weight')
+        b, co, r = grad_y.shape[0], grad_y.shape[1], grad_y.shape[2]
+        ci = weight.shape[1]
+        wt = self._conv_wt(weight, True)
+        gx = torch.empty((b, ci, r, r, r), dtype=torch.float32, device=grad_y.device)
+        with _Launch(grad_y) as s:   # a convolution with Ci and Co exchanged on the flipped weights
+            _lib.check(self.lib.pvcnn_conv3d_fwd(_p(grad_y), _p(wt), None, b, co, ci, r, _p(gx), s), 'conv3d_backward_data')
+        return gx
+
+    def conv3d_backward_weight(self, x, grad_y):
+        _f32(x, 'x'); _f32(grad_y, 'grad_y')
+        b, ci, r = x.shape[0], x.shape[1], x.shape[2]
+        co = grad_y.shape[1]
+        gw = torch.empty((co, ci, 3, 3, 3), dtype=torch.float32, device=x.device)
+        ws = self._scratch(self.lib.pvcnn_conv3d_bwd_weight_workspace_bytes(b, ci, co, r), x.device)
+        with _Launch(x) as s:
+            _lib.check(self.lib.pvcnn_conv3d_bwd_weight(_p(x), _p(grad_y), b, ci, co, r, _p(gw), _p(ws), ws.numel(), s), 'conv3d_backward_weight')
+        return gw
+
+
 _backend = HipBackend()

@@ -1,0 +1,34 @@
+"""voxel_conv3d: the 3x3x3, stride-1, padding-1 convolution of PVConv.voxel_layers.
+
+The reference calls nn.Conv3d (cuDNN) here (modules/pvconv.py:20-27).  On gfx950 the three GEMMs
+(forward, backward-data, backward-weight) run on the fp32-MFMA implicit-GEMM kernels of
+csrc/conv3d.hip; gradients w.r.t. the bias are a plain reduction."""
+from torch.autograd import Function
+
+from ._autograd import native, amp_fwd, amp_bwd
+
+__all__ = ['voxel_conv3d']
+
+
+class VoxelConv3d(Function):
+    @staticmethod
+    @amp_fwd
+    def forward(ctx, x, weight, bias):
+        x = x.contiguous()
+        weight = weight.contiguous()
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return native().conv3d_forward(x, weight, bias.contiguous() if bias is not None else None)
+
+    @staticmethod
+    @amp_bwd
+    def backward(ctx, grad_y):
+        x, weight = ctx.saved_tensors
+        grad_y = grad_y.contiguous()
+        gx = native().conv3d_backward_data(grad_y, weight) if ctx.needs_input_grad[0] else None
+        gw = native().conv3d_backward_weight(x, grad_y) if ctx.needs_input_grad[1] else None
+        gb = grad_y.sum(dim=(0, 2, 3, 4)) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return gx, gw, gb
+
+
+voxel_conv3d = VoxelConv3d.apply

@@ -11,11 +11,27 @@ The voxel branch's scatter / gather run on the hand-written gfx950 kernels
 import torch.nn as nn
 
 from . import functional as F
+from .functional._autograd import native
+from .functional.conv3d import voxel_conv3d
 from .se import SE3d
 from .shared_mlp import SharedMLP
 from .voxelization import Voxelization
 
 __all__ = ['PVConv']
+
+
+class _VoxelConv3d(nn.Conv3d):
+    """nn.Conv3d (same parameters, same state_dict keys) whose 3x3x3 / stride 1 / padding 1 case on
+    the GPU runs the fp32-MFMA implicit-GEMM kernels instead of the vendor library."""
+
+    def forward(self, x):
+        fast = (x.is_cuda and getattr(native(), 'has_conv3d', False) and self.kernel_size == (3, 3, 3)
+                and self.stride == (1, 1, 1) and self.padding == (1, 1, 1) and self.dilation == (1, 1, 1)
+                and self.groups == 1 and self.padding_mode == 'zeros' and x.dim() == 5
+                and x.shape[2] == x.shape[3] == x.shape[4])
+        if not fast:
+            return super().forward(x)
+        return voxel_conv3d(x, self.weight, self.bias)
 
 
 class PVConv(nn.Module):
@@ -30,7 +46,7 @@ class PVConv(nn.Module):
         pad = kernel_size // 2
         grid_ops = []
         for cin in (in_channels, out_channels):
-            grid_ops += [nn.Conv3d(cin, out_channels, kernel_size, stride=1, padding=pad),
+            grid_ops += [_VoxelConv3d(cin, out_channels, kernel_size, stride=1, padding=pad),
                          nn.BatchNorm3d(out_channels, eps=1e-4),
                          nn.LeakyReLU(0.1, True)]
         if with_se:

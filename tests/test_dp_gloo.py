@@ -43,7 +43,9 @@ def _worker(rank, world, port, bucket_mb, q):
             loss.backward()
             reducer.finish()
             grads.append([p.grad.clone() for p in model.parameters()])
-        q.put((rank, [p.detach().clone() for p in model.parameters()], grads, len(reducer.buckets)))
+        # plain numpy payloads: pickled by value, so nothing refers back to this (exiting) process
+        q.put((rank, [p.detach().numpy().copy() for p in model.parameters()],
+               [[g.numpy().copy() for g in step] for step in grads], len(reducer.buckets)))
     finally:
         dist.destroy_process_group()
 
@@ -60,7 +62,10 @@ def test_two_rank_gradients_equal_big_batch(bucket_mb):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    as_t = lambda xs: [torch.from_numpy(x) for x in xs]
     (_, params0, grads0, nb0), (_, params1, grads1, nb1) = results
+    params0, params1 = as_t(params0), as_t(params1)
+    grads0, grads1 = [as_t(s) for s in grads0], [as_t(s) for s in grads1]
     assert nb0 == nb1 and (nb0 > 1 if bucket_mb < 0.01 else nb0 == 1)
     for a, b in zip(params0, params1):
         assert torch.equal(a, b)                      # broadcast from rank 0

@@ -1,0 +1,57 @@
+"""The fp32-MFMA Conv3d (csrc/conv3d.hip) against an fp64 evaluation of the same convolution.
+
+There is no bit-exact bar here: the reference delegates this op to cuDNN, whose summation order
+is unspecified (parity unpinned at that boundary; oracle = the same torch op).
+Tolerance: fp32 round-off for K = 27*Ci terms -- 1e-5 relative to the tensor's scale, stated here."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+TOL = 1e-5
+
+CASES = [(2, 9, 64, 32), (1, 5, 7, 12), (2, 64, 64, 16), (1, 16, 130, 8), (1, 3, 4, 33), (1, 8, 8, 5), (3, 64, 128, 16),
+         (1, 1, 1, 1), (1, 2, 3, 2)]
+
+
+def _rel(a, b):
+    return (a.double() - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
+
+
+@pytest.mark.parametrize('b,ci,co,r', CASES)
+def test_conv3d_forward_backward(hip, b, ci, co, r):
+    g = torch.Generator().manual_seed(1588147245)
+    x = torch.randn(b, ci, r, r, r, generator=g).to(DEV)
+    w = (torch.randn(co, ci, 3, 3, 3, generator=g) * 0.1).to(DEV)
+    bias = torch.randn(co, generator=g).to(DEV)
+    gy = torch.randn(b, co, r, r, r, generator=g).to(DEV)
+    xd, wd, bd = x.double().requires_grad_(), w.double().requires_grad_(), bias.double().requires_grad_()
+    ref = F.conv3d(xd, wd, bd, padding=1)
+    ref.backward(gy.double())
+    assert _rel(hip.conv3d_forward(x, w, bias), ref.detach()) < TOL
+    assert _rel(hip.conv3d_forward(x, w, None), ref.detach() - bd.detach().view(1, -1, 1, 1, 1)) < TOL
+    assert _rel(hip.conv3d_backward_data(gy, w), xd.grad) < TOL
+    assert _rel(hip.conv3d_backward_weight(x, gy), wd.grad) < TOL
+
+
+def test_voxel_conv_module_matches_torch_autograd(hip):
+    from pvcnn_amd.modules.pvconv import _VoxelConv3d
+    torch.manual_seed(0)
+    mine = _VoxelConv3d(16, 32, 3, stride=1, padding=1).to(DEV)
+    theirs = torch.nn.Conv3d(16, 32, 3, stride=1, padding=1).to(DEV).double()
+    theirs.load_state_dict({k: v.double() for k, v in mine.state_dict().items()})
+    assert list(mine.state_dict()) == ['weight', 'bias']
+    x = torch.randn(2, 16, 16, 16, 16, device=DEV)
+    xa, xb = x.clone().requires_grad_(), x.double().requires_grad_()
+    ya, yb = mine(xa), theirs(xb)
+    ya.square().sum().backward(); yb.square().sum().backward()
+    assert _rel(ya, yb.detach()) < TOL and _rel(xa.grad, xb.grad) < TOL
+    assert _rel(mine.weight.grad, theirs.weight.grad) < TOL and _rel(mine.bias.grad, theirs.bias.grad) < TOL
+
+
+def test_conv3d_is_deterministic(hip):
+    x = torch.randn(2, 64, 16, 16, 16, device=DEV); w = torch.randn(64, 64, 3, 3, 3, device=DEV); gy = torch.randn(2, 64, 16, 16, 16, device=DEV)
+    a, b_ = hip.conv3d_forward(x, w, None), hip.conv3d_backward_weight(x, gy)
+    for _ in range(2):
+        assert torch.equal(hip.conv3d_forward(x, w, None), a) and torch.equal(hip.conv3d_backward_weight(x, gy), b_)

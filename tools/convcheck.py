@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""Correctness (vs an fp64 torch convolution) and speed of the MFMA Conv3d kernels, raw C-ABI calls."""
+import ctypes
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import torch.nn.functional as F
+
+from pvcnn_amd import _lib
+
+lib = _lib.load()
+dev = 'cuda:0'
+
+
+def P(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def S():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def fwd(x, w, bias):
+    b, ci, r = x.shape[0], x.shape[1], x.shape[2]
+    co = w.shape[0]
+    wt = torch.empty(ci * 27 * co, device=dev)
+    y = torch.empty(b, co, r, r, r, device=dev)
+    _lib.check(lib.pvcnn_conv3d_weight_transform(P(w), co, ci, 0, P(wt), S()), 'wt')
+    _lib.check(lib.pvcnn_conv3d_fwd(P(x), P(wt), P(bias), b, ci, co, r, P(y), S()), 'fwd')
+    return y
+
+
+def bwd_data(gy, w):
+    b, co, r = gy.shape[0], gy.shape[1], gy.shape[2]
+    ci = w.shape[1]
+    wt = torch.empty(ci * 27 * co, device=dev)
+    gx = torch.empty(b, ci, r, r, r, device=dev)
+    _lib.check(lib.pvcnn_conv3d_weight_transform(P(w), co, ci, 1, P(wt), S()), 'wt')
+    _lib.check(lib.pvcnn_conv3d_fwd(P(gy), P(wt), None, b, co, ci, r, P(gx), S()), 'bwd_data')
+    return gx
+
+
+def graph_time(fn, reps=5, iters=5):
+    fn()
+    torch.cuda.synchronize()
+    st = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(st):
+        fn()
+        st.synchronize()
+        with torch.cuda.graph(g, stream=st):
+            for _ in range(reps):
+                fn()
+    torch.cuda.synchronize()
+    g.replay()
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(iters):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        e1.synchronize()
+        best = min(best, e0.elapsed_time(e1) / reps)
+    return best
+
+
+def main():
+    torch.manual_seed(0)
+    for (b, ci, co, r) in [(2, 9, 64, 32), (1, 5, 7, 12), (2, 64, 64, 16), (1, 16, 130, 8), (1, 3, 4, 33), (1, 8, 8, 5)]:
+        x = torch.randn(b, ci, r, r, r, device=dev)
+        w = torch.randn(co, ci, 3, 3, 3, device=dev) * 0.1
+        bias = torch.randn(co, device=dev)
+        ref = F.conv3d(x.double(), w.double(), bias.double(), padding=1)
+        err = (fwd(x, w, bias).double() - ref).abs().max().item() / ref.abs().max().item()
+        gy = torch.randn(b, co, r, r, r, device=dev)
+        xd = x.double().requires_grad_()
+        F.conv3d(xd, w.double(), padding=1).backward(gy.double())
+        errd = (bwd_data(gy, w).double() - xd.grad).abs().max().item() / xd.grad.abs().max().item()
+        wd = w.double().requires_grad_()
+        F.conv3d(x.double(), wd, padding=1).backward(gy.double())
+        gw = torch.empty_like(w)
+        nb = lib.pvcnn_conv3d_bwd_weight_workspace_bytes(b, ci, co, r)
+        wsb = torch.empty(nb, dtype=torch.uint8, device=dev)
+        _lib.check(lib.pvcnn_conv3d_bwd_weight(P(x), P(gy), b, ci, co, r, P(gw), P(wsb), nb, S()), 'bwd_w')
+        errw = (gw.double() - wd.grad).abs().max().item() / wd.grad.abs().max().item()
+        print(json.dumps({'check_BCiCoR': [b, ci, co, r], 'fwd_rel_err': err, 'bwd_data_rel_err': errd, 'bwd_weight_rel_err': errw,
+                          'ok': max(err, errd, errw) < 1e-5}), flush=True)
+    if '--time' in sys.argv:
+        for (b, ci, co, r) in [(16, 9, 64, 32), (16, 64, 64, 32), (16, 64, 64, 16), (16, 64, 128, 16), (16, 128, 128, 16)]:
+            x = torch.randn(b, ci, r, r, r, device=dev)
+            w = torch.randn(co, ci, 3, 3, 3, device=dev) * 0.1
+            bias = torch.randn(co, device=dev)
+            wt = torch.empty(ci * 27 * co, device=dev)
+            y = torch.empty(b, co, r, r, r, device=dev)
+            lib.pvcnn_conv3d_weight_transform(P(w), co, ci, 0, P(wt), S())
+            ms = graph_time(lambda: lib.pvcnn_conv3d_fwd(P(x), P(wt), P(bias), b, ci, co, r, P(y), S()))
+            fl = 2 * b * r ** 3 * 27 * ci * co
+            gy = torch.randn_like(y)
+            gw = torch.empty_like(w)
+            nb = lib.pvcnn_conv3d_bwd_weight_workspace_bytes(b, ci, co, r)
+            wsb = torch.empty(nb, dtype=torch.uint8, device=dev)
+            msw = graph_time(lambda: lib.pvcnn_conv3d_bwd_weight(P(x), P(gy), b, ci, co, r, P(gw), P(wsb), nb, S()))
+            print(json.dumps({'time_BCiCoR': [b, ci, co, r], 'fwd_ms': round(ms, 4), 'TFLOPs': round(fl / ms / 1e9, 1),
+                              'frac_157TF': round(fl / ms / 1e9 / 157.3, 3), 'bwd_weight_ms': round(msw, 4),
+                              'bwd_weight_TFLOPs': round(fl / msw / 1e9, 1), 'wgrad_ws_MB': round(nb / 1e6, 1)}), flush=True)
+
+
+if __name__ == '__main__':
+    main()

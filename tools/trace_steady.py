@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Steady-state per-step kernel breakdown from a rocprofv3 kernel-trace CSV.
+
+usage: trace_steady.py <kernel_trace.csv> <timed_steps> [top]
+Training steps are delimited by the optimizer phase (runs of Adam's multi_tensor_apply kernels);
+the LAST `timed_steps` complete steps are aggregated, i.e. bench.py's timed region."""
+import csv
+import sys
+from collections import defaultdict
+
+path, steps = sys.argv[1], int(sys.argv[2])
+top = int(sys.argv[3]) if len(sys.argv) > 3 else 40
+rows = list(csv.DictReader(open(path)))
+name_k = 'Kernel_Name' if 'Kernel_Name' in rows[0] else 'Name'
+s_k = 'Start_Timestamp' if 'Start_Timestamp' in rows[0] else 'Start'
+e_k = 'End_Timestamp' if 'End_Timestamp' in rows[0] else 'End'
+rows.sort(key=lambda r: int(r[s_k]))
+is_opt = ['multi_tensor_apply' in r[name_k] for r in rows]
+ends = [i for i in range(len(rows)) if is_opt[i] and (i + 1 == len(rows) or not is_opt[i + 1])]   # last kernel of each optimizer phase
+if len(ends) < steps + 1:
+    raise SystemExit(f'only {len(ends)} optimizer phases in the trace, need {steps + 1}')
+lo, hi = ends[-steps - 1] + 1, ends[-1] + 1
+steady = rows[lo:hi]
+agg = defaultdict(lambda: [0, 0])
+for r in steady:
+    a = agg[r[name_k]]
+    a[0] += 1
+    a[1] += int(r[e_k]) - int(r[s_k])
+span = (int(steady[-1][e_k]) - int(steady[0][s_k])) / 1e6
+busy = sum(v[1] for v in agg.values()) / 1e6
+print(f'last {steps} steps: {len(steady)} kernel launches ({len(steady) / steps:.0f}/step), wall {span / steps:.3f} ms/step, '
+      f'kernel time {busy / steps:.3f} ms/step ({100 * busy / span:.1f}% GPU busy)')
+mine = sum(v[1] for k, v in agg.items() if 'pvcnn::' in k) / 1e6
+print(f'hand-written pvcnn:: kernels: {mine / steps:.3f} ms/step ({100 * mine / busy:.1f}% of kernel time)')
+for name, (calls, ns) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]:
+    print('%8.3f ms/step %5.1f%%  calls/step=%6.1f avg=%8.1f us  %s' % (ns / 1e6 / steps, 100 * ns / 1e6 / busy, calls / steps, ns / 1e3 / calls, name[:110]))
