@@ -115,7 +115,9 @@ def cpu_baseline(args, sample_batch):
     from oracle.oracle_backend import OracleBackend          # checker / baseline only
     from pvcnn_amd import workload
     from pvcnn_amd.modules.functional import backend as seam
-    cores = os.cpu_count() or 1
+    # threads actually used: torch intra-op pool capped at 32 (beyond that the small per-layer GEMMs of
+    # a B=2 step only pay fork/join overhead; on a 256-core host 256 threads ran 80x SLOWER)
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     hip = seam._backend
     seam._backend = OracleBackend()

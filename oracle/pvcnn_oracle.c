@@ -28,6 +28,7 @@
  * modules/functional/src/ of the reference tree).
  */
 #include <math.h>
+#include <omp.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -35,6 +36,13 @@
 #define ORC_API __attribute__((visibility("default")))
 
 ORC_API int orc_version(void) { return 1; }
+
+/* One thread per cloud at most (mirrors the reference's one-block-per-cloud launch).  Without the
+ * cap a 256-core host spins 256 OpenMP threads for a B=2 loop and starves torch's own thread pool. */
+static inline int orc_threads(int b) {
+  const int m = omp_get_max_threads();
+  return b < 1 ? 1 : (b < m ? b : m);
+}
 
 /* ------------------------------------------------------------------------------------
  * avg_voxelize forward: voxelization/vox.cu:18-34 (grid_stats_kernel) and
@@ -47,7 +55,7 @@ ORC_API int orc_version(void) { return 1; }
 ORC_API void orc_avg_voxelize_fwd(const float *feat, const int32_t *coords, int b, int c, int n,
                                   int r, float *out, int32_t *ind, int32_t *cnt) {
   const int r2 = r * r, s = r2 * r;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(orc_threads(b))
   for (int bi = 0; bi < b; ++bi) {
     const int32_t *co = coords + (size_t)bi * n * 3;
     int32_t *in_ = ind + (size_t)bi * n;
@@ -75,7 +83,7 @@ ORC_API void orc_avg_voxelize_fwd(const float *feat, const int32_t *coords, int 
 /* fp64-accumulated variant: the "true" value both fp32 implementations are measured against. */
 ORC_API void orc_avg_voxelize_fwd_f64(const float *feat, const int32_t *ind, const int32_t *cnt,
                                       int b, int c, int n, int s, double *out) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(orc_threads(b))
   for (int bi = 0; bi < b; ++bi) {
     for (int i = 0; i < n; ++i) {
       const int pos = ind[(size_t)bi * n + i];
@@ -91,7 +99,7 @@ ORC_API void orc_avg_voxelize_fwd_f64(const float *feat, const int32_t *ind, con
  * address is hit exactly once, so the atomicAdd is a plain store of one product. */
 ORC_API void orc_avg_voxelize_bwd(const float *grad_y, const int32_t *ind, const int32_t *cnt,
                                   int b, int c, int n, int s, float *grad_x) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(orc_threads(b))
   for (int bi = 0; bi < b; ++bi) {
     const int32_t *in_ = ind + (size_t)bi * n;
     const int32_t *cn = cnt + (size_t)bi * s;
@@ -147,7 +155,7 @@ ORC_API void orc_trilinear_devox_fwd(const float *coords, const float *feat, int
                                      int r, int is_training, int32_t *inds, float *wgts,
                                      float *outs) {
   const int r2 = r * r, r3 = r2 * r;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(orc_threads(b))
   for (int bi = 0; bi < b; ++bi) {
     const float *co = coords + (size_t)bi * n * 3;
     const float *f = feat + (size_t)bi * c * r3;
@@ -175,7 +183,7 @@ ORC_API void orc_trilinear_devox_fwd(const float *coords, const float *feat, int
 ORC_API void orc_trilinear_devox_fwd_f64(const float *coords, const float *feat, int b, int c,
                                          int n, int r, double *outs) {
   const int r2 = r * r, r3 = r2 * r;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(orc_threads(b))
   for (int bi = 0; bi < b; ++bi) {
     const float *co = coords + (size_t)bi * n * 3;
     for (int i = 0; i < n; ++i) {
@@ -196,7 +204,7 @@ ORC_API void orc_trilinear_devox_fwd_f64(const float *coords, const float *feat,
  * (trilinear_devox.cpp:85-86).  Canonical order: point i ascending, channel j, corner k. */
 ORC_API void orc_trilinear_devox_bwd(const float *grad_y, const int32_t *inds, const float *wgts,
                                      int b, int c, int n, int r3, float *grad_x) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(orc_threads(b))
   for (int bi = 0; bi < b; ++bi) {
     const int32_t *id = inds + (size_t)bi * n * 8;
     const float *wg = wgts + (size_t)bi * n * 8;
@@ -218,7 +226,7 @@ ORC_API void orc_trilinear_devox_bwd(const float *grad_y, const int32_t *inds, c
 ORC_API void orc_trilinear_devox_bwd_f64(const float *grad_y, const int32_t *inds,
                                          const float *wgts, int b, int c, int n, int r3,
                                          double *grad_x) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(orc_threads(b))
   for (int bi = 0; bi < b; ++bi)
     for (int i = 0; i < n; ++i)
       for (int j = 0; j < c; ++j) {
@@ -237,7 +245,7 @@ ORC_API void orc_trilinear_devox_bwd_f64(const float *grad_y, const int32_t *ind
  * ---------------------------------------------------------------------------------- */
 ORC_API void orc_ball_query(const float *centers, const float *points, int b, int n, int m,
                             float r2, int u, int32_t *out) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(orc_threads(b))
   for (int bi = 0; bi < b; ++bi) {
     const float *pc = points + (size_t)bi * n * 3;
     const float *cc = centers + (size_t)bi * m * 3;
@@ -261,7 +269,7 @@ ORC_API void orc_ball_query(const float *centers, const float *points, int b, in
 /* grouping forward/backward: grouping/grouping.cu:18-36, 58-77. */
 ORC_API void orc_grouping_fwd(const float *features, const int32_t *indices, int b, int c, int n,
                               int m, int u, float *out) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(orc_threads(b))
   for (int bi = 0; bi < b; ++bi) {
     const float *f = features + (size_t)bi * n * c;
     const int32_t *id = indices + (size_t)bi * m * u;
@@ -276,7 +284,7 @@ ORC_API void orc_grouping_fwd(const float *features, const int32_t *indices, int
 /* canonical order for the atomics: (j, k) ascending per channel */
 ORC_API void orc_grouping_bwd(const float *grad_y, const int32_t *indices, int b, int c, int n,
                               int m, int u, float *grad_x) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(orc_threads(b))
   for (int bi = 0; bi < b; ++bi) {
     const float *gy = grad_y + (size_t)bi * m * u * c;
     const int32_t *id = indices + (size_t)bi * m * u;
@@ -293,7 +301,7 @@ ORC_API void orc_grouping_bwd(const float *grad_y, const int32_t *indices, int b
 /* gather forward/backward: sampling/sampling.cu:17-31, 52-66. */
 ORC_API void orc_gather_fwd(const float *features, const int32_t *indices, int b, int c, int n,
                             int m, float *out) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(orc_threads(b))
   for (int bi = 0; bi < b; ++bi)
     for (int l = 0; l < c; ++l)
       for (int j = 0; j < m; ++j)
@@ -303,7 +311,7 @@ ORC_API void orc_gather_fwd(const float *features, const int32_t *indices, int b
 
 ORC_API void orc_gather_bwd(const float *grad_y, const int32_t *indices, int b, int c, int n,
                             int m, float *grad_x) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(orc_threads(b))
   for (int bi = 0; bi < b; ++bi)
     for (int l = 0; l < c; ++l)
       for (int j = 0; j < m; ++j) {
@@ -323,7 +331,7 @@ ORC_API void orc_gather_bwd(const float *grad_y, const int32_t *indices, int b, 
 ORC_API void orc_fps(const float *coords, int b, int n, int m, float *distances,
                      int32_t *indices) {
   if (m <= 0) return;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(orc_threads(b))
   for (int bi = 0; bi < b; ++bi) {
     const float *co = coords + (size_t)bi * n * 3;
     float *dist = distances + (size_t)bi * n;
@@ -374,7 +382,7 @@ ORC_API void orc_fps(const float *coords, int b, int n, int m, float *distances,
 ORC_API void orc_three_nn_interp_fwd(const float *points_coords, const float *centers_coords,
                                      const float *centers_features, int b, int c, int m, int n,
                                      int32_t *indices, float *weights, float *out) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(orc_threads(b))
   for (int bi = 0; bi < b; ++bi) {
     const float *pc = points_coords + (size_t)bi * 3 * n;
     const float *cc = centers_coords + (size_t)bi * 3 * m;
@@ -433,7 +441,7 @@ ORC_API void orc_three_nn_interp_fwd(const float *points_coords, const float *ce
 ORC_API void orc_three_nn_interp_bwd(const float *grad_y, const int32_t *indices,
                                      const float *weights, int b, int c, int n, int m,
                                      float *grad_x) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(orc_threads(b))
   for (int bi = 0; bi < b; ++bi) {
     const float *gy = grad_y + (size_t)bi * n * c;
     const int32_t *id = indices + (size_t)bi * n * 3;

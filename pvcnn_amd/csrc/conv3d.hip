@@ -266,6 +266,61 @@ constexpr int kWgCic = 8;
 constexpr int kWgN = kWgCic * 27;          // 216 real columns
 constexpr int kGyStride = 257;
 
+// register images of one tile (VEC path): issued as global loads, landed in LDS one tile later
+template <int TX, int TY, int TZ>
+struct WgradTileRegs {
+  static constexpr int HX = TX + 2, HY = TY + 2, HZ = TZ + 2;
+  static constexpr int QPR = TZ / 4;
+  static constexpr int GY_ITER = kCoTile * 256 / 4 / 256;                       // 16
+  static constexpr int X_NQ = kWgCic * HX * HY * QPR, X_ITER = (X_NQ + 255) / 256;
+  float4 gy[GY_ITER];
+  float4 x[X_ITER];
+
+  __device__ __forceinline__ void load(const float *xg, const float *gyg, int b, int c0, int co0, int Ci, int Co, int R,
+                                       int x0, int y0, int tid) {
+    const size_t RR = (size_t)R * R, S = RR * R;
+    const float *gyb = gyg + (size_t)b * Co * S;
+    const float *xb = xg + (size_t)b * Ci * S;
+#pragma unroll
+    for (int it = 0; it < GY_ITER; ++it) {
+      const int q = tid + it * 256;
+      const int co = q / 64, mq = q - co * 64;
+      const int zrow = mq / QPR, qi = mq - zrow * QPR;
+      const int gx = x0 + zrow / TY, gyy = y0 + zrow % TY;
+      gy[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (co0 + co < Co && gx < R && gyy < R) gy[it] = ld4g(gyb + (size_t)(co0 + co) * S + (size_t)gx * RR + (size_t)gyy * R + qi * 4);
+    }
+#pragma unroll
+    for (int it = 0; it < X_ITER; ++it) {
+      const int q = tid + it * 256;
+      const int row = q / QPR, qi = q - row * QPR;
+      const int c = row / (HX * HY), hx = (row / HY) % HX, hy = row % HY;
+      const int gx = x0 + hx - 1, gyy = y0 + hy - 1;
+      x[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (q < X_NQ && c0 + c < Ci && (unsigned)gx < (unsigned)R && (unsigned)gyy < (unsigned)R)
+        x[it] = ld4g(xb + (size_t)(c0 + c) * S + (size_t)gx * RR + (size_t)gyy * R + qi * 4);
+    }
+  }
+  __device__ __forceinline__ void store(float *gys, float *xs, int tid) const {
+#pragma unroll
+    for (int it = 0; it < GY_ITER; ++it) {
+      const int q = tid + it * 256;
+      const int co = q / 64, mq = q - co * 64;
+      float *d = gys + co * kGyStride + mq * 4;
+      d[0] = gy[it].x; d[1] = gy[it].y; d[2] = gy[it].z; d[3] = gy[it].w;
+    }
+#pragma unroll
+    for (int it = 0; it < X_ITER; ++it) {
+      const int q = tid + it * 256;
+      if (q < X_NQ) {
+        const int row = q / QPR, qi = q - row * QPR;
+        float *d = xs + row * HZ + 1 + qi * 4;
+        d[0] = x[it].x; d[1] = x[it].y; d[2] = x[it].z; d[3] = x[it].w;
+      }
+    }
+  }
+};
+
 template <int TX, int TY, int TZ, bool VEC>
 __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ gy,
                                                            float *__restrict__ part, int B, int Ci, int Co, int R,
@@ -292,7 +347,6 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float *__restri
     bval[q] = (wave + 4 * q) < 7 && n < kWgN && c0 + cl < Ci;
     boff[q] = bval[q] ? cl * HS + (dx * HY + dy) * HZ + dz : 0;
   }
-  const bool second = (wave + 4) < 7;        // wave 3 owns a single column block
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -304,37 +358,64 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float *__restri
 
   const int tiles_per_cloud = tiles_x * tiles_y * tiles_z;
   const int tiles_total = B * tiles_per_cloud;
-  for (int t = p; t < tiles_total; t += P) {
-    int tt = t;
-    const int tzi = tt % tiles_z; tt /= tiles_z;
-    const int tyi = tt % tiles_y; tt /= tiles_y;
-    const int txi = tt % tiles_x; tt /= tiles_x;
-    const int b = tt;
-    const int x0 = txi * TX, y0 = tyi * TY, z0 = tzi * TZ;
+  auto decode = [&](int t, int &b, int &x0, int &y0, int &z0) {
+    const int tzi = t % tiles_z; t /= tiles_z;
+    const int tyi = t % tiles_y; t /= tiles_y;
+    const int txi = t % tiles_x; t /= tiles_x;
+    b = t; x0 = txi * TX; y0 = tyi * TY; z0 = tzi * TZ;
+  };
+  // Columns that do not exist (padding of 216 -> 224, channels beyond Ci, wave 3's second block) still
+  // take part in the MFMAs with whatever xs[h] holds: an output column depends only on its own B
+  // column, and those columns are never stored -- this keeps the loop free of branches and selects.
+  auto k_loop = [&]() {
+#pragma unroll 8
+    for (int ks = 0; ks < 128; ++ks) {
+      const int v = 2 * ks + kh;
+      const int zt = v % TZ, yt = (v / TZ) % TY, xt = v / (TZ * TY);
+      const int h = (xt * HY + yt) * HZ + zt;
+      const float a0 = gys[j * kGyStride + v];
+      const float a1 = gys[(32 + j) * kGyStride + v];
+      const float b0 = xs[boff[0] + h];
+      const float b1 = xs[boff[1] + h];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+  };
+
+  if constexpr (VEC) {
+    // software pipeline: tile t+P's global loads are in flight while tile t's MFMA loop runs
+    constexpr int ROWS2 = kWgCic * HX * HY * 2;
+    for (int r = tid; r < ROWS2; r += 256) xs[(r >> 1) * HZ + ((r & 1) ? HZ - 1 : 0)] = 0.0f;   // z halo: always outside
+    WgradTileRegs<TX, TY, TZ> regs;
+    int t = p, b, x0, y0, z0;
+    if (t < tiles_total) {
+      decode(t, b, x0, y0, z0);
+      regs.load(x, gy, b, c0, co0, Ci, Co, R, x0, y0, tid);
+      regs.store(gys, xs, tid);
+    }
     __syncthreads();
-    // ---- stage gy[co][voxel of the tile] (zero outside the grid / beyond Co) ----
-    const float *gyb = gy + (size_t)b * Co * S;
-    if constexpr (VEC) {
-      constexpr int QPR = TZ / 4, NQ = kCoTile * 256 / 4, ITER = NQ / 256;   // 16 float4 per thread
-      float4 v[ITER];
-#pragma unroll
-      for (int it = 0; it < ITER; ++it) {
-        const int q = tid + it * 256;
-        const int co = q / (256 / 4), mq = q - co * (256 / 4);       // mq = quad index inside the 256-voxel tile
-        const int zrow = mq / QPR, qi = mq - zrow * QPR;
-        const int yt = zrow % TY, xt = zrow / TY;
-        const int gx = x0 + xt, gyy = y0 + yt;
-        v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (co0 + co < Co && gx < R && gyy < R) v[it] = ld4g(gyb + (size_t)(co0 + co) * S + (size_t)gx * RR + (size_t)gyy * R + qi * 4);
+    while (t < tiles_total) {
+      const int tn = t + P;
+      if (tn < tiles_total) {
+        decode(tn, b, x0, y0, z0);
+        regs.load(x, gy, b, c0, co0, Ci, Co, R, x0, y0, tid);
       }
-#pragma unroll
-      for (int it = 0; it < ITER; ++it) {
-        const int q = tid + it * 256;
-        const int co = q / (256 / 4), mq = q - co * (256 / 4);
-        float *d = gys + co * kGyStride + mq * 4;
-        d[0] = v[it].x; d[1] = v[it].y; d[2] = v[it].z; d[3] = v[it].w;
+      k_loop();
+      __syncthreads();
+      if (tn < tiles_total) {
+        regs.store(gys, xs, tid);
+        __syncthreads();
       }
-    } else {
+      t = tn;
+    }
+  } else {
+    for (int t = p; t < tiles_total; t += P) {
+      int b, x0, y0, z0;
+      decode(t, b, x0, y0, z0);
+      __syncthreads();
+      const float *gyb = gy + (size_t)b * Co * S;
       for (int e0 = 0; e0 < kCoTile * 256; e0 += 256 * 8) {
         float v[8];
 #pragma unroll
@@ -352,26 +433,9 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float *__restri
           gys[(e >> 8) * kGyStride + (e & 255)] = v[u];
         }
       }
-    }
-    // ---- stage the input halo tile of the 8 channels ----
-    stage_halo_tile<TX, TY, TZ, kWgCic, VEC>(xs, x + (size_t)b * Ci * S, c0, Ci, R, x0, y0, z0, tid);
-    __syncthreads();
-    // ---- K loop over the tile's 256 voxels, two per MFMA ----
-#pragma unroll 4
-    for (int ks = 0; ks < 128; ++ks) {
-      const int v = 2 * ks + kh;
-      const int zt = v % TZ, yt = (v / TZ) % TY, xt = v / (TZ * TY);
-      const int h = (xt * HY + yt) * HZ + zt;
-      const float a0 = gys[j * kGyStride + v];
-      const float a1 = gys[(32 + j) * kGyStride + v];
-      const float b0 = bval[0] ? xs[boff[0] + h] : 0.0f;
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      if (second) {   // wave-uniform
-        const float b1 = bval[1] ? xs[boff[1] + h] : 0.0f;
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-      }
+      stage_halo_tile<TX, TY, TZ, kWgCic, false>(xs, x + (size_t)b * Ci * S, c0, Ci, R, x0, y0, z0, tid);
+      __syncthreads();
+      k_loop();
     }
   }
   // ---- partial slab -> workspace[p][co][ci*27 + tap]: lanes = consecutive columns ----
