@@ -26,8 +26,7 @@
  *               they are evaluated without float atomics, in the serial point-index order
  *               the oracle defines, so results are run-to-run deterministic as well
  *               (the reference's atomicAdd order is undefined);
- *   <= 1e-5   : only the atomic fallbacks taken when a target row exceeds the LDS histogram
- *               (R > 33 grids; > 38000 scatter targets per cloud).
+ *   <= 1e-5   : only the atomic fallback taken beyond 2^20 scatter targets per cloud (R > 101 grids).
  *   Scatter-type calls take caller-owned scratch: `workspace` must hold at least the matching
  *   *_workspace_bytes(...) bytes and be 16-byte aligned.
  */
@@ -64,11 +63,11 @@ PVCNN_API const char *pvcnn_last_error_string(void);
  *      -> out (B,C,R^3) f32, ind (B,N) i32, cnt (B,R^3) i32.
  *      out[b,c,v] = sum_{i: ind[b,i]=v} feat[b,c,i] * (1/cnt[b,v]), summed in ascending i
  *      (deterministic; no float atomics).  `workspace` is scratch of at least
- *      pvcnn_avg_voxelize_fwd_workspace_bytes(B,N,R) bytes, 16-byte aligned.
+ *      pvcnn_avg_voxelize_fwd_workspace_bytes(B,C,N,R) bytes, 16-byte aligned.
  *      Out-of-range coords are clamped into the grid (the reference has no bounds check).
  * bwd: grad_y (B,C,S) f32, ind (B,N), cnt (B,S) -> grad_x (B,C,N) f32.
  */
-PVCNN_API size_t pvcnn_avg_voxelize_fwd_workspace_bytes(int B, int N, int R);
+PVCNN_API size_t pvcnn_avg_voxelize_fwd_workspace_bytes(int B, int C, int N, int R);
 PVCNN_API int pvcnn_avg_voxelize_fwd(const float *feat, const int32_t *coords, int B, int C, int N, int R,
                            float *out, int32_t *ind, int32_t *cnt, void *workspace,
                            size_t workspace_bytes, void *stream);
@@ -86,7 +85,7 @@ PVCNN_API int pvcnn_avg_voxelize_bwd(const float *grad_y, const int32_t *ind, co
 PVCNN_API int pvcnn_trilinear_devox_fwd(const float *coords, const float *feat, int B, int C, int N, int R,
                               int is_training, int32_t *inds, float *wgts, float *outs,
                               void *stream);
-PVCNN_API size_t pvcnn_trilinear_devox_bwd_workspace_bytes(int B, int N, int R);
+PVCNN_API size_t pvcnn_trilinear_devox_bwd_workspace_bytes(int B, int C, int N, int R);
 PVCNN_API int pvcnn_trilinear_devox_bwd(const float *grad_y, const int32_t *inds, const float *wgts, int B,
                               int C, int N, int R, float *grad_x, void *workspace,
                               size_t workspace_bytes, void *stream);
@@ -111,12 +110,12 @@ PVCNN_API int pvcnn_ball_query(const float *centers, const float *points, int B,
  */
 PVCNN_API int pvcnn_grouping_fwd(const float *features, const int32_t *indices, int B, int C, int N, int M,
                        int U, float *out, void *stream);
-PVCNN_API size_t pvcnn_grouping_bwd_workspace_bytes(int B, int N, int M, int U);
+PVCNN_API size_t pvcnn_grouping_bwd_workspace_bytes(int B, int C, int N, int M, int U);
 PVCNN_API int pvcnn_grouping_bwd(const float *grad_y, const int32_t *indices, int B, int C, int N, int M,
                        int U, float *grad_x, void *workspace, size_t workspace_bytes, void *stream);
 PVCNN_API int pvcnn_gather_fwd(const float *features, const int32_t *indices, int B, int C, int N, int M,
                      float *out, void *stream);
-PVCNN_API size_t pvcnn_gather_bwd_workspace_bytes(int B, int N, int M);
+PVCNN_API size_t pvcnn_gather_bwd_workspace_bytes(int B, int C, int N, int M);
 PVCNN_API int pvcnn_gather_bwd(const float *grad_y, const int32_t *indices, int B, int C, int N, int M,
                      float *grad_x, void *workspace, size_t workspace_bytes, void *stream);
 
@@ -141,7 +140,7 @@ PVCNN_API int pvcnn_fps(const float *coords, int B, int N, int M, float *distanc
 PVCNN_API int pvcnn_three_nn_interp_fwd(const float *points_coords, const float *centers_coords,
                               const float *centers_features, int B, int C, int M, int N,
                               int32_t *indices, float *weights, float *out, void *stream);
-PVCNN_API size_t pvcnn_three_nn_interp_bwd_workspace_bytes(int B, int N, int M);
+PVCNN_API size_t pvcnn_three_nn_interp_bwd_workspace_bytes(int B, int C, int N, int M);
 PVCNN_API int pvcnn_three_nn_interp_bwd(const float *grad_y, const int32_t *indices, const float *weights,
                               int B, int C, int N, int M, float *grad_x, void *workspace,
                               size_t workspace_bytes, void *stream);

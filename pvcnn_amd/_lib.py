@@ -23,22 +23,22 @@ _vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_
 SIGNATURES = {
     'pvcnn_version': (_i, []),
     'pvcnn_last_error_string': (ctypes.c_char_p, []),
-    'pvcnn_avg_voxelize_fwd_workspace_bytes': (_sz, [_i, _i, _i]),
+    'pvcnn_avg_voxelize_fwd_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'pvcnn_avg_voxelize_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     'pvcnn_avg_voxelize_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     'pvcnn_trilinear_devox_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
-    'pvcnn_trilinear_devox_bwd_workspace_bytes': (_sz, [_i, _i, _i]),
+    'pvcnn_trilinear_devox_bwd_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'pvcnn_trilinear_devox_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     'pvcnn_ball_query': (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp]),
     'pvcnn_grouping_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
-    'pvcnn_grouping_bwd_workspace_bytes': (_sz, [_i, _i, _i, _i]),
+    'pvcnn_grouping_bwd_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
     'pvcnn_grouping_bwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     'pvcnn_gather_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
-    'pvcnn_gather_bwd_workspace_bytes': (_sz, [_i, _i, _i]),
+    'pvcnn_gather_bwd_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'pvcnn_gather_bwd': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     'pvcnn_fps': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     'pvcnn_three_nn_interp_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
-    'pvcnn_three_nn_interp_bwd_workspace_bytes': (_sz, [_i, _i, _i]),
+    'pvcnn_three_nn_interp_bwd_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'pvcnn_three_nn_interp_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     'pvcnn_conv3d_weight_transform': (_i, [_vp, _i, _i, _i, _vp, _vp]),
     'pvcnn_conv3d_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),

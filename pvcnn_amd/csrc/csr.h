@@ -10,7 +10,7 @@
 //     ds_add_u32 / ds_read_b32 / ds_write_b32 : >= 4.2 lane-ops/clk/CU
 // So float atomics are avoided altogether.  The entries (e -> key, j, w) do not depend on the
 // channel, hence ONE pass per cloud sorts them by key with INTEGER LDS atomics:
-//   csr_prep_kernel (1 workgroup per cloud, histogram of the L targets in LDS)
+//   csr_prep_kernel (P workgroups per cloud, each owning a range of the L targets; LDS histogram)
 //       start[t]  exclusive prefix of the per-target counts (L+1 entries)
 //       ent[...]  (j, w) pairs grouped by target, in ASCENDING entry id inside each target
 //                 (a stable rank pass; its work is per entry, so a degenerate key
@@ -23,29 +23,37 @@
 // (point-major, then corner), which makes all of these ops bit-identical to
 // oracle/pvcnn_oracle.c, run-to-run deterministic, memset-free and atomic-free on fp32.
 #pragma once
+#include <algorithm>
+
 #include "slab.h"
 
 namespace pvcnn {
 
 constexpr int kCsrThreads = 1024;
-constexpr int kCsrMaxTargets = 38000;   // (L + L/32 + 34) * 4 bytes of histogram must fit 160 KiB
+constexpr int kCsrMaxTargets = 1 << 20;   // targets per cloud (split into ranges of <= kCsrMaxRange per workgroup)
+constexpr int kCsrMaxRange = 14336;      // (range + range/32 + 69 + 3*8192) * 4 bytes must fit the 160 KiB LDS
 
 __host__ __device__ __forceinline__ int pad32(int v) { return v + (v >> 5); }          // conflict-free scan layout
 __host__ __device__ __forceinline__ int start_stride(int L) { return (L + 1 + 3) & ~3; }   // per-cloud stride of start[]
 
+inline int cl_channels(int C) { return (C + 63) & ~63; }   // channel stride of the transposed source
+
 struct CsrWorkspace {
   int32_t *start;   // (B, start_stride(L))
-  int32_t *tmp;     // (B, E)   unordered placement (global; LDS copy used when it fits)
+  int32_t *tmp;     // (B, E)   unordered placement (overflow path of csr_prep_kernel)
   int2 *ent;        // (B, E)   {source index j, float bits of w}
+  float *srcT;      // (B, J, cl_channels(C))  channels-last copy of the source rows
   static size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
-  static size_t bytes(int B, int L, long E) {
-    return align16((size_t)B * start_stride(L) * 4) + align16((size_t)B * E * 4) + align16((size_t)B * E * 8) + 16;
+  static size_t bytes(int B, int C, int L, int J, long E) {
+    return align16((size_t)B * start_stride(L) * 4) + align16((size_t)B * E * 4) + align16((size_t)B * E * 8) +
+           align16((size_t)B * J * cl_channels(C) * 4) + 16;
   }
   void carve(void *ws, int B, int L, long E) {
     char *p = static_cast<char *>(ws);
     start = reinterpret_cast<int32_t *>(p); p += align16((size_t)B * start_stride(L) * 4);
     tmp = reinterpret_cast<int32_t *>(p);   p += align16((size_t)B * E * 4);
-    ent = reinterpret_cast<int2 *>(p);
+    ent = reinterpret_cast<int2 *>(p);      p += align16((size_t)B * E * 8);
+    srcT = reinterpret_cast<float *>(p);
   }
 };
 
@@ -53,22 +61,31 @@ struct CsrWorkspace {
 // Entry providers: entry id e in [0,E) of cloud b -> (key, source index, weight).
 // ---------------------------------------------------------------------------------------------
 
+// Entries are addressed as (plane k, index j) so that sweeps need no integer division and read every
+// plane with consecutive lanes on consecutive j (coalesced); the entry id  eid(k,j)  defines the
+// stable order inside a target and is chosen to be the reference's serial loop order.
+
 // avg_voxelize: one entry per point; key = voxel id (vox.cu:31), weight = 1/cnt[key] (vox.cu:66).
 struct VoxelEntries {
   static constexpr bool kInvCountWeight = true;
+  static constexpr int kPlanes = 1;
   const int32_t *coords;   // (B,3,N)
   int32_t *ind;            // (B,N) out
   int N, R, S;
-  __device__ __forceinline__ int key_first(int b, int e) const {
+  __device__ __forceinline__ int plane_len() const { return N; }
+  __device__ __forceinline__ int eid(int k, int j) const { return j; }
+  __device__ __forceinline__ int key(int b, int k, int j) const {
     const int32_t *c = coords + (size_t)b * 3 * N;
-    int v = c[e] * R * R + c[e + N] * R + c[e + 2 * N];
-    v = min(max(v, 0), S - 1);   // reference: unchecked (undefined behaviour when out of range)
-    ind[(size_t)b * N + e] = v;
+    const int v = c[j] * R * R + c[j + N] * R + c[j + 2 * N];
+    return min(max(v, 0), S - 1);   // reference: unchecked (undefined behaviour when out of range)
+  }
+  __device__ __forceinline__ int key_first(int b, int k, int j, bool writer) const {
+    const int v = key(b, k, j);
+    if (writer) ind[(size_t)b * N + j] = v;
     return v;
   }
-  __device__ __forceinline__ int key(int b, int e) const { return ind[(size_t)b * N + e]; }
-  __device__ __forceinline__ int src(int b, int e) const { return e; }
-  __device__ __forceinline__ float weight(int b, int e) const { return 1.0f; }
+  __device__ __forceinline__ int src(int k, int j) const { return j; }
+  __device__ __forceinline__ float weight(int b, int k, int j) const { return 1.0f; }
 };
 
 // (B,NC,J) index / weight planes; entry id = j*NC + k is the reference's (point, corner) loop
@@ -76,60 +93,103 @@ struct VoxelEntries {
 template <int NC>
 struct TapEntries {
   static constexpr bool kInvCountWeight = false;
+  static constexpr int kPlanes = NC;
   const int32_t *inds;
   const float *wgts;
   int J, L;
-  __device__ __forceinline__ int key_first(int b, int e) const { return key(b, e); }
-  __device__ __forceinline__ int key(int b, int e) const {
-    const int j = e / NC, k = e - j * NC;
-    return min(max(inds[((size_t)b * NC + k) * J + j], 0), L - 1);
-  }
-  __device__ __forceinline__ int src(int b, int e) const { return e / NC; }
-  __device__ __forceinline__ float weight(int b, int e) const {
-    const int j = e / NC, k = e - j * NC;
-    return wgts[((size_t)b * NC + k) * J + j];
-  }
+  __device__ __forceinline__ int plane_len() const { return J; }
+  __device__ __forceinline__ int eid(int k, int j) const { return j * NC + k; }
+  __device__ __forceinline__ int key(int b, int k, int j) const { return min(max(inds[((size_t)b * NC + k) * J + j], 0), L - 1); }
+  __device__ __forceinline__ int key_first(int b, int k, int j, bool) const { return key(b, k, j); }
+  __device__ __forceinline__ int src(int k, int j) const { return j; }
+  __device__ __forceinline__ float weight(int b, int k, int j) const { return wgts[((size_t)b * NC + k) * J + j]; }
 };
 
 // plain index list: grouping bwd (E = M*U), gather bwd (E = M); weight 1.
 struct IndexEntries {
   static constexpr bool kInvCountWeight = false;
+  static constexpr int kPlanes = 1;
   const int32_t *idx;   // (B,E)
   long E;
   int L;
-  __device__ __forceinline__ int key_first(int b, int e) const { return key(b, e); }
-  __device__ __forceinline__ int key(int b, int e) const { return min(max(idx[(size_t)b * E + e], 0), L - 1); }
-  __device__ __forceinline__ int src(int b, int e) const { return e; }
-  __device__ __forceinline__ float weight(int b, int e) const { return 1.0f; }
+  __device__ __forceinline__ int plane_len() const { return (int)E; }
+  __device__ __forceinline__ int eid(int k, int j) const { return j; }
+  __device__ __forceinline__ int key(int b, int k, int j) const { return min(max(idx[(size_t)b * E + j], 0), L - 1); }
+  __device__ __forceinline__ int key_first(int b, int k, int j, bool) const { return key(b, k, j); }
+  __device__ __forceinline__ int src(int k, int j) const { return j; }
+  __device__ __forceinline__ float weight(int b, int k, int j) const { return 1.0f; }
 };
 
 // ---------------------------------------------------------------------------------------------
-// csr_prep_kernel: grid = B, block = 1024, dynamic LDS = histogram (+ tmp copy when TMP_LDS).
+// csr_prep_kernel: grid = (P, B), block = 1024.
+// A cloud's sort is instruction-bound on one CU (~250 instructions per entry), so the TARGET RANGE
+// of each cloud is split over P workgroups: workgroup p owns targets [p*LP, (p+1)*LP).  Every
+// workgroup scans all E keys (cheap and redundant) but histograms / places / ranks only the
+// entries whose key is in its range; the global offset of its range is simply the number of
+// entries with a smaller key, counted in the same scan -- so the P workgroups never communicate.
 // ---------------------------------------------------------------------------------------------
-template <class EP, bool TMP_LDS>
-__global__ __launch_bounds__(kCsrThreads) void csr_prep_kernel(EP ep, int E, int L, int32_t *__restrict__ cnt_out,
+constexpr int kCsrList = 8192;   // in-range entries a workgroup can hold in LDS (list + placement buffer)
+
+template <class EP>
+__global__ __launch_bounds__(kCsrThreads) void csr_prep_kernel(EP ep, int E, int L, int LP, int32_t *__restrict__ cnt_out,
                                                               int32_t *__restrict__ start,
                                                               int32_t *__restrict__ tmp_g, int2 *__restrict__ ent) {
-  extern __shared__ __attribute__((aligned(16))) int hist[];   // pad32(L)+1 bins, 32 wave totals, [E tmp]
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const int HP = pad32(L) + 1;
+  // LDS: pad32(LP)+1 bins | 32 wave totals | 32 wave counts | 1 list counter (+3 pad) | list_kj[kCsrList] |
+  //      list_key[kCsrList] | tmp[kCsrList]
+  extern __shared__ __attribute__((aligned(16))) int hist[];
+  const int part = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int lo = part * LP, hi = min(L, lo + LP), nb = hi - lo;
+  const int HP = pad32(LP) + 1;
   int *wave_tot = hist + HP;
-  int *tmp = TMP_LDS ? (hist + HP + 32) : (tmp_g + (size_t)b * E);
+  int *wave_cnt = hist + HP + 32;
+  int *list_n = hist + HP + 64;
+  int *list_kj = hist + HP + 68;            // packed (k, j): k * PL + j  (fits: E < 2^31)
+  int *list_key = list_kj + kCsrList;
+  int *tmp_l = list_key + kCsrList;
   start += (size_t)b * start_stride(L);
   ent += (size_t)b * E;
+  const bool writer = (part == 0);   // side outputs of key_first (avg_voxelize's `ind`) are written once
 
   for (int i = tid; i < HP; i += kCsrThreads) hist[i] = 0;
+  if (tid == 0) *list_n = 0;
   __syncthreads();
-  for (int e = tid; e < E; e += kCsrThreads) atomicAdd(&hist[pad32(ep.key_first(b, e))], 1);   // ds_add_u32
+  // ---- light sweep over ALL entries: count keys below the range, histogram + compact the in-range ones ----
+  constexpr int kBatch = 8;
+  const int PL = ep.plane_len();
+  int below = 0;
+  for (int k = 0; k < EP::kPlanes; ++k)
+    for (int j0 = tid; j0 < PL; j0 += kCsrThreads * kBatch) {
+      int key[kBatch];
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u) {
+        const int j = j0 + u * kCsrThreads;
+        key[u] = (j < PL) ? ep.key_first(b, k, j, writer) : 0x7fffffff;
+      }
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u) {
+        below += (key[u] < lo) ? 1 : 0;
+        if (key[u] >= lo && key[u] < hi) {
+          atomicAdd(&hist[pad32(key[u] - lo)], 1);   // ds_add_u32
+          const int slot = atomicAdd(list_n, 1);
+          if (slot < kCsrList) { list_kj[slot] = k * PL + (j0 + u * kCsrThreads); list_key[slot] = key[u]; }
+        }
+      }
+    }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) below += __shfl_xor(below, d);
+  if ((tid & 63) == 0) wave_cnt[tid >> 6] = below;
   __syncthreads();
+  int base = 0;
+  for (int w = 0; w < kCsrThreads / kWave; ++w) base += wave_cnt[w];
+  const int n_in = *list_n;
   if (cnt_out)
-    for (int t = tid; t < L; t += kCsrThreads) cnt_out[(size_t)b * L + t] = hist[pad32(t)];
-  // exclusive scan: thread t owns bins [t*per, t*per + per)
-  const int per = (L + kCsrThreads - 1) / kCsrThreads;
+    for (int t = tid; t < nb; t += kCsrThreads) cnt_out[(size_t)b * L + lo + t] = hist[pad32(t)];
+  // ---- exclusive scan of this range's bins: thread t owns bins [t*per, t*per + per) ----
+  const int per = (LP + kCsrThreads - 1) / kCsrThreads;
   const int t0 = tid * per;
   int local = 0;
   for (int k = 0; k < per; ++k)
-    if (t0 + k < L) local += hist[pad32(t0 + k)];
+    if (t0 + k < nb) local += hist[pad32(t0 + k)];
   int incl = local;
 #pragma unroll
   for (int d = 1; d < kWave; d <<= 1) {
@@ -139,31 +199,63 @@ __global__ __launch_bounds__(kCsrThreads) void csr_prep_kernel(EP ep, int E, int
   __syncthreads();   // cnt_out reads of hist are done before bins are rewritten
   if ((tid & 63) == 63) wave_tot[tid >> 6] = incl;
   __syncthreads();
-  int run = incl - local;
+  int run = base + incl - local;
   for (int w = 0; w < (tid >> 6); ++w) run += wave_tot[w];
   for (int k = 0; k < per; ++k)
-    if (t0 + k < L) {
+    if (t0 + k < nb) {
       const int c = hist[pad32(t0 + k)];
-      hist[pad32(t0 + k)] = run;   // becomes the placement cursor
+      hist[pad32(t0 + k)] = run;   // becomes the placement cursor (global positions)
       run += c;
     }
   __syncthreads();
-  for (int t = tid; t < L; t += kCsrThreads) start[t] = hist[pad32(t)];
-  if (tid == 0) start[L] = E;
+  for (int t = tid; t < nb; t += kCsrThreads) start[lo + t] = hist[pad32(t)];
+  if (hi == L && tid == 0) start[L] = E;
   __syncthreads();
-  // unordered placement of entry ids inside each target's segment
-  for (int e = tid; e < E; e += kCsrThreads) tmp[atomicAdd(&hist[pad32(ep.key(b, e))], 1)] = e;
-  __syncthreads();   // after this hist[pad32(t)] = end of segment t = begin of segment t+1
-  // stable rank: position of e among the ids of its segment
-  for (int e = tid; e < E; e += kCsrThreads) {
-    const int t = ep.key(b, e);
-    const int end = hist[pad32(t)];
-    const int beg = (t == 0) ? 0 : hist[pad32(t - 1)];
-    int rank = 0;
-    for (int q = beg; q < end; ++q) rank += (tmp[q] < e) ? 1 : 0;
-    const float w = EP::kInvCountWeight ? (float)(1.0 / (double)(float)(end - beg)) : ep.weight(b, e);
-    ent[beg + rank] = make_int2(ep.src(b, e), __float_as_int(w));
+
+  if (n_in <= kCsrList) {
+    // ---- dense heavy passes over the compacted list: every lane has an in-range entry ----
+    for (int i = tid; i < n_in; i += kCsrThreads) {
+      const int kj = list_kj[i];
+      const int k = (EP::kPlanes == 1) ? 0 : kj / PL, j = (EP::kPlanes == 1) ? kj : kj - (kj / PL) * PL;
+      tmp_l[atomicAdd(&hist[pad32(list_key[i] - lo)], 1) - base] = ep.eid(k, j);
+    }
+    __syncthreads();   // hist[pad32(t)] = end of segment lo+t = begin of segment lo+t+1
+    for (int i = tid; i < n_in; i += kCsrThreads) {
+      const int kj = list_kj[i];
+      const int k = (EP::kPlanes == 1) ? 0 : kj / PL, j = (EP::kPlanes == 1) ? kj : kj - (kj / PL) * PL;
+      const int e = ep.eid(k, j);
+      const int t = list_key[i] - lo;
+      const int end = hist[pad32(t)];
+      const int beg = (t == 0) ? base : hist[pad32(t - 1)];
+      int rank = 0;
+      for (int q = beg; q < end; ++q) rank += (tmp_l[q - base] < e) ? 1 : 0;
+      const float w = EP::kInvCountWeight ? (float)(1.0 / (double)(float)(end - beg)) : ep.weight(b, k, j);
+      ent[beg + rank] = make_int2(ep.src(k, j), __float_as_int(w));
+    }
+    return;
   }
+  // ---- overflow path (a range holding more than kCsrList entries: degenerate key distribution):
+  //      same algorithm by re-sweeping all entries, placement buffer in global memory ----
+  int *tmp = tmp_g + (size_t)b * E + base;
+  for (int k = 0; k < EP::kPlanes; ++k)
+    for (int j = tid; j < PL; j += kCsrThreads) {
+      const int key = ep.key(b, k, j);
+      if (key >= lo && key < hi) tmp[atomicAdd(&hist[pad32(key - lo)], 1) - base] = ep.eid(k, j);
+    }
+  __syncthreads();
+  for (int k = 0; k < EP::kPlanes; ++k)
+    for (int j = tid; j < PL; j += kCsrThreads) {
+      const int key = ep.key(b, k, j);
+      if (key < lo || key >= hi) continue;
+      const int e = ep.eid(k, j);
+      const int t = key - lo;
+      const int end = hist[pad32(t)];
+      const int beg = (t == 0) ? base : hist[pad32(t - 1)];
+      int rank = 0;
+      for (int q = beg; q < end; ++q) rank += (tmp[q - base] < e) ? 1 : 0;
+      const float w = EP::kInvCountWeight ? (float)(1.0 / (double)(float)(end - beg)) : ep.weight(b, k, j);
+      ent[beg + rank] = make_int2(ep.src(k, j), __float_as_int(w));
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -205,7 +297,24 @@ __global__ __launch_bounds__(THREADS) void segsum_kernel(const float *__restrict
     for (int q = 0; q < VEC; ++q) {
 #pragma unroll
       for (int c = 0; c < G; ++c) acc[q][c] = 0.0f;
-      for (int e = s[q]; e < s[q + 1]; ++e) {
+      int e = s[q];
+      for (; e + 4 <= s[q + 1]; e += 4) {   // 4 entries' loads in flight; the adds stay in entry order
+        int2 t[4];
+        float xv[4][G];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t[u] = en[e + u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int c = 0; c < G; ++c) xv[u][c] = rows[roff[c] + t[u].x];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float w = __int_as_float(t[u].y);
+#pragma unroll
+          for (int c = 0; c < G; ++c) acc[q][c] = acc[q][c] + w * xv[u][c];
+        }
+      }
+      for (; e < s[q + 1]; ++e) {
         const int2 t = en[e];
         const float w = __int_as_float(t.y);
 #pragma unroll
@@ -219,6 +328,76 @@ __global__ __launch_bounds__(THREADS) void segsum_kernel(const float *__restrict
         else out[(size_t)c * L + v0] = acc[0][c];
       }
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Channel-per-lane segmented sums (dense targets: E >= 2 L).  Lane-per-target walks are hostage to the key
+// distribution: real clouds fill ~1/5 of the grid, so at R = 16 an occupied voxel owns ~45 corner
+// entries while most lanes idle.  Here the work is spread over CHANNELS instead:
+//   transpose_cj_kernel : src (B,C,J) -> srcT (B,J,Cp) (Cp = C rounded up to 64), LDS-tiled, coalesced;
+//   segsum_cl_kernel    : a wave owns one target at a time, its 64 lanes are 64 channels; the
+//                         target's entries (j, w) are wave-uniform (scalar loads), every source read
+//                         srcT[j][c0 .. c0+63] is one coalesced 256-byte row, and each lane adds
+//                         its channel's addends in entry order (bit-exact, any distribution);
+//                         results go through a 64 x 64 LDS tile so dst (B,C,L) is written as
+//                         256-byte rows.  Work is proportional to E, independent of how the
+//                         entries are spread over the targets.
+// ---------------------------------------------------------------------------------------------
+static __global__ __launch_bounds__(256) void transpose_cj_kernel(const float *__restrict__ src, float *__restrict__ dstT, int C,
+                                                           int J, int Cp) {
+  __shared__ float tile[64][65];
+  const int b = blockIdx.z, j0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4) {   // read rows of src: lanes along j
+    const int c = c0 + r, j = j0 + tx;
+    tile[r][tx] = (c < C && j < J) ? src[((size_t)b * C + c) * J + j] : 0.0f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 64; r += 4) {   // write rows of srcT: lanes along c
+    const int j = j0 + r;
+    if (j < J) dstT[((size_t)b * J + j) * Cp + c0 + tx] = tile[tx][r];
+  }
+}
+
+static __global__ __launch_bounds__(1024) void segsum_cl_kernel(const float *__restrict__ srcT,
+                                                                 const int32_t *__restrict__ start,
+                                                                 const int2 *__restrict__ ent, float *__restrict__ dst,
+                                                                 int C, int Cp, int L, int J, int E) {
+  __shared__ float tile[64][65];   // [channel][target]
+  constexpr int kVox = 4;          // targets per wave: 16 waves x 4 = the 64-target tile
+  const int b = blockIdx.z, v0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int32_t *st = start + (size_t)b * start_stride(L);
+  const int2 *en = ent + (size_t)b * E;
+  const float *sT = srcT + (size_t)b * J * Cp + c0 + lane;
+  // the wave's kVox + 1 segment boundaries with ONE vector load (then lane -> scalar by readlane)
+  const int vb = v0 + wave * kVox;
+  const int sv = st[min(vb + min(lane, kVox), L)];
+#pragma unroll
+  for (int q = 0; q < kVox; ++q) {
+    const int s_lo = __builtin_amdgcn_readlane(sv, q);
+    const int s_hi = (vb + q < L) ? __builtin_amdgcn_readlane(sv, q + 1) : s_lo;
+    float acc = 0.0f;
+    int e = s_lo;
+    for (; e + 4 <= s_hi; e += 4) {   // 4 row loads in flight, adds in entry order
+      const int2 t0 = en[e], t1 = en[e + 1], t2 = en[e + 2], t3 = en[e + 3];
+      const float x0 = sT[(size_t)t0.x * Cp], x1 = sT[(size_t)t1.x * Cp], x2 = sT[(size_t)t2.x * Cp], x3 = sT[(size_t)t3.x * Cp];
+      acc = acc + __int_as_float(t0.y) * x0;
+      acc = acc + __int_as_float(t1.y) * x1;
+      acc = acc + __int_as_float(t2.y) * x2;
+      acc = acc + __int_as_float(t3.y) * x3;
+    }
+    for (; e < s_hi; ++e) {
+      const int2 t = en[e];
+      acc = acc + __int_as_float(t.y) * sT[(size_t)t.x * Cp];
+    }
+    tile[lane][wave * kVox + q] = acc;
+  }
+  __syncthreads();
+  for (int r = wave; r < 64; r += 16) {   // one 256-byte row of dst per wave-store
+    const int c = c0 + r, v = v0 + lane;
+    if (c < C && v < L) dst[((size_t)b * C + c) * L + v] = tile[r][lane];
   }
 }
 
@@ -251,29 +430,40 @@ int launch_csr_scatter(const EP &ep, const float *src, float *dst, int B, int C,
                        int32_t *cnt_out, void *workspace, size_t workspace_bytes, hipStream_t s, const char *what) {
   const int E = (int)E_;
   if (B == 0) return 0;
-  if (!workspace || workspace_bytes < CsrWorkspace::bytes(B, L, E) || !aligned16(workspace)) {
-    set_error("%s: workspace missing, misaligned or too small (%zu bytes needed)", what, CsrWorkspace::bytes(B, L, E));
+  if (!workspace || workspace_bytes < CsrWorkspace::bytes(B, C, L, J, E) || !aligned16(workspace)) {
+    set_error("%s: workspace missing, misaligned or too small (%zu bytes needed)", what, CsrWorkspace::bytes(B, C, L, J, E));
     return PVCNN_ERR_INVALID_ARGUMENT;
   }
   CsrWorkspace ws;
   ws.carve(workspace, B, L, E);
-  // 1. per-cloud counting sort of the entries
-  const size_t hist_bytes = ((size_t)pad32(L) + 1 + 32) * sizeof(int);
-  const bool tmp_lds = hist_bytes + (size_t)E * 4 <= (size_t)kLdsBytesPerCU;
-  const size_t prep_lds = hist_bytes + (tmp_lds ? (size_t)E * 4 : 0);
-  if (tmp_lds) {
-    auto k = csr_prep_kernel<EP, true>;
+  // 1. per-cloud counting sort of the entries, target range split over P workgroups per cloud
+  int P = std::max(1, std::min(16, (2 * kNumCU) / std::max(B, 1)));
+  P = std::min(P, std::max(1, L / 64));
+  P = std::max(P, ceil_div(L, kCsrMaxRange));          // a range's histogram must fit LDS
+  int LP = ceil_div(L, P);
+  LP = (LP + 31) & ~31;
+  P = ceil_div(L, LP);
+  const size_t prep_lds = ((size_t)pad32(LP) + 1 + 68 + 3 * kCsrList) * sizeof(int);
+  {
+    auto k = csr_prep_kernel<EP>;
     if (int e = enable_big_lds(k, prep_lds)) { set_error("%s: LDS attribute: %d", what, e); return e; }
-    hipLaunchKernelGGL(k, dim3(B), dim3(kCsrThreads), prep_lds, s, ep, E, L, cnt_out, ws.start, ws.tmp, ws.ent);
-  } else {
-    auto k = csr_prep_kernel<EP, false>;
-    if (int e = enable_big_lds(k, prep_lds)) { set_error("%s: LDS attribute: %d", what, e); return e; }
-    hipLaunchKernelGGL(k, dim3(B), dim3(kCsrThreads), prep_lds, s, ep, E, L, cnt_out, ws.start, ws.tmp, ws.ent);
+    hipLaunchKernelGGL(k, dim3(P, B), dim3(kCsrThreads), prep_lds, s, ep, E, L, LP, cnt_out, ws.start, ws.tmp, ws.ent);
   }
   if (int e = check_launch(what)) return e;
   if (C == 0) return 0;
-  // 2. owned segmented sums.  G rows per workgroup: as many as keep the slab <= 64 KiB and the
-  //    grid >= 2 workgroups per CU (the entry list is re-read once per workgroup, from L2).
+  if ((long)E >= 2L * L) {
+    // dense targets: channels-last copy of the source rows + channel-per-lane segmented sums
+    const int Cp = cl_channels(C);
+    if (J > 0) {
+      hipLaunchKernelGGL(transpose_cj_kernel, dim3(ceil_div(J, 64), Cp / 64, B), dim3(256), 0, s, src, ws.srcT, C, J, Cp);
+      if (int e = check_launch(what)) return e;
+    }
+    hipLaunchKernelGGL(segsum_cl_kernel, dim3(ceil_div(L, 64), Cp / 64, B), dim3(1024), 0, s, ws.srcT, ws.start, ws.ent, dst,
+                       C, Cp, L, J, E);
+    return check_launch(what);
+  }
+  // sparse targets (most are empty, e.g. voxelize at R = 32): lane-per-target sums, source rows in LDS.
+  // G rows per workgroup: as many as keep the slab <= 64 KiB and the grid >= 2 workgroups per CU.
   const size_t row = (size_t)J * sizeof(float);
   const bool stage = row > 0 && row <= (size_t)kLdsBytesPerCU;
   int G = 1;

@@ -47,11 +47,11 @@ extern "C" int pvcnn_trilinear_devox_fwd(const float *coords, const float *feat,
   return launch_gather(p, feat, outs, B, C, /*L=*/R * R * R, /*J=*/N, vec, s, "trilinear_devox_fwd");
 }
 
-extern "C" size_t pvcnn_trilinear_devox_bwd_workspace_bytes(int B, int N, int R) {
-  if (B <= 0 || N < 0 || R <= 0) return 0;
+extern "C" size_t pvcnn_trilinear_devox_bwd_workspace_bytes(int B, int C, int N, int R) {
+  if (B <= 0 || C < 0 || N < 0 || R <= 0) return 0;
   const long S = (long)R * R * R;
   if (S > 0x7fffffffL || !csr_supported((int)S, 8L * N)) return 16;   // atomic fallback: no scratch
-  return CsrWorkspace::bytes(B, (int)S, 8L * N);
+  return CsrWorkspace::bytes(B, C, (int)S, N, 8L * N);
 }
 
 extern "C" int pvcnn_trilinear_devox_bwd(const float *grad_y, const int32_t *inds, const float *wgts, int B,

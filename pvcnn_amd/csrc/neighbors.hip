@@ -144,11 +144,11 @@ extern "C" int pvcnn_grouping_fwd(const float *features, const int32_t *indices,
   return launch_gather(p, features, out, B, C, N, J, vec, static_cast<hipStream_t>(stream), "grouping_fwd");
 }
 
-extern "C" size_t pvcnn_grouping_bwd_workspace_bytes(int B, int N, int M, int U) {
-  if (B <= 0 || N <= 0 || M < 0 || U < 0) return 0;
+extern "C" size_t pvcnn_grouping_bwd_workspace_bytes(int B, int C, int N, int M, int U) {
+  if (B <= 0 || C < 0 || N <= 0 || M < 0 || U < 0) return 0;
   const long E = (long)M * U;
   if (!csr_supported(N, E)) return 16;
-  return CsrWorkspace::bytes(B, N, E);
+  return CsrWorkspace::bytes(B, C, N, (int)E, E);
 }
 
 extern "C" int pvcnn_grouping_bwd(const float *grad_y, const int32_t *indices, int B, int C, int N, int M, int U,
@@ -174,8 +174,8 @@ extern "C" int pvcnn_gather_fwd(const float *features, const int32_t *indices, i
   return pvcnn_grouping_fwd(features, indices, B, C, N, M, 1, out, stream);
 }
 
-extern "C" size_t pvcnn_gather_bwd_workspace_bytes(int B, int N, int M) {
-  return pvcnn_grouping_bwd_workspace_bytes(B, N, M, 1);
+extern "C" size_t pvcnn_gather_bwd_workspace_bytes(int B, int C, int N, int M) {
+  return pvcnn_grouping_bwd_workspace_bytes(B, C, N, M, 1);
 }
 
 extern "C" int pvcnn_gather_bwd(const float *grad_y, const int32_t *indices, int B, int C, int N, int M,
@@ -202,10 +202,10 @@ extern "C" int pvcnn_three_nn_interp_fwd(const float *points_coords, const float
   return launch_gather(p, centers_features, out, B, C, /*L=*/M, /*J=*/N, vec, s, "three_nn_interp_fwd");
 }
 
-extern "C" size_t pvcnn_three_nn_interp_bwd_workspace_bytes(int B, int N, int M) {
-  if (B <= 0 || N < 0 || M <= 0) return 0;
+extern "C" size_t pvcnn_three_nn_interp_bwd_workspace_bytes(int B, int C, int N, int M) {
+  if (B <= 0 || C < 0 || N < 0 || M <= 0) return 0;
   if (!csr_supported(M, 3L * N)) return 16;
-  return CsrWorkspace::bytes(B, M, 3L * N);
+  return CsrWorkspace::bytes(B, C, M, N, 3L * N);
 }
 
 extern "C" int pvcnn_three_nn_interp_bwd(const float *grad_y, const int32_t *indices, const float *weights, int B,

@@ -20,6 +20,8 @@
 //
 // The index/weight source ("provider") is a template parameter; see the structs below.
 #pragma once
+#include <algorithm>
+
 #include "common.h"
 
 namespace pvcnn {
@@ -188,12 +190,24 @@ struct VoxelMean {
 // ---------------------------------------------------------------------------------------------
 // LDS slab kernels.  grid = (ceil(C/G), B); blockIdx.x = channel slab, blockIdx.y = cloud.
 // ---------------------------------------------------------------------------------------------
+// Streaming copy (HBM/L2 -> LDS or LDS -> HBM).  Latency-bound unless many loads are in flight, so a
+// thread issues 8 independent 16-byte loads before the first store (8 KiB in flight per wave).
 template <int THREADS>
 __device__ __forceinline__ void slab_copy(float *dst, const float *src, int total) {
-  // wave-uniform branch: 16-byte path when the slab start is aligned and a multiple of 4 floats
+  // wave-uniform branch: 16-byte path when both ends are aligned and the size is a multiple of 4 floats
   if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0 && (total & 3) == 0) {
-    for (int i = threadIdx.x * 4; i < total; i += THREADS * 4)
-      *reinterpret_cast<float4 *>(dst + i) = *reinterpret_cast<const float4 *>(src + i);
+    constexpr int kB = 8;
+    const int nq = total >> 2;
+    const float4 *s4 = reinterpret_cast<const float4 *>(src);
+    float4 *d4 = reinterpret_cast<float4 *>(dst);
+    for (int q0 = threadIdx.x; q0 < nq; q0 += THREADS * kB) {
+      float4 v[kB];
+#pragma unroll
+      for (int u = 0; u < kB; ++u) v[u] = s4[min(q0 + u * THREADS, nq - 1)];
+#pragma unroll
+      for (int u = 0; u < kB; ++u)
+        if (q0 + u * THREADS < nq) d4[q0 + u * THREADS] = v[u];
+    }
   } else {
     for (int i = threadIdx.x; i < total; i += THREADS) dst[i] = src[i];
   }

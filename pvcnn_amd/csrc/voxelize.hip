@@ -50,11 +50,11 @@ __global__ __launch_bounds__(256) void vox_scatter_atomic_kernel(
 
 using namespace pvcnn;
 
-extern "C" size_t pvcnn_avg_voxelize_fwd_workspace_bytes(int B, int N, int R) {
-  if (B <= 0 || N < 0 || R <= 0) return 0;
+extern "C" size_t pvcnn_avg_voxelize_fwd_workspace_bytes(int B, int C, int N, int R) {
+  if (B <= 0 || C < 0 || N < 0 || R <= 0) return 0;
   const long S = (long)R * R * R;
   if (!csr_supported((int)std::min<long>(S, 0x7fffffffL), N)) return 16;   // atomic fallback: no scratch
-  return CsrWorkspace::bytes(B, (int)S, N);
+  return CsrWorkspace::bytes(B, C, (int)S, N, N);
 }
 
 extern "C" int pvcnn_avg_voxelize_fwd(const float *feat, const int32_t *coords, int B, int C, int N, int R,

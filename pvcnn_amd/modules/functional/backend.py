@@ -101,7 +101,7 @@ class HipBackend:
                'gather backward: grad_y (B,C,M), indices (B,M) expected')
         b, c, m = grad_y.shape
         grad_x = torch.empty((b, c, int(n)), dtype=torch.float32, device=grad_y.device)
-        ws = self._scratch(self.lib.pvcnn_gather_bwd_workspace_bytes(b, int(n), m), grad_y.device)
+        ws = self._scratch(self.lib.pvcnn_gather_bwd_workspace_bytes(b, c, int(n), m), grad_y.device)
         with _Launch(grad_y) as s:
             _lib.check(self.lib.pvcnn_gather_bwd(_p(grad_y), _p(indices), b, c, int(n), m, _p(grad_x), _p(ws), ws.numel(), s),
                        'gather_features_backward')
@@ -153,7 +153,7 @@ class HipBackend:
                'grouping backward: grad_y (B,C,M,U), indices (B,M,U) expected')
         b, c, m, u = grad_y.shape
         grad_x = torch.empty((b, c, int(n)), dtype=torch.float32, device=grad_y.device)
-        ws = self._scratch(self.lib.pvcnn_grouping_bwd_workspace_bytes(b, int(n), m, u), grad_y.device)
+        ws = self._scratch(self.lib.pvcnn_grouping_bwd_workspace_bytes(b, c, int(n), m, u), grad_y.device)
         with _Launch(grad_y) as s:
             _lib.check(self.lib.pvcnn_grouping_bwd(_p(grad_y), _p(indices), b, c, int(n), m, u, _p(grad_x), _p(ws), ws.numel(), s),
                        'grouping_backward')
@@ -186,7 +186,7 @@ class HipBackend:
                '3-NN interpolate backward: grad_y (B,C,N), indices/weights (B,3,N) expected')
         b, c, n = grad_y.shape
         grad_x = torch.empty((b, c, int(m)), dtype=torch.float32, device=grad_y.device)
-        ws = self._scratch(self.lib.pvcnn_three_nn_interp_bwd_workspace_bytes(b, n, int(m)), grad_y.device)
+        ws = self._scratch(self.lib.pvcnn_three_nn_interp_bwd_workspace_bytes(b, c, n, int(m)), grad_y.device)
         with _Launch(grad_y) as s:
             _lib.check(self.lib.pvcnn_three_nn_interp_bwd(_p(grad_y), _p(indices), _p(weights), b, c, n, int(m), _p(grad_x),
                                                           _p(ws), ws.numel(), s),
@@ -225,7 +225,7 @@ class HipBackend:
         b, c, n = grad_y.shape
         r = int(r)
         grad_x = torch.empty((b, c, r * r * r), dtype=torch.float32, device=grad_y.device)
-        ws = self._scratch(self.lib.pvcnn_trilinear_devox_bwd_workspace_bytes(b, n, r), grad_y.device)
+        ws = self._scratch(self.lib.pvcnn_trilinear_devox_bwd_workspace_bytes(b, c, n, r), grad_y.device)
         with _Launch(grad_y) as s:
             _lib.check(self.lib.pvcnn_trilinear_devox_bwd(_p(grad_y), _p(indices), _p(weights), b, c, n, r, _p(grad_x),
                                                           _p(ws), ws.numel(), s),
@@ -245,7 +245,7 @@ class HipBackend:
         out = torch.empty((b, c, s3), dtype=torch.float32, device=dev)
         ind = torch.empty((b, n), dtype=torch.int32, device=dev)
         cnt = torch.empty((b, s3), dtype=torch.int32, device=dev)
-        ws = self._scratch(self.lib.pvcnn_avg_voxelize_fwd_workspace_bytes(b, n, r), dev)
+        ws = self._scratch(self.lib.pvcnn_avg_voxelize_fwd_workspace_bytes(b, c, n, r), dev)
         with _Launch(features) as s:
             _lib.check(self.lib.pvcnn_avg_voxelize_fwd(_p(features), _p(coords), b, c, n, r, _p(out), _p(ind), _p(cnt),
                                                        _p(ws), ws.numel(), s), 'avg_voxelize_forward')

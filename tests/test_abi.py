@@ -42,7 +42,7 @@ def test_binding_table_matches_header():
     lib = _lib.load()
     assert lib.pvcnn_version() == _lib.ABI_VERSION
     assert lib.pvcnn_last_error_string() is not None
-    assert lib.pvcnn_avg_voxelize_fwd_workspace_bytes(16, 4096, 32) >= 16 * 32768 * 4 + 2 * 16 * 4096 * 4
+    assert lib.pvcnn_avg_voxelize_fwd_workspace_bytes(16, 64, 4096, 32) >= 16 * 32768 * 4 + 16 * 4096 * 12 + 16 * 4096 * 64 * 4
 
 
 def test_product_path_refuses_cpu_tensors():
