@@ -126,3 +126,16 @@ def test_reference_models_run_unchanged_on_the_dropin(oracle_seam):
         for k in [k for k in sys.modules if k.split('.')[0] in ('modules', 'models')]:
             del sys.modules[k]
         sys.modules.update(saved)
+
+
+def test_baseline_config0_cpu_plumbing(oracle_seam):
+    """BASELINE.json configs[0]: PVCNN (0.125xC) S3DIS, B=1, N=4096, R=32 on the CPU reference path
+    (eval mode: BatchNorm1d on a (1,C) tensor raises in train mode, models/utils.py:11-12)."""
+    from pvcnn_amd import workload
+    torch.manual_seed(workload.SEED)
+    net = workload.PVCNN(13, 6, width_multiplier=0.125).eval()
+    x, _ = workload.make_s3dis_batch(1, 4096)
+    with torch.no_grad():
+        logits = net(x)
+    assert logits.shape == (1, 13, 4096) and torch.isfinite(logits).all()
+    assert [m.resolution for m in net.point_features[:4]] == [32, 16, 16, 16]
