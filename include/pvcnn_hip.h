@@ -160,11 +160,14 @@ PVCNN_API int pvcnn_conv3d_weight_transform(const float *w, int Co, int Ci, int 
 PVCNN_API int pvcnn_conv3d_fwd(const float *x, const float *wt, const float *bias, int B, int Ci, int Co,
                                int R, float *y, void *stream);
 /* grad_w (Co,Ci,3,3,3) = sum over batch and voxels of grad_y (B,Co,R^3) x shifted x (B,Ci,R^3);
- * every element written.  `workspace`: >= pvcnn_conv3d_bwd_weight_workspace_bytes(...) bytes of
- * 16-byte aligned scratch (per-partition partial sums; no float atomics). */
+ * grad_bias (Co) = sum of grad_y over batch and voxels (optional: NULL to skip; it comes for free
+ * from the grad_y tiles the kernel stages anyway).  Every element written.  `workspace`:
+ * >= pvcnn_conv3d_bwd_weight_workspace_bytes(...) bytes of 16-byte aligned scratch (per-partition
+ * partial sums; no float atomics). */
 PVCNN_API size_t pvcnn_conv3d_bwd_weight_workspace_bytes(int B, int Ci, int Co, int R);
 PVCNN_API int pvcnn_conv3d_bwd_weight(const float *x, const float *grad_y, int B, int Ci, int Co, int R,
-                                      float *grad_w, void *workspace, size_t workspace_bytes, void *stream);
+                                      float *grad_w, float *grad_bias, void *workspace, size_t workspace_bytes,
+                                      void *stream);
 
 #ifdef __cplusplus
 }

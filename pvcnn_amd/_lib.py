@@ -43,7 +43,7 @@ SIGNATURES = {
     'pvcnn_conv3d_weight_transform': (_i, [_vp, _i, _i, _i, _vp, _vp]),
     'pvcnn_conv3d_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     'pvcnn_conv3d_bwd_weight_workspace_bytes': (_sz, [_i, _i, _i, _i]),
-    'pvcnn_conv3d_bwd_weight': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    'pvcnn_conv3d_bwd_weight': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
 }
 
 _lib = None

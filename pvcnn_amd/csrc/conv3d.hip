@@ -323,8 +323,9 @@ struct WgradTileRegs {
 
 template <int TX, int TY, int TZ, bool VEC>
 __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ gy,
-                                                           float *__restrict__ part, int B, int Ci, int Co, int R,
-                                                           int tiles_x, int tiles_y, int tiles_z, int P) {
+                                                           float *__restrict__ part, float *__restrict__ bias_part,
+                                                           int B, int Ci, int Co, int R, int tiles_x, int tiles_y,
+                                                           int tiles_z, int P) {
   static_assert(TX * TY * TZ == 256, "a workgroup tile is 256 voxels");
   constexpr int HX = TX + 2, HY = TY + 2, HZ = TZ + 2, HS = HX * HY * HZ;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -384,6 +385,18 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float *__restri
     }
   };
 
+  // grad_bias[co] = sum of grad_y over batch and voxels: the channel-chunk-0 workgroups add up the rows of
+  // the gy tile they have in LDS anyway (4 threads per output channel, 64 voxels each).
+  const bool do_bias = (bias_part != nullptr) && (chunk == 0);
+  float bsum = 0.0f;
+  auto bias_acc = [&]() {
+    if (do_bias) {
+      const float *rowp = gys + (tid >> 2) * kGyStride + (tid & 3) * 64;
+#pragma unroll 16
+      for (int i = 0; i < 64; ++i) bsum += rowp[i];
+    }
+  };
+
   if constexpr (VEC) {
     // software pipeline: tile t+P's global loads are in flight while tile t's MFMA loop runs
     constexpr int ROWS2 = kWgCic * HX * HY * 2;
@@ -403,6 +416,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float *__restri
         regs.load(x, gy, b, c0, co0, Ci, Co, R, x0, y0, tid);
       }
       k_loop();
+      bias_acc();
       __syncthreads();
       if (tn < tiles_total) {
         regs.store(gys, xs, tid);
@@ -436,7 +450,14 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float *__restri
       stage_halo_tile<TX, TY, TZ, kWgCic, false>(xs, x + (size_t)b * Ci * S, c0, Ci, R, x0, y0, z0, tid);
       __syncthreads();
       k_loop();
+      bias_acc();
     }
+  }
+  if (do_bias) {   // 4 partial sums per channel -> one value per (partition, channel)
+    bsum += __shfl_xor(bsum, 1);
+    bsum += __shfl_xor(bsum, 2);
+    const int co = co0 + (tid >> 2);
+    if ((tid & 3) == 0 && co < Co) bias_part[(size_t)p * Co + co] = bsum;
   }
   // ---- partial slab -> workspace[p][co][ci*27 + tap]: lanes = consecutive columns ----
   float *out = part + (size_t)p * Co * Ci * 27;
@@ -473,8 +494,8 @@ inline int wgrad_partitions(int B, int Ci, int Co, int tiles_per_cloud) {
 }
 
 template <int TX, int TY, int TZ>
-static int launch_wgrad(const float *x, const float *gy, float *gw, float *part, int B, int Ci, int Co, int R, int P,
-                        hipStream_t s) {
+static int launch_wgrad(const float *x, const float *gy, float *gw, float *gb, float *part, int B, int Ci, int Co, int R,
+                        int P, hipStream_t s) {
   constexpr int HS = (TX + 2) * (TY + 2) * (TZ + 2);
   const size_t lds = (size_t)(kCoTile * kGyStride + kWgCic * HS) * sizeof(float);
   const int tx = ceil_div(R, TX), ty = ceil_div(R, TY), tz = ceil_div(R, TZ);
@@ -482,12 +503,18 @@ static int launch_wgrad(const float *x, const float *gy, float *gw, float *part,
   auto k = vec ? conv3d_wgrad_kernel<TX, TY, TZ, true> : conv3d_wgrad_kernel<TX, TY, TZ, false>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) { set_error("conv3d_wgrad: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
-  hipLaunchKernelGGL(k, dim3(ceil_div(Ci, kWgCic), P, ceil_div(Co, kCoTile)), dim3(256), lds, s, x, gy, part, B, Ci, Co, R,
-                     tx, ty, tz, P);
+  float *bias_part = gb ? part + (size_t)P * Co * Ci * 27 : nullptr;   // (P, Co) behind the weight partials
+  hipLaunchKernelGGL(k, dim3(ceil_div(Ci, kWgCic), P, ceil_div(Co, kCoTile)), dim3(256), lds, s, x, gy, part, bias_part, B,
+                     Ci, Co, R, tx, ty, tz, P);
   if (int rc = check_launch("conv3d_wgrad")) return rc;
   const int n = Co * Ci * 27;
   hipLaunchKernelGGL(conv3d_wgrad_reduce_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, part, n, P, gw);
-  return check_launch("conv3d_wgrad_reduce");
+  if (int rc = check_launch("conv3d_wgrad_reduce")) return rc;
+  if (gb) {
+    hipLaunchKernelGGL(conv3d_wgrad_reduce_kernel, dim3(ceil_div(Co, 256)), dim3(256), 0, s, bias_part, Co, P, gb);
+    return check_launch("conv3d_bias_reduce");
+  }
+  return 0;
 }
 
 inline void wgrad_tiles(int R, int &tpc) {
@@ -523,15 +550,20 @@ extern "C" size_t pvcnn_conv3d_bwd_weight_workspace_bytes(int B, int Ci, int Co,
   if (B <= 0 || Ci <= 0 || Co <= 0 || R <= 0) return 0;
   int tpc;
   wgrad_tiles(R, tpc);
-  return (size_t)wgrad_partitions(B, Ci, Co, tpc) * Co * Ci * 27 * sizeof(float) + 16;
+  const size_t P = (size_t)wgrad_partitions(B, Ci, Co, tpc);
+  return P * Co * Ci * 27 * sizeof(float) + P * Co * sizeof(float) + 16;
 }
 
 extern "C" int pvcnn_conv3d_bwd_weight(const float *x, const float *grad_y, int B, int Ci, int Co, int R, float *grad_w,
-                                       void *workspace, size_t workspace_bytes, void *stream) {
+                                       float *grad_bias, void *workspace, size_t workspace_bytes, void *stream) {
   PVCNN_REQUIRE(B >= 0 && Ci > 0 && Co > 0 && R > 0, "bad size");
   PVCNN_REQUIRE(grad_w, "null pointer");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (B == 0) { PVCNN_HIP_TRY(hipMemsetAsync(grad_w, 0, (size_t)Co * Ci * 27 * sizeof(float), s)); return 0; }
+  if (B == 0) {
+    PVCNN_HIP_TRY(hipMemsetAsync(grad_w, 0, (size_t)Co * Ci * 27 * sizeof(float), s));
+    if (grad_bias) PVCNN_HIP_TRY(hipMemsetAsync(grad_bias, 0, (size_t)Co * sizeof(float), s));
+    return 0;
+  }
   PVCNN_REQUIRE(x && grad_y, "null pointer");
   PVCNN_REQUIRE((long)R * R * R * (long)std::max(Ci, Co) <= 0x7fffffffL, "grid too large");
   PVCNN_REQUIRE(workspace && aligned16(workspace) && workspace_bytes >= pvcnn_conv3d_bwd_weight_workspace_bytes(B, Ci, Co, R),
@@ -540,7 +572,7 @@ extern "C" int pvcnn_conv3d_bwd_weight(const float *x, const float *grad_y, int 
   wgrad_tiles(R, tpc);
   const int P = wgrad_partitions(B, Ci, Co, tpc);
   float *part = static_cast<float *>(workspace);
-  if (R > 16) return launch_wgrad<2, 4, 32>(x, grad_y, grad_w, part, B, Ci, Co, R, P, s);
-  if (R > 8)  return launch_wgrad<4, 4, 16>(x, grad_y, grad_w, part, B, Ci, Co, R, P, s);
-  return launch_wgrad<4, 8, 8>(x, grad_y, grad_w, part, B, Ci, Co, R, P, s);
+  if (R > 16) return launch_wgrad<2, 4, 32>(x, grad_y, grad_w, grad_bias, part, B, Ci, Co, R, P, s);
+  if (R > 8)  return launch_wgrad<4, 4, 16>(x, grad_y, grad_w, grad_bias, part, B, Ci, Co, R, P, s);
+  return launch_wgrad<4, 8, 8>(x, grad_y, grad_w, grad_bias, part, B, Ci, Co, R, P, s);
 }

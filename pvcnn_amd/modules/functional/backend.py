@@ -299,15 +299,18 @@ class HipBackend:
             _lib.check(self.lib.pvcnn_conv3d_fwd(_p(grad_y), _p(wt), None, b, co, ci, r, _p(gx), s), 'conv3d_backward_data')
         return gx
 
-    def conv3d_backward_weight(self, x, grad_y):
+    def conv3d_backward_weight(self, x, grad_y, with_bias=False):
+        """-> grad_weight, or (grad_weight, grad_bias) when with_bias (the bias sum rides on the same pass)."""
         _f32(x, 'x'); _f32(grad_y, 'grad_y')
         b, ci, r = x.shape[0], x.shape[1], x.shape[2]
         co = grad_y.shape[1]
         gw = torch.empty((co, ci, 3, 3, 3), dtype=torch.float32, device=x.device)
+        gb = torch.empty((co,), dtype=torch.float32, device=x.device) if with_bias else None
         ws = self._scratch(self.lib.pvcnn_conv3d_bwd_weight_workspace_bytes(b, ci, co, r), x.device)
         with _Launch(x) as s:
-            _lib.check(self.lib.pvcnn_conv3d_bwd_weight(_p(x), _p(grad_y), b, ci, co, r, _p(gw), _p(ws), ws.numel(), s), 'conv3d_backward_weight')
-        return gw
+            _lib.check(self.lib.pvcnn_conv3d_bwd_weight(_p(x), _p(grad_y), b, ci, co, r, _p(gw), _p(gb) if with_bias else None,
+                                                        _p(ws), ws.numel(), s), 'conv3d_backward_weight')
+        return (gw, gb) if with_bias else gw
 
 
 _backend = HipBackend()

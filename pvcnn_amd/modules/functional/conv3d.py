@@ -26,8 +26,14 @@ class VoxelConv3d(Function):
         x, weight = ctx.saved_tensors
         grad_y = grad_y.contiguous()
         gx = native().conv3d_backward_data(grad_y, weight) if ctx.needs_input_grad[0] else None
-        gw = native().conv3d_backward_weight(x, grad_y) if ctx.needs_input_grad[1] else None
-        gb = grad_y.sum(dim=(0, 2, 3, 4)) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        want_bias = ctx.has_bias and ctx.needs_input_grad[2]
+        gw = gb = None
+        if ctx.needs_input_grad[1]:
+            # the bias gradient is accumulated by the same kernel from the grad_y tiles it stages anyway
+            res = native().conv3d_backward_weight(x, grad_y, with_bias=want_bias)
+            gw, gb = res if want_bias else (res, None)
+        elif want_bias:
+            gb = grad_y.sum(dim=(0, 2, 3, 4))
         return gx, gw, gb
 
 

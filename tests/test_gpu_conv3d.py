@@ -33,6 +33,8 @@ def test_conv3d_forward_backward(hip, b, ci, co, r):
     assert _rel(hip.conv3d_forward(x, w, None), ref.detach() - bd.detach().view(1, -1, 1, 1, 1)) < TOL
     assert _rel(hip.conv3d_backward_data(gy, w), xd.grad) < TOL
     assert _rel(hip.conv3d_backward_weight(x, gy), wd.grad) < TOL
+    gw2, gb2 = hip.conv3d_backward_weight(x, gy, with_bias=True)
+    assert _rel(gw2, wd.grad) < TOL and _rel(gb2, bd.grad) < TOL
 
 
 def test_voxel_conv_module_matches_torch_autograd(hip):

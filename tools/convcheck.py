@@ -86,7 +86,7 @@ def main():
         gw = torch.empty_like(w)
         nb = lib.pvcnn_conv3d_bwd_weight_workspace_bytes(b, ci, co, r)
         wsb = torch.empty(nb, dtype=torch.uint8, device=dev)
-        _lib.check(lib.pvcnn_conv3d_bwd_weight(P(x), P(gy), b, ci, co, r, P(gw), P(wsb), nb, S()), 'bwd_w')
+        _lib.check(lib.pvcnn_conv3d_bwd_weight(P(x), P(gy), b, ci, co, r, P(gw), None, P(wsb), nb, S()), 'bwd_w')
         errw = (gw.double() - wd.grad).abs().max().item() / wd.grad.abs().max().item()
         print(json.dumps({'check_BCiCoR': [b, ci, co, r], 'fwd_rel_err': err, 'bwd_data_rel_err': errd, 'bwd_weight_rel_err': errw,
                           'ok': max(err, errd, errw) < 1e-5}), flush=True)
@@ -104,7 +104,7 @@ def main():
             gw = torch.empty_like(w)
             nb = lib.pvcnn_conv3d_bwd_weight_workspace_bytes(b, ci, co, r)
             wsb = torch.empty(nb, dtype=torch.uint8, device=dev)
-            msw = graph_time(lambda: lib.pvcnn_conv3d_bwd_weight(P(x), P(gy), b, ci, co, r, P(gw), P(wsb), nb, S()))
+            msw = graph_time(lambda: lib.pvcnn_conv3d_bwd_weight(P(x), P(gy), b, ci, co, r, P(gw), None, P(wsb), nb, S()))
             print(json.dumps({'time_BCiCoR': [b, ci, co, r], 'fwd_ms': round(ms, 4), 'TFLOPs': round(fl / ms / 1e9, 1),
                               'frac_157TF': round(fl / ms / 1e9 / 157.3, 3), 'bwd_weight_ms': round(msw, 4),
                               'bwd_weight_TFLOPs': round(fl / msw / 1e9, 1), 'wgrad_ws_MB': round(nb / 1e6, 1)}), flush=True)
