@@ -48,11 +48,13 @@ class GradBucketReducer:
         reducer.zero_grad(); loss = f(model(x)); loss.backward(); reducer.finish(); optimizer.step()
     """
 
-    def __init__(self, model, bucket_mb=8.0, group=None, broadcast=True):
+    def __init__(self, model, bucket_mb=8.0, group=None, broadcast=True, always_reduce=False):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # always_reduce: issue the collectives even in a 1-rank group (exercises the RCCL path on one GPU)
+        self.collective = dist.is_initialized() and (self.world > 1 or always_reduce)
         self.params = [p for p in model.parameters() if p.requires_grad]
-        if self.world > 1 and broadcast:
+        if self.collective and broadcast:
             with torch.no_grad():
                 for t in list(model.parameters()) + list(model.buffers()):
                     dist.broadcast(t, src=0, group=group)
@@ -83,19 +85,20 @@ class GradBucketReducer:
     def _on_grad(self, p):
         b = self._owner[p]
         b.pending -= 1
-        if b.pending == 0 and self.world > 1:
+        if b.pending == 0 and self.collective:
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def finish(self):
         """Wait for the in-flight all-reduces, launch those of buckets that never filled (unused
         parameters) and turn sums into means.  Call after backward, before optimizer.step()."""
-        if self.world > 1:
+        if self.collective:
             for b in self.buckets:
                 if b.work is None:
                     b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             for b in self.buckets:
                 b.work.wait()
-                b.flat.div_(self.world)
+                if self.world > 1:
+                    b.flat.div_(self.world)
         for b in self.buckets:
             b.pending, b.work = len(b.params), None
 
