@@ -169,6 +169,26 @@ PVCNN_API int pvcnn_conv3d_bwd_weight(const float *x, const float *grad_y, int B
                                       float *grad_w, float *grad_bias, void *workspace, size_t workspace_bytes,
                                       void *stream);
 
+/* ---- BatchNorm fused with the following ReLU / LeakyReLU -----------------------------------------
+ * replaces the (nn.BatchNorm{1,2,3}d, nn.ReLU | nn.LeakyReLU) module pairs of modules/pvconv.py:20-27
+ * and modules/shared_mlp.py:20-25 (cuDNN BN + one more elementwise pass each way in the reference).
+ * x, y, grad_* are (B, C, S) channel-major; statistics per channel over B*S.  slope = 0 for ReLU.
+ * fwd, training != 0: computes mean / rstd (outputs, saved for backward), updates running_mean /
+ *      running_var in place with `momentum` (unbiased variance; NULL = do not track), writes y.
+ * fwd, training == 0: the caller supplies mean = running_mean and rstd = 1/sqrt(running_var+eps).
+ * bwd: grad_x, grad_gamma, grad_beta (batch statistics differentiated through when training != 0).
+ * gamma / beta may be NULL (affine = False).  `workspace`: >= pvcnn_bnact_workspace_bytes(B,C,S).
+ */
+PVCNN_API size_t pvcnn_bnact_workspace_bytes(int B, int C, int S);
+PVCNN_API int pvcnn_bnact_fwd(const float *x, const float *gamma, const float *beta, float *running_mean,
+                              float *running_var, int B, int C, int S, float eps, float momentum, float slope,
+                              int training, float *mean, float *rstd, float *y, void *workspace,
+                              size_t workspace_bytes, void *stream);
+PVCNN_API int pvcnn_bnact_bwd(const float *x, const float *grad_y, const float *gamma, const float *beta,
+                              const float *mean, const float *rstd, int B, int C, int S, float slope, int training,
+                              float *grad_x, float *grad_gamma, float *grad_beta, void *workspace,
+                              size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,224 @@
+// bnact.hip -- BatchNorm (training or eval) fused with the ReLU / LeakyReLU that follows it.
+//
+// Reference: every conv of the hot path is followed by BatchNorm + activation as separate modules
+// (modules/pvconv.py:20-27: BatchNorm3d(eps=1e-4) + LeakyReLU(0.1); modules/shared_mlp.py:20-25:
+// BatchNorm + ReLU), i.e. cuDNN BN plus an extra elementwise pass forward and backward.  On a
+// (16, 64, 32^3) grid every pass is 134 MB each way, so the activation is folded into the BN passes:
+//   forward : bn_stats (1 read)  + bnact_apply  (1 read, 1 write)          y = act(g*(x-m)*rstd + b)
+//   backward: bnact_bwd_reduce (2 reads) + bnact_bwd_apply (2 reads, 1 write)
+// Tensors are (B, C, S) channel-major (S = R^3 voxels or N points); statistics per channel over B*S.
+// Sums are accumulated in fp32 per workgroup slice (<= 8192 elements) and combined in fp64.
+#include <algorithm>
+
+#include "common.h"
+
+namespace pvcnn {
+
+constexpr int kBnThreads = 256;
+constexpr int kBnSlice = 8192;   // elements of one (b, c) row handled by one workgroup
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+  return v;
+}
+
+// block-wide sum of two values; result valid in thread 0
+__device__ __forceinline__ void block_sum2(float &a, float &b, float *sm) {
+  a = wave_sum(a);
+  b = wave_sum(b);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) { sm[wave] = a; sm[8 + wave] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    a = sm[0] + sm[1] + sm[2] + sm[3];
+    b = sm[8] + sm[9] + sm[10] + sm[11];
+  }
+}
+
+// grid = (slices, B, C): partial (sum, sum of squares) of one slice of row (b, c)
+__global__ __launch_bounds__(kBnThreads) void bn_stats_kernel(const float *__restrict__ x, int C, int S, int slices,
+                                                             float2 *__restrict__ part) {
+  __shared__ float sm[16];
+  const int sl = blockIdx.x, b = blockIdx.y, c = blockIdx.z;
+  const float *row = x + ((size_t)b * C + c) * S;
+  const int lo = sl * kBnSlice, hi = min(S, lo + kBnSlice);
+  float s = 0.f, q = 0.f;
+  if ((S & 3) == 0 && aligned16(row)) {
+    for (int i = lo + threadIdx.x * 4; i < hi; i += kBnThreads * 4) {
+      const float4 v = *reinterpret_cast<const float4 *>(row + i);
+      s += (v.x + v.y) + (v.z + v.w);
+      q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+  } else {
+    for (int i = lo + threadIdx.x; i < hi; i += kBnThreads) { const float v = row[i]; s += v; q += v * v; }
+  }
+  block_sum2(s, q, sm);
+  if (threadIdx.x == 0) part[((size_t)c * gridDim.y + b) * slices + sl] = make_float2(s, q);
+}
+
+// grid = C: combine the partials in fp64 -> mean, rstd; update the running statistics (unbiased var)
+__global__ __launch_bounds__(64) void bn_finalize_kernel(const float2 *__restrict__ part, int nparts, double count, float eps,
+                                                        float momentum, float *__restrict__ mean,
+                                                        float *__restrict__ rstd, float *__restrict__ running_mean,
+                                                        float *__restrict__ running_var) {
+  const int c = blockIdx.x;
+  double s = 0.0, q = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += 64) { const float2 p = part[(size_t)c * nparts + i]; s += p.x; q += p.y; }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { s += __shfl_xor(s, d); q += __shfl_xor(q, d); }
+  if (threadIdx.x == 0) {
+    const double m = s / count;
+    double var = q / count - m * m;
+    var = var < 0.0 ? 0.0 : var;
+    mean[c] = (float)m;
+    rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+      const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+      running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * m);
+      running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+    }
+  }
+}
+
+// grid = (slices, B, C): y = act(scale * x + shift), scale = gamma*rstd, shift = beta - mean*scale
+__global__ __launch_bounds__(kBnThreads) void bnact_apply_kernel(const float *__restrict__ x, const float *__restrict__ mean,
+                                                                const float *__restrict__ rstd,
+                                                                const float *__restrict__ gamma,
+                                                                const float *__restrict__ beta, float slope, int C, int S,
+                                                                float *__restrict__ y) {
+  const int sl = blockIdx.x, b = blockIdx.y, c = blockIdx.z;
+  const float scale = (gamma ? gamma[c] : 1.0f) * rstd[c];
+  const float shift = (beta ? beta[c] : 0.0f) - mean[c] * scale;
+  const size_t off = ((size_t)b * C + c) * S;
+  const int lo = sl * kBnSlice, hi = min(S, lo + kBnSlice);
+  if ((S & 3) == 0 && aligned16(x + off) && aligned16(y + off)) {
+    for (int i = lo + threadIdx.x * 4; i < hi; i += kBnThreads * 4) {
+      float4 v = *reinterpret_cast<const float4 *>(x + off + i);
+      v.x = fmaf(v.x, scale, shift); v.y = fmaf(v.y, scale, shift); v.z = fmaf(v.z, scale, shift); v.w = fmaf(v.w, scale, shift);
+      v.x = v.x > 0.f ? v.x : v.x * slope; v.y = v.y > 0.f ? v.y : v.y * slope;
+      v.z = v.z > 0.f ? v.z : v.z * slope; v.w = v.w > 0.f ? v.w : v.w * slope;
+      *reinterpret_cast<float4 *>(y + off + i) = v;
+    }
+  } else {
+    for (int i = lo + threadIdx.x; i < hi; i += kBnThreads) {
+      const float v = fmaf(x[off + i], scale, shift);
+      y[off + i] = v > 0.f ? v : v * slope;
+    }
+  }
+}
+
+// grid = (slices, B, C): partial (sum g', sum g' * xhat),  g' = gy * act'(z),  z = scale*x + shift
+__global__ __launch_bounds__(kBnThreads) void bnact_bwd_reduce_kernel(const float *__restrict__ x, const float *__restrict__ gy,
+                                                                     const float *__restrict__ mean,
+                                                                     const float *__restrict__ rstd,
+                                                                     const float *__restrict__ gamma,
+                                                                     const float *__restrict__ beta, float slope, int C,
+                                                                     int S, int slices, float2 *__restrict__ part) {
+  __shared__ float sm[16];
+  const int sl = blockIdx.x, b = blockIdx.y, c = blockIdx.z;
+  const float m = mean[c], r = rstd[c];
+  const float scale = (gamma ? gamma[c] : 1.0f) * r;
+  const float shift = (beta ? beta[c] : 0.0f) - m * scale;
+  const size_t off = ((size_t)b * C + c) * S;
+  const int lo = sl * kBnSlice, hi = min(S, lo + kBnSlice);
+  float s = 0.f, q = 0.f;
+  for (int i = lo + threadIdx.x; i < hi; i += kBnThreads) {
+    const float xv = x[off + i];
+    const float z = fmaf(xv, scale, shift);
+    const float g = gy[off + i] * (z > 0.f ? 1.0f : slope);
+    s += g;
+    q += g * ((xv - m) * r);
+  }
+  block_sum2(s, q, sm);
+  if (threadIdx.x == 0) part[((size_t)c * gridDim.y + b) * slices + sl] = make_float2(s, q);
+}
+
+// grid = C: dbeta = sum g', dgamma = sum g' xhat (fp64 combine)
+__global__ __launch_bounds__(64) void bnact_bwd_finalize_kernel(const float2 *__restrict__ part, int nparts,
+                                                               float *__restrict__ dgamma, float *__restrict__ dbeta) {
+  const int c = blockIdx.x;
+  double s = 0.0, q = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += 64) { const float2 p = part[(size_t)c * nparts + i]; s += p.x; q += p.y; }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { s += __shfl_xor(s, d); q += __shfl_xor(q, d); }
+  if (threadIdx.x == 0) { dbeta[c] = (float)s; dgamma[c] = (float)q; }
+}
+
+// grid = (slices, B, C): training: gx = gamma*rstd*(g' - dbeta/M - xhat*dgamma/M); eval: gx = gamma*rstd*g'
+__global__ __launch_bounds__(kBnThreads) void bnact_bwd_apply_kernel(const float *__restrict__ x, const float *__restrict__ gy,
+                                                                    const float *__restrict__ mean,
+                                                                    const float *__restrict__ rstd,
+                                                                    const float *__restrict__ gamma,
+                                                                    const float *__restrict__ beta,
+                                                                    const float *__restrict__ dgamma,
+                                                                    const float *__restrict__ dbeta, float slope,
+                                                                    float inv_count, int training, int C, int S,
+                                                                    float *__restrict__ gx) {
+  const int sl = blockIdx.x, b = blockIdx.y, c = blockIdx.z;
+  const float m = mean[c], r = rstd[c];
+  const float gmm = gamma ? gamma[c] : 1.0f;
+  const float scale = gmm * r;
+  const float shift = (beta ? beta[c] : 0.0f) - m * scale;
+  const float db = training ? dbeta[c] * inv_count : 0.0f, dg = training ? dgamma[c] * inv_count : 0.0f;
+  const size_t off = ((size_t)b * C + c) * S;
+  const int lo = sl * kBnSlice, hi = min(S, lo + kBnSlice);
+  for (int i = lo + threadIdx.x; i < hi; i += kBnThreads) {
+    const float xv = x[off + i];
+    const float z = fmaf(xv, scale, shift);
+    const float g = gy[off + i] * (z > 0.f ? 1.0f : slope);
+    const float xhat = (xv - m) * r;
+    gx[off + i] = scale * (g - db - xhat * dg);
+  }
+}
+
+}  // namespace pvcnn
+
+using namespace pvcnn;
+
+extern "C" size_t pvcnn_bnact_workspace_bytes(int B, int C, int S) {
+  if (B <= 0 || C <= 0 || S <= 0) return 16;
+  return (size_t)C * B * ceil_div(S, kBnSlice) * sizeof(float2) + 16;
+}
+
+extern "C" int pvcnn_bnact_fwd(const float *x, const float *gamma, const float *beta, float *running_mean,
+                               float *running_var, int B, int C, int S, float eps, float momentum, float slope, int training,
+                               float *mean, float *rstd, float *y, void *workspace, size_t workspace_bytes, void *stream) {
+  PVCNN_REQUIRE(B > 0 && C > 0 && S > 0 && x && y && mean && rstd, "bad argument");
+  PVCNN_REQUIRE(B <= 65535 && C <= 65535, "batch or channel count > 65535");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int slices = ceil_div(S, kBnSlice);
+  const dim3 grid(slices, B, C);
+  if (training) {
+    PVCNN_REQUIRE(workspace && workspace_bytes >= pvcnn_bnact_workspace_bytes(B, C, S), "workspace too small");
+    float2 *part = static_cast<float2 *>(workspace);
+    hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(kBnThreads), 0, s, x, C, S, slices, part);
+    if (int e = check_launch("bn_stats")) return e;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, s, part, B * slices, (double)B * S, eps, momentum, mean, rstd,
+                       running_mean, running_var);
+    if (int e = check_launch("bn_finalize")) return e;
+  }
+  // eval: the caller passes mean = running_mean and rstd = 1/sqrt(running_var + eps)
+  hipLaunchKernelGGL(bnact_apply_kernel, grid, dim3(kBnThreads), 0, s, x, mean, rstd, gamma, beta, slope, C, S, y);
+  return check_launch("bnact_apply");
+}
+
+extern "C" int pvcnn_bnact_bwd(const float *x, const float *grad_y, const float *gamma, const float *beta, const float *mean,
+                               const float *rstd, int B, int C, int S, float slope, int training, float *grad_x,
+                               float *grad_gamma, float *grad_beta, void *workspace, size_t workspace_bytes, void *stream) {
+  PVCNN_REQUIRE(B > 0 && C > 0 && S > 0 && x && grad_y && mean && rstd && grad_x && grad_gamma && grad_beta, "bad argument");
+  PVCNN_REQUIRE(B <= 65535 && C <= 65535, "batch or channel count > 65535");
+  PVCNN_REQUIRE(workspace && workspace_bytes >= pvcnn_bnact_workspace_bytes(B, C, S), "workspace too small");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int slices = ceil_div(S, kBnSlice);
+  const dim3 grid(slices, B, C);
+  float2 *part = static_cast<float2 *>(workspace);
+  hipLaunchKernelGGL(bnact_bwd_reduce_kernel, grid, dim3(kBnThreads), 0, s, x, grad_y, mean, rstd, gamma, beta, slope, C, S,
+                     slices, part);
+  if (int e = check_launch("bnact_bwd_reduce")) return e;
+  hipLaunchKernelGGL(bnact_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, part, B * slices, grad_gamma, grad_beta);
+  if (int e = check_launch("bnact_bwd_finalize")) return e;
+  hipLaunchKernelGGL(bnact_bwd_apply_kernel, grid, dim3(kBnThreads), 0, s, x, grad_y, mean, rstd, gamma, beta, grad_gamma,
+                     grad_beta, slope, (float)(1.0 / ((double)B * S)), training, C, S, grad_x);
+  return check_launch("bnact_bwd_apply");
+}

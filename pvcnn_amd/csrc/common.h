@@ -18,7 +18,7 @@ void set_error(const char *fmt, ...);
 int check_launch(const char *what);
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
-inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+__host__ __device__ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace pvcnn
 

@@ -313,4 +313,46 @@ class HipBackend:
         return (gw, gb) if with_bias else gw
 
 
+    # ---- BatchNorm + ReLU/LeakyReLU in two passes each way (csrc/bnact.hip) ---------------------------
+    has_bnact = True
+
+    def bnact_forward(self, x, gamma, beta, running_mean, running_var, training, momentum, eps, slope):
+        """x (B,C,S) -> (y, mean, rstd).  Training: batch statistics (running stats updated in place);
+        eval: running statistics."""
+        _f32(x, 'x')
+        b, c, s3 = x.shape
+        dev = x.device
+        y = torch.empty_like(x)
+        if training:
+            mean = torch.empty((c,), dtype=torch.float32, device=dev)
+            rstd = torch.empty((c,), dtype=torch.float32, device=dev)
+        else:
+            mean = running_mean.contiguous()
+            rstd = torch.rsqrt(running_var + eps)
+        ws = self._scratch(self.lib.pvcnn_bnact_workspace_bytes(b, c, s3), dev)
+        nul = ctypes.c_void_p(None)
+        with _Launch(x) as s:
+            _lib.check(self.lib.pvcnn_bnact_fwd(_p(x), _p(gamma) if gamma is not None else nul, _p(beta) if beta is not None else nul,
+                                                _p(running_mean) if (training and running_mean is not None) else nul,
+                                                _p(running_var) if (training and running_var is not None) else nul,
+                                                b, c, s3, float(eps), float(momentum), float(slope), int(bool(training)),
+                                                _p(mean), _p(rstd), _p(y), _p(ws), ws.numel(), s), 'bnact_forward')
+        return y, mean, rstd
+
+    def bnact_backward(self, x, grad_y, gamma, beta, mean, rstd, slope, training):
+        _f32(x, 'x'); _f32(grad_y, 'grad_y')
+        b, c, s3 = x.shape
+        dev = x.device
+        gx = torch.empty_like(x)
+        gg = torch.empty((c,), dtype=torch.float32, device=dev)
+        gb = torch.empty((c,), dtype=torch.float32, device=dev)
+        ws = self._scratch(self.lib.pvcnn_bnact_workspace_bytes(b, c, s3), dev)
+        nul = ctypes.c_void_p(None)
+        with _Launch(x) as s:
+            _lib.check(self.lib.pvcnn_bnact_bwd(_p(x), _p(grad_y), _p(gamma) if gamma is not None else nul,
+                                                _p(beta) if beta is not None else nul, _p(mean), _p(rstd), b, c, s3, float(slope),
+                                                int(bool(training)), _p(gx), _p(gg), _p(gb), _p(ws), ws.numel(), s), 'bnact_backward')
+        return gx, gg, gb
+
+
 _backend = HipBackend()

@@ -1,0 +1,76 @@
+"""batch_norm_act: BatchNorm{1,2,3}d fused with the ReLU / LeakyReLU that follows it.
+
+The reference stacks them as separate modules (modules/pvconv.py:20-27, modules/shared_mlp.py:20-25).
+Semantics kept: training mode normalises with biased batch statistics and updates running_mean /
+running_var (unbiased variance, `momentum`; cumulative average when momentum is None) and
+num_batches_tracked exactly like torch.nn.BatchNorm; eval mode uses the running statistics.
+`run_layers` walks an nn.Sequential and fuses every (BatchNorm, activation) pair it meets on a GPU
+tensor -- parameters, buffers and state_dict keys stay those of the plain modules."""
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from ._autograd import native, amp_fwd, amp_bwd
+
+__all__ = ['batch_norm_act', 'run_layers']
+
+
+class BatchNormAct(Function):
+    @staticmethod
+    @amp_fwd
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, slope):
+        shape = x.shape
+        x3 = x.contiguous().view(shape[0], shape[1], -1)
+        w = weight.contiguous() if weight is not None else None
+        b = bias.contiguous() if bias is not None else None
+        y, mean, rstd = native().bnact_forward(x3, w, b, running_mean, running_var, training, momentum, eps, slope)
+        ctx.save_for_backward(x3, w, b, mean, rstd)
+        ctx.slope, ctx.training, ctx.shape = slope, training, shape
+        return y.view(shape)
+
+    @staticmethod
+    @amp_bwd
+    def backward(ctx, grad_y):
+        x3, w, b, mean, rstd = ctx.saved_tensors
+        g3 = grad_y.contiguous().view(x3.shape)
+        gx, gw, gb = native().bnact_backward(x3, g3, w, b, mean, rstd, ctx.slope, ctx.training)
+        return (gx.view(ctx.shape), gw if w is not None else None, gb if b is not None else None,
+                None, None, None, None, None, None)
+
+
+def batch_norm_act(x, bn, slope):
+    """Apply BatchNorm module `bn` followed by LeakyReLU(slope) (slope = 0: ReLU) to x (B, C, ...)."""
+    use_batch_stats = bn.training or bn.running_mean is None
+    momentum = 0.0 if bn.momentum is None else bn.momentum
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+        if bn.momentum is None:                      # cumulative moving average
+            momentum = 1.0 / float(bn.num_batches_tracked)
+    rm = bn.running_mean if (bn.track_running_stats or not use_batch_stats) else None
+    rv = bn.running_var if (bn.track_running_stats or not use_batch_stats) else None
+    return BatchNormAct.apply(x, bn.weight, bn.bias, rm, rv, use_batch_stats, momentum, bn.eps, slope)
+
+
+def _slope(act):
+    if isinstance(act, nn.LeakyReLU):
+        return float(act.negative_slope)
+    if isinstance(act, nn.ReLU):
+        return 0.0
+    return None
+
+
+def run_layers(layers, x):
+    """nn.Sequential.forward with (BatchNorm, ReLU|LeakyReLU) pairs fused on the GPU path."""
+    mods = list(layers)
+    fuse = x.is_cuda and getattr(native(), 'has_bnact', False)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if (fuse and isinstance(m, nn.modules.batchnorm._BatchNorm) and i + 1 < len(mods) and x.dim() >= 3
+                and x.dtype == torch.float32 and _slope(mods[i + 1]) is not None and x.numel() > 0):
+            x = batch_norm_act(x, m, _slope(mods[i + 1]))
+            i += 2
+        else:
+            x = m(x)
+            i += 1
+    return x

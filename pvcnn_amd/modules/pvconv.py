@@ -12,6 +12,7 @@ import torch.nn as nn
 
 from . import functional as F
 from .functional._autograd import native
+from .functional.bnact import run_layers
 from .functional.conv3d import voxel_conv3d
 from .se import SE3d
 from .shared_mlp import SharedMLP
@@ -57,6 +58,6 @@ class PVConv(nn.Module):
     def forward(self, inputs):
         features, coords = inputs
         grid, grid_coords = self.voxelization(features, coords)
-        grid = self.voxel_layers(grid)
+        grid = run_layers(self.voxel_layers, grid)     # = self.voxel_layers(grid), BN + LeakyReLU fused
         from_voxels = F.trilinear_devoxelize(grid, grid_coords, self.resolution, self.training)
         return from_voxels + self.point_features(features), coords

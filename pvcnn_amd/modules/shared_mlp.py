@@ -6,6 +6,8 @@ nn.Sequential [conv, bn, relu, conv, bn, relu, ...] so checkpoint keys
 is treated as (features, *extras): only the features pass through the MLP."""
 import torch.nn as nn
 
+from .functional.bnact import run_layers
+
 __all__ = ['SharedMLP']
 
 _BY_DIM = {1: (nn.Conv1d, nn.BatchNorm1d), 2: (nn.Conv2d, nn.BatchNorm2d)}
@@ -25,7 +27,8 @@ class SharedMLP(nn.Module):
         self.layers = nn.Sequential(*stack)
 
     def forward(self, inputs):
+        # run_layers == self.layers(x) with each BatchNorm + ReLU pair fused into two passes on the GPU
         if isinstance(inputs, (list, tuple)):
             head, *rest = inputs
-            return (self.layers(head), *rest)
-        return self.layers(inputs)
+            return (run_layers(self.layers, head), *rest)
+        return run_layers(self.layers, inputs)
