@@ -123,12 +123,27 @@ __global__ __launch_bounds__(kBnThreads) void bnact_bwd_reduce_kernel(const floa
   const size_t off = ((size_t)b * C + c) * S;
   const int lo = sl * kBnSlice, hi = min(S, lo + kBnSlice);
   float s = 0.f, q = 0.f;
-  for (int i = lo + threadIdx.x; i < hi; i += kBnThreads) {
-    const float xv = x[off + i];
-    const float z = fmaf(xv, scale, shift);
-    const float g = gy[off + i] * (z > 0.f ? 1.0f : slope);
-    s += g;
-    q += g * ((xv - m) * r);
+  if ((S & 3) == 0 && aligned16(x + off) && aligned16(gy + off)) {
+    for (int i = lo + threadIdx.x * 4; i < hi; i += kBnThreads * 4) {
+      const float4 xv = *reinterpret_cast<const float4 *>(x + off + i);
+      const float4 gv = *reinterpret_cast<const float4 *>(gy + off + i);
+      const float xs_[4] = {xv.x, xv.y, xv.z, xv.w}, gs_[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float z = fmaf(xs_[u], scale, shift);
+        const float g = gs_[u] * (z > 0.f ? 1.0f : slope);
+        s += g;
+        q += g * ((xs_[u] - m) * r);
+      }
+    }
+  } else {
+    for (int i = lo + threadIdx.x; i < hi; i += kBnThreads) {
+      const float xv = x[off + i];
+      const float z = fmaf(xv, scale, shift);
+      const float g = gy[off + i] * (z > 0.f ? 1.0f : slope);
+      s += g;
+      q += g * ((xv - m) * r);
+    }
   }
   block_sum2(s, q, sm);
   if (threadIdx.x == 0) part[((size_t)c * gridDim.y + b) * slices + sl] = make_float2(s, q);
@@ -163,12 +178,28 @@ __global__ __launch_bounds__(kBnThreads) void bnact_bwd_apply_kernel(const float
   const float db = training ? dbeta[c] * inv_count : 0.0f, dg = training ? dgamma[c] * inv_count : 0.0f;
   const size_t off = ((size_t)b * C + c) * S;
   const int lo = sl * kBnSlice, hi = min(S, lo + kBnSlice);
-  for (int i = lo + threadIdx.x; i < hi; i += kBnThreads) {
-    const float xv = x[off + i];
-    const float z = fmaf(xv, scale, shift);
-    const float g = gy[off + i] * (z > 0.f ? 1.0f : slope);
-    const float xhat = (xv - m) * r;
-    gx[off + i] = scale * (g - db - xhat * dg);
+  if ((S & 3) == 0 && aligned16(x + off) && aligned16(gy + off) && aligned16(gx + off)) {
+    for (int i = lo + threadIdx.x * 4; i < hi; i += kBnThreads * 4) {
+      const float4 xv = *reinterpret_cast<const float4 *>(x + off + i);
+      const float4 gv = *reinterpret_cast<const float4 *>(gy + off + i);
+      const float xs_[4] = {xv.x, xv.y, xv.z, xv.w}, gs_[4] = {gv.x, gv.y, gv.z, gv.w};
+      float o[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float z = fmaf(xs_[u], scale, shift);
+        const float g = gs_[u] * (z > 0.f ? 1.0f : slope);
+        o[u] = scale * (g - db - ((xs_[u] - m) * r) * dg);
+      }
+      *reinterpret_cast<float4 *>(gx + off + i) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  } else {
+    for (int i = lo + threadIdx.x; i < hi; i += kBnThreads) {
+      const float xv = x[off + i];
+      const float z = fmaf(xv, scale, shift);
+      const float g = gy[off + i] * (z > 0.f ? 1.0f : slope);
+      const float xhat = (xv - m) * r;
+      gx[off + i] = scale * (g - db - xhat * dg);
+    }
   }
 }
 
