@@ -4,7 +4,7 @@
 // workgroups, run-to-run non-deterministic) and vox.cu:86-110 (backward).
 //
 // Forward here is the deterministic CSR scatter of csr.h with one entry per point:
-//   csr_prep_kernel<VoxelEntries>  (1 workgroup / cloud, histogram of the R^3 voxels in LDS)
+//   csr_prep_kernel<VoxelEntries>  (voxel range of a cloud split over workgroups, histogram in LDS)
 //       ind[b,i], cnt[b,v], and the points grouped by voxel in ASCENDING point index;
 //   segsum_kernel  (workgroup = G feature rows staged in LDS; lane = 4 consecutive voxels)
 //       out[b,c,v] = sum over the voxel's points, in ascending point index, of
@@ -12,7 +12,7 @@
 //       and every voxel (occupied or not) is written exactly once with 16-byte stores.
 // Result: no memset pass, no float atomics, bit-reproducible, and bit-identical to a serial
 // point-order evaluation (what oracle/pvcnn_oracle.c computes).  HBM traffic = compulsory.
-// Grids with R^3 > kCsrMaxTargets (R > 33) use the atomic fallback at the bottom.
+// Grids with R^3 > kCsrMaxTargets (2^20: R > 101) use the atomic fallback at the bottom.
 #include <algorithm>
 
 #include "csr.h"
