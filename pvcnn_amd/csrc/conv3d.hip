@@ -254,25 +254,50 @@ static int launch_igemm(const float *x, const float *wt, const float *bias, floa
 // ---------------------------------------------------------------------------------------------
 // Backward-weight:  gw[co][ci][tap] = sum_{b, v} gy[b,co,v] * x[b,ci,v + off(tap)]
 // as the GEMM  D[co][n] += A[co][k] * B[k][n]  with  n = (ci, tap)  and  K = voxels.
-//   * one workgroup owns a (64 co) x (CIC = 8 input channels x 27 taps = 216 -> 224 columns) slab
-//     of gw and walks a strided subset of the spatial tiles, accumulating in registers; its 7
-//     column blocks are spread over the 4 waves (2,2,2,1), each wave holding 2 x 2 MFMA tiles;
-//   * per tile it stages gy[64][256 voxels] (row stride 257: conflict-free A reads) and the input
-//     halo tile xs[8][(TX+2)(TY+2)(TZ+2)]; B reads gather xs at (channel, tap) offsets fixed per lane;
+//   * one workgroup owns a (64 co) x (16 input channels x 27 taps = 432 -> 448 columns) slab of gw
+//     and walks a strided subset of the spatial tiles, accumulating in registers: wave w holds
+//     row block (w & 1) x 7 of the 14 column blocks, i.e. 7 MFMA tiles fed by 1 A + 7 B LDS reads
+//     per K-step, with the next step's operands fetched while this step's MFMAs run;
+//   * per tile it stages gy[64][256 voxels] (row stride 260) and the input halo tile
+//     xs[16][(TX+2)(TY+2)][TZ+8] with z = 0 at float 4 of a row, so both land with 16-byte LDS
+//     stores; B reads gather xs at (channel, tap) offsets fixed per lane;
+//   * on the fast path the next tile's global loads are issued before the MFMA loop and land in
+//     LDS after it (one workgroup per CU: there is no other wave to hide them behind);
 //   * the partial slab goes to workspace[p] with plain coalesced stores; conv3d_wgrad_reduce_kernel
 //     sums the P partials (float atomics would cost more than the whole GEMM on this chip).
 // ---------------------------------------------------------------------------------------------
-constexpr int kWgCic = 8;
-constexpr int kWgN = kWgCic * 27;          // 216 real columns
-constexpr int kGyStride = 257;
+constexpr int kWgCic = 16;
+constexpr int kWgN = kWgCic * 27;          // 432 real columns
+constexpr int kWgBlocksPerWave = 7;        // 14 column blocks of 32 over 2 wave pairs
+constexpr int kGyStride = 260;
+constexpr int kWgZOff = 4;                 // xs row: z = -1 at float 3, z = 0..TZ-1 at 4.., z = TZ at 4+TZ
 
-// register images of one tile (VEC path): issued as global loads, landed in LDS one tile later
+// xs strides (floats): z-row HZP, x-plane PS, channel CS.  Rows start 16-byte aligned; the pads are chosen
+// (brute force over multiples of 4) so that the 32 lanes of a B read -- 27 taps of one channel + 5 of the
+// next -- spread over the 32 LDS banks with at most 2 addresses per bank (4 with the dense strides).
+template <int TX, int TY, int TZ> struct WgradPad { static constexpr int HZP = TZ + 8, PSPAD = 0, CSPAD = 0; };
+template <> struct WgradPad<2, 4, 32> { static constexpr int HZP = 40, PSPAD = 4, CSPAD = 4; };    // PS 244, CS 980
+template <> struct WgradPad<4, 4, 16> { static constexpr int HZP = 24, PSPAD = 4, CSPAD = 4; };    // PS 148, CS 892
+template <> struct WgradPad<4, 8, 8>  { static constexpr int HZP = 20, PSPAD = 8, CSPAD = 16; };   // PS 208, CS 1264
+
+template <int TX, int TY, int TZ>
+struct WgradGeom {
+  static constexpr int HX = TX + 2, HY = TY + 2, ROWS = HX * HY;
+  static constexpr int HZP = WgradPad<TX, TY, TZ>::HZP;
+  static constexpr int PS = HY * HZP + WgradPad<TX, TY, TZ>::PSPAD;
+  static constexpr int CS = HX * PS + WgradPad<TX, TY, TZ>::CSPAD;
+  static constexpr size_t kLdsBytes = (size_t)(kCoTile * kGyStride + kWgCic * CS) * sizeof(float);
+  static_assert(HZP >= TZ + kWgZOff + 1 && HZP % 4 == 0 && PS % 4 == 0 && CS % 4 == 0, "xs row layout");
+  __host__ __device__ static constexpr int row_offset(int c, int hx, int hy) { return c * CS + hx * PS + hy * HZP; }
+};
+
+// register images of one tile (fast path): issued as global loads, landed in LDS one tile later
 template <int TX, int TY, int TZ>
 struct WgradTileRegs {
-  static constexpr int HX = TX + 2, HY = TY + 2, HZ = TZ + 2;
+  using G = WgradGeom<TX, TY, TZ>;
   static constexpr int QPR = TZ / 4;
   static constexpr int GY_ITER = kCoTile * 256 / 4 / 256;                       // 16
-  static constexpr int X_NQ = kWgCic * HX * HY * QPR, X_ITER = (X_NQ + 255) / 256;
+  static constexpr int X_NQ = kWgCic * G::ROWS * QPR, X_ITER = (X_NQ + 255) / 256;
   float4 gy[GY_ITER];
   float4 x[X_ITER];
 
@@ -294,7 +319,7 @@ struct WgradTileRegs {
     for (int it = 0; it < X_ITER; ++it) {
       const int q = tid + it * 256;
       const int row = q / QPR, qi = q - row * QPR;
-      const int c = row / (HX * HY), hx = (row / HY) % HX, hy = row % HY;
+      const int c = row / G::ROWS, hx = (row / G::HY) % G::HX, hy = row % G::HY;
       const int gx = x0 + hx - 1, gyy = y0 + hy - 1;
       x[it] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (q < X_NQ && c0 + c < Ci && (unsigned)gx < (unsigned)R && (unsigned)gyy < (unsigned)R)
@@ -306,16 +331,15 @@ struct WgradTileRegs {
     for (int it = 0; it < GY_ITER; ++it) {
       const int q = tid + it * 256;
       const int co = q / 64, mq = q - co * 64;
-      float *d = gys + co * kGyStride + mq * 4;
-      d[0] = gy[it].x; d[1] = gy[it].y; d[2] = gy[it].z; d[3] = gy[it].w;
+      *reinterpret_cast<float4 *>(gys + co * kGyStride + mq * 4) = gy[it];
     }
 #pragma unroll
     for (int it = 0; it < X_ITER; ++it) {
       const int q = tid + it * 256;
       if (q < X_NQ) {
-        const int row = q / QPR, qi = q - row * QPR;
-        float *d = xs + row * HZ + 1 + qi * 4;
-        d[0] = x[it].x; d[1] = x[it].y; d[2] = x[it].z; d[3] = x[it].w;
+        const int row = q / QPR, qi = q - row * QPR;     // row = c*ROWS + hx*HY + hy
+        const int c = row / G::ROWS, hx = (row / G::HY) % G::HX, hy = row % G::HY;
+        *reinterpret_cast<float4 *>(xs + G::row_offset(c, hx, hy) + kWgZOff + qi * 4) = x[it];
       }
     }
   }
@@ -327,35 +351,35 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float *__restri
                                                            int B, int Ci, int Co, int R, int tiles_x, int tiles_y,
                                                            int tiles_z, int P) {
   static_assert(TX * TY * TZ == 256, "a workgroup tile is 256 voxels");
-  constexpr int HX = TX + 2, HY = TY + 2, HZ = TZ + 2, HS = HX * HY * HZ;
+  using G = WgradGeom<TX, TY, TZ>;
+  constexpr int HY = G::HY, HZP = G::HZP, PS = G::PS, CS = G::CS;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float *gys = lds;                          // [64][257]
-  float *xs = lds + kCoTile * kGyStride;     // [8][HS]
+  float *gys = lds;                          // [64][260]
+  float *xs = lds + kCoTile * kGyStride;     // [16][HX planes of PS][HY rows of HZP]
 
   const int chunk = blockIdx.x, p = blockIdx.y;
   const int co0 = blockIdx.z * kCoTile, c0 = chunk * kWgCic;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, kh = lane >> 5;
+  const int mb = wave & 1, nb0 = (wave >> 1) * kWgBlocksPerWave;
   const size_t RR = (size_t)R * R, S = RR * R;
 
-  // this lane's B-operand columns: n = nb*32 + j for nb in {wave, wave + 4}
-  int boff[2];
-  bool bval[2];
+  // this lane's B-operand columns: n = (nb0 + q)*32 + j
+  int boff[kWgBlocksPerWave];
+  bool bval[kWgBlocksPerWave];
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int n = (wave + 4 * q) * 32 + j;
+  for (int q = 0; q < kWgBlocksPerWave; ++q) {
+    const int n = (nb0 + q) * 32 + j;
     const int cl = n / 27, tap = n - cl * 27;
     const int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
-    bval[q] = (wave + 4 * q) < 7 && n < kWgN && c0 + cl < Ci;
-    boff[q] = bval[q] ? cl * HS + (dx * HY + dy) * HZ + dz : 0;
+    bval[q] = n < kWgN && c0 + cl < Ci;
+    boff[q] = bval[q] ? G::row_offset(cl, dx, dy) + dz + (kWgZOff - 1) : kWgZOff;
   }
 
-  f32x16 acc[2][2];
+  f32x16 acc[kWgBlocksPerWave];
 #pragma unroll
-  for (int mb = 0; mb < 2; ++mb)
+  for (int q = 0; q < kWgBlocksPerWave; ++q)
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mb][q][r] = 0.0f;
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
 
   const int tiles_per_cloud = tiles_x * tiles_y * tiles_z;
   const int tiles_total = B * tiles_per_cloud;
@@ -365,23 +389,66 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float *__restri
     const int txi = t % tiles_x; t /= tiles_x;
     b = t; x0 = txi * TX; y0 = tyi * TY; z0 = tzi * TZ;
   };
-  // Columns that do not exist (padding of 216 -> 224, channels beyond Ci, wave 3's second block) still
-  // take part in the MFMAs with whatever xs[h] holds: an output column depends only on its own B
-  // column, and those columns are never stored -- this keeps the loop free of branches and selects.
+  // K order.  MFMA step (pair pi, sub c) contracts voxels 4*pi + c (lanes 0-31) and 4*pi + 2 + c (lanes
+  // 32-63), so a lane needs two CONSECUTIVE floats of its A row and of each B column per pair of steps:
+  // one ds_read_b64 + 7 ds_read2_b32 feed 14 MFMAs, with immediate offsets inside a z-row.  With a single
+  // wave per SIMD every instruction issued between two MFMAs delays the second, so the loop is kept at
+  // ~0.6 non-MFMA instructions per MFMA and the next pair's reads are issued under this pair's MFMAs.
+  // Columns that do not exist (padding of 432 -> 448, channels beyond Ci) still take part in the MFMAs
+  // with whatever xs holds: an output column depends only on its own B column, and those columns are
+  // never stored -- this keeps the loop free of branches and selects.
   auto k_loop = [&]() {
-#pragma unroll 8
-    for (int ks = 0; ks < 128; ++ks) {
-      const int v = 2 * ks + kh;
-      const int zt = v % TZ, yt = (v / TZ) % TY, xt = v / (TZ * TY);
-      const int h = (xt * HY + yt) * HZ + zt;
-      const float a0 = gys[j * kGyStride + v];
-      const float a1 = gys[(32 + j) * kGyStride + v];
-      const float b0 = xs[boff[0] + h];
-      const float b1 = xs[boff[1] + h];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    constexpr int PPR = TZ / 4, NROW = 256 / TZ;      // pairs per z-row, z-rows per tile
+    const float *a_row = gys + (mb * 32 + j) * kGyStride + 2 * kh;
+    const float *b_row[kWgBlocksPerWave];
+#pragma unroll
+    for (int q = 0; q < kWgBlocksPerWave; ++q) b_row[q] = xs + boff[q] + 2 * kh;
+    float2 a_cur;
+    float b_cur[kWgBlocksPerWave][2];
+    a_cur = *reinterpret_cast<const float2 *>(a_row);
+#pragma unroll
+    for (int q = 0; q < kWgBlocksPerWave; ++q) { b_cur[q][0] = b_row[q][0]; b_cur[q][1] = b_row[q][1]; }
+#pragma unroll 1
+    for (int row = 0; row < NROW; ++row) {
+      const int rn = (row + 1) & (NROW - 1);          // the wrap-around fetch of the last row is unused
+      const int shift = (rn / TY) * PS + (rn % TY) * HZP - ((row / TY) * PS + (row % TY) * HZP);
+      const float *a_next = a_row + (rn - row) * TZ;
+      const float *b_next[kWgBlocksPerWave];
+#pragma unroll
+      for (int q = 0; q < kWgBlocksPerWave; ++q) b_next[q] = b_row[q] + shift;
+#pragma unroll
+      for (int pi = 0; pi < PPR; ++pi) {
+        float2 a_nxt;
+        float b_nxt[kWgBlocksPerWave][2];
+        if (pi + 1 < PPR) {
+          a_nxt = *reinterpret_cast<const float2 *>(a_row + 4 * (pi + 1));
+#pragma unroll
+          for (int q = 0; q < kWgBlocksPerWave; ++q) { b_nxt[q][0] = b_row[q][4 * (pi + 1)]; b_nxt[q][1] = b_row[q][4 * (pi + 1) + 1]; }
+        } else {
+          a_nxt = *reinterpret_cast<const float2 *>(a_next);
+#pragma unroll
+          for (int q = 0; q < kWgBlocksPerWave; ++q) { b_nxt[q][0] = b_next[q][0]; b_nxt[q][1] = b_next[q][1]; }
+        }
+#pragma unroll
+        for (int q = 0; q < kWgBlocksPerWave; ++q)
+          acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.x, b_cur[q][0], acc[q], 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < kWgBlocksPerWave; ++q)
+          acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.y, b_cur[q][1], acc[q], 0, 0, 0);
+        a_cur = a_nxt;
+#pragma unroll
+        for (int q = 0; q < kWgBlocksPerWave; ++q) { b_cur[q][0] = b_nxt[q][0]; b_cur[q][1] = b_nxt[q][1]; }
+        // issue order: MFMA, LDS read, MFMA, LDS read, ... (8 reads under the first 8 of the 14 MFMAs)
+#pragma unroll
+        for (int g = 0; g < kWgBlocksPerWave + 1; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, kWgBlocksPerWave - 1, 0);
+      }
+      a_row = a_next;
+#pragma unroll
+      for (int q = 0; q < kWgBlocksPerWave; ++q) b_row[q] = b_next[q];
     }
   };
 
@@ -399,8 +466,11 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float *__restri
 
   if constexpr (VEC) {
     // software pipeline: tile t+P's global loads are in flight while tile t's MFMA loop runs
-    constexpr int ROWS2 = kWgCic * HX * HY * 2;
-    for (int r = tid; r < ROWS2; r += 256) xs[(r >> 1) * HZ + ((r & 1) ? HZ - 1 : 0)] = 0.0f;   // z halo: always outside
+    constexpr int ROWS2 = kWgCic * G::ROWS * 2;
+    for (int r = tid; r < ROWS2; r += 256) {   // z halo: always outside the grid (R == TZ)
+      const int row = r >> 1;
+      xs[G::row_offset(row / G::ROWS, (row / HY) % G::HX, row % HY) + ((r & 1) ? kWgZOff + TZ : kWgZOff - 1)] = 0.0f;
+    }
     WgradTileRegs<TX, TY, TZ> regs;
     int t = p, b, x0, y0, z0;
     if (t < tiles_total) {
@@ -411,15 +481,20 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float *__restri
     __syncthreads();
     while (t < tiles_total) {
       const int tn = t + P;
+      // the thread index is made opaque per tile: otherwise the ~60 per-thread load/store addresses are
+      // hoisted out of this loop, stay live across the MFMA loop and push it into a spill-bound schedule
+      int tid_o = tid;
+      asm volatile("" : "+v"(tid_o));
       if (tn < tiles_total) {
         decode(tn, b, x0, y0, z0);
-        regs.load(x, gy, b, c0, co0, Ci, Co, R, x0, y0, tid);
+        regs.load(x, gy, b, c0, co0, Ci, Co, R, x0, y0, tid_o);
       }
       k_loop();
       bias_acc();
       __syncthreads();
       if (tn < tiles_total) {
-        regs.store(gys, xs, tid);
+        asm volatile("" : "+v"(tid_o));
+        regs.store(gys, xs, tid_o);
         __syncthreads();
       }
       t = tn;
@@ -447,7 +522,30 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float *__restri
           gys[(e >> 8) * kGyStride + (e & 255)] = v[u];
         }
       }
-      stage_halo_tile<TX, TY, TZ, kWgCic, false>(xs, x + (size_t)b * Ci * S, c0, Ci, R, x0, y0, z0, tid);
+      // input halo tile, scalar: element e = (c, hx, hy, hz) with hz = 0 <-> z0 - 1 stored at float kWgZOff - 1
+      const float *xb = x + (size_t)b * Ci * S;
+      constexpr int HZ = TZ + 2, NE = kWgCic * G::ROWS * HZ;
+      for (int e0 = 0; e0 < NE; e0 += 256 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int e = e0 + u * 256 + tid;
+          const int row = e / HZ, hz = e - row * HZ;
+          const int c = row / G::ROWS, hx = (row / HY) % G::HX, hy = row % HY;
+          const int gx = x0 + hx - 1, gyy = y0 + hy - 1, gz = z0 + hz - 1;
+          v[u] = 0.0f;
+          if (e < NE && c0 + c < Ci && (unsigned)gx < (unsigned)R && (unsigned)gyy < (unsigned)R && (unsigned)gz < (unsigned)R)
+            v[u] = xb[(size_t)(c0 + c) * S + (size_t)gx * RR + (size_t)gyy * R + gz];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int e = e0 + u * 256 + tid;
+          if (e < NE) {
+            const int row = e / HZ, hz = e - row * HZ;
+            xs[G::row_offset(row / G::ROWS, (row / HY) % G::HX, row % HY) + (kWgZOff - 1) + hz] = v[u];
+          }
+        }
+      }
       __syncthreads();
       k_loop();
       bias_acc();
@@ -462,16 +560,14 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float *__restri
   // ---- partial slab -> workspace[p][co][ci*27 + tap]: lanes = consecutive columns ----
   float *out = part + (size_t)p * Co * Ci * 27;
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
+  for (int q = 0; q < kWgBlocksPerWave; ++q) {
     if (!bval[q]) continue;
-    const int n = (wave + 4 * q) * 32 + j;
+    const int n = (nb0 + q) * 32 + j;
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = co0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        if (co < Co) out[(size_t)co * Ci * 27 + (size_t)c0 * 27 + n] = acc[mb][q][r];
-      }
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+      if (co < Co) out[(size_t)co * Ci * 27 + (size_t)c0 * 27 + n] = acc[q][r];
+    }
   }
 }
 
@@ -480,14 +576,22 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_reduce_kernel(const float *_
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= n) return;
   float s = 0.0f;
-  for (int p = 0; p < P; ++p) s += part[(size_t)p * n + e];
+  int p = 0;
+  for (; p + 8 <= P; p += 8) {          // 8 loads in flight, summed in partition order
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(p + u) * n + e];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; p < P; ++p) s += part[(size_t)p * n + e];
   gw[e] = s;
 }
 
 inline int wgrad_partitions(int B, int Ci, int Co, int tiles_per_cloud) {
   const int tiles_total = B * tiles_per_cloud;
   const int slabs = ceil_div(Ci, kWgCic) * ceil_div(Co, kCoTile);
-  int P = std::max(1, (3 * kNumCU) / slabs);          // ~3 workgroups per CU in the grid
+  int P = std::max(1, kNumCU / slabs);                // one workgroup per CU (LDS) -> one full round
   P = std::min(P, tiles_total);
   while (P > 1 && tiles_total % P) --P;               // equal work per partition
   return P;
@@ -496,8 +600,7 @@ inline int wgrad_partitions(int B, int Ci, int Co, int tiles_per_cloud) {
 template <int TX, int TY, int TZ>
 static int launch_wgrad(const float *x, const float *gy, float *gw, float *gb, float *part, int B, int Ci, int Co, int R,
                         int P, hipStream_t s) {
-  constexpr int HS = (TX + 2) * (TY + 2) * (TZ + 2);
-  const size_t lds = (size_t)(kCoTile * kGyStride + kWgCic * HS) * sizeof(float);
+  const size_t lds = WgradGeom<TX, TY, TZ>::kLdsBytes;
   const int tx = ceil_div(R, TX), ty = ceil_div(R, TY), tz = ceil_div(R, TZ);
   const bool vec = (R == TZ) && aligned16(x) && aligned16(gy);
   auto k = vec ? conv3d_wgrad_kernel<TX, TY, TZ, true> : conv3d_wgrad_kernel<TX, TY, TZ, false>;
