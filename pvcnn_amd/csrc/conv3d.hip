@@ -208,6 +208,14 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(const float *__restri
 
   // ---- epilogue: D[i = co][j = voxel]; lane -> voxel j, register r -> co row ----
   float *yb = y + (size_t)b * Co * R * RR;
+  float bv[2][16];   // this lane's 32 bias values, fetched as one batch (not one dependent load per store)
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+      bv[mb][r] = (bias != nullptr && co < Co) ? bias[co] : 0.0f;
+    }
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb) {
     const int m = wave * 64 + nb * 32 + j;
@@ -220,7 +228,7 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(const float *__restri
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = co0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        if (vok && co < Co) yb[(size_t)co * R * RR + voff] = acc[mb][nb][r] + (bias ? bias[co] : 0.0f);
+        if (vok && co < Co) yb[(size_t)co * R * RR + voff] = acc[mb][nb][r] + bv[mb][r];
       }
   }
 }

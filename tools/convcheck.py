@@ -71,7 +71,7 @@ def graph_time(fn, reps=5, iters=5):
 
 def main():
     torch.manual_seed(0)
-    for (b, ci, co, r) in [(2, 9, 64, 32), (1, 5, 7, 12), (2, 64, 64, 16), (1, 16, 130, 8), (1, 3, 4, 33), (1, 8, 8, 5)]:
+    for (b, ci, co, r) in [] if '--no-check' in sys.argv else [(2, 9, 64, 32), (1, 5, 7, 12), (2, 64, 64, 16), (1, 16, 130, 8), (1, 3, 4, 33), (1, 8, 8, 5)]:
         x = torch.randn(b, ci, r, r, r, device=dev)
         w = torch.randn(co, ci, 3, 3, 3, device=dev) * 0.1
         bias = torch.randn(co, device=dev)
@@ -91,7 +91,10 @@ def main():
         print(json.dumps({'check_BCiCoR': [b, ci, co, r], 'fwd_rel_err': err, 'bwd_data_rel_err': errd, 'bwd_weight_rel_err': errw,
                           'ok': max(err, errd, errw) < 1e-5}), flush=True)
     if '--time' in sys.argv:
-        for (b, ci, co, r) in [(16, 9, 64, 32), (16, 64, 64, 32), (16, 64, 64, 16), (16, 64, 128, 16), (16, 128, 128, 16)]:
+        shapes = [(16, 9, 64, 32), (16, 64, 64, 32), (16, 64, 64, 16), (16, 64, 128, 16), (16, 128, 128, 16)]
+        if '--shapes' in sys.argv:   # e.g. --shapes 16x64x64x16,16x128x128x16
+            shapes = [tuple(int(v) for v in t.split('x')) for t in sys.argv[sys.argv.index('--shapes') + 1].split(',')]
+        for (b, ci, co, r) in shapes:
             x = torch.randn(b, ci, r, r, r, device=dev)
             w = torch.randn(co, ci, 3, 3, 3, device=dev) * 0.1
             bias = torch.randn(co, device=dev)
