@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float *__restri
                                                            int tiles_z, int P) {
   static_assert(TX * TY * TZ == 256, "a workgroup tile is 256 voxels");
   using G = WgradGeom<TX, TY, TZ>;
-  constexpr int HY = G::HY, HZP = G::HZP, PS = G::PS, CS = G::CS;
+  constexpr int HY = G::HY, HZP = G::HZP, PS = G::PS;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *gys = lds;                          // [64][260]
   float *xs = lds + kCoTile * kGyStride;     // [16][HX planes of PS][HY rows of HZP]

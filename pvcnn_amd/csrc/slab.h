@@ -75,14 +75,27 @@ struct TrilinearFromCoords {
   float *wgts;           // (B,8,N) or nullptr
   int N, R, R2;
 
-  __device__ __forceinline__ void setup(float x, float y, float z, Taps<8> &t) const {
+  // Packed form of a point's taps (4 registers instead of 16): base corner + the three fractions.
+  // unpack() evaluates exactly the expressions of setup(), so keeping points packed across channel
+  // slabs and expanding them per slab changes no bit of the result.
+  struct Packed {
+    int32_t i000;
+    float xd1, yd1, zd1;
+  };
+  __device__ __forceinline__ Packed pack(float x, float y, float z) const {
     const float xl = floorf(x), yl = floorf(y), zl = floorf(z);
-    const float xd1 = x - xl, yd1 = y - yl, zd1 = z - zl;
+    Packed pk;
+    pk.xd1 = x - xl; pk.yd1 = y - yl; pk.zd1 = z - zl;
+    pk.i000 = (int)xl * R2 + (int)yl * R + (int)zl;
+    return pk;
+  }
+  __device__ __forceinline__ void unpack(const Packed &pk, Taps<8> &t) const {
+    const float xd1 = pk.xd1, yd1 = pk.yd1, zd1 = pk.zd1;
     const float xd0 = 1.0f - xd1, yd0 = 1.0f - yd1, zd0 = 1.0f - zd1;
     const float w00 = xd0 * yd0, w01 = xd0 * yd1, w10 = xd1 * yd0, w11 = xd1 * yd1;
     t.w[0] = w00 * zd0; t.w[1] = w00 * zd1; t.w[2] = w01 * zd0; t.w[3] = w01 * zd1;
     t.w[4] = w10 * zd0; t.w[5] = w10 * zd1; t.w[6] = w11 * zd0; t.w[7] = w11 * zd1;
-    const int i000 = (int)xl * R2 + (int)yl * R + (int)zl;
+    const int i000 = pk.i000;
     const int zo = (zd1 > 0) ? 1 : 0;
     const int yo = (yd1 > 0) ? R : 0;
     const int xo = (xd1 > 0) ? R2 : 0;
@@ -90,6 +103,17 @@ struct TrilinearFromCoords {
     t.idx[2] = i000 + yo;      t.idx[3] = i000 + yo + zo;
     t.idx[4] = i000 + xo;      t.idx[5] = i000 + xo + zo;
     t.idx[6] = i000 + xo + yo; t.idx[7] = i000 + xo + yo + zo;
+  }
+  __device__ __forceinline__ void setup(float x, float y, float z, Taps<8> &t) const { unpack(pack(x, y, z), t); }
+  __device__ __forceinline__ void pack1(int b, int j, Packed &pk) const {
+    const float *c = coords + (size_t)b * 3 * N;
+    pk = pack(c[j], c[j + N], c[j + 2 * N]);
+  }
+  __device__ __forceinline__ void pack4(int b, int j0, Packed (&pk)[4]) const {
+    const float *c = coords + (size_t)b * 3 * N;
+    const float4 x = ld4(c + j0), y = ld4(c + N + j0), z = ld4(c + 2 * N + j0);
+    pk[0] = pack(x.x, y.x, z.x); pk[1] = pack(x.y, y.y, z.y);
+    pk[2] = pack(x.z, y.z, z.z); pk[3] = pack(x.w, y.w, z.w);
   }
   __device__ __forceinline__ void load1(int b, int j, Taps<8> &t) const {
     const float *c = coords + (size_t)b * 3 * N;
@@ -143,6 +167,10 @@ struct SavedTaps {
       t[0].w[k] = w.x; t[1].w[k] = w.y; t[2].w[k] = w.z; t[3].w[k] = w.w;
     }
   }
+  using Packed = Taps<NC>;   // nothing to compress: the taps are what is kept across channel slabs
+  __device__ __forceinline__ void pack1(int b, int j, Packed &pk) const { load1(b, j, pk); }
+  __device__ __forceinline__ void pack4(int b, int j0, Packed (&pk)[4]) const { load4(b, j0, pk); }
+  __device__ __forceinline__ void unpack(const Packed &pk, Taps<NC> &t) const { t = pk; }
   __device__ __forceinline__ void post1(int, int, const Taps<NC> &) const {}
   __device__ __forceinline__ void post4(int, int, const Taps<NC> (&)[4]) const {}
 };
@@ -162,6 +190,10 @@ struct IndexOnly {
     t[0].idx[0] = i.x; t[1].idx[0] = i.y; t[2].idx[0] = i.z; t[3].idx[0] = i.w;
     t[0].w[0] = t[1].w[0] = t[2].w[0] = t[3].w[0] = 1.0f;
   }
+  using Packed = Taps<NC>;   // nothing to compress: the taps are what is kept across channel slabs
+  __device__ __forceinline__ void pack1(int b, int j, Packed &pk) const { load1(b, j, pk); }
+  __device__ __forceinline__ void pack4(int b, int j0, Packed (&pk)[4]) const { load4(b, j0, pk); }
+  __device__ __forceinline__ void unpack(const Packed &pk, Taps<NC> &t) const { t = pk; }
   __device__ __forceinline__ void post1(int, int, const Taps<1> &) const {}
   __device__ __forceinline__ void post4(int, int, const Taps<1> (&)[4]) const {}
 };
@@ -183,6 +215,10 @@ struct VoxelMean {
     const int4 p = ld4(ind + (size_t)b * N + j0);
     one(b, p.x, t[0]); one(b, p.y, t[1]); one(b, p.z, t[2]); one(b, p.w, t[3]);
   }
+  using Packed = Taps<NC>;   // nothing to compress: the taps are what is kept across channel slabs
+  __device__ __forceinline__ void pack1(int b, int j, Packed &pk) const { load1(b, j, pk); }
+  __device__ __forceinline__ void pack4(int b, int j0, Packed (&pk)[4]) const { load4(b, j0, pk); }
+  __device__ __forceinline__ void unpack(const Packed &pk, Taps<NC> &t) const { t = pk; }
   __device__ __forceinline__ void post1(int, int, const Taps<1> &) const {}
   __device__ __forceinline__ void post4(int, int, const Taps<1> (&)[4]) const {}
 };
@@ -213,36 +249,59 @@ __device__ __forceinline__ void slab_copy(float *dst, const float *src, int tota
   }
 }
 
-template <class P, int VEC, int THREADS>
+// A workgroup walks SEQ consecutive channel slabs of one cloud through the same LDS buffer.  When a
+// thread owns all of its elements in one pass (J <= THREADS*VEC, the usual case) their taps are fetched and
+// packed ONCE and stay in registers for all slabs: coordinates / indices are read from memory once per
+// SEQ*G channels instead of once per slab, and only "stream slab, barrier, LDS gather, store" repeats.
+template <class P, int VEC, int THREADS, bool RESIDENT>
 __global__ __launch_bounds__(THREADS) void gather_lds_kernel(P p, const float *__restrict__ src,
                                                              float *__restrict__ dst, int C, int L,
-                                                             int J, int G) {
+                                                             int J, int G, int SEQ) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int NC = P::NC;
   const int b = blockIdx.y;
-  const int c0 = blockIdx.x * G;
-  const int g = min(G, C - c0);
-  slab_copy<THREADS>(lds, src + ((size_t)b * C + c0) * L, g * L);
-  __syncthreads();
-  float *out = dst + ((size_t)b * C + c0) * J;
   const bool side = (blockIdx.x == 0);
-  for (int j0 = threadIdx.x * VEC; j0 < J; j0 += THREADS * VEC) {
-    Taps<NC> t[VEC];
-    if constexpr (VEC == 4) {
-      p.load4(b, j0, t);
-      if (side) p.post4(b, j0, t);
-    } else {
-      p.load1(b, j0, t[0]);
-      if (side) p.post1(b, j0, t[0]);
+  constexpr bool resident = RESIDENT;                  // J <= THREADS * VEC
+  const int jf = threadIdx.x * VEC;
+  typename P::Packed pk[VEC];
+  if (resident && jf < J) {
+    if constexpr (VEC == 4) p.pack4(b, jf, pk); else p.pack1(b, jf, pk[0]);
+    if (side) {   // side outputs (devoxelize: inds / wgts) once per cloud
+      Taps<NC> t[VEC];
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) p.unpack(pk[v], t[v]);
+      if constexpr (VEC == 4) p.post4(b, jf, t); else p.post1(b, jf, t[0]);
     }
-    for (int c = 0; c < g; ++c) {
-      const float *row = lds + c * L;
-      if constexpr (VEC == 4) {
-        const float r0 = combine<NC, P::kMaySkip>(t[0], row), r1 = combine<NC, P::kMaySkip>(t[1], row);
-        const float r2 = combine<NC, P::kMaySkip>(t[2], row), r3 = combine<NC, P::kMaySkip>(t[3], row);
-        st4(out + (size_t)c * J + j0, r0, r1, r2, r3);
+  }
+  for (int sq = 0; sq < SEQ; ++sq) {
+    const int c0 = (blockIdx.x * SEQ + sq) * G;
+    if (c0 >= C) break;
+    const int g = min(G, C - c0);
+    if (sq > 0) __syncthreads();                       // all reads of the previous slab are done
+    slab_copy<THREADS>(lds, src + ((size_t)b * C + c0) * L, g * L);
+    __syncthreads();
+    float *out = dst + ((size_t)b * C + c0) * J;
+    for (int j0 = jf; j0 < J; j0 += THREADS * VEC) {
+      Taps<NC> t[VEC];
+      if constexpr (resident) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) p.unpack(pk[v], t[v]);
+      } else if constexpr (VEC == 4) {
+        p.load4(b, j0, t);
+        if (side && sq == 0) p.post4(b, j0, t);
       } else {
-        out[(size_t)c * J + j0] = combine<NC, P::kMaySkip>(t[0], row);
+        p.load1(b, j0, t[0]);
+        if (side && sq == 0) p.post1(b, j0, t[0]);
+      }
+      for (int c = 0; c < g; ++c) {
+        const float *row = lds + c * L;
+        if constexpr (VEC == 4) {
+          const float r0 = combine<NC, P::kMaySkip>(t[0], row), r1 = combine<NC, P::kMaySkip>(t[1], row);
+          const float r2 = combine<NC, P::kMaySkip>(t[2], row), r3 = combine<NC, P::kMaySkip>(t[3], row);
+          st4(out + (size_t)c * J + j0, r0, r1, r2, r3);
+        } else {
+          out[(size_t)c * J + j0] = combine<NC, P::kMaySkip>(t[0], row);
+        }
       }
     }
   }
@@ -292,7 +351,8 @@ __global__ __launch_bounds__(256) void scatter_direct_kernel(P p, const float *_
 // ---------------------------------------------------------------------------------------------
 struct SlabPlan {
   bool lds;       // LDS slab path possible
-  int G;          // channel rows per workgroup
+  int G;          // channel rows per slab
+  int seq;        // consecutive slabs one workgroup walks (gather only)
   int threads;    // 256 or 1024
   size_t bytes;   // dynamic LDS bytes
 };
@@ -314,6 +374,11 @@ inline SlabPlan plan_slab(int B, int C, int L) {
   pl.G = G;
   pl.bytes = (size_t)G * row;
   pl.threads = (pl.bytes > 48 * 1024) ? 1024 : 256;
+  // More slabs than the chip holds at once (R = 32: 1024 single-row slabs, one per CU at a time):
+  // let a workgroup walk several in sequence so the per-cloud tap work is paid once per workgroup.
+  const long resident_wgs = (long)kNumCU * std::max<long>(1, (long)(kLdsBytesPerCU / pl.bytes));
+  const long slabs = (long)B * ceil_div(C, G);
+  pl.seq = (int)std::min<long>(8, std::max<long>(1, slabs / resident_wgs));
   return pl;
 }
 
@@ -337,12 +402,12 @@ int launch_gather(const P &p, const float *src, float *dst, int B, int C, int L,
                        p, src, dst, C, L, J, CT);
     return check_launch(what);
   }
-  const dim3 grid(ceil_div(C, pl.G), B);
+  const dim3 grid(ceil_div(ceil_div(C, pl.G), pl.seq), B);
 #define PVCNN_LAUNCH_GATHER(VEC, T)                                                              \
   do {                                                                                           \
-    auto k = gather_lds_kernel<P, VEC, T>;                                                       \
+    auto k = (J <= T * VEC) ? gather_lds_kernel<P, VEC, T, true> : gather_lds_kernel<P, VEC, T, false>; \
     if (int e = enable_big_lds(k, pl.bytes)) { set_error("%s: LDS attribute: %d", what, e); return e; } \
-    hipLaunchKernelGGL(k, grid, dim3(T), pl.bytes, s, p, src, dst, C, L, J, pl.G);               \
+    hipLaunchKernelGGL(k, grid, dim3(T), pl.bytes, s, p, src, dst, C, L, J, pl.G, pl.seq);       \
   } while (0)
   if (pl.threads == 1024) { if (vec_ok) PVCNN_LAUNCH_GATHER(4, 1024); else PVCNN_LAUNCH_GATHER(1, 1024); }
   else                    { if (vec_ok) PVCNN_LAUNCH_GATHER(4, 256);  else PVCNN_LAUNCH_GATHER(1, 256); }
