@@ -10,7 +10,7 @@
 //     ds_add_u32 / ds_read_b32 / ds_write_b32 : >= 4.2 lane-ops/clk/CU
 // So float atomics are avoided altogether.  The entries (e -> key, j, w) do not depend on the
 // channel, hence ONE pass per cloud sorts them by key with INTEGER LDS atomics:
-//   csr_prep_kernel (P workgroups per cloud, each owning a range of the L targets; LDS histogram)
+//   csr_prep_kernel (up to 16 workgroups per cloud, each owning an entry-balanced range of the L targets)
 //       start[t]  exclusive prefix of the per-target counts (L+1 entries)
 //       ent[...]  (j, w) pairs grouped by target, in ASCENDING entry id inside each target
 //                 (a stable rank pass; its work is per entry, so a degenerate key
@@ -122,70 +122,170 @@ struct IndexEntries {
 
 // ---------------------------------------------------------------------------------------------
 // csr_prep_kernel: grid = (P, B), block = 1024.
-// A cloud's sort is instruction-bound on one CU (~250 instructions per entry), so the TARGET RANGE
-// of each cloud is split over P workgroups: workgroup p owns targets [p*LP, (p+1)*LP).  Every
-// workgroup scans all E keys (cheap and redundant) but histograms / places / ranks only the
-// entries whose key is in its range; the global offset of its range is simply the number of
-// entries with a smaller key, counted in the same scan -- so the P workgroups never communicate.
+// A cloud's sort is instruction-bound on one CU (~250 instructions per entry), so the TARGETS of each
+// cloud are split into up to P contiguous ranges, one workgroup each.  Real clouds are anything but
+// uniform (walls and floors put a third of the points into one slice of the grid), so the ranges are
+// balanced by ENTRIES, not by targets: every workgroup first builds the same coarse histogram (256
+// buckets of 2^BS targets, LDS integer atomics), prefix-sums it, and derives the same range table --
+// a new range starts where floor(entries_before / Q) changes, and at every BPM-th bucket so that a
+// range's fine histogram fits LDS.  Workgroup p takes range p (or exits if there are fewer ranges);
+// the global offset of its range (entries with a smaller key) falls out of the same prefix sum, so the
+// P workgroups never communicate.  Every workgroup sweeps all E keys twice (cheap, L2-resident) but
+// histograms / places / ranks only the entries of its own range.
 // ---------------------------------------------------------------------------------------------
-constexpr int kCsrList = 8192;   // in-range entries a workgroup can hold in LDS (list + placement buffer)
+constexpr int kCsrList = 8192;     // in-range entries a workgroup can hold in LDS (list + placement buffer)
+constexpr int kCsrCoarse = 256;    // coarse buckets
+
+struct CsrSplit {
+  int BS;    // log2 of the bucket width (targets)
+  int BPM;   // max buckets per range (fine histogram must fit LDS)
+  int Q;     // entries per range aimed at
+  int P;     // workgroups per cloud (>= number of ranges that can arise)
+  int HP;    // LDS ints reserved for the fine histogram
+};
+
+inline CsrSplit csr_split(int B, int L, int E) {
+  CsrSplit sp{};
+  sp.BS = 0;
+  while (((long)kCsrCoarse << sp.BS) < L) ++sp.BS;
+  const int BW = 1 << sp.BS;
+  sp.BPM = std::max(1, std::min(kCsrCoarse, kCsrMaxRange / BW));
+  const int forced = ceil_div(ceil_div(L, BW), sp.BPM);          // ranges forced by the LDS bound alone
+  // workgroups per cloud: the launch should fit the chip in one round (a workgroup takes most of a CU's LDS)
+  int PT = std::max(1, std::min(16, kNumCU / std::max(B, 1)));
+  PT = std::min(PT, std::max(1, L / 64));
+  PT = std::max(PT, forced);
+  const int P0 = PT - forced + 1;                                // entry-balanced ranges on top of the forced cuts
+  sp.Q = std::max(1, ceil_div(std::max(E, 1), P0));
+  sp.P = PT;                                                      // ranges <= P0 + forced - 1 (bucket 0 is both)
+  sp.HP = pad32(std::min(L, sp.BPM * BW)) + 1;
+  return sp;
+}
 
 template <class EP>
-__global__ __launch_bounds__(kCsrThreads) void csr_prep_kernel(EP ep, int E, int L, int LP, int32_t *__restrict__ cnt_out,
+__global__ __launch_bounds__(kCsrThreads) void csr_prep_kernel(EP ep, int E, int L, CsrSplit sp, int32_t *__restrict__ cnt_out,
                                                               int32_t *__restrict__ start,
                                                               int32_t *__restrict__ tmp_g, int2 *__restrict__ ent) {
-  // LDS: pad32(LP)+1 bins | 32 wave totals | 32 wave counts | 1 list counter (+3 pad) | list_kj[kCsrList] |
-  //      list_key[kCsrList] | tmp[kCsrList]
-  extern __shared__ __attribute__((aligned(16))) int hist[];
+  // LDS: coarse[256] | cpre[257] (+3 pad) | 32 wave totals | 4 range words | list_kj[kCsrList] |
+  //      list_key[kCsrList] | tmp[kCsrList] | fine histogram (pad32 layout, sp.HP ints)
+  extern __shared__ __attribute__((aligned(16))) int csr_lds[];
   const int part = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-  const int lo = part * LP, hi = min(L, lo + LP), nb = hi - lo;
-  const int HP = pad32(LP) + 1;
-  int *wave_tot = hist + HP;
-  int *wave_cnt = hist + HP + 32;
-  int *list_n = hist + HP + 64;
-  int *list_kj = hist + HP + 68;            // packed (k, j): k * PL + j  (fits: E < 2^31)
+  int *coarse = csr_lds;
+  int *cpre = coarse + kCsrCoarse;               // exclusive prefix, cpre[256] = E
+  int *wave_tot = cpre + kCsrCoarse + 4;
+  int *rng = wave_tot + 32;                      // [0] first bucket, [1] end bucket, [2] list counter
+  int *list_n = rng + 2;
+  int *list_kj = rng + 4;                        // packed (k, j): k * PL + j  (fits: E < 2^31)
   int *list_key = list_kj + kCsrList;
   int *tmp_l = list_key + kCsrList;
+  int *hist = tmp_l + kCsrList;
   start += (size_t)b * start_stride(L);
   ent += (size_t)b * E;
   const bool writer = (part == 0);   // side outputs of key_first (avg_voxelize's `ind`) are written once
+  constexpr int kJB = (16 / EP::kPlanes) > 0 ? (16 / EP::kPlanes) : 1;   // elements per thread and sweep step
+  const int PL = ep.plane_len();
+
+  // ---- sweep 1: coarse histogram of ALL entries ----
+  if (tid < kCsrCoarse) coarse[tid] = 0;
+  if (tid == 0) { rng[0] = -1; rng[1] = kCsrCoarse; *list_n = 0; }
+  __syncthreads();
+  // (both sweeps keep kJB * kPlanes independent key loads in flight per thread: a sweep is a handful of
+  //  L2 round trips, not one per plane)
+  for (int j0 = tid; j0 < PL; j0 += kCsrThreads * kJB) {
+    int key[kJB][EP::kPlanes];
+#pragma unroll
+    for (int u = 0; u < kJB; ++u)
+#pragma unroll
+      for (int k = 0; k < EP::kPlanes; ++k) {
+        const int j = j0 + u * kCsrThreads;
+        key[u][k] = (j < PL) ? ep.key_first(b, k, j, writer) : -1;
+      }
+#pragma unroll
+    for (int u = 0; u < kJB; ++u)
+#pragma unroll
+      for (int k = 0; k < EP::kPlanes; ++k)
+        if (key[u][k] >= 0) atomicAdd(&coarse[key[u][k] >> sp.BS], 1);   // ds_add_u32
+  }
+  __syncthreads();
+  // ---- range table (wave 0): prefix sum of the buckets, range id per bucket ----
+  if (tid < kWave) {
+    int c[4], run = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { c[u] = coarse[tid * 4 + u]; run += c[u]; }
+    int incl = run;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+      const int up = __shfl_up(incl, d);
+      if (tid >= d) incl += up;
+    }
+    int ex = incl - run;                          // entries before bucket 4*tid
+    const int prev_last = __shfl_up(ex + run - c[3], 1);   // entries before bucket 4*tid - 1
+    const int emax = max(E - 1, 0);
+    int flag[4], nflag = 0, before_prev = prev_last;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = tid * 4 + u;
+      cpre[i] = ex;
+      // entries-before is clamped to E-1 so that the trailing (entry-free) buckets stay in the last range
+      flag[u] = (i == 0) || (min(ex, emax) / sp.Q != min(before_prev, emax) / sp.Q) || (i % sp.BPM == 0);
+      nflag += flag[u];
+      before_prev = ex;
+      ex += c[u];
+    }
+    if (tid == kWave - 1) cpre[kCsrCoarse] = ex;
+    int fincl = nflag;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+      const int up = __shfl_up(fincl, d);
+      if (tid >= d) fincl += up;
+    }
+    int rid = fincl - nflag - 1;                  // range id of the bucket before 4*tid
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      rid += flag[u];
+      if (flag[u] && rid == part) rng[0] = tid * 4 + u;
+      if (flag[u] && rid == part + 1) rng[1] = tid * 4 + u;
+    }
+  }
+  __syncthreads();
+  const int lo_b = rng[0];
+  if (lo_b < 0) return;                           // fewer ranges than workgroups
+  const int lo = lo_b << sp.BS;
+  if (lo >= L) return;                            // buckets beyond the last target
+  const int hi = min(L, rng[1] << sp.BS), nb = hi - lo;
+  const int base = cpre[lo_b];                    // entries with a key below this range
+  const int HP = pad32(nb) + 1;
 
   for (int i = tid; i < HP; i += kCsrThreads) hist[i] = 0;
-  if (tid == 0) *list_n = 0;
   __syncthreads();
-  // ---- light sweep over ALL entries: count keys below the range, histogram + compact the in-range ones ----
-  constexpr int kBatch = 8;
-  const int PL = ep.plane_len();
-  int below = 0;
-  for (int k = 0; k < EP::kPlanes; ++k)
-    for (int j0 = tid; j0 < PL; j0 += kCsrThreads * kBatch) {
-      int key[kBatch];
+  // ---- sweep 2: fine histogram + compaction of the in-range entries ----
+  for (int j0 = tid; j0 < PL; j0 += kCsrThreads * kJB) {
+    int key[kJB][EP::kPlanes];
 #pragma unroll
-      for (int u = 0; u < kBatch; ++u) {
+    for (int u = 0; u < kJB; ++u)
+#pragma unroll
+      for (int k = 0; k < EP::kPlanes; ++k) {
         const int j = j0 + u * kCsrThreads;
-        key[u] = (j < PL) ? ep.key_first(b, k, j, writer) : 0x7fffffff;
+        key[u][k] = (j < PL) ? ep.key(b, k, j) : 0x7fffffff;
       }
 #pragma unroll
-      for (int u = 0; u < kBatch; ++u) {
-        below += (key[u] < lo) ? 1 : 0;
-        if (key[u] >= lo && key[u] < hi) {
-          atomicAdd(&hist[pad32(key[u] - lo)], 1);   // ds_add_u32
+    for (int u = 0; u < kJB; ++u)
+#pragma unroll
+      for (int k = 0; k < EP::kPlanes; ++k) {
+        const int kv = key[u][k];
+        if (kv >= lo && kv < hi) {
+          atomicAdd(&hist[pad32(kv - lo)], 1);   // ds_add_u32
           const int slot = atomicAdd(list_n, 1);
-          if (slot < kCsrList) { list_kj[slot] = k * PL + (j0 + u * kCsrThreads); list_key[slot] = key[u]; }
+          if (slot < kCsrList) { list_kj[slot] = k * PL + (j0 + u * kCsrThreads); list_key[slot] = kv; }
         }
       }
-    }
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) below += __shfl_xor(below, d);
-  if ((tid & 63) == 0) wave_cnt[tid >> 6] = below;
+  }
   __syncthreads();
-  int base = 0;
-  for (int w = 0; w < kCsrThreads / kWave; ++w) base += wave_cnt[w];
   const int n_in = *list_n;
   if (cnt_out)
     for (int t = tid; t < nb; t += kCsrThreads) cnt_out[(size_t)b * L + lo + t] = hist[pad32(t)];
   // ---- exclusive scan of this range's bins: thread t owns bins [t*per, t*per + per) ----
-  const int per = (LP + kCsrThreads - 1) / kCsrThreads;
+  const int per = (nb + kCsrThreads - 1) / kCsrThreads;
   const int t0 = tid * per;
   int local = 0;
   for (int k = 0; k < per; ++k)
@@ -436,18 +536,13 @@ int launch_csr_scatter(const EP &ep, const float *src, float *dst, int B, int C,
   }
   CsrWorkspace ws;
   ws.carve(workspace, B, L, E);
-  // 1. per-cloud counting sort of the entries, target range split over P workgroups per cloud
-  int P = std::max(1, std::min(16, (2 * kNumCU) / std::max(B, 1)));
-  P = std::min(P, std::max(1, L / 64));
-  P = std::max(P, ceil_div(L, kCsrMaxRange));          // a range's histogram must fit LDS
-  int LP = ceil_div(L, P);
-  LP = (LP + 31) & ~31;
-  P = ceil_div(L, LP);
-  const size_t prep_lds = ((size_t)pad32(LP) + 1 + 68 + 3 * kCsrList) * sizeof(int);
+  // 1. per-cloud counting sort of the entries, targets split into entry-balanced ranges (one workgroup each)
+  const CsrSplit sp = csr_split(B, L, E);
+  const size_t prep_lds = ((size_t)kCsrCoarse * 2 + 4 + 32 + 4 + 3 * kCsrList + sp.HP) * sizeof(int);
   {
     auto k = csr_prep_kernel<EP>;
     if (int e = enable_big_lds(k, prep_lds)) { set_error("%s: LDS attribute: %d", what, e); return e; }
-    hipLaunchKernelGGL(k, dim3(P, B), dim3(kCsrThreads), prep_lds, s, ep, E, L, LP, cnt_out, ws.start, ws.tmp, ws.ent);
+    hipLaunchKernelGGL(k, dim3(sp.P, B), dim3(kCsrThreads), prep_lds, s, ep, E, L, sp, cnt_out, ws.start, ws.tmp, ws.ent);
   }
   if (int e = check_launch(what)) return e;
   if (C == 0) return 0;
