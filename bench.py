@@ -92,7 +92,23 @@ class KernelClock:
             except AttributeError:
                 pass
 
-    def summary(self):
+    @staticmethod
+    def event_pair_overhead_us(pairs=200):
+        """What an (event, event) pair with NOTHING in between reads on a busy stream: the part of every
+        measurement below that is not the kernel.  The pairs are queued behind a long kernel so that, as in
+        the timed steps, the GPU consumes them back to back instead of waiting for the host."""
+        filler = torch.randn(8192, 8192, device='cuda')
+        for _ in range(3):                       # ~30 ms of queued work: far longer than recording the pairs takes
+            filler = (filler @ filler) * 1e-4
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(pairs)]
+        for e0, e1 in evs:
+            e0.record()
+            e1.record()
+        torch.cuda.synchronize()
+        t = sorted(e0.elapsed_time(e1) * 1e3 for e0, e1 in evs)
+        return t[len(t) // 2]
+
+    def summary(self, overhead_us=0.0):
         agg = {}
         for (kernel, nbytes, shape), e0, e1 in self.records:
             k = (kernel, shape)
@@ -102,9 +118,11 @@ class KernelClock:
             a[1] += ms
         out = []
         for (kernel, shape), (calls, ms, nbytes) in sorted(agg.items()):
-            us = ms * 1e3 / calls
+            raw_us = ms * 1e3 / calls
+            us = max(raw_us - overhead_us, 1e-3)
             gbs = nbytes / (us * 1e-6) / 1e9
             out.append({'kernel': kernel, 'shape_BCNR': list(shape), 'calls': calls, 'avg_us': round(us, 2),
+                        'event_pair_us': round(raw_us, 2),
                         'algorithmic_MB': round(nbytes / 1e6, 3), 'achieved_GBs': round(gbs, 1),
                         'frac_of_8TBs': round(gbs / HBM_PEAK_GBS, 4)})
         return out
@@ -219,7 +237,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     final_loss = float(loss)
-    kernels = clock.summary()
+    event_overhead_us = KernelClock.event_pair_overhead_us()
+    kernels = clock.summary(event_overhead_us)
     clock.uninstall()
 
     if rank == 0:
@@ -232,7 +251,11 @@ def main():
                         'shape_BCNR': head['shape_BCNR'], 'achieved': head['achieved_GBs'], 'peak': HBM_PEAK_GBS,
                         'unit': 'GB/s', 'frac': round(head['achieved_GBs'] / HBM_PEAK_GBS, 4),
                         'frac_of_achievable_6300': round(head['achieved_GBs'] / 6300.0, 4),
-                        'avg_us': head['avg_us'], 'algorithmic_MB': head['algorithmic_MB'], 'traffic': None}
+                        'avg_us': head['avg_us'], 'event_pair_us': head['event_pair_us'],
+                        'event_overhead_us': round(event_overhead_us, 2),
+                        'timing': 'HIP events around every launch inside the timed steps, on the launch stream; '
+                                  'avg_us = mean event-pair time - the time an empty event pair reads on a busy stream',
+                        'algorithmic_MB': head['algorithmic_MB'], 'traffic': None}
             if head['shape_BCNR'] == [16, 64, 4096, 32]:
                 # HBM bytes per launch from rocprofv3 PMC passes on this kernel and shape (separate runs:
                 # FETCH_SIZE 68642 KiB, doubled per MI355X_MICROARCH.md for gfx950; WRITE_SIZE 20480 KiB)
