@@ -44,6 +44,10 @@ SIGNATURES = {
     'pvcnn_conv3d_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     'pvcnn_conv3d_bwd_weight_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'pvcnn_conv3d_bwd_weight': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    'pvcnn_pwconv_transpose': (_i, [_vp, _i, _i, _vp, _vp]),
+    'pvcnn_pwconv_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    'pvcnn_pwconv_bwd_weight_workspace_bytes': (_sz, [_i, _i, _i, _i]),
+    'pvcnn_pwconv_bwd_weight': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     'pvcnn_bnact_workspace_bytes': (_sz, [_i, _i, _i]),
     'pvcnn_bnact_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _f, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     'pvcnn_bnact_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _sz, _vp]),

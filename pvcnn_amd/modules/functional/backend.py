@@ -313,6 +313,47 @@ class HipBackend:
         return (gw, gb) if with_bias else gw
 
 
+    # ---- SharedMLP 1x1 convolutions as channel-major MFMA GEMMs (csrc/pointwise.hip) --------------------
+    has_pwconv = True
+
+    def pwconv_forward(self, x, weight, bias):
+        """x (B,Ci,N), weight (Co,Ci), bias (Co) or None -> y (B,Co,N)."""
+        _f32(x, 'x'); _f32(weight, 'weight')
+        _shape(x.dim() == 3 and weight.dim() == 2 and weight.shape[1] == x.shape[1], 'pwconv: x (B,Ci,N), weight (Co,Ci) expected')
+        if bias is not None:
+            _f32(bias, 'bias')
+        b, ci, n = x.shape
+        co = weight.shape[0]
+        wt = torch.empty((ci, co), dtype=torch.float32, device=x.device)
+        y = torch.empty((b, co, n), dtype=torch.float32, device=x.device)
+        with _Launch(x) as s:
+            _lib.check(self.lib.pvcnn_pwconv_transpose(_p(weight), co, ci, _p(wt), s), 'pwconv_transpose')
+            _lib.check(self.lib.pvcnn_pwconv_fwd(_p(x), _p(wt), _p(bias) if bias is not None else None, b, ci, co, n, _p(y), s), 'pwconv_forward')
+        return y
+
+    def pwconv_backward_data(self, grad_y, weight):
+        """grad_y (B,Co,N), weight (Co,Ci) -> grad_x (B,Ci,N): the forward GEMM with K = Co on the weight as stored."""
+        _f32(grad_y, 'grad_y'); _f32(weight, 'weight')
+        b, co, n = grad_y.shape
+        ci = weight.shape[1]
+        gx = torch.empty((b, ci, n), dtype=torch.float32, device=grad_y.device)
+        with _Launch(grad_y) as s:
+            _lib.check(self.lib.pvcnn_pwconv_fwd(_p(grad_y), _p(weight), None, b, co, ci, n, _p(gx), s), 'pwconv_backward_data')
+        return gx
+
+    def pwconv_backward_weight(self, x, grad_y, with_bias=False):
+        """-> grad_weight (Co,Ci), or (grad_weight, grad_bias) when with_bias."""
+        _f32(x, 'x'); _f32(grad_y, 'grad_y')
+        b, ci, n = x.shape
+        co = grad_y.shape[1]
+        gw = torch.empty((co, ci), dtype=torch.float32, device=x.device)
+        gb = torch.empty((co,), dtype=torch.float32, device=x.device) if with_bias else None
+        ws = self._scratch(self.lib.pvcnn_pwconv_bwd_weight_workspace_bytes(b, ci, co, n), x.device)
+        with _Launch(x) as s:
+            _lib.check(self.lib.pvcnn_pwconv_bwd_weight(_p(x), _p(grad_y), b, ci, co, n, _p(gw), _p(gb) if with_bias else None,
+                                                        _p(ws), ws.numel(), s), 'pwconv_backward_weight')
+        return (gw, gb) if with_bias else gw
+
     # ---- BatchNorm + ReLU/LeakyReLU in two passes each way (csrc/bnact.hip) ---------------------------
     has_bnact = True
 

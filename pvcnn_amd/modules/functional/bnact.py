@@ -59,14 +59,28 @@ def _slope(act):
     return None
 
 
+def _is_pointwise(m):
+    """kernel-size-1, stride-1, unpadded, ungrouped Conv1d / Conv2d: the SharedMLP convolutions."""
+    return (isinstance(m, (nn.Conv1d, nn.Conv2d)) and all(k == 1 for k in m.kernel_size) and all(v == 1 for v in m.stride)
+            and all(v == 0 for v in m.padding) and all(v == 1 for v in m.dilation) and m.groups == 1
+            and isinstance(m.padding, tuple))
+
+
 def run_layers(layers, x):
-    """nn.Sequential.forward with (BatchNorm, ReLU|LeakyReLU) pairs fused on the GPU path."""
+    """nn.Sequential.forward with the GPU path's own kernels: 1x1 convolutions as channel-major MFMA GEMMs,
+    (BatchNorm, ReLU|LeakyReLU) pairs fused."""
     mods = list(layers)
     fuse = x.is_cuda and getattr(native(), 'has_bnact', False)
+    pw = x.is_cuda and getattr(native(), 'has_pwconv', False)
     i = 0
     while i < len(mods):
         m = mods[i]
-        if (fuse and isinstance(m, nn.modules.batchnorm._BatchNorm) and i + 1 < len(mods) and x.dim() >= 3
+        if (pw and _is_pointwise(m) and x.dtype == torch.float32 and x.dim() == len(m.kernel_size) + 2 and x.numel() > 0
+                and not torch.is_autocast_enabled()):
+            from .pwconv import pointwise_conv
+            x = pointwise_conv(x, m.weight, m.bias)
+            i += 1
+        elif (fuse and isinstance(m, nn.modules.batchnorm._BatchNorm) and i + 1 < len(mods) and x.dim() >= 3
                 and x.dtype == torch.float32 and _slope(mods[i + 1]) is not None and x.numel() > 0):
             x = batch_norm_act(x, m, _slope(mods[i + 1]))
             i += 2

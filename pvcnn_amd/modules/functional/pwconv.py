@@ -1,0 +1,42 @@
+"""pointwise_conv: the kernel-size-1 Conv1d / Conv2d of SharedMLP (reference: modules/shared_mlp.py:9-25).
+
+The reference calls nn.Conv1d / nn.Conv2d (cuDNN / cuBLAS).  On gfx950 the three GEMMs (forward,
+backward-data, backward-weight + bias gradient) run on the fp32-MFMA kernels of csrc/pointwise.hip, directly
+on the channel-major (B, C, N) tensors."""
+from torch.autograd import Function
+
+from ._autograd import native, amp_fwd, amp_bwd
+
+__all__ = ['pointwise_conv']
+
+
+class PointwiseConv(Function):
+    @staticmethod
+    @amp_fwd
+    def forward(ctx, x, weight, bias):
+        shape = x.shape
+        x3 = x.contiguous().view(shape[0], shape[1], -1)
+        w2 = weight.contiguous().view(weight.shape[0], weight.shape[1])
+        ctx.save_for_backward(x3, w2)
+        ctx.has_bias, ctx.x_shape, ctx.w_shape = bias is not None, shape, weight.shape
+        y = native().pwconv_forward(x3, w2, bias.contiguous() if bias is not None else None)
+        return y.view(shape[0], w2.shape[0], *shape[2:])
+
+    @staticmethod
+    @amp_bwd
+    def backward(ctx, grad_y):
+        x3, w2 = ctx.saved_tensors
+        g3 = grad_y.contiguous().view(x3.shape[0], w2.shape[0], -1)
+        gx = native().pwconv_backward_data(g3, w2).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
+        want_bias = ctx.has_bias and ctx.needs_input_grad[2]
+        gw = gb = None
+        if ctx.needs_input_grad[1]:
+            res = native().pwconv_backward_weight(x3, g3, with_bias=want_bias)
+            gw, gb = res if want_bias else (res, None)
+            gw = gw.view(ctx.w_shape)
+        elif want_bias:
+            gb = g3.sum(dim=(0, 2))
+        return gx, gw, gb
+
+
+pointwise_conv = PointwiseConv.apply

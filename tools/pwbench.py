@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Speed of the 1x1-convolution GEMM kernels (csrc/pointwise.hip) at PVCNN's SharedMLP shapes, next to torch."""
+import json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import torch.nn.functional as F
+from pvcnn_amd.modules.functional.backend import HipBackend
+
+be = HipBackend()
+dev = 'cuda:0'
+
+
+def t(fn, n=10):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+shapes = [(16, 9, 64, 4096), (16, 64, 64, 4096), (16, 64, 128, 4096), (16, 128, 1024, 4096), (16, 1472, 512, 4096), (16, 512, 256, 4096)]
+if '--shapes' in sys.argv:
+    shapes = [tuple(int(v) for v in s.split('x')) for s in sys.argv[sys.argv.index('--shapes') + 1].split(',')]
+for (b, ci, co, n) in shapes:
+    x = torch.randn(b, ci, n, device=dev)
+    w = torch.randn(co, ci, device=dev) * 0.1
+    bias = torch.randn(co, device=dev)
+    gy = torch.randn(b, co, n, device=dev)
+    fl = 2.0 * b * n * ci * co
+    f = t(lambda: be.pwconv_forward(x, w, bias))
+    d = t(lambda: be.pwconv_backward_data(gy, w))
+    g = t(lambda: be.pwconv_backward_weight(x, gy, with_bias=True))
+    w3 = w.view(co, ci, 1).clone().requires_grad_()
+    x3 = x.clone().requires_grad_()
+    tf = t(lambda: F.conv1d(x, w3, bias))
+    y = F.conv1d(x3, w3, bias)
+    tb = t(lambda: torch.autograd.grad(y, (x3, w3), gy, retain_graph=True))
+    print(json.dumps({'BCiCoN': [b, ci, co, n], 'GF': round(fl / 1e9, 1), 'fwd_ms': round(f, 4), 'fwd_TF': round(fl / f / 1e9, 1),
+                      'bwd_data_ms': round(d, 4), 'bwd_data_TF': round(fl / d / 1e9, 1), 'bwd_w_ms': round(g, 4),
+                      'bwd_w_TF': round(fl / g / 1e9, 1), 'torch_fwd_ms': round(tf, 4), 'torch_bwd_both_ms': round(tb, 4)}), flush=True)
