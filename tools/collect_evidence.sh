@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 (cd $R && timeout 900 python bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/bench.json)
 # 2. kernel trace of the same command (no cpu baseline) -> stats + steady-state reduction
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_under_rocprof.log 2>&1
-tail -1 $O/bench_under_rocprof.log | cut -c1-3000 > $O/bench_under_rocprof.json
+grep "^{\"metric\"" $O/bench_under_rocprof.log | tail -1 > $O/bench_under_rocprof.json
 f=$(find /tmp/kt -name "*kernel_stats.csv" | head -1); head -60 $f > $O/bench_kernel_stats.csv
 t=$(find /tmp/kt -name "*kernel_trace.csv" | head -1); python $R/tools/trace_steady.py $t 20 60 > $O/bench_steady_state.txt
 # 3. PMC passes (separate), op-level shape of the headline kernel
