@@ -334,6 +334,106 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Backward-weight for SMALL layers (M*K <= 128*128, e.g. the 9->64 / 64->64 / 64->128 point branches of PVConv):
+// a 128 x 128 tile would be mostly padding there.  grid = (ceil(K/64), P, ceil(M/64)); a workgroup owns a
+// 64 x 64 tile of gW and stages 64-point chunks; its 4 waves split the chunk's POINTS (16 each) and each
+// keeps its own 2 x 2 accumulator tiles -- they leave as 4 separate partials (index 4p + wave), so the waves
+// never have to add their tiles together; pw_reduce_kernel sums 4P partials.
+// ---------------------------------------------------------------------------------------------
+constexpr int kPwSmT = 64;      // gW tile edge
+constexpr int kPwSmC = 64;      // points per chunk (16 per wave)
+constexpr int kPwSmS = 68;      // LDS row stride (floats)
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void pw_wgrad_small_kernel(
+    const float *__restrict__ x, const float *__restrict__ gy, float *__restrict__ part, float *__restrict__ bias_part, int B,
+    int K, int M, int N, int chunks_per_cloud, int P) {
+  __shared__ __attribute__((aligned(16))) float gys[kPwSmT * kPwSmS];
+  __shared__ __attribute__((aligned(16))) float xs[kPwSmT * kPwSmS];
+  const int k0 = blockIdx.x * kPwSmT, p = blockIdx.y, m0 = blockIdx.z * kPwSmT;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, kh = lane >> 5;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.0f;
+
+  const float *a0 = gys + j * kPwSmS + wave * 16 + 2 * kh, *a1 = a0 + 32 * kPwSmS;
+  const float *b0 = xs + j * kPwSmS + wave * 16 + 2 * kh, *b1 = b0 + 32 * kPwSmS;
+  const bool do_bias = bias_part != nullptr && blockIdx.x == 0;
+  float bsum = 0.0f;
+  const int chunks_total = B * chunks_per_cloud;
+
+  // 64 rows x 16 quads = 1024 quads per operand, 4 + 4 per thread; N % 64 == 0 on this kernel (launcher)
+  float4 g[4], v[4];
+  auto load_chunk = [&](int ch, int t) {
+    const int b = ch / chunks_per_cloud, n0 = (ch - b * chunks_per_cloud) * kPwSmC;
+    const float *gyb = gy + (size_t)b * M * N, *xb = x + (size_t)b * K * N;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int q = t + it * 256;
+      const int row = q >> 4, n = n0 + (q & 15) * 4;
+      g[it] = pw_ld4(gyb + (size_t)min(m0 + row, M - 1) * N + n);
+      v[it] = pw_ld4(xb + (size_t)min(k0 + row, K - 1) * N + n);
+    }
+  };
+  load_chunk(p, tid);
+  for (int ch = p; ch < chunks_total; ch += P) {
+    __syncthreads();
+    int t = tid;
+    asm volatile("" : "+v"(t));
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int q = t + it * 256;
+      *reinterpret_cast<float4 *>(gys + (q >> 4) * kPwSmS + (q & 15) * 4) = g[it];
+      *reinterpret_cast<float4 *>(xs + (q >> 4) * kPwSmS + (q & 15) * 4) = v[it];
+    }
+    __syncthreads();
+    if (ch + P < chunks_total) load_chunk(ch + P, t);
+#pragma unroll
+    for (int pr = 0; pr < 4; ++pr) {
+      const float2 av0 = *reinterpret_cast<const float2 *>(a0 + 4 * pr), av1 = *reinterpret_cast<const float2 *>(a1 + 4 * pr);
+      const float2 bw0 = *reinterpret_cast<const float2 *>(b0 + 4 * pr), bw1 = *reinterpret_cast<const float2 *>(b1 + 4 * pr);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0.x, bw0.x, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0.x, bw1.x, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1.x, bw0.x, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1.x, bw1.x, acc[1][1], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0.y, bw0.y, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0.y, bw1.y, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1.y, bw0.y, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1.y, bw1.y, acc[1][1], 0, 0, 0);
+    }
+    if (do_bias) {                                         // 4 threads per gy row, 16 points each
+      const float *rowp = gys + (tid >> 2) * kPwSmS + (tid & 3) * 16;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) bsum += rowp[i];
+    }
+  }
+  if (do_bias) {
+    bsum += __shfl_xor(bsum, 1);
+    bsum += __shfl_xor(bsum, 2);
+    const int m = m0 + (tid >> 2);
+    if ((tid & 3) == 0 && m < M) bias_part[(size_t)p * M + m] = bsum;
+  }
+  float *out = part + (size_t)(p * 4 + wave) * M * K;
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    const int k = k0 + nb * 32 + j;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        float val;
+        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(val) : "a"(acc[mb][nb][r]));
+        if (m < M && k < K) out[(size_t)m * K + k] = val;
+      }
+  }
+}
+
 __global__ __launch_bounds__(256) void pw_reduce_kernel(const float *__restrict__ part, int n, int P, float *__restrict__ out) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= n) return;
@@ -350,7 +450,18 @@ __global__ __launch_bounds__(256) void pw_reduce_kernel(const float *__restrict_
   out[e] = s;
 }
 
+inline bool pw_wgrad_small(int K, int M, int N) { return (long)M * K <= 128L * 128L && N % kPwSmC == 0; }
+
+// partitions of the point range; the small-layer kernel produces 4 partial tiles per partition (one per wave)
 inline int pw_wgrad_partitions(int B, int K, int M, int N) {
+  if (pw_wgrad_small(K, M, N)) {
+    const int tiles = ceil_div(K, kPwSmT) * ceil_div(M, kPwSmT);
+    const long chunks = (long)B * (N / kPwSmC);
+    long P = std::max<long>(1, (2L * kNumCU) / tiles);
+    P = std::min<long>(P, std::max<long>(1, chunks / 2));   // >= 2 chunks per workgroup: the pipeline needs a next one
+    P = std::min<long>(P, 128);
+    return (int)P;
+  }
   const int tiles = ceil_div(K, kPwWgT) * ceil_div(M, kPwWgT);
   const long chunks = (long)B * ceil_div(N, kPwWgC);
   long P = std::max<long>(1, (2L * kNumCU) / tiles);      // ~2 workgroups per CU in the launch
@@ -398,7 +509,8 @@ extern "C" int pvcnn_pwconv_fwd(const float *x, const float *wt, const float *bi
 extern "C" size_t pvcnn_pwconv_bwd_weight_workspace_bytes(int B, int K, int M, int N) {
   if (B <= 0 || K <= 0 || M <= 0 || N <= 0) return 16;
   const size_t P = (size_t)pw_wgrad_partitions(B, K, M, N);
-  return P * M * K * sizeof(float) + P * M * sizeof(float) + 16;
+  const size_t tiles_per_p = pw_wgrad_small(K, M, N) ? 4 : 1;
+  return P * tiles_per_p * M * K * sizeof(float) + P * M * sizeof(float) + 16;
 }
 
 extern "C" int pvcnn_pwconv_bwd_weight(const float *x, const float *grad_y, int B, int K, int M, int N, float *grad_w,
@@ -416,16 +528,23 @@ extern "C" int pvcnn_pwconv_bwd_weight(const float *x, const float *grad_y, int 
   PVCNN_REQUIRE(workspace && aligned16(workspace) && workspace_bytes >= pvcnn_pwconv_bwd_weight_workspace_bytes(B, K, M, N),
                 "workspace missing, misaligned or too small (see pvcnn_pwconv_bwd_weight_workspace_bytes)");
   const int P = pw_wgrad_partitions(B, K, M, N);
+  const bool small = pw_wgrad_small(K, M, N) && aligned16(x) && aligned16(grad_y);
+  const int PT = small ? 4 * P : P;                         // partial tiles to reduce
   float *part = static_cast<float *>(workspace);
-  float *bias_part = grad_bias ? part + (size_t)P * M * K : nullptr;
-  const dim3 grid(ceil_div(K, kPwWgT), P, ceil_div(M, kPwWgT));
-  const bool vec = (N % kPwWgC == 0) && aligned16(x) && aligned16(grad_y);   // whole chunks, 16-byte rows
-  const int cpc = ceil_div(N, kPwWgC);
-  if (vec) hipLaunchKernelGGL(pw_wgrad_kernel<true>, grid, dim3(256), 0, s, x, grad_y, part, bias_part, B, K, M, N, cpc, P);
-  else     hipLaunchKernelGGL(pw_wgrad_kernel<false>, grid, dim3(256), 0, s, x, grad_y, part, bias_part, B, K, M, N, cpc, P);
+  float *bias_part = grad_bias ? part + (size_t)(pw_wgrad_small(K, M, N) ? 4 : 1) * P * M * K : nullptr;
+  if (small) {
+    const dim3 grid(ceil_div(K, kPwSmT), P, ceil_div(M, kPwSmT));
+    hipLaunchKernelGGL(pw_wgrad_small_kernel, grid, dim3(256), 0, s, x, grad_y, part, bias_part, B, K, M, N, N / kPwSmC, P);
+  } else {
+    const dim3 grid(ceil_div(K, kPwWgT), P, ceil_div(M, kPwWgT));
+    const bool vec = (N % kPwWgC == 0) && aligned16(x) && aligned16(grad_y);   // whole chunks, 16-byte rows
+    const int cpc = ceil_div(N, kPwWgC);
+    if (vec) hipLaunchKernelGGL(pw_wgrad_kernel<true>, grid, dim3(256), 0, s, x, grad_y, part, bias_part, B, K, M, N, cpc, P);
+    else     hipLaunchKernelGGL(pw_wgrad_kernel<false>, grid, dim3(256), 0, s, x, grad_y, part, bias_part, B, K, M, N, cpc, P);
+  }
   if (int rc = check_launch("pwconv_wgrad")) return rc;
   const int n = M * K;
-  hipLaunchKernelGGL(pw_reduce_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, part, n, P, grad_w);
+  hipLaunchKernelGGL(pw_reduce_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, part, n, PT, grad_w);
   if (int rc = check_launch("pwconv_wgrad_reduce")) return rc;
   if (grad_bias) {
     hipLaunchKernelGGL(pw_reduce_kernel, dim3(ceil_div(M, 256)), dim3(256), 0, s, bias_part, M, P, grad_bias);
