@@ -105,11 +105,13 @@ __device__ __forceinline__ void stage_halo_tile(float *xs, const float *xb, int 
   }
 }
 
-template <int TX, int TY, int TZ, int CIC, bool VEC>
+// NBW = MFMA column blocks (32 voxels) per wave: 2 -> a 256-voxel workgroup tile, 1 -> a 128-voxel tile (twice
+// the workgroups: used when a 256-voxel grid would leave the chip with about one workgroup per CU).
+template <int TX, int TY, int TZ, int CIC, bool VEC, int NBW>
 __global__ __launch_bounds__(256) void conv3d_igemm_kernel(const float *__restrict__ x, const float *__restrict__ wt,
                                                            const float *__restrict__ bias, float *__restrict__ y,
                                                            int Ci, int Co, int R, int tiles_x, int tiles_y, int tiles_z) {
-  static_assert(TX * TY * TZ == 256, "a workgroup tile is 256 voxels");
+  static_assert(TX * TY * TZ == 128 * NBW, "a workgroup tile is 4 waves x NBW x 32 voxels");
   static_assert(CIC % 2 == 0, "channels are consumed in pairs (MFMA K = 2)");
   constexpr int HX = TX + 2, HY = TY + 2, HZ = TZ + 2, HS = HX * HY * HZ;
   constexpr int WS = 27 * kCoTile;
@@ -127,20 +129,20 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(const float *__restri
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, kh = lane >> 5;
   const size_t RR = (size_t)R * R;
 
-  int hb[2];   // LDS offset of this lane's voxel (N-block 0/1) incl. the k-half channel offset
+  int hb[NBW];   // LDS offset of this lane's voxel (N-block 0/1) incl. the k-half channel offset
 #pragma unroll
-  for (int nb = 0; nb < 2; ++nb) {
-    const int m = wave * 64 + nb * 32 + j;
+  for (int nb = 0; nb < NBW; ++nb) {
+    const int m = wave * 32 * NBW + nb * 32 + j;
     const int zt = m % TZ, yt = (m / TZ) % TY, xt = m / (TZ * TY);
     hb[nb] = (xt * HY + yt) * HZ + zt + kh * HS;
   }
   const int a_off = kh * WS + j;
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][NBW];
 #pragma unroll
   for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
+    for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.0f;
 
@@ -195,51 +197,59 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(const float *__restri
         for (int cc = 0; cc < CIC; cc += 2) {
           const float a0 = ws[cc * WS + tap * kCoTile + a_off];
           const float a1 = ws[cc * WS + tap * kCoTile + a_off + 32];
-          const float b0 = xs[cc * HS + hb[0] + toff_xy + dz];
-          const float b1 = xs[cc * HS + hb[1] + toff_xy + dz];
-          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-          acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-          acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+#pragma unroll
+          for (int nb = 0; nb < NBW; ++nb) {
+            const float bv_ = xs[cc * HS + hb[nb] + toff_xy + dz];
+            acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv_, acc[0][nb], 0, 0, 0);
+            acc[1][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv_, acc[1][nb], 0, 0, 0);
+          }
         }
       }
     }
   }
 
   // ---- epilogue: D[i = co][j = voxel]; lane -> voxel j, register r -> co row ----
+  // One 32-row block at a time: its 16 bias values as one batch of loads, and every accumulator fetched from
+  // its AGPR at the point of use (left to the compiler, all 64 are copied to VGPRs in one block at the loop
+  // exit and the kernel drops from 3 to 2 waves per SIMD).
   float *yb = y + (size_t)b * Co * R * RR;
-  float bv[2][16];   // this lane's 32 bias values, fetched as one batch (not one dependent load per store)
+  size_t voff[NBW];
+  bool vok[NBW];
 #pragma unroll
-  for (int mb = 0; mb < 2; ++mb)
+  for (int nb = 0; nb < NBW; ++nb) {
+    const int m = wave * 32 * NBW + nb * 32 + j;
+    const int zt = m % TZ, yt = (m / TZ) % TY, xt = m / (TZ * TY);
+    const int gx = x0 + xt, gy = y0 + yt, gz = z0 + zt;
+    vok[nb] = gx < R && gy < R && gz < R;
+    voff[nb] = (size_t)gx * RR + (size_t)gy * R + gz;
+  }
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb) {
+    float bv[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = co0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-      bv[mb][r] = (bias != nullptr && co < Co) ? bias[co] : 0.0f;
+      bv[r] = (bias != nullptr && co < Co) ? bias[co] : 0.0f;
     }
 #pragma unroll
-  for (int nb = 0; nb < 2; ++nb) {
-    const int m = wave * 64 + nb * 32 + j;
-    const int zt = m % TZ, yt = (m / TZ) % TY, xt = m / (TZ * TY);
-    const int gx = x0 + xt, gy = y0 + yt, gz = z0 + zt;
-    const bool vok = gx < R && gy < R && gz < R;
-    const size_t voff = (size_t)gx * RR + (size_t)gy * R + gz;
-#pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
+    for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = co0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        if (vok && co < Co) yb[(size_t)co * R * RR + voff] = acc[mb][nb][r] + bv[mb][r];
+        float v;
+        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(acc[mb][nb][r]));
+        if (vok[nb] && co < Co) yb[(size_t)co * R * RR + voff[nb]] = v + bv[r];
       }
   }
 }
 
-template <int TX, int TY, int TZ, int CIC, bool VEC>
+template <int TX, int TY, int TZ, int CIC, bool VEC, int NBW>
 static int launch_igemm_v(const float *x, const float *wt, const float *bias, float *y, int B, int Ci, int Co, int R,
                           hipStream_t s) {
   constexpr int HS = (TX + 2) * (TY + 2) * (TZ + 2);
   const size_t lds = (size_t)(CIC * HS + CIC * 27 * kCoTile) * sizeof(float);
   const int tx = ceil_div(R, TX), ty = ceil_div(R, TY), tz = ceil_div(R, TZ);
-  auto k = conv3d_igemm_kernel<TX, TY, TZ, CIC, VEC>;
+  auto k = conv3d_igemm_kernel<TX, TY, TZ, CIC, VEC, NBW>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { set_error("conv3d: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
@@ -249,13 +259,13 @@ static int launch_igemm_v(const float *x, const float *wt, const float *bias, fl
   return check_launch("conv3d_igemm");
 }
 
-template <int TX, int TY, int TZ, int CIC>
+template <int TX, int TY, int TZ, int CIC, int NBW = 2>
 static int launch_igemm(const float *x, const float *wt, const float *bias, float *y, int B, int Ci, int Co, int R,
                         hipStream_t s) {
   // vector staging needs full aligned z-rows (R == TZ) and whole 64-wide, 16-byte aligned co tiles
   const bool vec = (R == TZ) && (Co % kCoTile == 0) && aligned16(x) && aligned16(wt);
-  return vec ? launch_igemm_v<TX, TY, TZ, CIC, true>(x, wt, bias, y, B, Ci, Co, R, s)
-             : launch_igemm_v<TX, TY, TZ, CIC, false>(x, wt, bias, y, B, Ci, Co, R, s);
+  return vec ? launch_igemm_v<TX, TY, TZ, CIC, true, NBW>(x, wt, bias, y, B, Ci, Co, R, s)
+             : launch_igemm_v<TX, TY, TZ, CIC, false, NBW>(x, wt, bias, y, B, Ci, Co, R, s);
 }
 
 
@@ -653,7 +663,12 @@ extern "C" int pvcnn_conv3d_fwd(const float *x, const float *wt, const float *bi
   PVCNN_REQUIRE((long)R * R * R * (long)std::max(Ci, Co) <= 0x7fffffffL, "grid too large");
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (R > 16) return launch_igemm<2, 4, 32, 4>(x, wt, bias, y, B, Ci, Co, R, s);
-  if (R > 8)  return launch_igemm<4, 4, 16, 4>(x, wt, bias, y, B, Ci, Co, R, s);
+  if (R > 8) {
+    // 256-voxel tiles would give this launch fewer than ~2 workgroups per CU: halve the tile instead
+    const long wgs256 = (long)B * ceil_div(R, 4) * ceil_div(R, 4) * ceil_div(R, 16) * ceil_div(Co, kCoTile);
+    if (wgs256 < 2L * kNumCU) return launch_igemm<2, 4, 16, 4, 1>(x, wt, bias, y, B, Ci, Co, R, s);
+    return launch_igemm<4, 4, 16, 4>(x, wt, bias, y, B, Ci, Co, R, s);
+  }
   return launch_igemm<4, 8, 8, 4>(x, wt, bias, y, B, Ci, Co, R, s);
 }
 
