@@ -61,6 +61,10 @@ class KernelClock:
         'trilinear_devoxelize_forward': lambda a, out: ('trilinear_devoxelize_fwd',
                                                         bytes_devox_fwd(a[3].shape[0], a[3].shape[1], a[2].shape[2], int(a[0]) ** 3, bool(a[1])),
                                                         (a[3].shape[0], a[3].shape[1], a[2].shape[2], int(a[0]))),
+        # the same gather with BatchNorm + LeakyReLU applied while the grid is staged (same argument positions)
+        'trilinear_devoxelize_bnact_forward': lambda a, out: ('trilinear_devoxelize_fwd',
+                                                              bytes_devox_fwd(a[3].shape[0], a[3].shape[1], a[2].shape[2], int(a[0]) ** 3, bool(a[1])),
+                                                              (a[3].shape[0], a[3].shape[1], a[2].shape[2], int(a[0]))),
         'trilinear_devoxelize_backward': lambda a, out: ('trilinear_devoxelize_bwd',
                                                          bytes_devox_bwd(a[0].shape[0], a[0].shape[1], a[0].shape[2], int(a[3]) ** 3),
                                                          (a[0].shape[0], a[0].shape[1], a[0].shape[2], int(a[3]))),
@@ -247,7 +251,7 @@ def main():
             kk['shape_BCNR'][3] for kk in kernels if kk['kernel'] == 'trilinear_devoxelize_fwd')), None)
         roofline = None
         if head:
-            roofline = {'bound': 'hbm', 'kernel': 'trilinear_devoxelize_fwd (gather_lds_kernel<TrilinearFromCoords>)',
+            roofline = {'bound': 'hbm', 'kernel': 'trilinear_devoxelize_fwd (gather_lds_kernel<TrilinearFromCoords>; BatchNorm+LeakyReLU fused into its LDS staging inside PVConv)',
                         'shape_BCNR': head['shape_BCNR'], 'achieved': head['achieved_GBs'], 'peak': HBM_PEAK_GBS,
                         'unit': 'GB/s', 'frac': round(head['achieved_GBs'] / HBM_PEAK_GBS, 4),
                         'frac_of_achievable_6300': round(head['achieved_GBs'] / 6300.0, 4),

@@ -202,6 +202,18 @@ PVCNN_API int pvcnn_bnact_fwd(const float *x, const float *gamma, const float *b
                               float *running_var, int B, int C, int S, float eps, float momentum, float slope,
                               int training, float *mean, float *rstd, float *y, void *workspace,
                               size_t workspace_bytes, void *stream);
+/* Batch statistics only (training): mean / rstd per channel + running-stat update; the first half of bnact_fwd.
+ * Used with pvcnn_trilinear_devox_bnact_fwd, which applies BatchNorm + LeakyReLU while it stages the voxel
+ * grid into LDS -- out = trilinear_devoxelize(leaky_relu(bn(feat))) without writing the activated grid
+ * (PVConv: the last BatchNorm3d + LeakyReLU of voxel_layers followed by the devoxelization, modules/pvconv.py:
+ * 25-27,36).  Bit-identical to bnact_fwd followed by trilinear_devox_fwd.  Requires R^3 * 4 bytes <= 160 KiB. */
+PVCNN_API int pvcnn_bn_stats(const float *x, float *running_mean, float *running_var, int B, int C, int S,
+                   float eps, float momentum, float *mean, float *rstd, void *workspace,
+                   size_t workspace_bytes, void *stream);
+PVCNN_API int pvcnn_trilinear_devox_bnact_fwd(const float *coords, const float *feat, const float *gamma,
+                                    const float *beta, const float *mean, const float *rstd, float slope,
+                                    int B, int C, int N, int R, int is_training, int32_t *inds, float *wgts,
+                                    float *outs, void *stream);
 PVCNN_API int pvcnn_bnact_bwd(const float *x, const float *grad_y, const float *gamma, const float *beta,
                               const float *mean, const float *rstd, int B, int C, int S, float slope, int training,
                               float *grad_x, float *grad_gamma, float *grad_beta, void *workspace,

@@ -240,6 +240,21 @@ extern "C" int pvcnn_bnact_fwd(const float *x, const float *gamma, const float *
   return check_launch("bnact_apply");
 }
 
+extern "C" int pvcnn_bn_stats(const float *x, float *running_mean, float *running_var, int B, int C, int S, float eps,
+                              float momentum, float *mean, float *rstd, void *workspace, size_t workspace_bytes, void *stream) {
+  PVCNN_REQUIRE(B > 0 && C > 0 && S > 0 && x && mean && rstd, "bad argument");
+  PVCNN_REQUIRE(B <= 65535 && C <= 65535, "batch or channel count > 65535");
+  PVCNN_REQUIRE(workspace && workspace_bytes >= pvcnn_bnact_workspace_bytes(B, C, S), "workspace too small");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int slices = ceil_div(S, kBnSlice);
+  float2 *part = static_cast<float2 *>(workspace);
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(slices, B, C), dim3(kBnThreads), 0, s, x, C, S, slices, part);
+  if (int e = check_launch("bn_stats")) return e;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, s, part, B * slices, (double)B * S, eps, momentum, mean, rstd,
+                     running_mean, running_var);
+  return check_launch("bn_finalize");
+}
+
 extern "C" int pvcnn_bnact_bwd(const float *x, const float *grad_y, const float *gamma, const float *beta, const float *mean,
                                const float *rstd, int B, int C, int S, float slope, int training, float *grad_x,
                                float *grad_gamma, float *grad_beta, void *workspace, size_t workspace_bytes, void *stream) {

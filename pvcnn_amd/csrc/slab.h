@@ -249,12 +249,67 @@ __device__ __forceinline__ void slab_copy(float *dst, const float *src, int tota
   }
 }
 
+// Optional per-row transform applied while a slab is staged into LDS ("gather of f(row)" without ever writing
+// f(row) to memory).  XfNone: plain copy.  XfBnAct: BatchNorm (per-channel scale/shift) + LeakyReLU with the
+// very expressions of bnact_apply_kernel (bnact.hip), so gathering through it is bit-identical to gathering
+// the tensor that kernel would have written.
+struct XfNone {
+  static constexpr bool kIdentity = true;
+};
+struct XfBnAct {
+  static constexpr bool kIdentity = false;
+  const float *gamma, *beta, *mean, *rstd;   // per channel; gamma / beta may be null
+  float slope;
+  __device__ __forceinline__ void params(int c, float &scale, float &shift) const {
+    scale = (gamma ? gamma[c] : 1.0f) * rstd[c];
+    shift = (beta ? beta[c] : 0.0f) - mean[c] * scale;
+  }
+  __device__ __forceinline__ float apply(float v, float scale, float shift) const {
+    v = fmaf(v, scale, shift);
+    return v > 0.f ? v : v * slope;
+  }
+};
+
+// one row of a slab through a transform (row = channel c of the cloud)
+template <int THREADS, class XF>
+__device__ __forceinline__ void slab_copy_row_xf(float *dst, const float *src, int len, const XF &xf, int c) {
+  float scale, shift;
+  xf.params(c, scale, shift);
+  if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0 && (len & 3) == 0) {
+    constexpr int kB = 8;
+    const int nq = len >> 2;
+    const float4 *s4 = reinterpret_cast<const float4 *>(src);
+    float4 *d4 = reinterpret_cast<float4 *>(dst);
+    for (int q0 = threadIdx.x; q0 < nq; q0 += THREADS * kB) {
+      float4 v[kB];
+#pragma unroll
+      for (int u = 0; u < kB; ++u) v[u] = s4[min(q0 + u * THREADS, nq - 1)];
+#pragma unroll
+      for (int u = 0; u < kB; ++u)
+        if (q0 + u * THREADS < nq)
+          d4[q0 + u * THREADS] = make_float4(xf.apply(v[u].x, scale, shift), xf.apply(v[u].y, scale, shift),
+                                             xf.apply(v[u].z, scale, shift), xf.apply(v[u].w, scale, shift));
+    }
+  } else {
+    for (int i = threadIdx.x; i < len; i += THREADS) dst[i] = xf.apply(src[i], scale, shift);
+  }
+}
+
+template <int THREADS, class XF>
+__device__ __forceinline__ void slab_stage(float *lds, const float *src, int g, int L, const XF &xf, int c0) {
+  if constexpr (XF::kIdentity) {
+    slab_copy<THREADS>(lds, src, g * L);
+  } else {
+    for (int c = 0; c < g; ++c) slab_copy_row_xf<THREADS>(lds + c * L, src + (size_t)c * L, L, xf, c0 + c);
+  }
+}
+
 // A workgroup walks SEQ consecutive channel slabs of one cloud through the same LDS buffer.  When a
 // thread owns all of its elements in one pass (J <= THREADS*VEC, the usual case) their taps are fetched and
 // packed ONCE and stay in registers for all slabs: coordinates / indices are read from memory once per
 // SEQ*G channels instead of once per slab, and only "stream slab, barrier, LDS gather, store" repeats.
-template <class P, int VEC, int THREADS, bool RESIDENT>
-__global__ __launch_bounds__(THREADS) void gather_lds_kernel(P p, const float *__restrict__ src,
+template <class P, int VEC, int THREADS, bool RESIDENT, class XF>
+__global__ __launch_bounds__(THREADS) void gather_lds_kernel(P p, XF xf, const float *__restrict__ src,
                                                              float *__restrict__ dst, int C, int L,
                                                              int J, int G, int SEQ) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -278,7 +333,7 @@ __global__ __launch_bounds__(THREADS) void gather_lds_kernel(P p, const float *_
     if (c0 >= C) break;
     const int g = min(G, C - c0);
     if (sq > 0) __syncthreads();                       // all reads of the previous slab are done
-    slab_copy<THREADS>(lds, src + ((size_t)b * C + c0) * L, g * L);
+    slab_stage<THREADS>(lds, src + ((size_t)b * C + c0) * L, g, L, xf, c0);
     __syncthreads();
     float *out = dst + ((size_t)b * C + c0) * J;
     for (int j0 = jf; j0 < J; j0 += THREADS * VEC) {
@@ -391,23 +446,28 @@ inline int enable_big_lds(K kernel, size_t bytes) {
 }
 
 // vec_ok: J % 4 == 0 and every per-element array (incl. src/dst rows of length J) 16-byte aligned
-template <class P>
+template <class P, class XF = XfNone>
 int launch_gather(const P &p, const float *src, float *dst, int B, int C, int L, int J, bool vec_ok,
-                  hipStream_t s, const char *what) {
+                  hipStream_t s, const char *what, const XF &xf = XF{}) {
   if (B == 0 || C == 0 || J == 0) return 0;
   const SlabPlan pl = plan_slab(B, C, L);
   if (!pl.lds) {
-    const int CT = 16;
-    hipLaunchKernelGGL((gather_direct_kernel<P>), dim3(ceil_div(J, 256), ceil_div(C, CT), B), dim3(256), 0, s,
-                       p, src, dst, C, L, J, CT);
-    return check_launch(what);
+    if constexpr (!XF::kIdentity) {
+      set_error("%s: row does not fit LDS; the fused transform needs the LDS path", what);
+      return PVCNN_ERR_INVALID_ARGUMENT;
+    } else {
+      const int CT = 16;
+      hipLaunchKernelGGL((gather_direct_kernel<P>), dim3(ceil_div(J, 256), ceil_div(C, CT), B), dim3(256), 0, s,
+                         p, src, dst, C, L, J, CT);
+      return check_launch(what);
+    }
   }
   const dim3 grid(ceil_div(ceil_div(C, pl.G), pl.seq), B);
 #define PVCNN_LAUNCH_GATHER(VEC, T)                                                              \
   do {                                                                                           \
-    auto k = (J <= T * VEC) ? gather_lds_kernel<P, VEC, T, true> : gather_lds_kernel<P, VEC, T, false>; \
+    auto k = (J <= T * VEC) ? gather_lds_kernel<P, VEC, T, true, XF> : gather_lds_kernel<P, VEC, T, false, XF>; \
     if (int e = enable_big_lds(k, pl.bytes)) { set_error("%s: LDS attribute: %d", what, e); return e; } \
-    hipLaunchKernelGGL(k, grid, dim3(T), pl.bytes, s, p, src, dst, C, L, J, pl.G, pl.seq);       \
+    hipLaunchKernelGGL(k, grid, dim3(T), pl.bytes, s, p, xf, src, dst, C, L, J, pl.G, pl.seq);   \
   } while (0)
   if (pl.threads == 1024) { if (vec_ok) PVCNN_LAUNCH_GATHER(4, 1024); else PVCNN_LAUNCH_GATHER(1, 1024); }
   else                    { if (vec_ok) PVCNN_LAUNCH_GATHER(4, 256);  else PVCNN_LAUNCH_GATHER(1, 256); }

@@ -380,6 +380,50 @@ class HipBackend:
                                                 _p(mean), _p(rstd), _p(y), _p(ws), ws.numel(), s), 'bnact_forward')
         return y, mean, rstd
 
+    has_devox_bnact = True
+
+    def bn_stats(self, x, running_mean, running_var, momentum, eps):
+        """Training-mode statistics of x (B,C,S): -> (mean, rstd); running stats updated in place (may be None)."""
+        _f32(x, 'x')
+        b, c, s3 = x.shape
+        dev = x.device
+        mean = torch.empty((c,), dtype=torch.float32, device=dev)
+        rstd = torch.empty((c,), dtype=torch.float32, device=dev)
+        ws = self._scratch(self.lib.pvcnn_bnact_workspace_bytes(b, c, s3), dev)
+        nul = ctypes.c_void_p(None)
+        with _Launch(x) as s:
+            _lib.check(self.lib.pvcnn_bn_stats(_p(x), _p(running_mean) if running_mean is not None else nul,
+                                               _p(running_var) if running_var is not None else nul, b, c, s3, float(eps),
+                                               float(momentum), _p(mean), _p(rstd), _p(ws), ws.numel(), s), 'bn_stats')
+        return mean, rstd
+
+    def trilinear_devoxelize_bnact_forward(self, r, is_training, coords, features, gamma, beta, mean, rstd, slope):
+        """trilinear_devoxelize_forward of leaky_relu(bn(features)) without materialising that tensor:
+        features (B,C,R^3) is the PRE-BatchNorm grid, mean / rstd (C) its statistics."""
+        _f32(features, 'features'); _f32(coords, 'coords')
+        r = int(r)
+        _shape(features.dim() == 3 and coords.dim() == 3 and coords.shape[1] == 3
+               and coords.shape[0] == features.shape[0] and features.shape[2] == r * r * r,
+               'trilinear_devoxelize: coords (B,3,N), features (B,C,R^3) expected')
+        b, c = features.shape[:2]
+        n = coords.shape[2]
+        dev = features.device
+        outs = torch.empty((b, c, n), dtype=torch.float32, device=dev)
+        if is_training:
+            inds = torch.empty((b, 8, n), dtype=torch.int32, device=dev)
+            wgts = torch.empty((b, 8, n), dtype=torch.float32, device=dev)
+        else:
+            inds = torch.zeros((1,), dtype=torch.int32, device=dev)
+            wgts = torch.zeros((1,), dtype=torch.float32, device=dev)
+        nul = ctypes.c_void_p(None)
+        with _Launch(features) as s:
+            _lib.check(self.lib.pvcnn_trilinear_devox_bnact_fwd(
+                _p(coords), _p(features), _p(gamma) if gamma is not None else nul, _p(beta) if beta is not None else nul,
+                _p(mean), _p(rstd), float(slope), b, c, n, r, int(bool(is_training)),
+                _p(inds) if is_training else None, _p(wgts) if is_training else None, _p(outs), s),
+                'trilinear_devoxelize_bnact_forward')
+        return [outs, inds, wgts]
+
     def bnact_backward(self, x, grad_y, gamma, beta, mean, rstd, slope, training):
         _f32(x, 'x'); _f32(grad_y, 'grad_y')
         b, c, s3 = x.shape

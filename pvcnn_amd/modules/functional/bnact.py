@@ -12,7 +12,7 @@ from torch.autograd import Function
 
 from ._autograd import native, amp_fwd, amp_bwd
 
-__all__ = ['batch_norm_act', 'run_layers']
+__all__ = ['batch_norm_act', 'batch_norm_act_devoxelize', 'fusable_tail', 'run_layers']
 
 
 class BatchNormAct(Function):
@@ -38,8 +38,9 @@ class BatchNormAct(Function):
                 None, None, None, None, None, None)
 
 
-def batch_norm_act(x, bn, slope):
-    """Apply BatchNorm module `bn` followed by LeakyReLU(slope) (slope = 0: ReLU) to x (B, C, ...)."""
+def _bn_mode(bn):
+    """-> (use_batch_stats, momentum, running_mean, running_var) of one forward call of module `bn`, with the
+    side effects torch.nn.BatchNorm has (num_batches_tracked)."""
     use_batch_stats = bn.training or bn.running_mean is None
     momentum = 0.0 if bn.momentum is None else bn.momentum
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
@@ -48,7 +49,64 @@ def batch_norm_act(x, bn, slope):
             momentum = 1.0 / float(bn.num_batches_tracked)
     rm = bn.running_mean if (bn.track_running_stats or not use_batch_stats) else None
     rv = bn.running_var if (bn.track_running_stats or not use_batch_stats) else None
+    return use_batch_stats, momentum, rm, rv
+
+
+def batch_norm_act(x, bn, slope):
+    """Apply BatchNorm module `bn` followed by LeakyReLU(slope) (slope = 0: ReLU) to x (B, C, ...)."""
+    use_batch_stats, momentum, rm, rv = _bn_mode(bn)
     return BatchNormAct.apply(x, bn.weight, bn.bias, rm, rv, use_batch_stats, momentum, bn.eps, slope)
+
+
+class BatchNormActDevoxelize(Function):
+    """trilinear_devoxelize(leaky_relu(batch_norm(grid)), coords): PVConv's last BatchNorm3d + LeakyReLU and the
+    devoxelization (modules/pvconv.py:25-27,36) with the activated grid never written to memory -- the gather
+    kernel normalises and activates while it stages the grid into LDS.  Bit-identical to the two separate ops."""
+
+    @staticmethod
+    @amp_fwd
+    def forward(ctx, grid, coords, weight, bias, running_mean, running_var, use_batch_stats, momentum, eps, slope,
+                resolution, is_training):
+        shape = grid.shape
+        x3 = grid.contiguous().view(shape[0], shape[1], -1)
+        w = weight.contiguous() if weight is not None else None
+        b = bias.contiguous() if bias is not None else None
+        if use_batch_stats:
+            mean, rstd = native().bn_stats(x3, running_mean, running_var, momentum, eps)
+        else:
+            mean, rstd = running_mean.contiguous(), torch.rsqrt(running_var + eps)
+        out, inds, wgts = native().trilinear_devoxelize_bnact_forward(int(resolution), is_training, coords.contiguous(), x3,
+                                                                      w, b, mean, rstd, slope)
+        if is_training:
+            ctx.save_for_backward(x3, w, b, mean, rstd, inds, wgts)
+            ctx.slope, ctx.use_batch_stats, ctx.shape, ctx.r = slope, use_batch_stats, shape, int(resolution)
+        return out
+
+    @staticmethod
+    @amp_bwd
+    def backward(ctx, grad_out):
+        x3, w, b, mean, rstd, inds, wgts = ctx.saved_tensors
+        g_act = native().trilinear_devoxelize_backward(grad_out.contiguous(), inds, wgts, ctx.r)
+        gx, gw, gb = native().bnact_backward(x3, g_act.view(x3.shape), w, b, mean, rstd, ctx.slope, ctx.use_batch_stats)
+        return (gx.view(ctx.shape), None, gw if w is not None else None, gb if b is not None else None,
+                None, None, None, None, None, None, None, None)
+
+
+def batch_norm_act_devoxelize(grid, coords, bn, slope, resolution, is_training):
+    use_batch_stats, momentum, rm, rv = _bn_mode(bn)
+    return BatchNormActDevoxelize.apply(grid, coords, bn.weight, bn.bias, rm, rv, use_batch_stats, momentum, bn.eps, slope,
+                                        resolution, is_training)
+
+
+def fusable_tail(layers, x):
+    """If the nn.Sequential ends in (BatchNorm, ReLU|LeakyReLU) and the GPU path can fuse that pair into the
+    devoxelize gather for tensor x (the Sequential's INPUT: same device / dtype), return (bn, slope)."""
+    mods = list(layers)
+    if (len(mods) >= 2 and x.is_cuda and x.dtype == torch.float32 and getattr(native(), 'has_devox_bnact', False)
+            and isinstance(mods[-2], nn.modules.batchnorm._BatchNorm) and _slope(mods[-1]) is not None
+            and not torch.is_autocast_enabled()):
+        return mods[-2], _slope(mods[-1])
+    return None
 
 
 def _slope(act):
@@ -66,10 +124,10 @@ def _is_pointwise(m):
             and isinstance(m.padding, tuple))
 
 
-def run_layers(layers, x):
+def run_layers(layers, x, stop=None):
     """nn.Sequential.forward with the GPU path's own kernels: 1x1 convolutions as channel-major MFMA GEMMs,
-    (BatchNorm, ReLU|LeakyReLU) pairs fused."""
-    mods = list(layers)
+    (BatchNorm, ReLU|LeakyReLU) pairs fused.  `stop`: run only the first `stop` modules."""
+    mods = list(layers)[:stop]
     fuse = x.is_cuda and getattr(native(), 'has_bnact', False)
     pw = x.is_cuda and getattr(native(), 'has_pwconv', False)
     i = 0

@@ -12,7 +12,7 @@ import torch.nn as nn
 
 from . import functional as F
 from .functional._autograd import native
-from .functional.bnact import run_layers
+from .functional.bnact import batch_norm_act_devoxelize, fusable_tail, run_layers
 from .functional.conv3d import voxel_conv3d
 from .se import SE3d
 from .shared_mlp import SharedMLP
@@ -58,10 +58,17 @@ class PVConv(nn.Module):
     def forward(self, inputs):
         features, coords = inputs
         grid, grid_coords = self.voxelization(features, coords)
-        grid = run_layers(self.voxel_layers, grid)     # = self.voxel_layers(grid), BN + LeakyReLU fused
-        # The point branch runs BETWEEN the last grid write and the devoxelize gather: a gather that starts
-        # while the grid's dirty lines are still draining from L2/MALL to HBM is 1.5x slower (measured:
-        # 49.6 vs 33.3 us at (16,64,4096,R=32), tools/devox_after_writer.py).  Same operands, same sum.
-        per_point = self.point_features(features)
-        from_voxels = F.trilinear_devoxelize(grid, grid_coords, self.resolution, self.training)
+        tail = fusable_tail(self.voxel_layers, grid) if self.resolution ** 3 * 4 <= 160 * 1024 else None
+        if tail is not None:
+            # the last BatchNorm3d + LeakyReLU ride on the devoxelize gather: the activated grid is never written
+            # (and the gather does not start on a grid whose write is still draining to HBM: 1.5x slower, see
+            # tools/devox_after_writer.py)
+            bn, slope = tail
+            grid = run_layers(self.voxel_layers, grid, stop=len(self.voxel_layers) - 2)
+            per_point = self.point_features(features)
+            from_voxels = batch_norm_act_devoxelize(grid, grid_coords, bn, slope, self.resolution, self.training)
+        else:
+            grid = run_layers(self.voxel_layers, grid)     # = self.voxel_layers(grid), BN + LeakyReLU fused
+            per_point = self.point_features(features)
+            from_voxels = F.trilinear_devoxelize(grid, grid_coords, self.resolution, self.training)
         return from_voxels + per_point, coords

@@ -41,3 +41,45 @@ def test_bn_act_matches_torch(hip, shape, bn_cls, eps, slope, training):
     assert _rel(mine[0].weight.grad, ref[0].weight.grad) < 2e-5 and _rel(mine[0].bias.grad, ref[0].bias.grad) < 2e-5
     assert _rel(mine[0].running_mean, ref[0].running_mean) < 1e-5 and _rel(mine[0].running_var, ref[0].running_var) < 1e-5
     assert int(mine[0].num_batches_tracked) == int(ref[0].num_batches_tracked)
+
+
+def test_bn_act_fused_into_devoxelize_is_bit_identical(hip):
+    """PVConv with its last BatchNorm3d + LeakyReLU fused into the devoxelize gather vs the two separate ops:
+    same bits forward and backward (the gather applies bnact_apply_kernel's expressions while staging)."""
+    import copy
+    from pvcnn_amd.modules import PVConv
+    from pvcnn_amd.modules.functional._autograd import native
+    torch.manual_seed(11)
+    dev = 'cuda:0'
+    for r, cin, cout in [(16, 9, 32), (32, 16, 16)]:
+        fused = PVConv(cin, cout, 3, r).to(dev).train()
+        plain = copy.deepcopy(fused)
+        feats = torch.randn(2, cin, 1024, device=dev)
+        coords = torch.rand(2, 3, 1024, device=dev) * 2 - 1
+        fa, fb = feats.clone().requires_grad_(), feats.clone().requires_grad_()
+        ya, _ = fused((fa, coords))
+        ya.square().sum().backward()
+        be = native()
+        assert be.has_devox_bnact
+        try:
+            type(be).has_devox_bnact = False
+            yb, _ = plain((fb, coords))
+            yb.square().sum().backward()
+        finally:
+            type(be).has_devox_bnact = True
+        assert torch.equal(ya, yb)
+        assert torch.equal(fa.grad, fb.grad)
+        for (na, pa), (nb, pb) in zip(fused.named_parameters(), plain.named_parameters()):
+            assert torch.equal(pa.grad, pb.grad), na
+        for (na, ba), (nb, bb) in zip(fused.named_buffers(), plain.named_buffers()):
+            assert torch.equal(ba, bb), na
+        # eval mode: running statistics
+        fused.eval(); plain.eval()
+        with torch.no_grad():
+            ya, _ = fused((feats, coords))
+            try:
+                type(be).has_devox_bnact = False
+                yb, _ = plain((feats, coords))
+            finally:
+                type(be).has_devox_bnact = True
+        assert torch.equal(ya, yb)
