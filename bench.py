@@ -207,7 +207,7 @@ def main():
     torch.manual_seed(workload.SEED)
     model = workload.PVCNN(13, 6, width_multiplier=args.width).to(dev).train()
     reducer = GradBucketReducer(model, bucket_mb=args.bucket_mb)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5, fused=True)   # one multi-tensor kernel per step
     x, y = workload.make_s3dis_batch(args.batch, args.points, device=dev, seed=workload.SEED + rank)
 
     clock = KernelClock(seam._backend)
