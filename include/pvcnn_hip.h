@@ -207,6 +207,18 @@ PVCNN_API int pvcnn_bnact_fwd(const float *x, const float *gamma, const float *b
  * grid into LDS -- out = trilinear_devoxelize(leaky_relu(bn(feat))) without writing the activated grid
  * (PVConv: the last BatchNorm3d + LeakyReLU of voxel_layers followed by the devoxelization, modules/pvconv.py:
  * 25-27,36).  Bit-identical to bnact_fwd followed by trilinear_devox_fwd.  Requires R^3 * 4 bytes <= 160 KiB. */
+/* Convolution forward WITH BatchNorm statistics: as pvcnn_conv3d_fwd / pvcnn_pwconv_fwd, and the epilogue also
+ * writes per-workgroup partial (sum, sum of squares) of every output channel to stats_part -- (C, nparts) pairs of
+ * floats, nparts = *_fwd_stats_parts(...) -- so the BatchNorm that follows needs no pass over y:
+ * pvcnn_bn_finalize turns the partials into mean / rstd (fp64 combine) and updates the running statistics. */
+PVCNN_API size_t pvcnn_conv3d_fwd_stats_parts(int B, int Co, int R);
+PVCNN_API int pvcnn_conv3d_fwd_stats(const float *x, const float *wt, const float *bias, int B, int Ci, int Co, int R,
+                           float *y, float *stats_part, void *stream);
+PVCNN_API size_t pvcnn_pwconv_fwd_stats_parts(int B, int N);
+PVCNN_API int pvcnn_pwconv_fwd_stats(const float *x, const float *wt, const float *bias, int B, int K, int M, int N,
+                           float *y, float *stats_part, void *stream);
+PVCNN_API int pvcnn_bn_finalize(const float *part, int C, long nparts, double count, float eps, float momentum,
+                      float *running_mean, float *running_var, float *mean, float *rstd, void *stream);
 PVCNN_API int pvcnn_bn_stats(const float *x, float *running_mean, float *running_var, int B, int C, int S,
                    float eps, float momentum, float *mean, float *rstd, void *workspace,
                    size_t workspace_bytes, void *stream);

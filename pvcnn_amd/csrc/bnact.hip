@@ -240,6 +240,17 @@ extern "C" int pvcnn_bnact_fwd(const float *x, const float *gamma, const float *
   return check_launch("bnact_apply");
 }
 
+// mean / rstd (+ running statistics) from per-workgroup partials produced by a convolution epilogue
+// (pvcnn_conv3d_fwd_stats, pvcnn_pwconv_fwd_stats): part is (C, nparts) float2 {sum, sum of squares}.
+extern "C" int pvcnn_bn_finalize(const float *part, int C, long nparts, double count, float eps, float momentum,
+                                 float *running_mean, float *running_var, float *mean, float *rstd, void *stream) {
+  PVCNN_REQUIRE(C > 0 && nparts > 0 && nparts <= 0x7fffffffL && count > 0 && part && mean && rstd, "bad argument");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, static_cast<hipStream_t>(stream),
+                     reinterpret_cast<const float2 *>(part), (int)nparts, count, eps, momentum, mean, rstd, running_mean,
+                     running_var);
+  return check_launch("bn_finalize");
+}
+
 extern "C" int pvcnn_bn_stats(const float *x, float *running_mean, float *running_var, int B, int C, int S, float eps,
                               float momentum, float *mean, float *rstd, void *workspace, size_t workspace_bytes, void *stream) {
   PVCNN_REQUIRE(B > 0 && C > 0 && S > 0 && x && mean && rstd, "bad argument");

@@ -20,6 +20,26 @@ int check_launch(const char *what);
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 __host__ __device__ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+#ifdef __HIPCC__
+// Sum each of 16 per-lane values over the 32 lanes of a half-wave (lanes that differ in bits 0..4) with a
+// transposing butterfly: every step halves the number of values a lane carries (the lane keeps one half and
+// ships the other), so it takes 8+4+2+1+1 = 16 shuffles instead of 16*5.  Returns, in lane j, the total of
+// value index (j >> 1) & 15 (both lanes of a pair hold the same total).
+__device__ __forceinline__ float half_wave_sum16(const float (&v)[16], int lane) {
+  float a[8], b[4], c[2];
+  const bool b4 = lane & 16, b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) a[r] = (b4 ? v[r + 8] : v[r]) + __shfl_xor(b4 ? v[r] : v[r + 8], 16);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) b[r] = (b3 ? a[r + 4] : a[r]) + __shfl_xor(b3 ? a[r] : a[r + 4], 8);
+#pragma unroll
+  for (int r = 0; r < 2; ++r) c[r] = (b2 ? b[r + 2] : b[r]) + __shfl_xor(b2 ? b[r] : b[r + 2], 4);
+  float d = (b1 ? c[1] : c[0]) + __shfl_xor(b1 ? c[0] : c[1], 2);
+  d += __shfl_xor(d, 1);
+  return d;
+}
+#endif
+
 }  // namespace pvcnn
 
 #define PVCNN_REQUIRE(cond, msg)                                       \

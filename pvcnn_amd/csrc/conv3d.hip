@@ -110,7 +110,8 @@ __device__ __forceinline__ void stage_halo_tile(float *xs, const float *xb, int 
 template <int TX, int TY, int TZ, int CIC, bool VEC, int NBW>
 __global__ __launch_bounds__(256) void conv3d_igemm_kernel(const float *__restrict__ x, const float *__restrict__ wt,
                                                            const float *__restrict__ bias, float *__restrict__ y,
-                                                           int Ci, int Co, int R, int tiles_x, int tiles_y, int tiles_z) {
+                                                           int Ci, int Co, int R, int tiles_x, int tiles_y, int tiles_z,
+                                                           float2 *__restrict__ stats_part) {
   static_assert(TX * TY * TZ == 128 * NBW, "a workgroup tile is 4 waves x NBW x 32 voxels");
   static_assert(CIC % 2 == 0, "channels are consumed in pairs (MFMA K = 2)");
   constexpr int HX = TX + 2, HY = TY + 2, HZ = TZ + 2, HS = HX * HY * HZ;
@@ -223,6 +224,12 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(const float *__restri
     vok[nb] = gx < R && gy < R && gz < R;
     voff[nb] = (size_t)gx * RR + (size_t)gy * R + gz;
   }
+  // stats_part != nullptr: per-channel (sum, sum of squares) of this workgroup's outputs ride on the epilogue --
+  // the BatchNorm that follows the convolution then needs no statistics pass over y (bn_finalize combines the
+  // per-workgroup partials in fp64 exactly like bn_stats_kernel's).
+  const bool want_stats = stats_part != nullptr;
+  float2 *stat_lds = reinterpret_cast<float2 *>(lds);       // [4 waves][64 channels]
+  if (want_stats) __syncthreads();                          // all waves are done reading xs / ws
 #pragma unroll
   for (int mb = 0; mb < 2; ++mb) {
     float bv[16];
@@ -231,6 +238,9 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(const float *__restri
       const int co = co0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
       bv[r] = (bias != nullptr && co < Co) ? bias[co] : 0.0f;
     }
+    float ss[16], qq[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ss[r] = qq[r] = 0.0f;
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
@@ -238,14 +248,35 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(const float *__restri
         const int co = co0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
         float v;
         asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(acc[mb][nb][r]));
-        if (vok[nb] && co < Co) yb[(size_t)co * R * RR + voff[nb]] = v + bv[r];
+        v += bv[r];
+        if (vok[nb] && co < Co) yb[(size_t)co * R * RR + voff[nb]] = v;
+        if (want_stats) {
+          const float m = vok[nb] ? v : 0.0f;
+          ss[r] += m;
+          qq[r] += m * m;
+        }
       }
+    if (want_stats) {
+      // lane j ends up with the totals of register (j >> 1) & 15 over its 32 voxels / points
+      const float st = half_wave_sum16(ss, j), qt = half_wave_sum16(qq, j);
+      const int rr = (j >> 1) & 15;
+      if ((j & 1) == 0) stat_lds[wave * kCoTile + mb * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * kh] = make_float2(st, qt);
+    }
+  }
+  if (want_stats) {
+    __syncthreads();
+    if (tid < kCoTile && co0 + tid < Co) {
+      float2 t = stat_lds[tid];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) { t.x += stat_lds[w * kCoTile + tid].x; t.y += stat_lds[w * kCoTile + tid].y; }
+      stats_part[(size_t)(co0 + tid) * gridDim.x + blockIdx.x] = t;
+    }
   }
 }
 
 template <int TX, int TY, int TZ, int CIC, bool VEC, int NBW>
 static int launch_igemm_v(const float *x, const float *wt, const float *bias, float *y, int B, int Ci, int Co, int R,
-                          hipStream_t s) {
+                          hipStream_t s, float2 *stats_part) {
   constexpr int HS = (TX + 2) * (TY + 2) * (TZ + 2);
   const size_t lds = (size_t)(CIC * HS + CIC * 27 * kCoTile) * sizeof(float);
   const int tx = ceil_div(R, TX), ty = ceil_div(R, TY), tz = ceil_div(R, TZ);
@@ -255,17 +286,17 @@ static int launch_igemm_v(const float *x, const float *wt, const float *bias, fl
     if (e != hipSuccess) { set_error("conv3d: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
   }
   hipLaunchKernelGGL(k, dim3((unsigned)((long)B * tx * ty * tz), ceil_div(Co, kCoTile)), dim3(256), lds, s, x, wt, bias,
-                     y, Ci, Co, R, tx, ty, tz);
+                     y, Ci, Co, R, tx, ty, tz, stats_part);
   return check_launch("conv3d_igemm");
 }
 
 template <int TX, int TY, int TZ, int CIC, int NBW = 2>
 static int launch_igemm(const float *x, const float *wt, const float *bias, float *y, int B, int Ci, int Co, int R,
-                        hipStream_t s) {
+                        hipStream_t s, float2 *stats_part) {
   // vector staging needs full aligned z-rows (R == TZ) and whole 64-wide, 16-byte aligned co tiles
   const bool vec = (R == TZ) && (Co % kCoTile == 0) && aligned16(x) && aligned16(wt);
-  return vec ? launch_igemm_v<TX, TY, TZ, CIC, true, NBW>(x, wt, bias, y, B, Ci, Co, R, s)
-             : launch_igemm_v<TX, TY, TZ, CIC, false, NBW>(x, wt, bias, y, B, Ci, Co, R, s);
+  return vec ? launch_igemm_v<TX, TY, TZ, CIC, true, NBW>(x, wt, bias, y, B, Ci, Co, R, s, stats_part)
+             : launch_igemm_v<TX, TY, TZ, CIC, false, NBW>(x, wt, bias, y, B, Ci, Co, R, s, stats_part);
 }
 
 
@@ -655,21 +686,54 @@ extern "C" int pvcnn_conv3d_weight_transform(const float *w, int Co, int Ci, int
   return check_launch("conv3d_weight_transform");
 }
 
+// tile variant of a forward launch: 0 -> (2,4,32), 1 -> (2,4,16) half tile, 2 -> (4,4,16), 3 -> (4,8,8); *nparts = spatial
+// workgroups = statistics partials per output channel
+static int igemm_variant(int B, int Co, int R, long *nparts) {
+  int v, tx, ty, tz;
+  if (R > 16) { v = 0; tx = 2; ty = 4; tz = 32; }
+  else if (R > 8) {
+    // 256-voxel tiles would give this launch fewer than ~2 workgroups per CU: halve the tile instead
+    const long wgs256 = (long)B * ceil_div(R, 4) * ceil_div(R, 4) * ceil_div(R, 16) * ceil_div(Co, kCoTile);
+    if (wgs256 < 2L * kNumCU) { v = 1; tx = 2; ty = 4; tz = 16; } else { v = 2; tx = 4; ty = 4; tz = 16; }
+  } else { v = 3; tx = 4; ty = 8; tz = 8; }
+  *nparts = (long)B * ceil_div(R, tx) * ceil_div(R, ty) * ceil_div(R, tz);
+  return v;
+}
+
+static int conv3d_fwd_impl(const float *x, const float *wt, const float *bias, int B, int Ci, int Co, int R, float *y,
+                           float2 *stats_part, hipStream_t s) {
+  long nparts;
+  switch (igemm_variant(B, Co, R, &nparts)) {
+    case 0: return launch_igemm<2, 4, 32, 4>(x, wt, bias, y, B, Ci, Co, R, s, stats_part);
+    case 1: return launch_igemm<2, 4, 16, 4, 1>(x, wt, bias, y, B, Ci, Co, R, s, stats_part);
+    case 2: return launch_igemm<4, 4, 16, 4>(x, wt, bias, y, B, Ci, Co, R, s, stats_part);
+    default: return launch_igemm<4, 8, 8, 4>(x, wt, bias, y, B, Ci, Co, R, s, stats_part);
+  }
+}
+
 extern "C" int pvcnn_conv3d_fwd(const float *x, const float *wt, const float *bias, int B, int Ci, int Co, int R,
                                 float *y, void *stream) {
   PVCNN_REQUIRE(B >= 0 && Ci > 0 && Co > 0 && R > 0, "bad size");
   if (B == 0) return 0;
   PVCNN_REQUIRE(x && wt && y, "null pointer");
   PVCNN_REQUIRE((long)R * R * R * (long)std::max(Ci, Co) <= 0x7fffffffL, "grid too large");
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  if (R > 16) return launch_igemm<2, 4, 32, 4>(x, wt, bias, y, B, Ci, Co, R, s);
-  if (R > 8) {
-    // 256-voxel tiles would give this launch fewer than ~2 workgroups per CU: halve the tile instead
-    const long wgs256 = (long)B * ceil_div(R, 4) * ceil_div(R, 4) * ceil_div(R, 16) * ceil_div(Co, kCoTile);
-    if (wgs256 < 2L * kNumCU) return launch_igemm<2, 4, 16, 4, 1>(x, wt, bias, y, B, Ci, Co, R, s);
-    return launch_igemm<4, 4, 16, 4>(x, wt, bias, y, B, Ci, Co, R, s);
-  }
-  return launch_igemm<4, 8, 8, 4>(x, wt, bias, y, B, Ci, Co, R, s);
+  return conv3d_fwd_impl(x, wt, bias, B, Ci, Co, R, y, nullptr, static_cast<hipStream_t>(stream));
+}
+
+extern "C" size_t pvcnn_conv3d_fwd_stats_parts(int B, int Co, int R) {
+  if (B <= 0 || Co <= 0 || R <= 0) return 0;
+  long nparts;
+  igemm_variant(B, Co, R, &nparts);
+  return (size_t)nparts;
+}
+
+extern "C" int pvcnn_conv3d_fwd_stats(const float *x, const float *wt, const float *bias, int B, int Ci, int Co, int R,
+                                      float *y, float *stats_part, void *stream) {
+  PVCNN_REQUIRE(B > 0 && Ci > 0 && Co > 0 && R > 0, "bad size");
+  PVCNN_REQUIRE(x && wt && y && stats_part, "null pointer");
+  PVCNN_REQUIRE((reinterpret_cast<uintptr_t>(stats_part) & 7) == 0, "stats_part must be 8-byte aligned");
+  PVCNN_REQUIRE((long)R * R * R * (long)std::max(Ci, Co) <= 0x7fffffffL, "grid too large");
+  return conv3d_fwd_impl(x, wt, bias, B, Ci, Co, R, y, reinterpret_cast<float2 *>(stats_part), static_cast<hipStream_t>(stream));
 }
 
 extern "C" size_t pvcnn_conv3d_bwd_weight_workspace_bytes(int B, int Ci, int Co, int R) {

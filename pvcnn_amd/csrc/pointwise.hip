@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void pw_transpose_kernel(const float *__restri
 template <int MB, bool FAST, bool BIAS>
 __global__ __launch_bounds__(256) void pw_gemm_kernel(const float *__restrict__ x, const float *__restrict__ wt,
                                                       const float *__restrict__ bias, float *__restrict__ y, int K, int M,
-                                                      int N, int tiles_n, int tiles_total) {
+                                                      int N, int tiles_n, int tiles_total, float2 *__restrict__ stats_part) {
   constexpr int TM = 32 * MB;
   __shared__ __attribute__((aligned(16))) float xs[kPwK * kPwN];
   __shared__ __attribute__((aligned(16))) float ws[kPwK * TM];
@@ -162,6 +162,11 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const float *__restrict__ 
   }
 
   // ---- epilogue: D[i = m][j = point]; lanes = consecutive points (128-byte rows) ----
+  // stats_part != nullptr: per-channel (sum, sum of squares) of this workgroup's outputs ride on the epilogue, so
+  // the BatchNorm that follows needs no statistics pass over y (partials (M, tiles_total), combined by bn_finalize).
+  const bool want_stats = stats_part != nullptr;
+  float2 *stat_lds = reinterpret_cast<float2 *>(xs);        // [4 waves][TM]
+  if (want_stats) __syncthreads();                          // all waves are done reading xs / ws
   float *yb = y + (size_t)b * M * N;
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
@@ -172,6 +177,9 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const float *__restrict__ 
       const int m = m0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
       bv[r] = (BIAS && (FAST || m < M)) ? bias[m] : 0.0f;
     }
+    float ss[16], qq[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ss[r] = qq[r] = 0.0f;
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
       const int n = n0 + wave * 64 + nb * 32 + j;
@@ -182,8 +190,29 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const float *__restrict__ 
         // VGPRs in one block at the loop exit (+128 VGPRs for MB = 4: one wave per SIMD instead of two)
         float v;
         asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(acc[mb][nb][r]));
-        if (FAST || (n < N && m < M)) yb[(size_t)m * N + n] = v + bv[r];
+        v += bv[r];
+        if (FAST || (n < N && m < M)) yb[(size_t)m * N + n] = v;
+        if (want_stats) {
+          const float mv = (FAST || n < N) ? v : 0.0f;
+          ss[r] += mv;
+          qq[r] += mv * mv;
+        }
       }
+    }
+    if (want_stats) {
+      // lane j ends up with the totals of register (j >> 1) & 15 over its 32 voxels / points
+      const float st = half_wave_sum16(ss, j), qt = half_wave_sum16(qq, j);
+      const int rr = (j >> 1) & 15;
+      if ((j & 1) == 0) stat_lds[wave * TM + mb * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * kh] = make_float2(st, qt);
+    }
+  }
+  if (want_stats) {
+    __syncthreads();
+    if (tid < TM && m0 + tid < M) {
+      float2 t = stat_lds[tid];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) { t.x += stat_lds[w * TM + tid].x; t.y += stat_lds[w * TM + tid].y; }
+      stats_part[(size_t)(m0 + tid) * tiles_total + tile] = t;
     }
   }
 }
@@ -481,29 +510,47 @@ extern "C" int pvcnn_pwconv_transpose(const float *w, int M, int K, float *wt, v
   return check_launch("pwconv_transpose");
 }
 
-extern "C" int pvcnn_pwconv_fwd(const float *x, const float *wt, const float *bias, int B, int K, int M, int N, float *y,
-                                void *stream) {
-  PVCNN_REQUIRE(B >= 0 && K > 0 && M > 0 && N >= 0, "bad size");
-  if (B == 0 || N == 0) return 0;
-  PVCNN_REQUIRE(x && wt && y, "null pointer");
-  PVCNN_REQUIRE((long)N * std::max(K, M) <= 0x7fffffffL, "cloud too large");
+static int pwconv_fwd_impl(const float *x, const float *wt, const float *bias, int B, int K, int M, int N, float *y,
+                           float2 *stats_part, hipStream_t s) {
   const int tiles_n = ceil_div(N, kPwN);
   const int MB = M > 64 ? 4 : 2;                         // output channels per workgroup: 128 or 64
   const long tiles_total = (long)B * tiles_n;
   const long wgs = ((tiles_total + 7) / 8) * 8 * ceil_div(M, 32 * MB);   // tiles padded to the 8 XCDs
   PVCNN_REQUIRE(wgs <= 0x7fffffffL, "grid too large");
   const dim3 grid((unsigned)wgs);
-  hipStream_t s = static_cast<hipStream_t>(stream);
   const bool fast = (K % kPwK == 0) && (N % kPwN == 0) && (M % 32 == 0) && aligned16(x) && aligned16(wt);
 #define PVCNN_PW_LAUNCH(MBV, FASTV)                                                                                   \
   do {                                                                                                                \
-    if (bias) hipLaunchKernelGGL((pw_gemm_kernel<MBV, FASTV, true>), grid, dim3(256), 0, s, x, wt, bias, y, K, M, N, tiles_n, (int)tiles_total);  \
-    else      hipLaunchKernelGGL((pw_gemm_kernel<MBV, FASTV, false>), grid, dim3(256), 0, s, x, wt, bias, y, K, M, N, tiles_n, (int)tiles_total); \
+    if (bias) hipLaunchKernelGGL((pw_gemm_kernel<MBV, FASTV, true>), grid, dim3(256), 0, s, x, wt, bias, y, K, M, N, tiles_n, (int)tiles_total, stats_part);  \
+    else      hipLaunchKernelGGL((pw_gemm_kernel<MBV, FASTV, false>), grid, dim3(256), 0, s, x, wt, bias, y, K, M, N, tiles_n, (int)tiles_total, stats_part); \
   } while (0)
   if (MB == 4) { if (fast) PVCNN_PW_LAUNCH(4, true); else PVCNN_PW_LAUNCH(4, false); }
   else         { if (fast) PVCNN_PW_LAUNCH(2, true); else PVCNN_PW_LAUNCH(2, false); }
 #undef PVCNN_PW_LAUNCH
   return check_launch("pwconv_fwd");
+}
+
+extern "C" int pvcnn_pwconv_fwd(const float *x, const float *wt, const float *bias, int B, int K, int M, int N, float *y,
+                                void *stream) {
+  PVCNN_REQUIRE(B >= 0 && K > 0 && M > 0 && N >= 0, "bad size");
+  if (B == 0 || N == 0) return 0;
+  PVCNN_REQUIRE(x && wt && y, "null pointer");
+  PVCNN_REQUIRE((long)N * std::max(K, M) <= 0x7fffffffL, "cloud too large");
+  return pwconv_fwd_impl(x, wt, bias, B, K, M, N, y, nullptr, static_cast<hipStream_t>(stream));
+}
+
+extern "C" size_t pvcnn_pwconv_fwd_stats_parts(int B, int N) {
+  if (B <= 0 || N <= 0) return 0;
+  return (size_t)B * ceil_div(N, kPwN);
+}
+
+extern "C" int pvcnn_pwconv_fwd_stats(const float *x, const float *wt, const float *bias, int B, int K, int M, int N, float *y,
+                                      float *stats_part, void *stream) {
+  PVCNN_REQUIRE(B > 0 && K > 0 && M > 0 && N > 0, "bad size");
+  PVCNN_REQUIRE(x && wt && y && stats_part, "null pointer");
+  PVCNN_REQUIRE((reinterpret_cast<uintptr_t>(stats_part) & 7) == 0, "stats_part must be 8-byte aligned");
+  PVCNN_REQUIRE((long)N * std::max(K, M) <= 0x7fffffffL, "cloud too large");
+  return pwconv_fwd_impl(x, wt, bias, B, K, M, N, y, reinterpret_cast<float2 *>(stats_part), static_cast<hipStream_t>(stream));
 }
 
 extern "C" size_t pvcnn_pwconv_bwd_weight_workspace_bytes(int B, int K, int M, int N) {

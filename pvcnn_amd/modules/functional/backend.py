@@ -275,7 +275,7 @@ class HipBackend:
             _lib.check(self.lib.pvcnn_conv3d_weight_transform(_p(weight), co, ci, int(for_bwd_data), _p(wt), s), 'conv3d_weight_transform')
         return wt
 
-    def conv3d_forward(self, x, weight, bias):
+    def conv3d_forward(self, x, weight, bias, want_stats=False):
         _f32(x, 'x'); _f32(weight, 'weight')
         _shape(x.dim() == 5 and weight.dim() == 5 and tuple(weight.shape[2:]) == (3, 3, 3) and weight.shape[1] == x.shape[1]
                and x.shape[2] == x.shape[3] == x.shape[4], 'conv3d: x (B,Ci,R,R,R), weight (Co,Ci,3,3,3) expected')
@@ -285,6 +285,12 @@ class HipBackend:
         co = weight.shape[0]
         wt = self._conv_wt(weight, False)
         y = torch.empty((b, co, r, r, r), dtype=torch.float32, device=x.device)
+        if want_stats:   # per-workgroup (sum, sum of squares) partials for the BatchNorm that follows
+            part = torch.empty((co, self.lib.pvcnn_conv3d_fwd_stats_parts(b, co, r), 2), dtype=torch.float32, device=x.device)
+            with _Launch(x) as s:
+                _lib.check(self.lib.pvcnn_conv3d_fwd_stats(_p(x), _p(wt), _p(bias) if bias is not None else None, b, ci, co, r,
+                                                           _p(y), _p(part), s), 'conv3d_forward')
+            return y, part
         with _Launch(x) as s:
             _lib.check(self.lib.pvcnn_conv3d_fwd(_p(x), _p(wt), _p(bias) if bias is not None else None, b, ci, co, r, _p(y), s), 'conv3d_forward')
         return y
@@ -316,7 +322,7 @@ class HipBackend:
     # ---- SharedMLP 1x1 convolutions as channel-major MFMA GEMMs (csrc/pointwise.hip) --------------------
     has_pwconv = True
 
-    def pwconv_forward(self, x, weight, bias):
+    def pwconv_forward(self, x, weight, bias, want_stats=False):
         """x (B,Ci,N), weight (Co,Ci), bias (Co) or None -> y (B,Co,N)."""
         _f32(x, 'x'); _f32(weight, 'weight')
         _shape(x.dim() == 3 and weight.dim() == 2 and weight.shape[1] == x.shape[1], 'pwconv: x (B,Ci,N), weight (Co,Ci) expected')
@@ -326,10 +332,17 @@ class HipBackend:
         co = weight.shape[0]
         wt = torch.empty((ci, co), dtype=torch.float32, device=x.device)
         y = torch.empty((b, co, n), dtype=torch.float32, device=x.device)
+        part = None
+        if want_stats:
+            part = torch.empty((co, self.lib.pvcnn_pwconv_fwd_stats_parts(b, n), 2), dtype=torch.float32, device=x.device)
         with _Launch(x) as s:
             _lib.check(self.lib.pvcnn_pwconv_transpose(_p(weight), co, ci, _p(wt), s), 'pwconv_transpose')
-            _lib.check(self.lib.pvcnn_pwconv_fwd(_p(x), _p(wt), _p(bias) if bias is not None else None, b, ci, co, n, _p(y), s), 'pwconv_forward')
-        return y
+            if want_stats:
+                _lib.check(self.lib.pvcnn_pwconv_fwd_stats(_p(x), _p(wt), _p(bias) if bias is not None else None, b, ci, co, n,
+                                                           _p(y), _p(part), s), 'pwconv_forward')
+            else:
+                _lib.check(self.lib.pvcnn_pwconv_fwd(_p(x), _p(wt), _p(bias) if bias is not None else None, b, ci, co, n, _p(y), s), 'pwconv_forward')
+        return (y, part) if want_stats else y
 
     def pwconv_backward_data(self, grad_y, weight):
         """grad_y (B,Co,N), weight (Co,Ci) -> grad_x (B,Ci,N): the forward GEMM with K = Co on the weight as stored."""
@@ -357,14 +370,18 @@ class HipBackend:
     # ---- BatchNorm + ReLU/LeakyReLU in two passes each way (csrc/bnact.hip) ---------------------------
     has_bnact = True
 
-    def bnact_forward(self, x, gamma, beta, running_mean, running_var, training, momentum, eps, slope):
+    def bnact_forward(self, x, gamma, beta, running_mean, running_var, training, momentum, eps, slope, stats=None):
         """x (B,C,S) -> (y, mean, rstd).  Training: batch statistics (running stats updated in place);
-        eval: running statistics."""
+        eval: running statistics.  stats = (mean, rstd) already known (from a convolution epilogue +
+        bn_finalize): only the normalise + activate pass runs."""
         _f32(x, 'x')
         b, c, s3 = x.shape
         dev = x.device
         y = torch.empty_like(x)
-        if training:
+        if stats is not None:
+            mean, rstd = stats
+            training = False                    # the kernel entry's "statistics are given" mode
+        elif training:
             mean = torch.empty((c,), dtype=torch.float32, device=dev)
             rstd = torch.empty((c,), dtype=torch.float32, device=dev)
         else:
@@ -381,6 +398,20 @@ class HipBackend:
         return y, mean, rstd
 
     has_devox_bnact = True
+
+    def bn_finalize(self, part, count, running_mean, running_var, momentum, eps):
+        """(C, nparts, 2) partial sums from a convolution epilogue -> (mean, rstd); running stats updated in place."""
+        c, nparts = part.shape[0], part.shape[1]
+        dev = part.device
+        mean = torch.empty((c,), dtype=torch.float32, device=dev)
+        rstd = torch.empty((c,), dtype=torch.float32, device=dev)
+        nul = ctypes.c_void_p(None)
+        with _Launch(part) as s:
+            _lib.check(self.lib.pvcnn_bn_finalize(_p(part), c, nparts, float(count), float(eps), float(momentum),
+                                                  _p(running_mean) if running_mean is not None else nul,
+                                                  _p(running_var) if running_var is not None else nul, _p(mean), _p(rstd), s),
+                       'bn_finalize')
+        return mean, rstd
 
     def bn_stats(self, x, running_mean, running_var, momentum, eps):
         """Training-mode statistics of x (B,C,S): -> (mean, rstd); running stats updated in place (may be None)."""

@@ -18,12 +18,15 @@ __all__ = ['batch_norm_act', 'batch_norm_act_devoxelize', 'fusable_tail', 'run_l
 class BatchNormAct(Function):
     @staticmethod
     @amp_fwd
-    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, slope):
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, slope, stats_part=None):
         shape = x.shape
         x3 = x.contiguous().view(shape[0], shape[1], -1)
         w = weight.contiguous() if weight is not None else None
         b = bias.contiguous() if bias is not None else None
-        y, mean, rstd = native().bnact_forward(x3, w, b, running_mean, running_var, training, momentum, eps, slope)
+        stats = None
+        if training and stats_part is not None:   # partial sums from the producing convolution's epilogue
+            stats = native().bn_finalize(stats_part, x3.shape[0] * x3.shape[2], running_mean, running_var, momentum, eps)
+        y, mean, rstd = native().bnact_forward(x3, w, b, running_mean, running_var, training, momentum, eps, slope, stats=stats)
         ctx.save_for_backward(x3, w, b, mean, rstd)
         ctx.slope, ctx.training, ctx.shape = slope, training, shape
         return y.view(shape)
@@ -35,7 +38,7 @@ class BatchNormAct(Function):
         g3 = grad_y.contiguous().view(x3.shape)
         gx, gw, gb = native().bnact_backward(x3, g3, w, b, mean, rstd, ctx.slope, ctx.training)
         return (gx.view(ctx.shape), gw if w is not None else None, gb if b is not None else None,
-                None, None, None, None, None, None)
+                None, None, None, None, None, None, None)
 
 
 def _bn_mode(bn):
@@ -52,10 +55,11 @@ def _bn_mode(bn):
     return use_batch_stats, momentum, rm, rv
 
 
-def batch_norm_act(x, bn, slope):
-    """Apply BatchNorm module `bn` followed by LeakyReLU(slope) (slope = 0: ReLU) to x (B, C, ...)."""
+def batch_norm_act(x, bn, slope, stats_part=None):
+    """Apply BatchNorm module `bn` followed by LeakyReLU(slope) (slope = 0: ReLU) to x (B, C, ...).
+    stats_part: per-workgroup partial sums of x written by the convolution that produced it."""
     use_batch_stats, momentum, rm, rv = _bn_mode(bn)
-    return BatchNormAct.apply(x, bn.weight, bn.bias, rm, rv, use_batch_stats, momentum, bn.eps, slope)
+    return BatchNormAct.apply(x, bn.weight, bn.bias, rm, rv, use_batch_stats, momentum, bn.eps, slope, stats_part)
 
 
 class BatchNormActDevoxelize(Function):
@@ -66,12 +70,14 @@ class BatchNormActDevoxelize(Function):
     @staticmethod
     @amp_fwd
     def forward(ctx, grid, coords, weight, bias, running_mean, running_var, use_batch_stats, momentum, eps, slope,
-                resolution, is_training):
+                resolution, is_training, stats_part=None):
         shape = grid.shape
         x3 = grid.contiguous().view(shape[0], shape[1], -1)
         w = weight.contiguous() if weight is not None else None
         b = bias.contiguous() if bias is not None else None
-        if use_batch_stats:
+        if use_batch_stats and stats_part is not None:
+            mean, rstd = native().bn_finalize(stats_part, x3.shape[0] * x3.shape[2], running_mean, running_var, momentum, eps)
+        elif use_batch_stats:
             mean, rstd = native().bn_stats(x3, running_mean, running_var, momentum, eps)
         else:
             mean, rstd = running_mean.contiguous(), torch.rsqrt(running_var + eps)
@@ -89,13 +95,13 @@ class BatchNormActDevoxelize(Function):
         g_act = native().trilinear_devoxelize_backward(grad_out.contiguous(), inds, wgts, ctx.r)
         gx, gw, gb = native().bnact_backward(x3, g_act.view(x3.shape), w, b, mean, rstd, ctx.slope, ctx.use_batch_stats)
         return (gx.view(ctx.shape), None, gw if w is not None else None, gb if b is not None else None,
-                None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None)
 
 
-def batch_norm_act_devoxelize(grid, coords, bn, slope, resolution, is_training):
+def batch_norm_act_devoxelize(grid, coords, bn, slope, resolution, is_training, stats_part=None):
     use_batch_stats, momentum, rm, rv = _bn_mode(bn)
     return BatchNormActDevoxelize.apply(grid, coords, bn.weight, bn.bias, rm, rv, use_batch_stats, momentum, bn.eps, slope,
-                                        resolution, is_training)
+                                        resolution, is_training, stats_part)
 
 
 def fusable_tail(layers, x):
@@ -124,25 +130,48 @@ def _is_pointwise(m):
             and isinstance(m.padding, tuple))
 
 
-def run_layers(layers, x, stop=None):
+def _wants_batch_stats(m):
+    return isinstance(m, nn.modules.batchnorm._BatchNorm) and (m.training or m.running_mean is None)
+
+
+def run_layers(layers, x, stop=None, tail_stats=False):
     """nn.Sequential.forward with the GPU path's own kernels: 1x1 convolutions as channel-major MFMA GEMMs,
-    (BatchNorm, ReLU|LeakyReLU) pairs fused.  `stop`: run only the first `stop` modules."""
-    mods = list(layers)[:stop]
+    (BatchNorm, ReLU|LeakyReLU) pairs fused, and the statistics of a BatchNorm that directly follows one of our
+    convolutions taken from that convolution's epilogue instead of a pass over its output.
+    `stop`: run only the first `stop` modules.  `tail_stats`: return (x, stats_part) where stats_part belongs
+    to the BatchNorm at position `stop` if the last module run was such a convolution (else None)."""
+    all_mods = list(layers)
+    mods = all_mods[:stop]
     fuse = x.is_cuda and getattr(native(), 'has_bnact', False)
     pw = x.is_cuda and getattr(native(), 'has_pwconv', False)
+    part = carried = None
     i = 0
     while i < len(mods):
         m = mods[i]
+        nxt = all_mods[i + 1] if i + 1 < len(all_mods) else None
+        want = fuse and x.dtype == torch.float32 and _wants_batch_stats(nxt) and not torch.is_autocast_enabled()
+        part = None
         if (pw and _is_pointwise(m) and x.dtype == torch.float32 and x.dim() == len(m.kernel_size) + 2 and x.numel() > 0
                 and not torch.is_autocast_enabled()):
             from .pwconv import pointwise_conv
-            x = pointwise_conv(x, m.weight, m.bias)
+            if want:
+                x, part = pointwise_conv(x, m.weight, m.bias, True)
+            else:
+                x = pointwise_conv(x, m.weight, m.bias)
+            i += 1
+        elif want and hasattr(m, 'forward_with_stats') and x.numel() > 0:
+            res = m.forward_with_stats(x)
+            if isinstance(res, tuple):
+                x, part = res
+            else:
+                x = res
             i += 1
         elif (fuse and isinstance(m, nn.modules.batchnorm._BatchNorm) and i + 1 < len(mods) and x.dim() >= 3
                 and x.dtype == torch.float32 and _slope(mods[i + 1]) is not None and x.numel() > 0):
-            x = batch_norm_act(x, m, _slope(mods[i + 1]))
+            x = batch_norm_act(x, m, _slope(mods[i + 1]), stats_part=carried)
             i += 2
         else:
             x = m(x)
             i += 1
-    return x
+        carried = part
+    return (x, part) if tail_stats else x

@@ -13,17 +13,25 @@ __all__ = ['voxel_conv3d']
 class VoxelConv3d(Function):
     @staticmethod
     @amp_fwd
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, want_stats=False):
         x = x.contiguous()
         weight = weight.contiguous()
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        return native().conv3d_forward(x, weight, bias.contiguous() if bias is not None else None)
+        b = bias.contiguous() if bias is not None else None
+        if want_stats:   # second output: BatchNorm partial sums from the epilogue (not differentiable)
+            y, part = native().conv3d_forward(x, weight, b, want_stats=True)
+            ctx.mark_non_differentiable(part)
+            ctx.set_materialize_grads(False)     # no zero tensor for the (non-existent) gradient of `part`
+            return y, part
+        return native().conv3d_forward(x, weight, b)
 
     @staticmethod
     @amp_bwd
-    def backward(ctx, grad_y):
+    def backward(ctx, grad_y, grad_part=None):
         x, weight = ctx.saved_tensors
+        if grad_y is None:
+            return None, None, None, None
         grad_y = grad_y.contiguous()
         gx = native().conv3d_backward_data(grad_y, weight) if ctx.needs_input_grad[0] else None
         want_bias = ctx.has_bias and ctx.needs_input_grad[2]
@@ -34,7 +42,7 @@ class VoxelConv3d(Function):
             gw, gb = res if want_bias else (res, None)
         elif want_bias:
             gb = grad_y.sum(dim=(0, 2, 3, 4))
-        return gx, gw, gb
+        return gx, gw, gb, None
 
 
 voxel_conv3d = VoxelConv3d.apply

@@ -13,19 +13,26 @@ __all__ = ['pointwise_conv']
 class PointwiseConv(Function):
     @staticmethod
     @amp_fwd
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, want_stats=False):
         shape = x.shape
         x3 = x.contiguous().view(shape[0], shape[1], -1)
         w2 = weight.contiguous().view(weight.shape[0], weight.shape[1])
         ctx.save_for_backward(x3, w2)
         ctx.has_bias, ctx.x_shape, ctx.w_shape = bias is not None, shape, weight.shape
-        y = native().pwconv_forward(x3, w2, bias.contiguous() if bias is not None else None)
-        return y.view(shape[0], w2.shape[0], *shape[2:])
+        b = bias.contiguous() if bias is not None else None
+        if want_stats:   # second output: BatchNorm partial sums from the epilogue (not differentiable)
+            y, part = native().pwconv_forward(x3, w2, b, want_stats=True)
+            ctx.mark_non_differentiable(part)
+            ctx.set_materialize_grads(False)     # no zero tensor for the (non-existent) gradient of `part`
+            return y.view(shape[0], w2.shape[0], *shape[2:]), part
+        return native().pwconv_forward(x3, w2, b).view(shape[0], w2.shape[0], *shape[2:])
 
     @staticmethod
     @amp_bwd
-    def backward(ctx, grad_y):
+    def backward(ctx, grad_y, grad_part=None):
         x3, w2 = ctx.saved_tensors
+        if grad_y is None:
+            return None, None, None, None
         g3 = grad_y.contiguous().view(x3.shape[0], w2.shape[0], -1)
         gx = native().pwconv_backward_data(g3, w2).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
         want_bias = ctx.has_bias and ctx.needs_input_grad[2]
@@ -36,7 +43,7 @@ class PointwiseConv(Function):
             gw = gw.view(ctx.w_shape)
         elif want_bias:
             gb = g3.sum(dim=(0, 2))
-        return gx, gw, gb
+        return gx, gw, gb, None
 
 
 pointwise_conv = PointwiseConv.apply

@@ -8,6 +8,7 @@ Sub-module names are the reference's, so released checkpoints load unchanged:
 The voxel branch's scatter / gather run on the hand-written gfx950 kernels
 (avg_voxelize -> pvcnn_avg_voxelize_fwd, trilinear_devoxelize -> pvcnn_trilinear_devox_fwd).
 """
+import torch
 import torch.nn as nn
 
 from . import functional as F
@@ -33,6 +34,17 @@ class _VoxelConv3d(nn.Conv3d):
         if not fast:
             return super().forward(x)
         return voxel_conv3d(x, self.weight, self.bias)
+
+    def forward_with_stats(self, x):
+        """-> (y, stats_part) on the fast path: the epilogue also emits the per-channel partial sums the
+        BatchNorm behind this convolution needs (functional.bnact.run_layers); else plain forward(x)."""
+        fast = (x.is_cuda and getattr(native(), 'has_conv3d', False) and self.kernel_size == (3, 3, 3)
+                and self.stride == (1, 1, 1) and self.padding == (1, 1, 1) and self.dilation == (1, 1, 1)
+                and self.groups == 1 and self.padding_mode == 'zeros' and x.dim() == 5
+                and x.shape[2] == x.shape[3] == x.shape[4] and x.dtype == torch.float32)
+        if not fast:
+            return self.forward(x)
+        return voxel_conv3d(x, self.weight, self.bias, True)
 
 
 class PVConv(nn.Module):
@@ -64,9 +76,9 @@ class PVConv(nn.Module):
             # (and the gather does not start on a grid whose write is still draining to HBM: 1.5x slower, see
             # tools/devox_after_writer.py)
             bn, slope = tail
-            grid = run_layers(self.voxel_layers, grid, stop=len(self.voxel_layers) - 2)
+            grid, stats_part = run_layers(self.voxel_layers, grid, stop=len(self.voxel_layers) - 2, tail_stats=True)
             per_point = self.point_features(features)
-            from_voxels = batch_norm_act_devoxelize(grid, grid_coords, bn, slope, self.resolution, self.training)
+            from_voxels = batch_norm_act_devoxelize(grid, grid_coords, bn, slope, self.resolution, self.training, stats_part)
         else:
             grid = run_layers(self.voxel_layers, grid)     # = self.voxel_layers(grid), BN + LeakyReLU fused
             per_point = self.point_features(features)
