@@ -44,7 +44,7 @@ extern "C" int pvcnn_trilinear_devox_fwd(const float *coords, const float *feat,
     hipLaunchKernelGGL(trilinear_taps_only_kernel, dim3(ceil_div(N, 256), B), dim3(256), 0, s, p, N);
     return check_launch("trilinear_taps_only");
   }
-  return launch_gather(p, feat, outs, B, C, /*L=*/R * R * R, /*J=*/N, vec, s, "trilinear_devox_fwd");
+  return launch_gather(p, feat, outs, B, C, /*L=*/R * R * R, /*J=*/N, vec, s, "trilinear_devox_fwd", XfNone{}, grid_pad_shift(R));
 }
 
 extern "C" int pvcnn_trilinear_devox_bnact_fwd(const float *coords, const float *feat, const float *gamma,
@@ -62,7 +62,7 @@ extern "C" int pvcnn_trilinear_devox_bnact_fwd(const float *coords, const float 
   bool vec = (N % 4 == 0) && aligned16(coords) && aligned16(outs);
   if (is_training) vec = vec && aligned16(inds) && aligned16(wgts);
   const XfBnAct xf{gamma, beta, mean, rstd, slope};
-  return launch_gather(p, feat, outs, B, C, /*L=*/R * R * R, /*J=*/N, vec, s, "trilinear_devox_bnact_fwd", xf);
+  return launch_gather(p, feat, outs, B, C, /*L=*/R * R * R, /*J=*/N, vec, s, "trilinear_devox_bnact_fwd", xf, grid_pad_shift(R));
 }
 
 extern "C" size_t pvcnn_trilinear_devox_bwd_workspace_bytes(int B, int C, int N, int R) {

@@ -94,6 +94,9 @@ extern "C" int pvcnn_avg_voxelize_bwd(const float *grad_y, const int32_t *ind, c
   PVCNN_REQUIRE(B <= 65535, "batch > 65535");
   VoxelMean p{ind, cnt, N, S};
   const bool vec = (N % 4 == 0) && aligned16(ind) && aligned16(grad_x);
+  int pshift = 0;                                          // S = R^3 with R = 2^k >= 4: padded LDS rows
+  for (int k = 2; k <= 10; ++k)
+    if ((1L << (3 * k)) == (long)S) pshift = k;
   return launch_gather(p, grad_y, grad_x, B, C, /*L=*/S, /*J=*/N, vec, static_cast<hipStream_t>(stream),
-                       "avg_voxelize_bwd");
+                       "avg_voxelize_bwd", XfNone{}, pshift);
 }
