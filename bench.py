@@ -262,8 +262,8 @@ def main():
                         'algorithmic_MB': head['algorithmic_MB'], 'traffic': None}
             if head['shape_BCNR'] == [16, 64, 4096, 32]:
                 # HBM bytes per launch from rocprofv3 PMC passes on this kernel and shape (separate runs:
-                # FETCH_SIZE 68634 KiB, doubled per MI355X_MICROARCH.md for gfx950; WRITE_SIZE 20480 KiB)
-                roofline['traffic'] = (2 * 68634 + 20480) * 1024
+                # FETCH_SIZE 68656 KiB, doubled per MI355X_MICROARCH.md for gfx950; WRITE_SIZE 20480 KiB)
+                roofline['traffic'] = (2 * 68656 + 20480) * 1024
                 roofline['traffic_source'] = 'profiles/r01_pmc_FETCH_SIZE_*.txt + r01_pmc_WRITE_SIZE_*.txt (rocprofv3 --pmc, separate passes)'
         line = {
             'metric': 'point-clouds/sec fwd+bwd, PVCNN S3DIS N=4096 R=32',
