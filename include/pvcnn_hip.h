@@ -230,6 +230,17 @@ PVCNN_API int pvcnn_bnact_bwd(const float *x, const float *grad_y, const float *
                               const float *mean, const float *rstd, int B, int C, int S, float slope, int training,
                               float *grad_x, float *grad_gamma, float *grad_beta, void *workspace,
                               size_t workspace_bytes, void *stream);
+/* As pvcnn_bnact_bwd / pvcnn_trilinear_devox_bwd, but grad_y may be a channel-slice VIEW of a wider tensor (what
+ * the backward of torch.cat hands to each consumer): the C rows of one sample / cloud are contiguous, samples
+ * are grad_y_batch_stride elements apart (>= C*S resp. C*N).  Saves the .contiguous() copy of every gradient. */
+PVCNN_API int pvcnn_bnact_bwd_strided(const float *x, const float *grad_y, long grad_y_batch_stride, const float *gamma,
+                            const float *beta, const float *mean, const float *rstd, int B, int C, int S,
+                            float slope, int training, float *grad_x, float *grad_gamma, float *grad_beta,
+                            void *workspace, size_t workspace_bytes, void *stream);
+PVCNN_API int pvcnn_trilinear_devox_bwd_strided(const float *grad_y, long grad_y_batch_stride, const int32_t *inds,
+                                      const float *wgts, int B, int C, int N, int R, float *grad_x,
+                                      void *workspace, size_t workspace_bytes, void *stream);
+
 
 #ifdef __cplusplus
 }

@@ -118,19 +118,21 @@ __global__ __launch_bounds__(kBnThreads) void bnact_bwd_reduce_kernel(const floa
                                                                      const float *__restrict__ rstd,
                                                                      const float *__restrict__ gamma,
                                                                      const float *__restrict__ beta, float slope, int C,
-                                                                     int S, int slices, float2 *__restrict__ part) {
+                                                                     int S, int slices, float2 *__restrict__ part,
+                                                                     long gy_bstride) {
   __shared__ float sm[16];
   const int sl = blockIdx.x, b = blockIdx.y, c = blockIdx.z;
   const float m = mean[c], r = rstd[c];
   const float scale = (gamma ? gamma[c] : 1.0f) * r;
   const float shift = (beta ? beta[c] : 0.0f) - m * scale;
   const size_t off = ((size_t)b * C + c) * S;
+  const size_t goff = (size_t)b * gy_bstride + (size_t)c * S;   // grad_y: channels of a cloud contiguous, clouds gy_bstride apart
   const int lo = sl * kBnSlice, hi = min(S, lo + kBnSlice);
   float s = 0.f, q = 0.f;
-  if ((S & 3) == 0 && aligned16(x + off) && aligned16(gy + off)) {
+  if ((S & 3) == 0 && aligned16(x + off) && aligned16(gy + goff)) {
     for (int i = lo + threadIdx.x * 4; i < hi; i += kBnThreads * 4) {
       const float4 xv = *reinterpret_cast<const float4 *>(x + off + i);
-      const float4 gv = *reinterpret_cast<const float4 *>(gy + off + i);
+      const float4 gv = *reinterpret_cast<const float4 *>(gy + goff + i);
       const float xs_[4] = {xv.x, xv.y, xv.z, xv.w}, gs_[4] = {gv.x, gv.y, gv.z, gv.w};
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(kBnThreads) void bnact_bwd_reduce_kernel(const floa
     for (int i = lo + threadIdx.x; i < hi; i += kBnThreads) {
       const float xv = x[off + i];
       const float z = fmaf(xv, scale, shift);
-      const float g = gy[off + i] * (z > 0.f ? 1.0f : slope);
+      const float g = gy[goff + i] * (z > 0.f ? 1.0f : slope);
       s += g;
       q += g * ((xv - m) * r);
     }
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(kBnThreads) void bnact_bwd_apply_kernel(const float
                                                                     const float *__restrict__ dgamma,
                                                                     const float *__restrict__ dbeta, float slope,
                                                                     float inv_count, int training, int C, int S,
-                                                                    float *__restrict__ gx) {
+                                                                    float *__restrict__ gx, long gy_bstride) {
   const int sl = blockIdx.x, b = blockIdx.y, c = blockIdx.z;
   const float m = mean[c], r = rstd[c];
   const float gmm = gamma ? gamma[c] : 1.0f;
@@ -181,11 +183,12 @@ __global__ __launch_bounds__(kBnThreads) void bnact_bwd_apply_kernel(const float
   const float shift = (beta ? beta[c] : 0.0f) - m * scale;
   const float db = training ? dbeta[c] * inv_count : 0.0f, dg = training ? dgamma[c] * inv_count : 0.0f;
   const size_t off = ((size_t)b * C + c) * S;
+  const size_t goff = (size_t)b * gy_bstride + (size_t)c * S;
   const int lo = sl * kBnSlice, hi = min(S, lo + kBnSlice);
-  if ((S & 3) == 0 && aligned16(x + off) && aligned16(gy + off) && aligned16(gx + off)) {
+  if ((S & 3) == 0 && aligned16(x + off) && aligned16(gy + goff) && aligned16(gx + off)) {
     for (int i = lo + threadIdx.x * 4; i < hi; i += kBnThreads * 4) {
       const float4 xv = *reinterpret_cast<const float4 *>(x + off + i);
-      const float4 gv = *reinterpret_cast<const float4 *>(gy + off + i);
+      const float4 gv = *reinterpret_cast<const float4 *>(gy + goff + i);
       const float xs_[4] = {xv.x, xv.y, xv.z, xv.w}, gs_[4] = {gv.x, gv.y, gv.z, gv.w};
       float o[4];
 #pragma unroll
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(kBnThreads) void bnact_bwd_apply_kernel(const float
     for (int i = lo + threadIdx.x; i < hi; i += kBnThreads) {
       const float xv = x[off + i];
       const float z = fmaf(xv, scale, shift);
-      const float g = gy[off + i] * (z > 0.f ? 1.0f : slope);
+      const float g = gy[goff + i] * (z > 0.f ? 1.0f : slope);
       const float xhat = (xv - m) * r;
       gx[off + i] = scale * (g - db - xhat * dg);
     }
@@ -266,22 +269,40 @@ extern "C" int pvcnn_bn_stats(const float *x, float *running_mean, float *runnin
   return check_launch("bn_finalize");
 }
 
-extern "C" int pvcnn_bnact_bwd(const float *x, const float *grad_y, const float *gamma, const float *beta, const float *mean,
-                               const float *rstd, int B, int C, int S, float slope, int training, float *grad_x,
-                               float *grad_gamma, float *grad_beta, void *workspace, size_t workspace_bytes, void *stream) {
+static int bnact_bwd_impl(const float *x, const float *grad_y, long gy_bstride, const float *gamma, const float *beta,
+                          const float *mean, const float *rstd, int B, int C, int S, float slope, int training, float *grad_x,
+                          float *grad_gamma, float *grad_beta, void *workspace, size_t workspace_bytes, void *stream) {
   PVCNN_REQUIRE(B > 0 && C > 0 && S > 0 && x && grad_y && mean && rstd && grad_x && grad_gamma && grad_beta, "bad argument");
   PVCNN_REQUIRE(B <= 65535 && C <= 65535, "batch or channel count > 65535");
+  PVCNN_REQUIRE(gy_bstride >= (long)C * S, "grad_y batch stride smaller than one sample");
   PVCNN_REQUIRE(workspace && workspace_bytes >= pvcnn_bnact_workspace_bytes(B, C, S), "workspace too small");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int slices = ceil_div(S, kBnSlice);
   const dim3 grid(slices, B, C);
   float2 *part = static_cast<float2 *>(workspace);
   hipLaunchKernelGGL(bnact_bwd_reduce_kernel, grid, dim3(kBnThreads), 0, s, x, grad_y, mean, rstd, gamma, beta, slope, C, S,
-                     slices, part);
+                     slices, part, gy_bstride);
   if (int e = check_launch("bnact_bwd_reduce")) return e;
   hipLaunchKernelGGL(bnact_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, part, B * slices, grad_gamma, grad_beta);
   if (int e = check_launch("bnact_bwd_finalize")) return e;
   hipLaunchKernelGGL(bnact_bwd_apply_kernel, grid, dim3(kBnThreads), 0, s, x, grad_y, mean, rstd, gamma, beta, grad_gamma,
-                     grad_beta, slope, (float)(1.0 / ((double)B * S)), training, C, S, grad_x);
+                     grad_beta, slope, (float)(1.0 / ((double)B * S)), training, C, S, grad_x, gy_bstride);
   return check_launch("bnact_bwd_apply");
+}
+
+extern "C" int pvcnn_bnact_bwd(const float *x, const float *grad_y, const float *gamma, const float *beta, const float *mean,
+                               const float *rstd, int B, int C, int S, float slope, int training, float *grad_x,
+                               float *grad_gamma, float *grad_beta, void *workspace, size_t workspace_bytes, void *stream) {
+  return bnact_bwd_impl(x, grad_y, (long)C * S, gamma, beta, mean, rstd, B, C, S, slope, training, grad_x, grad_gamma, grad_beta,
+                        workspace, workspace_bytes, stream);
+}
+
+// grad_y may be a channel-slice view of a wider (B, C_total, S) tensor (what torch.cat's backward hands out):
+// channels of one sample contiguous, samples grad_y_batch_stride elements apart -- no .contiguous() copy needed.
+extern "C" int pvcnn_bnact_bwd_strided(const float *x, const float *grad_y, long grad_y_batch_stride, const float *gamma,
+                                       const float *beta, const float *mean, const float *rstd, int B, int C, int S, float slope,
+                                       int training, float *grad_x, float *grad_gamma, float *grad_beta, void *workspace,
+                                       size_t workspace_bytes, void *stream) {
+  return bnact_bwd_impl(x, grad_y, grad_y_batch_stride, gamma, beta, mean, rstd, B, C, S, slope, training, grad_x, grad_gamma,
+                        grad_beta, workspace, workspace_bytes, stream);
 }

@@ -367,12 +367,12 @@ template <int G, int VEC, int THREADS, bool STAGE>
 __global__ __launch_bounds__(THREADS) void segsum_kernel(const float *__restrict__ src,
                                                          const int32_t *__restrict__ start,
                                                          const int2 *__restrict__ ent, float *__restrict__ dst,
-                                                         int C, int L, int J, int E) {
+                                                         int C, int L, int J, int E, long src_bstride) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int b = blockIdx.y;
   const int c0 = blockIdx.x * G;
   const int g = min(G, C - c0);
-  const float *rows = src + ((size_t)b * C + c0) * J;
+  const float *rows = src + (size_t)b * src_bstride + (size_t)c0 * J;   // src: rows of one cloud contiguous, clouds src_bstride apart
   if (STAGE) {
     slab_copy<THREADS>(lds, rows, g * J);
     __syncthreads();
@@ -445,13 +445,13 @@ __global__ __launch_bounds__(THREADS) void segsum_kernel(const float *__restrict
 //                         entries are spread over the targets.
 // ---------------------------------------------------------------------------------------------
 static __global__ __launch_bounds__(256) void transpose_cj_kernel(const float *__restrict__ src, float *__restrict__ dstT, int C,
-                                                           int J, int Cp) {
+                                                           int J, int Cp, long src_bstride) {
   __shared__ float tile[64][65];
   const int b = blockIdx.z, j0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (int r = ty; r < 64; r += 4) {   // read rows of src: lanes along j
     const int c = c0 + r, j = j0 + tx;
-    tile[r][tx] = (c < C && j < J) ? src[((size_t)b * C + c) * J + j] : 0.0f;
+    tile[r][tx] = (c < C && j < J) ? src[(size_t)b * src_bstride + (size_t)c * J + j] : 0.0f;
   }
   __syncthreads();
   for (int r = ty; r < 64; r += 4) {   // write rows of srcT: lanes along c
@@ -508,14 +508,14 @@ inline bool csr_supported(int L, long E) { return L <= kCsrMaxTargets && E <= 0x
 
 template <int G, bool STAGE>
 int launch_segsum_g(const float *src, const CsrWorkspace &ws, float *dst, int B, int C, int L, int J, int E,
-                    bool vec, int threads, hipStream_t s, const char *what) {
+                    bool vec, int threads, hipStream_t s, const char *what, long src_bstride) {
   const size_t lds = STAGE ? (size_t)G * J * sizeof(float) : 0;
   const dim3 grid(ceil_div(C, G), B);
 #define PVCNN_SEGSUM(VEC, T)                                                                          \
   do {                                                                                                \
     auto k = segsum_kernel<G, VEC, T, STAGE>;                                                         \
     if (int e = enable_big_lds(k, lds)) { set_error("%s: LDS attribute: %d", what, e); return e; }    \
-    hipLaunchKernelGGL(k, grid, dim3(T), lds, s, src, ws.start, ws.ent, dst, C, L, J, E);             \
+    hipLaunchKernelGGL(k, grid, dim3(T), lds, s, src, ws.start, ws.ent, dst, C, L, J, E, src_bstride); \
   } while (0)
   if (threads == 1024) { if (vec) PVCNN_SEGSUM(4, 1024); else PVCNN_SEGSUM(1, 1024); }
   else                 { if (vec) PVCNN_SEGSUM(4, 256);  else PVCNN_SEGSUM(1, 256); }
@@ -527,7 +527,9 @@ int launch_segsum_g(const float *src, const CsrWorkspace &ws, float *dst, int B,
 // cnt_out: optional (B,L) per-target counts (avg_voxelize's `cnt`).
 template <class EP>
 int launch_csr_scatter(const EP &ep, const float *src, float *dst, int B, int C, int L, int J, long E_,
-                       int32_t *cnt_out, void *workspace, size_t workspace_bytes, hipStream_t s, const char *what) {
+                       int32_t *cnt_out, void *workspace, size_t workspace_bytes, hipStream_t s, const char *what,
+                       long src_bstride = 0) {
+  if (src_bstride <= 0) src_bstride = (long)C * J;          // default: src is a contiguous (B,C,J) tensor
   const int E = (int)E_;
   if (B == 0) return 0;
   if (!workspace || workspace_bytes < CsrWorkspace::bytes(B, C, L, J, E) || !aligned16(workspace)) {
@@ -550,7 +552,7 @@ int launch_csr_scatter(const EP &ep, const float *src, float *dst, int B, int C,
     // dense targets: channels-last copy of the source rows + channel-per-lane segmented sums
     const int Cp = cl_channels(C);
     if (J > 0) {
-      hipLaunchKernelGGL(transpose_cj_kernel, dim3(ceil_div(J, 64), Cp / 64, B), dim3(256), 0, s, src, ws.srcT, C, J, Cp);
+      hipLaunchKernelGGL(transpose_cj_kernel, dim3(ceil_div(J, 64), Cp / 64, B), dim3(256), 0, s, src, ws.srcT, C, J, Cp, src_bstride);
       if (int e = check_launch(what)) return e;
     }
     hipLaunchKernelGGL(segsum_cl_kernel, dim3(ceil_div(L, 64), Cp / 64, B), dim3(1024), 0, s, ws.srcT, ws.start, ws.ent, dst,
@@ -570,12 +572,12 @@ int launch_csr_scatter(const EP &ep, const float *src, float *dst, int B, int C,
   }
   const bool vec = (L % 4 == 0) && aligned16(dst);
   const int threads = (L >= 8192 || (size_t)G * row > 48 * 1024) ? 1024 : 256;
-  if (!stage) return launch_segsum_g<1, false>(src, ws, dst, B, C, L, J, E, vec, threads, s, what);
+  if (!stage) return launch_segsum_g<1, false>(src, ws, dst, B, C, L, J, E, vec, threads, s, what, src_bstride);
   switch (G) {
-    case 8: return launch_segsum_g<8, true>(src, ws, dst, B, C, L, J, E, vec, threads, s, what);
-    case 4: return launch_segsum_g<4, true>(src, ws, dst, B, C, L, J, E, vec, threads, s, what);
-    case 2: return launch_segsum_g<2, true>(src, ws, dst, B, C, L, J, E, vec, threads, s, what);
-    default: return launch_segsum_g<1, true>(src, ws, dst, B, C, L, J, E, vec, threads, s, what);
+    case 8: return launch_segsum_g<8, true>(src, ws, dst, B, C, L, J, E, vec, threads, s, what, src_bstride);
+    case 4: return launch_segsum_g<4, true>(src, ws, dst, B, C, L, J, E, vec, threads, s, what, src_bstride);
+    case 2: return launch_segsum_g<2, true>(src, ws, dst, B, C, L, J, E, vec, threads, s, what, src_bstride);
+    default: return launch_segsum_g<1, true>(src, ws, dst, B, C, L, J, E, vec, threads, s, what, src_bstride);
   }
 }
 

@@ -72,21 +72,34 @@ extern "C" size_t pvcnn_trilinear_devox_bwd_workspace_bytes(int B, int C, int N,
   return CsrWorkspace::bytes(B, C, (int)S, N, 8L * N);
 }
 
-extern "C" int pvcnn_trilinear_devox_bwd(const float *grad_y, const int32_t *inds, const float *wgts, int B,
-                                         int C, int N, int R, float *grad_x, void *workspace,
-                                         size_t workspace_bytes, void *stream) {
+static int devox_bwd_impl(const float *grad_y, long gy_bstride, const int32_t *inds, const float *wgts, int B, int C, int N,
+                          int R, float *grad_x, void *workspace, size_t workspace_bytes, void *stream) {
   PVCNN_REQUIRE(B >= 0 && C >= 0 && N >= 0 && R > 0, "negative size");
   PVCNN_REQUIRE((long)R * R * R <= 0x7fffffffL / 4, "resolution too large");
   if (B == 0 || C == 0) return 0;
   PVCNN_REQUIRE(grad_x && (N == 0 || (grad_y && inds && wgts)), "null pointer");
   PVCNN_REQUIRE(B <= 65535, "batch > 65535");
+  PVCNN_REQUIRE(gy_bstride >= (long)C * N, "grad_y batch stride smaller than one cloud");
   const int S = R * R * R;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (!csr_supported(S, 8L * N)) {
+    PVCNN_REQUIRE(gy_bstride == (long)C * N, "the atomic fallback needs a contiguous grad_y");
     SavedTaps<8> p{inds, wgts, N};
     return launch_scatter_direct(p, grad_y, grad_x, B, C, S, N, s, "trilinear_devox_bwd(atomic)");
   }
   TapEntries<8> ep{inds, wgts, N, S};
   return launch_csr_scatter(ep, grad_y, grad_x, B, C, /*L=*/S, /*J=*/N, /*E=*/8L * N, nullptr, workspace,
-                            workspace_bytes, s, "trilinear_devox_bwd");
+                            workspace_bytes, s, "trilinear_devox_bwd", gy_bstride);
+}
+
+extern "C" int pvcnn_trilinear_devox_bwd(const float *grad_y, const int32_t *inds, const float *wgts, int B,
+                                         int C, int N, int R, float *grad_x, void *workspace,
+                                         size_t workspace_bytes, void *stream) {
+  return devox_bwd_impl(grad_y, (long)C * N, inds, wgts, B, C, N, R, grad_x, workspace, workspace_bytes, stream);
+}
+
+extern "C" int pvcnn_trilinear_devox_bwd_strided(const float *grad_y, long grad_y_batch_stride, const int32_t *inds,
+                                                 const float *wgts, int B, int C, int N, int R, float *grad_x,
+                                                 void *workspace, size_t workspace_bytes, void *stream) {
+  return devox_bwd_impl(grad_y, grad_y_batch_stride, inds, wgts, B, C, N, R, grad_x, workspace, workspace_bytes, stream);
 }

@@ -34,6 +34,27 @@ def _f32(t, name):
         raise RuntimeError(f'{name} must be a float tensor')
 
 
+def _f32_rows(t, name):
+    """float32 (B, C, S) tensor whose C*S rows of a sample are contiguous; samples may be further apart (a channel
+    slice of a wider tensor, e.g. a gradient coming out of torch.cat's backward).  -> batch stride in elements."""
+    _dev(t, name)
+    if t.dtype != torch.float32:
+        raise RuntimeError(f'{name} must be a float tensor')
+    b, c, n = t.shape
+    ok = (n == 1 or t.stride(2) == 1) and (c == 1 or t.stride(1) == n) and (b == 1 or t.stride(0) >= c * n)
+    if not ok:
+        raise RuntimeError(f'{name} must be contiguous within each sample')
+    return t.stride(0) if b > 1 else c * n
+
+
+def batch_strided_ok(t):
+    """True when _f32_rows would accept t (callers use it to skip a .contiguous() copy)."""
+    if t.dim() != 3 or t.dtype != torch.float32:
+        return False
+    b, c, n = t.shape
+    return (n == 1 or t.stride(2) == 1) and (c == 1 or t.stride(1) == n) and (b == 1 or t.stride(0) >= c * n)
+
+
 def _i32(t, name):
     _dev(t, name)
     if not t.is_contiguous():
@@ -218,7 +239,7 @@ class HipBackend:
         return [outs, inds, wgts]
 
     def trilinear_devoxelize_backward(self, grad_y, indices, weights, r):
-        _f32(grad_y, 'grad_y'); _f32(weights, 'weights'); _i32(indices, 'indices')
+        gy_bstride = _f32_rows(grad_y, 'grad_y'); _f32(weights, 'weights'); _i32(indices, 'indices')
         _shape(grad_y.dim() == 3 and tuple(indices.shape) == (grad_y.shape[0], 8, grad_y.shape[2])
                and indices.shape == weights.shape,
                'trilinear_devoxelize backward: grad_y (B,C,N), indices/weights (B,8,N) expected')
@@ -227,8 +248,8 @@ class HipBackend:
         grad_x = torch.empty((b, c, r * r * r), dtype=torch.float32, device=grad_y.device)
         ws = self._scratch(self.lib.pvcnn_trilinear_devox_bwd_workspace_bytes(b, c, n, r), grad_y.device)
         with _Launch(grad_y) as s:
-            _lib.check(self.lib.pvcnn_trilinear_devox_bwd(_p(grad_y), _p(indices), _p(weights), b, c, n, r, _p(grad_x),
-                                                          _p(ws), ws.numel(), s),
+            _lib.check(self.lib.pvcnn_trilinear_devox_bwd_strided(_p(grad_y), gy_bstride, _p(indices), _p(weights), b, c, n, r,
+                                                                  _p(grad_x), _p(ws), ws.numel(), s),
                        'trilinear_devoxelize_backward')
         return grad_x
 
@@ -456,7 +477,8 @@ class HipBackend:
         return [outs, inds, wgts]
 
     def bnact_backward(self, x, grad_y, gamma, beta, mean, rstd, slope, training):
-        _f32(x, 'x'); _f32(grad_y, 'grad_y')
+        _f32(x, 'x')
+        gy_bstride = _f32_rows(grad_y, 'grad_y')
         b, c, s3 = x.shape
         dev = x.device
         gx = torch.empty_like(x)
@@ -465,7 +487,7 @@ class HipBackend:
         ws = self._scratch(self.lib.pvcnn_bnact_workspace_bytes(b, c, s3), dev)
         nul = ctypes.c_void_p(None)
         with _Launch(x) as s:
-            _lib.check(self.lib.pvcnn_bnact_bwd(_p(x), _p(grad_y), _p(gamma) if gamma is not None else nul,
+            _lib.check(self.lib.pvcnn_bnact_bwd_strided(_p(x), _p(grad_y), gy_bstride, _p(gamma) if gamma is not None else nul,
                                                 _p(beta) if beta is not None else nul, _p(mean), _p(rstd), b, c, s3, float(slope),
                                                 int(bool(training)), _p(gx), _p(gg), _p(gb), _p(ws), ws.numel(), s), 'bnact_backward')
         return gx, gg, gb

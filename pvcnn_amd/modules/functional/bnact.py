@@ -12,6 +12,20 @@ from torch.autograd import Function
 
 from ._autograd import native, amp_fwd, amp_bwd
 
+
+def _rows(t, shape):
+    """grad tensor -> (B, C, S) view without a copy when each sample's rows are contiguous (channel slices of a
+    wider tensor, as torch.cat's backward produces), else a contiguous copy."""
+    from .backend import batch_strided_ok
+    if t.dim() == len(shape) and t.dim() >= 3:
+        try:
+            v = t.view(shape[0], shape[1], -1) if t.dim() > 3 else t
+            if batch_strided_ok(v):
+                return v
+        except RuntimeError:
+            pass
+    return t.contiguous().view(shape[0], shape[1], -1)
+
 __all__ = ['batch_norm_act', 'batch_norm_act_devoxelize', 'fusable_tail', 'run_layers']
 
 
@@ -35,7 +49,7 @@ class BatchNormAct(Function):
     @amp_bwd
     def backward(ctx, grad_y):
         x3, w, b, mean, rstd = ctx.saved_tensors
-        g3 = grad_y.contiguous().view(x3.shape)
+        g3 = _rows(grad_y, ctx.shape)
         gx, gw, gb = native().bnact_backward(x3, g3, w, b, mean, rstd, ctx.slope, ctx.training)
         return (gx.view(ctx.shape), gw if w is not None else None, gb if b is not None else None,
                 None, None, None, None, None, None, None)
@@ -92,7 +106,7 @@ class BatchNormActDevoxelize(Function):
     @amp_bwd
     def backward(ctx, grad_out):
         x3, w, b, mean, rstd, inds, wgts = ctx.saved_tensors
-        g_act = native().trilinear_devoxelize_backward(grad_out.contiguous(), inds, wgts, ctx.r)
+        g_act = native().trilinear_devoxelize_backward(_rows(grad_out, grad_out.shape), inds, wgts, ctx.r)
         gx, gw, gb = native().bnact_backward(x3, g_act.view(x3.shape), w, b, mean, rstd, ctx.slope, ctx.use_batch_stats)
         return (gx.view(ctx.shape), None, gw if w is not None else None, gb if b is not None else None,
                 None, None, None, None, None, None, None, None, None)

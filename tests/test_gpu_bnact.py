@@ -83,3 +83,31 @@ def test_bn_act_fused_into_devoxelize_is_bit_identical(hip):
             finally:
                 type(be).has_devox_bnact = True
         assert torch.equal(ya, yb)
+
+
+def test_backward_kernels_take_batch_strided_gradients(hip):
+    """Gradients that are channel slices of a wider tensor (torch.cat's backward) are consumed in place:
+    same bits as with a contiguous copy, for the BN+act backward and the devoxelize backward."""
+    dev = 'cuda:0'
+    torch.manual_seed(5)
+    b, c, n, r = 3, 24, 1000, 8
+    wide = torch.randn(b, c + 40, n, device=dev)
+    g_view = wide[:, 8:8 + c, :]
+    assert not g_view.is_contiguous()
+    g_copy = g_view.contiguous()
+    x = torch.randn(b, c, n, device=dev)
+    gamma, beta = torch.rand(c, device=dev) + 0.5, torch.randn(c, device=dev)
+    _, mean, rstd = hip.bnact_forward(x, gamma, beta, None, None, True, 0.1, 1e-5, 0.1)
+    for a, bb in zip(hip.bnact_backward(x, g_view, gamma, beta, mean, rstd, 0.1, True),
+                     hip.bnact_backward(x, g_copy, gamma, beta, mean, rstd, 0.1, True)):
+        assert torch.equal(a, bb)
+    coords = torch.rand(b, 3, n, device=dev) * (r - 1)
+    grid = torch.randn(b, c, r ** 3, device=dev)
+    _, inds, wgts = hip.trilinear_devoxelize_forward(r, True, coords, grid)
+    assert torch.equal(hip.trilinear_devoxelize_backward(g_view, inds, wgts, r),
+                       hip.trilinear_devoxelize_backward(g_copy, inds, wgts, r))
+    # dense-target path of the scatter (many points per voxel)
+    coords2 = torch.rand(b, 3, n, device=dev) * 3
+    _, inds2, wgts2 = hip.trilinear_devoxelize_forward(4, True, coords2, torch.randn(b, c, 64, device=dev))
+    assert torch.equal(hip.trilinear_devoxelize_backward(g_view, inds2, wgts2, 4),
+                       hip.trilinear_devoxelize_backward(g_copy, inds2, wgts2, 4))
