@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(const float *__restri
     __syncthreads();
     stage_halo_tile<TX, TY, TZ, CIC, VEC>(xs, xb, c0, Ci, R, x0, y0, z0, tid);
     // ---- weights of this channel chunk: wt is (Ci, 27, Co) -> ws[c][tap][64] ----
-    if (VEC) {   // Co % 4 == 0 and the 64-wide co tile lies inside Co: whole 16-byte quads
+    if (VEC) {   // Co % 4 == 0: whole 16-byte quads, those beyond Co are zero
       constexpr int NQ = CIC * 27 * (kCoTile / 4), ITER = (NQ + 255) / 256;
       float4 v[ITER];
 #pragma unroll
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(const float *__restri
         const int q = tid + it * 256;
         const int rowi = q / (kCoTile / 4), qi = q - rowi * (kCoTile / 4);   // rowi = c*27 + tap
         v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (q < NQ && c0 + rowi / 27 < Ci) v[it] = ld4g(wt + ((size_t)c0 * 27 + rowi) * Co + co0 + qi * 4);
+        if (q < NQ && c0 + rowi / 27 < Ci && co0 + qi * 4 < Co) v[it] = ld4g(wt + ((size_t)c0 * 27 + rowi) * Co + co0 + qi * 4);
       }
 #pragma unroll
       for (int it = 0; it < ITER; ++it) {
@@ -293,8 +293,8 @@ static int launch_igemm_v(const float *x, const float *wt, const float *bias, fl
 template <int TX, int TY, int TZ, int CIC, int NBW = 2>
 static int launch_igemm(const float *x, const float *wt, const float *bias, float *y, int B, int Ci, int Co, int R,
                         hipStream_t s, float2 *stats_part) {
-  // vector staging needs full aligned z-rows (R == TZ) and whole 64-wide, 16-byte aligned co tiles
-  const bool vec = (R == TZ) && (Co % kCoTile == 0) && aligned16(x) && aligned16(wt);
+  // vector staging needs full aligned z-rows (R == TZ) and 16-byte aligned weight rows (whole quads of co)
+  const bool vec = (R == TZ) && (Co % 4 == 0) && aligned16(x) && aligned16(wt);
   return vec ? launch_igemm_v<TX, TY, TZ, CIC, true, NBW>(x, wt, bias, y, B, Ci, Co, R, s, stats_part)
              : launch_igemm_v<TX, TY, TZ, CIC, false, NBW>(x, wt, bias, y, B, Ci, Co, R, s, stats_part);
 }
@@ -686,7 +686,8 @@ extern "C" int pvcnn_conv3d_weight_transform(const float *w, int Co, int Ci, int
   return check_launch("conv3d_weight_transform");
 }
 
-// tile variant of a forward launch: 0 -> (2,4,32), 1 -> (2,4,16) half tile, 2 -> (4,4,16), 3 -> (4,8,8); *nparts = spatial
+// tile variant of a forward launch: 0 -> (2,4,32), 1 -> (2,4,16) half tile, 2 -> (4,4,16), 3 -> (4,8,8), 4 -> (2,8,8) half tile;
+// *nparts = spatial
 // workgroups = statistics partials per output channel
 static int igemm_variant(int B, int Co, int R, long *nparts) {
   int v, tx, ty, tz;
@@ -695,7 +696,10 @@ static int igemm_variant(int B, int Co, int R, long *nparts) {
     // 256-voxel tiles would give this launch fewer than ~2 workgroups per CU: halve the tile instead
     const long wgs256 = (long)B * ceil_div(R, 4) * ceil_div(R, 4) * ceil_div(R, 16) * ceil_div(Co, kCoTile);
     if (wgs256 < 2L * kNumCU) { v = 1; tx = 2; ty = 4; tz = 16; } else { v = 2; tx = 4; ty = 4; tz = 16; }
-  } else { v = 3; tx = 4; ty = 8; tz = 8; }
+  } else {
+    const long wgs256 = (long)B * ceil_div(R, 4) * ceil_div(R, 8) * ceil_div(R, 8) * ceil_div(Co, kCoTile);
+    if (wgs256 < 2L * kNumCU) { v = 4; tx = 2; ty = 8; tz = 8; } else { v = 3; tx = 4; ty = 8; tz = 8; }
+  }
   *nparts = (long)B * ceil_div(R, tx) * ceil_div(R, ty) * ceil_div(R, tz);
   return v;
 }
@@ -707,6 +711,7 @@ static int conv3d_fwd_impl(const float *x, const float *wt, const float *bias, i
     case 0: return launch_igemm<2, 4, 32, 4>(x, wt, bias, y, B, Ci, Co, R, s, stats_part);
     case 1: return launch_igemm<2, 4, 16, 4, 1>(x, wt, bias, y, B, Ci, Co, R, s, stats_part);
     case 2: return launch_igemm<4, 4, 16, 4>(x, wt, bias, y, B, Ci, Co, R, s, stats_part);
+    case 4: return launch_igemm<2, 8, 8, 4, 1>(x, wt, bias, y, B, Ci, Co, R, s, stats_part);
     default: return launch_igemm<4, 8, 8, 4>(x, wt, bias, y, B, Ci, Co, R, s, stats_part);
   }
 }

@@ -12,7 +12,10 @@ DEV = 'cuda:0'
 TOL = 1e-5
 
 CASES = [(2, 9, 64, 32), (1, 5, 7, 12), (2, 64, 64, 16), (1, 16, 130, 8), (1, 3, 4, 33), (1, 8, 8, 5), (3, 64, 128, 16),
-         (1, 1, 1, 1), (1, 2, 3, 2)]
+         (1, 1, 1, 1), (1, 2, 3, 2),
+         (2, 8, 32, 16),     # vector staging with a partial 64-wide output tile (Co % 4 == 0, Co < 64): PVCNN++ widths
+         (2, 16, 96, 8),     # R = 8: half tile (2,8,8), Co = 64 + 32
+         (20, 32, 64, 16)]   # enough workgroups for the full 256-voxel tile at R = 16
 
 
 def _rel(a, b):
