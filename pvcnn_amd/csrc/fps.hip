@@ -19,14 +19,36 @@ namespace pvcnn {
 __device__ __forceinline__ unsigned tie_key(int k) { return ((unsigned)(k & 511) << 20) | (unsigned)(k >> 9); }
 __device__ __forceinline__ int tie_decode(unsigned key) { return (int)(((key & 0xFFFFFu) << 9) | (key >> 20)); }
 
+// Maximum of a 64-bit key over the wave, returned wave-uniform.  The M-1 steps of FPS are a dependent chain,
+// so this reduction IS the kernel's critical path: four DPP steps (cross-lane moves inside the VALU, a few
+// cycles each: quad xor 1, quad xor 2, half-row mirror, row mirror) leave every 16-lane row with its maximum,
+// then four v_readlane pairs + scalar compares combine the rows.  (The generic __shfl_xor lowers to
+// ds_bpermute_b32 -- an LDS round trip of ~100 cycles -- twice per 64-bit step: 12 of them per reduction.)
+#define PVCNN_DPP_MAX_STEP(CTRL)                                                                  \
+  do {                                                                                            \
+    const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, 0xF, 0xF, false); \
+    const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, 0xF, 0xF, false); \
+    const bool take = (ohi > hi) || (ohi == hi && olo > lo);                                      \
+    hi = take ? ohi : hi;                                                                         \
+    lo = take ? olo : lo;                                                                         \
+  } while (0)
+
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+  unsigned hi = (unsigned)(v >> 32), lo = (unsigned)v;
+  PVCNN_DPP_MAX_STEP(0xB1);    // quad_perm [1,0,3,2]
+  PVCNN_DPP_MAX_STEP(0x4E);    // quad_perm [2,3,0,1]
+  PVCNN_DPP_MAX_STEP(0x141);   // row_half_mirror
+  PVCNN_DPP_MAX_STEP(0x140);   // row_mirror
+  unsigned long long best = 0ull;
 #pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) {
-    const unsigned long long o = __shfl_xor(v, d);
-    v = (o > v) ? o : v;
+  for (int row = 0; row < 4; ++row) {
+    const unsigned long long r = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)hi, row * 16) << 32) |
+                                 (unsigned)__builtin_amdgcn_readlane((int)lo, row * 16);
+    best = (r > best) ? r : best;
   }
-  return v;
+  return best;
 }
+#undef PVCNN_DPP_MAX_STEP
 
 template <int THREADS, int PPT>
 __global__ __launch_bounds__(THREADS) void fps_kernel(const float *__restrict__ coords, int N, int M,
@@ -59,25 +81,50 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(const float *__restrict__ 
     float x1, y1, z1;
     if (lds_coords) { x1 = lc[old]; y1 = lc[old + N]; z1 = lc[old + 2 * N]; }
     else            { x1 = coords[old]; y1 = coords[old + N]; z1 = coords[old + 2 * N]; }
-    unsigned long long best = 0ull;
+    // With 8 points per thread and 16 waves on one CU the step is VALU-bound, so the per-point work is kept to
+    // ten instructions: the thread's own winner is tracked as (distance, q) with a strict '>' -- its points
+    // k = tid + q*THREADS share k mod 512 when THREADS is a multiple of 512, so among equal distances the
+    // smallest q IS the tie rule's winner -- and the 64-bit key is built once per thread, not once per point.
+    float bd = -1.0f;
+    int bq = 0;
 #pragma unroll
     for (int q = 0; q < PPT; ++q) {
       const float ex = x[q] - x1, ey = y[q] - y1, ez = z[q] - z1;
       const float d = fmaf(ez, ez, fmaf(ex, ex, ey * ey));
       const float d2 = fminf(d, dist[q]);
       dist[q] = d2;
-      const int k = tid + q * THREADS;
-      const unsigned long long cand =
-          (d2 >= 0.0f) ? (((unsigned long long)__float_as_uint(d2) << 32) | (0xFFFFFFFFu - tie_key(k))) : 0ull;
-      best = (cand > best) ? cand : best;
+      if (THREADS % 512 == 0) {
+        const bool better = d2 > bd;
+        bd = better ? d2 : bd;
+        bq = better ? q : bq;
+      }
+    }
+    unsigned long long best = 0ull;
+    if (THREADS % 512 == 0) {
+      best = (bd >= 0.0f) ? (((unsigned long long)__float_as_uint(bd) << 32) | (0xFFFFFFFFu - tie_key(tid + bq * THREADS))) : 0ull;
+    } else {
+#pragma unroll
+      for (int q = 0; q < PPT; ++q) {
+        const int k = tid + q * THREADS;
+        const unsigned long long cand =
+            (dist[q] >= 0.0f) ? (((unsigned long long)__float_as_uint(dist[q]) << 32) | (0xFFFFFFFFu - tie_key(k))) : 0ull;
+        best = (cand > best) ? cand : best;
+      }
     }
     best = wave_max_u64(best);
     if (W > 1) {
+      // cross-wave, 16 waves: lane w of every wave fetches wave w's key (one LDS read per lane, not 16 per thread)
+      // and the same DPP reduction makes the result uniform again
       unsigned long long *sl = slots + (j & 1) * W;
       if ((tid & 63) == 0) sl[tid >> 6] = best;
       __syncthreads();
+      if (W >= 16) {
+        const int lane = tid & 63;
+        best = wave_max_u64(lane < W ? sl[lane] : 0ull);
+      } else {   // few waves: W broadcast reads + compares per thread are cheaper than a second reduction (measured)
 #pragma unroll
-      for (int w = 0; w < W; ++w) { const unsigned long long o = sl[w]; best = (o > best) ? o : best; }
+        for (int w = 0; w < W; ++w) { const unsigned long long o = sl[w]; best = (o > best) ? o : best; }
+      }
     }
     old = tie_decode(0xFFFFFFFFu - (unsigned)(best & 0xFFFFFFFFull));
     if (tid == 0) indices[j] = old;
