@@ -10,7 +10,8 @@ on one synthetic batch already resident in HBM.
 Extra objects on the JSON line:
   roofline     : the hot path's headline kernel (trilinear_devoxelize fwd at the R=32 stage,
                  16x64x4096 points from a 16x64x32^3 grid), timed LIVE inside the timed region with
-                 HIP events on the launch stream; achieved = algorithmic bytes / mean launch time.
+                 HIP events on the launch stream; achieved = algorithmic bytes / (mean event-pair time -
+                 the calibrated time of an empty event pair on a busy stream).
   kernels      : the same for every hand-written kernel family that ran in the step.
   cpu_baseline : the same network on the host cores with the CPU oracle as native backend
                  (kind "port": the reference has no CPU implementation), bounded sample.

@@ -7,7 +7,8 @@
 // as an implicit GEMM  D[co][voxel] += A[co][k] * B[k][voxel],  k = (ci, tap), on
 // v_mfma_f32_32x32x2_f32 (exact fp32 in / fp32 accumulate; 157 TFLOP/s peak; no TF32 on gfx950).
 //
-// Mapping (wave64, one workgroup = 4 waves = 256 output voxels x 64 output channels):
+// Mapping (wave64, one workgroup = 4 waves = 256 output voxels x 64 output channels; a 128-voxel variant with one
+// column block per wave is used when the 256-voxel grid would leave the chip below ~2 workgroups per CU):
 //   * M = output channels, N = voxels: the MFMA C/D layout then puts 32 CONSECUTIVE-z voxels of
 //     one channel in the 32 lanes of a half-wave, so results leave as full 128-byte rows of the
 //     channel-major (B, C, R^3) tensor -- no transpose on the way out;
@@ -19,7 +20,9 @@
 //     (tap, channel pair) it issues 2 + 2 ds_read_b32 (conflict-free: consecutive z / consecutive
 //     co) and 4 MFMAs;
 //   * ~41 KiB of LDS per workgroup -> 3 workgroups per CU: one workgroup's global->LDS staging
-//     overlaps the others' MFMA phases without explicit double buffering.
+//     overlaps the others' MFMA phases without explicit double buffering;
+//   * the epilogue adds the bias, optionally emits per-workgroup BatchNorm partial sums of its outputs
+//     (pvcnn_conv3d_fwd_stats), and reads each accumulator from its AGPR at the point of use.
 // Backward-data is the same kernel on the flipped, channel-transposed weights (one tiny transform
 // kernel).  Backward-weight is the transposed problem (K = voxels) -- conv3d_wgrad_kernel below.
 #include <algorithm>

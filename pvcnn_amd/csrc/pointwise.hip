@@ -6,10 +6,11 @@
 //
 // The tensors stay in the reference's channel-major (B,C,N) layout -- no NHWC round trips (the library path
 // spends ~0.45 ms/step of PVCNN in layout transposes alone) -- and bias / bias-gradient ride on the GEMMs.
-// All three run on v_mfma_f32_32x32x2_f32 (fp32 in, fp32 accumulate).  Layout rules learned on the 3-D
-// convolution kernels apply: operands of both 32-row blocks of a lane sit next to each other in LDS so
-// that one ds_read_b64 feeds two MFMAs, all LDS offsets inside the K loop are immediates, LDS stores are
-// 16 bytes wide, and the loop carries ~0.5 non-MFMA instructions per MFMA.
+// All three run on v_mfma_f32_32x32x2_f32 (fp32 in, fp32 accumulate).  Rules learned on the 3-D convolution
+// kernels apply: staging is "16-byte load -> 16-byte LDS store" with nothing in between (so the loads of the next
+// chunk can stay in flight across the MFMA loop), every LDS offset inside the K loop is an immediate, one LDS
+// instruction feeds at least two MFMAs (ds_read2_b32 / ds_read_b64), the next step's operands are fetched
+// under this step's MFMAs, and accumulators are read from their AGPRs only at the point of use.
 #include <algorithm>
 
 #include "common.h"

@@ -15,6 +15,9 @@
 //            are a per-cloud counting sort + lane-owned segmented sums instead.
 // HBM traffic is therefore the compulsory minimum (slab once + per-element streams once).
 // An R=32 grid row is 128 KiB: it fits the 160 KiB LDS of a gfx950 CU as a single-row slab.
+// Refinements (all below): a workgroup walks several slabs with its elements' taps packed in registers;
+// voxel-grid rows are staged with a padded z-row stride so planar clouds do not serialise on one LDS bank;
+// a per-row transform (BatchNorm + LeakyReLU) can be applied while a slab is staged.
 // Rows that do not fit LDS (R > 34, N > 40960) take the *_direct kernels (global gathers /
 // global atomics after a memset).
 //
