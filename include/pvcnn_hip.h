@@ -173,15 +173,16 @@ PVCNN_API int pvcnn_conv3d_bwd_weight(const float *x, const float *grad_y, int B
  * replaces the nn.Conv1d / nn.Conv2d (kernel 1) calls of modules/shared_mlp.py:9-25 (cuDNN / cuBLAS in the
  * reference) with fp32-MFMA GEMMs that work on the reference's channel-major layout directly:
  *     x (B,K,N), y (B,M,N);  N = points (Conv2d: N = M_centres * U_neighbours, flattened)
- * pwconv_fwd:  y[b,m,n] = sum_k wt[k,m] * x[b,k,n] + bias[m]   -- wt is the weight k-major, (K,M):
- *     forward       : wt = pwconv_transpose(w (Co,Ci)),  K = Ci, M = Co
- *     backward-data : wt = w (Co,Ci) as it is,           K = Co, M = Ci, bias = NULL, x = grad_y
+ * pwconv_fwd:  y[b,m,n] = sum_k wt[k,m] * x[b,k,n] + bias[m]   -- wt is the weight k-major, (wt_rows >= K, M):
+ *     forward       : wt = pwconv_transpose(w (Co,Ci)): (Ci rounded up to 32, Co), zero tail rows; K = Ci, M = Co
+ *     backward-data : wt = w (Co,Ci) as it is, wt_rows = Co; K = Co, M = Ci, bias = NULL, x = grad_y
+ *   (rows K..wt_rows-1 must be zero; with wt_rows a multiple of 32 the unguarded fast path is available)
  * pwconv_bwd_weight: grad_w (M,K) = sum_{b,n} grad_y[b,m,n] * x[b,k,n]; grad_bias (M) optional (NULL).
  * fp32 in / fp32 accumulate; results agree with an fp64 evaluation to fp32 round-off.
  */
 PVCNN_API int pvcnn_pwconv_transpose(const float *w, int M, int K, float *wt, void *stream);
-PVCNN_API int pvcnn_pwconv_fwd(const float *x, const float *wt, const float *bias, int B, int K, int M, int N,
-                     float *y, void *stream);
+PVCNN_API int pvcnn_pwconv_fwd(const float *x, const float *wt, int wt_rows, const float *bias, int B, int K, int M,
+                     int N, float *y, void *stream);
 PVCNN_API size_t pvcnn_pwconv_bwd_weight_workspace_bytes(int B, int K, int M, int N);
 PVCNN_API int pvcnn_pwconv_bwd_weight(const float *x, const float *grad_y, int B, int K, int M, int N,
                             float *grad_w, float *grad_bias, void *workspace, size_t workspace_bytes,
@@ -215,8 +216,8 @@ PVCNN_API size_t pvcnn_conv3d_fwd_stats_parts(int B, int Co, int R);
 PVCNN_API int pvcnn_conv3d_fwd_stats(const float *x, const float *wt, const float *bias, int B, int Ci, int Co, int R,
                            float *y, float *stats_part, void *stream);
 PVCNN_API size_t pvcnn_pwconv_fwd_stats_parts(int B, int N);
-PVCNN_API int pvcnn_pwconv_fwd_stats(const float *x, const float *wt, const float *bias, int B, int K, int M, int N,
-                           float *y, float *stats_part, void *stream);
+PVCNN_API int pvcnn_pwconv_fwd_stats(const float *x, const float *wt, int wt_rows, const float *bias, int B, int K, int M,
+                           int N, float *y, float *stats_part, void *stream);
 PVCNN_API int pvcnn_bn_finalize(const float *part, int C, long nparts, double count, float eps, float momentum,
                       float *running_mean, float *running_var, float *mean, float *rstd, void *stream);
 PVCNN_API int pvcnn_bn_stats(const float *x, float *running_mean, float *running_var, int B, int C, int S,

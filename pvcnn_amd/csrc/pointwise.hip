@@ -24,7 +24,8 @@ constexpr int kPwK = 32;      // reduction channels per LDS chunk
 
 __device__ __forceinline__ float4 pw_ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 
-// (M,K) -> (K,M): the forward kernel wants the weights k-major
+// (M,K) -> (K32,M), K32 = K rounded up to 32 with zero rows: the forward kernel wants the weights k-major, and
+// the zero rows let its unguarded fast path run a K that is not a multiple of the 32-channel chunk
 __global__ __launch_bounds__(256) void pw_transpose_kernel(const float *__restrict__ w, int M, int K, float *__restrict__ wt) {
   __shared__ float tile[32][33];
   const int k0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
@@ -33,7 +34,7 @@ __global__ __launch_bounds__(256) void pw_transpose_kernel(const float *__restri
     tile[r][tx] = (m0 + r < M && k0 + tx < K) ? w[(size_t)(m0 + r) * K + k0 + tx] : 0.0f;
   __syncthreads();
   for (int r = ty; r < 32; r += 8)
-    if (k0 + r < K && m0 + tx < M) wt[(size_t)(k0 + r) * M + m0 + tx] = tile[tx][r];
+    if (m0 + tx < M) wt[(size_t)(k0 + r) * M + m0 + tx] = tile[tx][r];   // rows K..K32-1 receive the zeros
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -120,7 +121,8 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const float *__restrict__ 
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
         const int q = t + it * 256;
-        xq[it] = pw_ld4(xb + (size_t)(k0 + (q >> 6)) * N + n0 + (q & 63) * 4);
+        // K tail (K % 32 != 0): the row index is clamped; the matching weight rows are zero (wt is zero-padded)
+        xq[it] = pw_ld4(xb + (size_t)min(k0 + (q >> 6), K - 1) * N + n0 + (q & 63) * 4);
       }
 #pragma unroll
       for (int it = 0; it < MB; ++it) {
@@ -511,7 +513,7 @@ extern "C" int pvcnn_pwconv_transpose(const float *w, int M, int K, float *wt, v
   return check_launch("pwconv_transpose");
 }
 
-static int pwconv_fwd_impl(const float *x, const float *wt, const float *bias, int B, int K, int M, int N, float *y,
+static int pwconv_fwd_impl(const float *x, const float *wt, int wt_rows, const float *bias, int B, int K, int M, int N, float *y,
                            float2 *stats_part, hipStream_t s) {
   const int tiles_n = ceil_div(N, kPwN);
   const int MB = M > 64 ? 4 : 2;                         // output channels per workgroup: 128 or 64
@@ -519,7 +521,8 @@ static int pwconv_fwd_impl(const float *x, const float *wt, const float *bias, i
   const long wgs = ((tiles_total + 7) / 8) * 8 * ceil_div(M, 32 * MB);   // tiles padded to the 8 XCDs
   PVCNN_REQUIRE(wgs <= 0x7fffffffL, "grid too large");
   const dim3 grid((unsigned)wgs);
-  const bool fast = (K % kPwK == 0) && (N % kPwN == 0) && (M % 32 == 0) && aligned16(x) && aligned16(wt);
+  // the fast path reads whole 32-row chunks of wt: K must be a multiple of 32 or wt zero-padded to one (wt_rows)
+  const bool fast = (wt_rows >= ceil_div(K, kPwK) * kPwK) && (N % kPwN == 0) && (M % 32 == 0) && aligned16(x) && aligned16(wt);
 #define PVCNN_PW_LAUNCH(MBV, FASTV)                                                                                   \
   do {                                                                                                                \
     if (bias) hipLaunchKernelGGL((pw_gemm_kernel<MBV, FASTV, true>), grid, dim3(256), 0, s, x, wt, bias, y, K, M, N, tiles_n, (int)tiles_total, stats_part);  \
@@ -531,13 +534,14 @@ static int pwconv_fwd_impl(const float *x, const float *wt, const float *bias, i
   return check_launch("pwconv_fwd");
 }
 
-extern "C" int pvcnn_pwconv_fwd(const float *x, const float *wt, const float *bias, int B, int K, int M, int N, float *y,
-                                void *stream) {
+extern "C" int pvcnn_pwconv_fwd(const float *x, const float *wt, int wt_rows, const float *bias, int B, int K, int M, int N,
+                                float *y, void *stream) {
   PVCNN_REQUIRE(B >= 0 && K > 0 && M > 0 && N >= 0, "bad size");
   if (B == 0 || N == 0) return 0;
   PVCNN_REQUIRE(x && wt && y, "null pointer");
   PVCNN_REQUIRE((long)N * std::max(K, M) <= 0x7fffffffL, "cloud too large");
-  return pwconv_fwd_impl(x, wt, bias, B, K, M, N, y, nullptr, static_cast<hipStream_t>(stream));
+  PVCNN_REQUIRE(wt_rows >= K, "wt has fewer rows than K");
+  return pwconv_fwd_impl(x, wt, wt_rows, bias, B, K, M, N, y, nullptr, static_cast<hipStream_t>(stream));
 }
 
 extern "C" size_t pvcnn_pwconv_fwd_stats_parts(int B, int N) {
@@ -545,13 +549,14 @@ extern "C" size_t pvcnn_pwconv_fwd_stats_parts(int B, int N) {
   return (size_t)B * ceil_div(N, kPwN);
 }
 
-extern "C" int pvcnn_pwconv_fwd_stats(const float *x, const float *wt, const float *bias, int B, int K, int M, int N, float *y,
-                                      float *stats_part, void *stream) {
+extern "C" int pvcnn_pwconv_fwd_stats(const float *x, const float *wt, int wt_rows, const float *bias, int B, int K, int M,
+                                      int N, float *y, float *stats_part, void *stream) {
   PVCNN_REQUIRE(B > 0 && K > 0 && M > 0 && N > 0, "bad size");
   PVCNN_REQUIRE(x && wt && y && stats_part, "null pointer");
   PVCNN_REQUIRE((reinterpret_cast<uintptr_t>(stats_part) & 7) == 0, "stats_part must be 8-byte aligned");
   PVCNN_REQUIRE((long)N * std::max(K, M) <= 0x7fffffffL, "cloud too large");
-  return pwconv_fwd_impl(x, wt, bias, B, K, M, N, y, reinterpret_cast<float2 *>(stats_part), static_cast<hipStream_t>(stream));
+  PVCNN_REQUIRE(wt_rows >= K, "wt has fewer rows than K");
+  return pwconv_fwd_impl(x, wt, wt_rows, bias, B, K, M, N, y, reinterpret_cast<float2 *>(stats_part), static_cast<hipStream_t>(stream));
 }
 
 extern "C" size_t pvcnn_pwconv_bwd_weight_workspace_bytes(int B, int K, int M, int N) {

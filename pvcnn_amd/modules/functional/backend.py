@@ -351,7 +351,8 @@ class HipBackend:
             _f32(bias, 'bias')
         b, ci, n = x.shape
         co = weight.shape[0]
-        wt = torch.empty((ci, co), dtype=torch.float32, device=x.device)
+        k32 = (ci + 31) // 32 * 32                 # wt rows: K rounded up to the kernel's 32-channel chunk (zero tail)
+        wt = torch.empty((k32, co), dtype=torch.float32, device=x.device)
         y = torch.empty((b, co, n), dtype=torch.float32, device=x.device)
         part = None
         if want_stats:
@@ -359,10 +360,10 @@ class HipBackend:
         with _Launch(x) as s:
             _lib.check(self.lib.pvcnn_pwconv_transpose(_p(weight), co, ci, _p(wt), s), 'pwconv_transpose')
             if want_stats:
-                _lib.check(self.lib.pvcnn_pwconv_fwd_stats(_p(x), _p(wt), _p(bias) if bias is not None else None, b, ci, co, n,
+                _lib.check(self.lib.pvcnn_pwconv_fwd_stats(_p(x), _p(wt), k32, _p(bias) if bias is not None else None, b, ci, co, n,
                                                            _p(y), _p(part), s), 'pwconv_forward')
             else:
-                _lib.check(self.lib.pvcnn_pwconv_fwd(_p(x), _p(wt), _p(bias) if bias is not None else None, b, ci, co, n, _p(y), s), 'pwconv_forward')
+                _lib.check(self.lib.pvcnn_pwconv_fwd(_p(x), _p(wt), k32, _p(bias) if bias is not None else None, b, ci, co, n, _p(y), s), 'pwconv_forward')
         return (y, part) if want_stats else y
 
     def pwconv_backward_data(self, grad_y, weight):
@@ -372,7 +373,7 @@ class HipBackend:
         ci = weight.shape[1]
         gx = torch.empty((b, ci, n), dtype=torch.float32, device=grad_y.device)
         with _Launch(grad_y) as s:
-            _lib.check(self.lib.pvcnn_pwconv_fwd(_p(grad_y), _p(weight), None, b, co, ci, n, _p(gx), s), 'pwconv_backward_data')
+            _lib.check(self.lib.pvcnn_pwconv_fwd(_p(grad_y), _p(weight), co, None, b, co, ci, n, _p(gx), s), 'pwconv_backward_data')
         return gx
 
     def pwconv_backward_weight(self, x, grad_y, with_bias=False):
