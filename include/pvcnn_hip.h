@@ -56,6 +56,13 @@ PVCNN_API int pvcnn_version(void);
 /* Description of the calling thread's last error ("" if none).  Never NULL. */
 PVCNN_API const char *pvcnn_last_error_string(void);
 
+/* ---- coordinate pre-pass of modules/voxelization.py:16-25 (a dozen torch kernels in the reference) ------------
+ * coords (B,3,N) float -> norm_coords (B,3,N) float in [0,R-1] (centred, optionally normalised to the unit cube,
+ * scaled by R, clamped) and vox_coords (B,3,N) int32 = round-half-even(norm_coords).  normalize != 0:
+ * c / (max ||c||_2 * 2 + eps) + 0.5, else (c + 1) / 2.  A degenerate cloud with eps = 0 gives NaN like the reference. */
+PVCNN_API int pvcnn_voxel_coords(const float *coords, int B, int N, int R, int normalize, float eps, float *norm_coords,
+                       int32_t *vox_coords, void *stream);
+
 /* ---- avg_voxelize -------------------------------------------------------------------------
  * replaces avg_voxelize_forward  (voxelization/vox.cpp:17-43, kernels vox.cu:18-72)
  *          avg_voxelize_backward (voxelization/vox.cpp:54-76, kernel  vox.cu:86-110)

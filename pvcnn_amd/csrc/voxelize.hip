@@ -46,9 +46,86 @@ __global__ __launch_bounds__(256) void vox_scatter_atomic_kernel(
     atomicAdd(out + ((size_t)b * C + c) * S + pos, feat[((size_t)b * C + c) * N + i] * rcp);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Coordinate pre-pass of Voxelization.forward (modules/voxelization.py:16-25) in ONE launch instead of a
+// dozen tiny library kernels:   c = coords - mean_N(coords);
+//   normalize: c / (max_N ||c||_2 * 2 + eps) + 0.5      else: (c + 1) / 2
+//   norm = clamp(c * R, 0, R - 1)  (float, kept for the devoxelization);  vox = rint(norm) (half to even)
+// One workgroup per cloud; the 12 N bytes of a cloud stay in L2 over the three sweeps.  Every per-element
+// expression is the reference's fp32 expression; the two reductions are order-free here (mean from an fp64
+// sum = the correctly rounded mean; max is exact), where the reference's depend on the library's reduction tree.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void voxel_coords_kernel(const float *__restrict__ coords, int N, int R, int normalize,
+                                                            float eps, float *__restrict__ norm_out,
+                                                            int32_t *__restrict__ vox_out) {
+  __shared__ double red[3][16];
+  __shared__ float fred[16];
+  __shared__ float stat[4];
+  const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const float *c = coords + (size_t)b * 3 * N;
+  double s[3] = {0.0, 0.0, 0.0};
+  for (int i = tid; i < N; i += 1024) { s[0] += c[i]; s[1] += c[i + N]; s[2] += c[i + 2 * N]; }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s[a] += __shfl_xor(s[a], d);
+    if (lane == 0) red[a][wave] = s[a];
+  }
+  __syncthreads();
+  if (tid < 3) {
+    double t = 0.0;
+    for (int w = 0; w < 16; ++w) t += red[tid][w];
+    stat[tid] = (float)(t / (double)N);
+  }
+  __syncthreads();
+  const float mx = stat[0], my = stat[1], mz = stat[2];
+  float denom = 1.0f;
+  if (normalize) {
+    float m2 = 0.0f;
+    for (int i = tid; i < N; i += 1024) {
+      const float x = c[i] - mx, y = c[i + N] - my, z = c[i + 2 * N] - mz;
+      m2 = fmaxf(m2, (x * x + y * y) + z * z);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m2 = fmaxf(m2, __shfl_xor(m2, d));
+    if (lane == 0) fred[wave] = m2;
+    __syncthreads();
+    if (tid == 0) {
+      float t = 0.0f;
+      for (int w = 0; w < 16; ++w) t = fmaxf(t, fred[w]);
+      stat[3] = sqrtf(t) * 2.0f + eps;
+    }
+    __syncthreads();
+    denom = stat[3];
+  }
+  const float rf = (float)R, hi = (float)(R - 1);
+  float *no = norm_out + (size_t)b * 3 * N;
+  int32_t *vo = vox_out + (size_t)b * 3 * N;
+  for (int i = tid; i < N; i += 1024) {
+    float v[3] = {c[i] - mx, c[i + N] - my, c[i + 2 * N] - mz};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float unit = normalize ? v[a] / denom + 0.5f : (v[a] + 1.0f) / 2.0f;
+      const float g = fminf(fmaxf(unit * rf, 0.0f), hi);
+      no[i + a * N] = g;
+      vo[i + a * N] = (int32_t)rintf(g);
+    }
+  }
+}
+
 }  // namespace pvcnn
 
 using namespace pvcnn;
+
+extern "C" int pvcnn_voxel_coords(const float *coords, int B, int N, int R, int normalize, float eps, float *norm_coords,
+                                  int32_t *vox_coords, void *stream) {
+  PVCNN_REQUIRE(B >= 0 && N >= 0 && R > 0, "negative size");
+  if (B == 0 || N == 0) return 0;
+  PVCNN_REQUIRE(coords && norm_coords && vox_coords, "null pointer");
+  hipLaunchKernelGGL(voxel_coords_kernel, dim3(B), dim3(1024), 0, static_cast<hipStream_t>(stream), coords, N, R, normalize, eps,
+                     norm_coords, vox_coords);
+  return check_launch("voxel_coords");
+}
 
 extern "C" size_t pvcnn_avg_voxelize_fwd_workspace_bytes(int B, int C, int N, int R) {
   if (B <= 0 || C < 0 || N < 0 || R <= 0) return 0;

@@ -253,6 +253,21 @@ class HipBackend:
                        'trilinear_devoxelize_backward')
         return grad_x
 
+    # ---- modules/voxelization.py:16-25 ---------------------------------------------------------
+    has_voxel_coords = True
+
+    def voxel_coords(self, coords, resolution, normalize, eps):
+        """coords (B,3,N) -> (norm_coords float (B,3,N) in [0,R-1], vox_coords int32 (B,3,N)) in one launch."""
+        _f32(coords, 'coords')
+        _shape(coords.dim() == 3 and coords.shape[1] == 3, 'voxel_coords: coords (B,3,N) expected')
+        b, _, n = coords.shape
+        norm = torch.empty_like(coords)
+        vox = torch.empty((b, 3, n), dtype=torch.int32, device=coords.device)
+        with _Launch(coords) as s:
+            _lib.check(self.lib.pvcnn_voxel_coords(_p(coords), b, n, int(resolution), int(bool(normalize)), float(eps),
+                                                   _p(norm), _p(vox), s), 'voxel_coords')
+        return norm, vox
+
     # ---- vox.cpp:17-76 ----------------------------------------------------------------------
     def avg_voxelize_forward(self, features, coords, resolution):
         _f32(features, 'features'); _i32(coords, 'coords')

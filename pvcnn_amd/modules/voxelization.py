@@ -6,13 +6,16 @@ Reference: modules/voxelization.py:9-28.  Semantics kept exactly:
   normalize=False: (c + 1) / 2                             (coords already in the unit ball)
   norm_coords = clamp(c * R, 0, R - 1)      float, returned for the later devoxelization
   vox_coords  = round(norm_coords) -> int32 (round-half-to-even, torch.round)
-The three small reductions stay in torch so that the rounding decisions (and therefore the
-voxel indices, which parity tests compare bit for bit) are the reference's own.
+On the GPU the whole pre-pass is one kernel (csrc/voxelize.hip: voxel_coords_kernel): the per-element
+expressions are the reference's fp32 expressions, the mean is the correctly rounded one (fp64 sum) and the
+max is exact -- where the reference's two reductions depend on the library's reduction tree.  The torch
+formulation below remains for CPU tensors (oracle stack, reference comparison).
 """
 import torch
 import torch.nn as nn
 
 from . import functional as F
+from .functional._autograd import native
 
 __all__ = ['Voxelization']
 
@@ -36,8 +39,13 @@ class Voxelization(nn.Module):
         return torch.clamp(unit * self.r, 0, self.r - 1)
 
     def forward(self, features, coords):
-        norm_coords = self.normalized_coords(coords)
-        vox_coords = torch.round(norm_coords).to(torch.int32)
+        be = native()
+        if coords.is_cuda and coords.dtype == torch.float32 and getattr(be, 'has_voxel_coords', False):
+            # one launch instead of a dozen tiny library kernels (csrc/voxelize.hip: voxel_coords_kernel)
+            norm_coords, vox_coords = be.voxel_coords(coords.detach().contiguous(), self.r, self.normalize, self.eps)
+        else:
+            norm_coords = self.normalized_coords(coords)
+            vox_coords = torch.round(norm_coords).to(torch.int32)
         return F.avg_voxelize(features, vox_coords, self.r), norm_coords
 
     def extra_repr(self):
