@@ -12,7 +12,9 @@ Extra objects on the JSON line:
                  16x64x4096 points from a 16x64x32^3 grid), timed LIVE inside the timed region with
                  HIP events on the launch stream; achieved = algorithmic bytes / (mean event-pair time -
                  the calibrated time of an empty event pair on a busy stream).
-  kernels      : the same for every hand-written kernel family that ran in the step.
+  roofline_mfma: the step's largest MFMA-bound launch (Conv3d forward, 64->64 at 32^3), same live timing,
+                 against the 157.3 TF fp32-MFMA peak.
+  kernels      : the same for every watched kernel family that ran in the step.
   cpu_baseline : the same network on the host cores with the CPU oracle as native backend
                  (kind "port": the reference has no CPU implementation), bounded sample.
 """
@@ -30,6 +32,7 @@ import torch
 import torch.distributed as dist
 import torch.nn.functional as tf
 
+MFMA_FP32_PEAK_TF = 157.3      # v_mfma_f32_32x32x2_f32, dense, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable copy)
 
 
@@ -71,20 +74,26 @@ class KernelClock:
                                                          (a[0].shape[0], a[0].shape[1], a[0].shape[2], int(a[3]))),
     }
 
+    # MFMA-bound family: Conv3d forward (x (B,Ci,R,R,R), weight (Co,Ci,3,3,3)); "bytes" slot carries FLOPs here
+    WATCH_FLOPS = {
+        'conv3d_forward': lambda a, out: ('conv3d_forward', 2.0 * a[0].shape[0] * a[0].shape[2] ** 3 * 27 * a[0].shape[1] * a[1].shape[0],
+                                          (a[0].shape[0], a[0].shape[1], a[1].shape[0], a[0].shape[2])),
+    }
+
     def __init__(self, backend):
         self.backend, self.records, self.enabled, self._orig = backend, [], False, {}
 
     def install(self):
-        for name, describe in self.WATCH.items():
+        for name, describe in list(self.WATCH.items()) + list(self.WATCH_FLOPS.items()):
             orig = getattr(self.backend, name)
             self._orig[name] = orig
 
-            def timed(*args, _orig=orig, _describe=describe):
+            def timed(*args, _orig=orig, _describe=describe, **kw):
                 if not self.enabled:
-                    return _orig(*args)
+                    return _orig(*args, **kw)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                out = _orig(*args)
+                out = _orig(*args, **kw)
                 e1.record()
                 self.records.append((_describe(args, out), e0, e1))
                 return out
@@ -125,6 +134,12 @@ class KernelClock:
         for (kernel, shape), (calls, ms, nbytes) in sorted(agg.items()):
             raw_us = ms * 1e3 / calls
             us = max(raw_us - overhead_us, 1e-3)
+            if kernel in self.WATCH_FLOPS:       # MFMA-bound: TFLOP/s against the fp32-MFMA peak
+                tf_s = nbytes / (us * 1e-6) / 1e12
+                out.append({'kernel': kernel, 'shape_BCiCoR': list(shape), 'calls': calls, 'avg_us': round(us, 2),
+                            'event_pair_us': round(raw_us, 2), 'GFLOP': round(nbytes / 1e9, 2),
+                            'achieved_TFLOPs': round(tf_s, 1), 'frac_of_157TF': round(tf_s / MFMA_FP32_PEAK_TF, 4)})
+                continue
             gbs = nbytes / (us * 1e-6) / 1e9
             out.append({'kernel': kernel, 'shape_BCNR': list(shape), 'calls': calls, 'avg_us': round(us, 2),
                         'event_pair_us': round(raw_us, 2),
@@ -250,6 +265,8 @@ def main():
         global_batch = args.batch * world
         head = next((k for k in kernels if k['kernel'] == 'trilinear_devoxelize_fwd' and k['shape_BCNR'][3] == max(
             kk['shape_BCNR'][3] for kk in kernels if kk['kernel'] == 'trilinear_devoxelize_fwd')), None)
+        convs = [k for k in kernels if k['kernel'] == 'conv3d_forward']
+        mfma = max(convs, key=lambda k: k['GFLOP']) if convs else None
         roofline = None
         if head:
             roofline = {'bound': 'hbm', 'kernel': 'trilinear_devoxelize_fwd (gather_lds_kernel<TrilinearFromCoords>; BatchNorm+LeakyReLU fused into its LDS staging inside PVConv)',
@@ -278,6 +295,11 @@ def main():
                        'global_batch': global_batch, 'points': args.points, 'parallelism': f'dp{world}',
                        'gradient_bytes': reducer.gradient_bytes, 'final_loss': round(final_loss, 4)},
             'roofline': roofline,
+            # the step's largest MFMA-bound launch (Conv3d forward of the R=32 stage), same live event timing
+            'roofline_mfma': None if mfma is None else {
+                'bound': 'mfma', 'kernel': 'conv3d_igemm_kernel (Conv3d 3x3x3 forward)', 'shape_BCiCoR': mfma['shape_BCiCoR'],
+                'achieved': mfma['achieved_TFLOPs'], 'peak': MFMA_FP32_PEAK_TF, 'unit': 'TFLOP/s', 'frac': mfma['frac_of_157TF'],
+                'avg_us': mfma['avg_us'], 'GFLOP': mfma['GFLOP']},
             'kernels': kernels,
         }
         if world == 1 and not args.no_cpu_baseline:
