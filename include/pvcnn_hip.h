@@ -63,6 +63,17 @@ PVCNN_API const char *pvcnn_last_error_string(void);
 PVCNN_API int pvcnn_voxel_coords(const float *coords, int B, int N, int R, int normalize, float eps, float *norm_coords,
                        int32_t *vox_coords, void *stream);
 
+/* The same pre-pass with the two reductions left to the caller (DEFAULT path of pvcnn_amd.modules.Voxelization): the
+ * reference computes mean = coords.mean(2) and radius = (coords - mean).norm(dim=1).max(dim=2) with torch ops; calling
+ * those same ops on the same device and handing the results to this fused elementwise tail (centre, / (radius*2+eps),
+ * + 0.5, * R, clamp, round-half-even -- each step separately rounded like the reference's separate kernels) gives
+ * norm_coords / vox_coords BIT-IDENTICAL to modules/voxelization.py:16-25, whatever reduction tree the library uses.
+ * coords: rows of a cloud contiguous, clouds coords_batch_stride floats apart (>= 3N: a channel slice of the input);
+ * mean (B,3); radius (B) or NULL for normalize=False [(c + 1) / 2]. pvcnn_voxel_coords above (one launch, fp64 mean,
+ * exact max: the correctly rounded statistics) remains as an opt-in; it may differ from torch in the last bit of the mean. */
+PVCNN_API int pvcnn_voxel_coords_tail(const float *coords, long coords_batch_stride, const float *mean, const float *radius,
+                            int B, int N, int R, float eps, float *norm_coords, int32_t *vox_coords, void *stream);
+
 /* ---- avg_voxelize -------------------------------------------------------------------------
  * replaces avg_voxelize_forward  (voxelization/vox.cpp:17-43, kernels vox.cu:18-72)
  *          avg_voxelize_backward (voxelization/vox.cpp:54-76, kernel  vox.cu:86-110)

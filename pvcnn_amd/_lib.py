@@ -24,6 +24,7 @@ SIGNATURES = {
     'pvcnn_version': (_i, []),
     'pvcnn_last_error_string': (ctypes.c_char_p, []),
     'pvcnn_voxel_coords': (_i, [_vp, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
+    'pvcnn_voxel_coords_tail': (_i, [_vp, ctypes.c_long, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp]),
     'pvcnn_avg_voxelize_fwd_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'pvcnn_avg_voxelize_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     'pvcnn_avg_voxelize_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),

@@ -113,6 +113,53 @@ __global__ __launch_bounds__(1024) void voxel_coords_kernel(const float *__restr
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// DEFAULT coordinate pre-pass: the two reductions of modules/voxelization.py:17-20 (mean over the points,
+// max over the points of the centred norm) stay the caller's torch ops -- the reference's own calls on the same
+// device, hence the same reduction trees -- and this kernel is the fused elementwise TAIL: centre, divide,
+// + 0.5, * R, clamp, round-half-even.  Every expression is one separately rounded fp32 operation in the
+// reference (each is its own torch kernel), and so it is here (-ffp-contract=off): norm / vox are bit-identical
+// to Voxelization.forward's on the same device, for any reduction tree the library picks.
+//   mean   (B,3)  = coords.mean(2)
+//   radius (B)    = (coords - mean).norm(dim=1).max(dim=2)      (normalize only; else NULL)
+// coords rows of one cloud are contiguous, clouds cstride floats apart (a channel slice of the input tensor).
+// ---------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(256) void voxel_coords_tail_kernel(const float *__restrict__ coords, long cstride,
+                                                               const float *__restrict__ mean,
+                                                               const float *__restrict__ radius, int N, int R, float eps,
+                                                               float *__restrict__ norm_out, int32_t *__restrict__ vox_out) {
+  const int b = blockIdx.z, a = blockIdx.y, i0 = (blockIdx.x * 256 + threadIdx.x) * VEC;
+  if (i0 >= N) return;
+  const float m = mean[b * 3 + a];
+  const bool normalize = radius != nullptr;
+  float denom = 1.0f;
+  if (normalize) { denom = radius[b] * 2.0f; denom = denom + eps; }
+  const float rf = (float)R, hi = (float)(R - 1);
+  const float *src = coords + (size_t)b * cstride + (size_t)a * N + i0;
+  float x[VEC];
+  if constexpr (VEC == 4) { const float4 v = *reinterpret_cast<const float4 *>(src); x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w; }
+  else x[0] = src[0];
+  float g[VEC];
+  int32_t q[VEC];
+#pragma unroll
+  for (int u = 0; u < VEC; ++u) {
+    const float c = x[u] - m;
+    float unit;
+    if (normalize) { unit = c / denom; unit = unit + 0.5f; }
+    else { unit = c + 1.0f; unit = unit * 0.5f; }      // torch: division by the host scalar 2.0 = multiplication by 0.5
+    const float sc = unit * rf;
+    g[u] = (sc != sc) ? sc : fminf(fmaxf(sc, 0.0f), hi);   // torch.clamp propagates NaN (degenerate cloud, eps = 0)
+    q[u] = (int32_t)rintf(g[u]);
+  }
+  const size_t o = ((size_t)b * 3 + a) * N + i0;
+  if constexpr (VEC == 4) {
+    *reinterpret_cast<float4 *>(norm_out + o) = make_float4(g[0], g[1], g[2], g[3]);
+    *reinterpret_cast<int4 *>(vox_out + o) = make_int4(q[0], q[1], q[2], q[3]);
+  } else { norm_out[o] = g[0]; vox_out[o] = q[0]; }
+}
+
 }  // namespace pvcnn
 
 using namespace pvcnn;
@@ -125,6 +172,24 @@ extern "C" int pvcnn_voxel_coords(const float *coords, int B, int N, int R, int 
   hipLaunchKernelGGL(voxel_coords_kernel, dim3(B), dim3(1024), 0, static_cast<hipStream_t>(stream), coords, N, R, normalize, eps,
                      norm_coords, vox_coords);
   return check_launch("voxel_coords");
+}
+
+extern "C" int pvcnn_voxel_coords_tail(const float *coords, long coords_batch_stride, const float *mean, const float *radius,
+                                       int B, int N, int R, float eps, float *norm_coords, int32_t *vox_coords, void *stream) {
+  PVCNN_REQUIRE(B >= 0 && N >= 0 && R > 0, "negative size");
+  if (B == 0 || N == 0) return 0;
+  PVCNN_REQUIRE(coords && mean && norm_coords && vox_coords, "null pointer");
+  PVCNN_REQUIRE(B <= 65535, "batch > 65535");
+  PVCNN_REQUIRE(coords_batch_stride >= 3L * N, "coords batch stride smaller than one cloud");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool vec = (N % 4 == 0) && (coords_batch_stride % 4 == 0) && aligned16(coords) && aligned16(norm_coords) && aligned16(vox_coords);
+  if (vec)
+    hipLaunchKernelGGL(voxel_coords_tail_kernel<4>, dim3(ceil_div(N, 1024), 3, B), dim3(256), 0, s, coords, coords_batch_stride,
+                       mean, radius, N, R, eps, norm_coords, vox_coords);
+  else
+    hipLaunchKernelGGL(voxel_coords_tail_kernel<1>, dim3(ceil_div(N, 256), 3, B), dim3(256), 0, s, coords, coords_batch_stride,
+                       mean, radius, N, R, eps, norm_coords, vox_coords);
+  return check_launch("voxel_coords_tail");
 }
 
 extern "C" size_t pvcnn_avg_voxelize_fwd_workspace_bytes(int B, int C, int N, int R) {

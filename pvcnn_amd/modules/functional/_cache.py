@@ -1,0 +1,54 @@
+"""Per-tensor memo of coordinate-derived products.
+
+Every PVConv of a network sees the SAME coords tensor object (the reference's models pass `coords` through
+unchanged: models/s3dis/pvcnn.py:38-42, modules/pvconv.py:39), and everything the voxel branch derives from
+coordinates -- the centred statistics, the float grid coordinates / integer voxel ids per resolution, the
+counting-sort plans of the two scatters, the trilinear corner indices / weights -- depends on (coords, R) only,
+not on the layer.  PVCNN has three PVConvs at R = 16 (PVCNN++ two or three per stage): they share one set.
+
+Entries are keyed by the identity of a live tensor object and its in-place version counter; they die with the
+tensor (weak reference), so nothing outlives the forward/backward pass that created it and an address reused
+by a later tensor can never hit a stale entry.
+"""
+import threading
+import weakref
+
+__all__ = ['memo', 'clear', 'enabled']
+
+_lock = threading.Lock()
+_entries = {}          # id(tensor) -> (weakref, version, dict)
+enabled = True
+
+
+def _drop(key, ref):
+    with _lock:
+        cur = _entries.get(key)
+        if cur is not None and cur[0] is ref:
+            del _entries[key]
+
+
+def memo(tensor, key, make):
+    """make() computed once per (tensor object, tensor._version, key); the result is shared afterwards."""
+    if not enabled:
+        return make()
+    tid = id(tensor)
+    with _lock:
+        ent = _entries.get(tid)
+        if ent is not None and (ent[0]() is not tensor or ent[1] != tensor._version):
+            ent = None
+        if ent is None:
+            ref = weakref.ref(tensor, lambda r, k=tid: _drop(k, r))
+            ent = (ref, tensor._version, {})
+            _entries[tid] = ent
+        store = ent[2]
+        if key in store:
+            return store[key]
+    value = make()
+    with _lock:
+        store.setdefault(key, value)
+        return store[key]
+
+
+def clear():
+    with _lock:
+        _entries.clear()

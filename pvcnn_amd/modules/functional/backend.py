@@ -268,6 +268,25 @@ class HipBackend:
                                                    _p(norm), _p(vox), s), 'voxel_coords')
         return norm, vox
 
+    def voxel_coords_tail(self, coords, mean, radius, resolution, eps):
+        """The fused elementwise tail of Voxelization.forward: coords (B,3,N) (rows contiguous within a cloud; may be a
+        channel slice of a wider tensor), mean (B,3,1) and radius (B,1,1) | None from the reference's own torch
+        reductions -> (norm_coords, vox_coords), bit-identical to modules/voxelization.py:16-25 on this device."""
+        cstride = _f32_rows(coords, 'coords')
+        _shape(coords.dim() == 3 and coords.shape[1] == 3, 'voxel_coords: coords (B,3,N) expected')
+        b, _, n = coords.shape
+        _f32(mean, 'mean')
+        _shape(mean.numel() == b * 3, 'voxel_coords: mean (B,3) expected')
+        if radius is not None:
+            _f32(radius, 'radius')
+            _shape(radius.numel() == b, 'voxel_coords: radius (B) expected')
+        norm = torch.empty((b, 3, n), dtype=torch.float32, device=coords.device)
+        vox = torch.empty((b, 3, n), dtype=torch.int32, device=coords.device)
+        with _Launch(coords) as s:
+            _lib.check(self.lib.pvcnn_voxel_coords_tail(_p(coords), cstride, _p(mean), _p(radius) if radius is not None else None,
+                                                        b, n, int(resolution), float(eps), _p(norm), _p(vox), s), 'voxel_coords_tail')
+        return norm, vox
+
     # ---- vox.cpp:17-76 ----------------------------------------------------------------------
     def avg_voxelize_forward(self, features, coords, resolution):
         _f32(features, 'features'); _i32(coords, 'coords')

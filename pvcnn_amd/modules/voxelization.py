@@ -6,21 +6,30 @@ Reference: modules/voxelization.py:9-28.  Semantics kept exactly:
   normalize=False: (c + 1) / 2                             (coords already in the unit ball)
   norm_coords = clamp(c * R, 0, R - 1)      float, returned for the later devoxelization
   vox_coords  = round(norm_coords) -> int32 (round-half-to-even, torch.round)
-On the GPU the whole pre-pass is one kernel (csrc/voxelize.hip: voxel_coords_kernel): the per-element
-expressions are the reference's fp32 expressions, the mean is the correctly rounded one (fp64 sum) and the
-max is exact -- where the reference's two reductions depend on the library's reduction tree.  The torch
-formulation below remains for CPU tensors (oracle stack, reference comparison).
+
+GPU path (default): the two REDUCTIONS are the reference's own torch calls (`mean(2)`, `norm(dim=1).max(dim=2)`)
+on the same device -- same library kernels, same reduction trees -- and everything elementwise behind them is one
+fused kernel (csrc/voxelize.hip: voxel_coords_tail_kernel) whose steps are rounded one by one like the reference's
+separate kernels: norm_coords and vox_coords are BIT-IDENTICAL to the reference formulation on that device
+(tests/test_gpu_voxel_coords.py).  The statistics do not depend on R and the grid coordinates do not depend on the
+layer, so both are memoised per coords tensor (functional/_cache.py): the three R = 16 PVConvs of PVCNN share one
+pre-pass.  `Voxelization.single_launch = True` opts into the one-launch kernel with order-free statistics (fp64 mean,
+exact max: voxel_coords_kernel), which can differ from torch in the last bit of the mean and hence in a voxel id
+of a point that sits on a rounding boundary.
 """
 import torch
 import torch.nn as nn
 
 from . import functional as F
+from .functional import _cache
 from .functional._autograd import native
 
 __all__ = ['Voxelization']
 
 
 class Voxelization(nn.Module):
+    single_launch = False      # opt-in: order-free statistics in one launch (not bit-identical to torch's reductions)
+
     def __init__(self, resolution, normalize=True, eps=0):
         super().__init__()
         self.r = int(resolution)
@@ -28,7 +37,9 @@ class Voxelization(nn.Module):
         self.eps = eps
 
     def normalized_coords(self, coords):
-        """coords (B,3,N) -> float grid coordinates in [0, R-1]; no gradient flows through."""
+        """coords (B,3,N) -> float grid coordinates in [0, R-1]; no gradient flows through.
+        The reference formulation op by op (modules/voxelization.py:17-23); used for CPU tensors and as the
+        same-device checker of the fused GPU path."""
         centred = coords.detach()
         centred = centred - centred.mean(2, keepdim=True)
         if self.normalize:
@@ -38,11 +49,37 @@ class Voxelization(nn.Module):
             unit = (centred + 1) / 2.0
         return torch.clamp(unit * self.r, 0, self.r - 1)
 
+    @staticmethod
+    def _statistics(coords, normalize):
+        """(mean (B,3,1), radius (B,1,1) | None): the reference's reductions, called exactly as it calls them."""
+        c = coords.detach()
+        mean = c.mean(2, keepdim=True)
+        radius = None
+        if normalize:
+            radius = (c - mean).norm(dim=1, keepdim=True).max(dim=2, keepdim=True).values
+        return mean, radius
+
+    def grid_coordinates(self, coords):
+        """coords (B,3,N) on the GPU -> (norm_coords float (B,3,N), vox_coords int32 (B,3,N))."""
+        be = native()
+        normalize = bool(self.normalize)
+        if self.single_launch:
+            return _cache.memo(coords, ('vox1', self.r, normalize, float(self.eps)),
+                               lambda: be.voxel_coords(coords.detach().contiguous(), self.r, normalize, self.eps))
+
+        def tail():
+            mean, radius = _cache.memo(coords, ('stats', normalize), lambda: self._statistics(coords, normalize))
+            c = coords.detach()
+            from .functional.backend import batch_strided_ok
+            if not batch_strided_ok(c):
+                c = c.contiguous()
+            return be.voxel_coords_tail(c, mean.contiguous(), radius.contiguous() if radius is not None else None, self.r, self.eps)
+        return _cache.memo(coords, ('vox', self.r, normalize, float(self.eps)), tail)
+
     def forward(self, features, coords):
         be = native()
-        if coords.is_cuda and coords.dtype == torch.float32 and getattr(be, 'has_voxel_coords', False):
-            # one launch instead of a dozen tiny library kernels (csrc/voxelize.hip: voxel_coords_kernel)
-            norm_coords, vox_coords = be.voxel_coords(coords.detach().contiguous(), self.r, self.normalize, self.eps)
+        if coords.is_cuda and coords.dtype == torch.float32 and coords.dim() == 3 and getattr(be, 'has_voxel_coords', False):
+            norm_coords, vox_coords = self.grid_coordinates(coords)
         else:
             norm_coords = self.normalized_coords(coords)
             vox_coords = torch.round(norm_coords).to(torch.int32)

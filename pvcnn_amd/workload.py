@@ -3,9 +3,11 @@
 The reference's `models/` are callers of the hot path and are NOT part of this package: with
 `pvcnn_amd.install_dropin()` they run unchanged on top of `pvcnn_amd.modules`.  bench.py and
 smoke() however run on a GPU box where the reference tree does not exist, so the two S3DIS
-networks BASELINE.json names are assembled here from a small declarative spec.  Parameter
+networks BASELINE.json names (plus the ShapeNet part-segmentation PVCNN of configs[3] and the
+Frustum-PVCNN of configs[4]) are assembled here from a small declarative spec.  Parameter
 names match the reference classes (models/s3dis/pvcnn.py:9-46, models/s3dis/pvcnnpp.py:8-59,
-builders models/utils.py:15-140), so `state_dict`s are interchangeable;
+models/shapenet/pvcnn.py:9-42, models/kitti/frustum/frustum_net.py:14-113, builders
+models/utils.py:15-140), so `state_dict`s are interchangeable;
 tests/test_reference_python.py checks keys, shapes and outputs against the reference itself.
 
 Synthetic inputs follow SURVEY.md 8(d): seed 1588147245 (configs/__init__.py:3), channel
@@ -19,7 +21,8 @@ from .modules import PVConv, PointNetAModule, PointNetFPModule, PointNetSAModule
 
 SEED = 1588147245
 
-__all__ = ['PVCNN', 'PVCNN2', 'make_s3dis_batch', 'SEED']
+__all__ = ['PVCNN', 'PVCNN2', 'PVCNNShapeNet', 'FrustumPVCNNE', 'make_s3dis_batch', 'make_shapenet_batch',
+           'make_frustum_batch', 'frustum_size_templates', 'SEED']
 
 
 def _scaled(width, k):
@@ -173,6 +176,135 @@ class PVCNN2(nn.Module):
         return self.classifier(feats)
 
 
+class PVCNNShapeNet(nn.Module):
+    """PVCNN for ShapeNet part segmentation (BASELINE configs[3]; reference models/shapenet/pvcnn.py:9-42):
+    three PVConvs WITH squeeze-excitation on coordinates that are already in the unit ball (normalize=False),
+    two SharedMLP point stages, and a classifier over [shape one-hot, every stage's output, global max]."""
+    blocks = ((64, 1, 32), (128, 2, 16), (512, 1, None), (2048, 1, None))
+
+    def __init__(self, num_classes, num_shapes, extra_feature_channels=3, width_multiplier=1, voxel_resolution_multiplier=1):
+        super().__init__()
+        self.in_channels = extra_feature_channels + 3
+        self.num_shapes = num_shapes
+        stages, cin, concat = [], self.in_channels, 0
+        for spec in self.blocks:
+            blocks, cin = _pv_stack(cin, spec, width_multiplier, voxel_resolution_multiplier,
+                                    with_se=True, normalize=False, eps=0)
+            stages += blocks
+            concat += cin * len(blocks)
+        self.point_features = nn.ModuleList(stages)
+        layers, _ = _head(num_shapes + cin + concat, [256, 0.2, 256, 0.2, 128, num_classes], width_multiplier,
+                          pointwise=True, classify=True)
+        self.classifier = nn.Sequential(*layers)
+
+    def forward(self, inputs):
+        # inputs (B, in_channels + num_shapes, N): xyz, extra features, then the shape one-hot repeated over N
+        feats = inputs[:, :self.in_channels, :]
+        taps = [inputs[:, -self.num_shapes:, :]]
+        coords = feats[:, :3, :]
+        for stage in self.point_features:
+            feats, _ = stage((feats, coords))
+            taps.append(feats)
+        taps.append(feats.max(dim=-1, keepdim=True).values.repeat([1, 1, coords.size(-1)]))
+        return self.classifier(torch.cat(taps, dim=1))
+
+
+class _FrustumSegmentation(nn.Module):
+    """Foreground / background point segmentation of one frustum (models/kitti/frustum/segmentation/pointnet.py:9-70,
+    PVCNN variant): PVConvs at R = 16, 16, 12, 12 -- non-power-of-two grids -- then a SharedMLP to 1024."""
+    point_blocks = ((64, 2, 16), (64, 1, 12), (128, 1, 12), (1024, 1, None))
+
+    def __init__(self, num_classes, extra_feature_channels, width_multiplier, voxel_resolution_multiplier):
+        super().__init__()
+        self.in_channels = extra_feature_channels + 3
+        self.num_classes = num_classes
+        stages, cin = [], self.in_channels
+        for spec in self.point_blocks:
+            blocks, cin = _pv_stack(cin, spec, width_multiplier, voxel_resolution_multiplier, with_se=False)
+            stages += blocks
+        self.point_features = nn.Sequential(*stages)
+        self.cloud_features = nn.Sequential()                      # the PVCNN variant has no cloud stages
+        layers, _ = _head(cin + cin + num_classes, [512, 256, 128, 128, 0.5, 2], width_multiplier, pointwise=True, classify=True)
+        self.classifier = nn.Sequential(*layers)
+
+    def forward(self, inputs):
+        feats = inputs['features']
+        npts = feats.size(-1)
+        one_hot = inputs['one_hot_vectors'].unsqueeze(-1).repeat([1, 1, npts])
+        per_point, coords = self.point_features((feats, feats[:, :3, :]))
+        pooled, _ = self.cloud_features((per_point, coords)) if len(self.cloud_features) else (per_point, coords)
+        pooled = pooled.max(dim=-1, keepdim=True).values.repeat([1, 1, npts])
+        return self.classifier(torch.cat([one_hot, per_point, pooled], dim=1))
+
+
+class _CloudRegressor(nn.Module):
+    """SharedMLP stack on coordinates -> global max -> dense head on [descriptor, class one-hot].  With
+    `point_attr='features'` / `head_attr='regression'` it is the centre-regression T-Net
+    (models/kitti/frustum/center_regression_net.py:9-35); with 'features' / 'classifier' the box-estimation
+    PointNet (models/kitti/frustum/box_estimation/pointnet.py:9-52)."""
+
+    def __init__(self, widths, head, num_classes, width_multiplier, head_attr, coords_tuple):
+        super().__init__()
+        self.in_channels, self.num_classes = 3, num_classes
+        self._head_attr, self._coords_tuple = head_attr, coords_tuple
+        stack, cin = [], 3
+        for w in widths:
+            stack.append(SharedMLP(cin, _scaled(w, width_multiplier)))
+            cin = _scaled(w, width_multiplier)
+        self.features = nn.Sequential(*stack)
+        layers, _ = _head(cin + num_classes, head, width_multiplier, pointwise=False, classify=True)
+        setattr(self, head_attr, nn.Sequential(*layers))
+
+    def forward(self, inputs):
+        coords = inputs['coords']
+        if self._coords_tuple:                                     # box estimation feeds (features, coords) tuples
+            desc, _ = self.features((coords, coords))
+        else:
+            desc = self.features(coords)
+        desc = desc.max(dim=-1, keepdim=False).values
+        return getattr(self, self._head_attr)(torch.cat([desc, inputs['one_hot_vectors']], dim=1))
+
+
+class FrustumPVCNNE(nn.Module):
+    """Frustum-PVCNN (efficient variant), BASELINE configs[4]; reference models/kitti/frustum/frustum_net.py:14-76,
+    105-113: per-point segmentation with PVConvs -> foreground sampling (logits_mask) -> centre regression ->
+    box estimation; returns the reference's dict of box parameters."""
+
+    def __init__(self, num_classes, num_heading_angle_bins, num_size_templates, num_points_per_object, size_templates,
+                 extra_feature_channels=1, width_multiplier=1, voxel_resolution_multiplier=1):
+        super().__init__()
+        wm = list(width_multiplier) if isinstance(width_multiplier, (list, tuple)) else [width_multiplier] * 3
+        self.in_channels = 3 + extra_feature_channels
+        self.num_classes = num_classes
+        self.num_heading_angle_bins = num_heading_angle_bins
+        self.num_size_templates = num_size_templates
+        self.num_points_per_object = num_points_per_object
+        self.inst_seg_net = _FrustumSegmentation(num_classes, extra_feature_channels, wm[0], voxel_resolution_multiplier)
+        self.center_reg_net = _CloudRegressor((128, 128, 256), [256, 128, 3], num_classes, wm[1], 'regression', False)
+        n_out = 3 + num_heading_angle_bins * 2 + num_size_templates * 4
+        self.box_est_net = _CloudRegressor((128, 128, 256, 512), [512, 256, n_out], num_classes, wm[2], 'classifier', True)
+        self.register_buffer('size_templates', size_templates.view(1, num_size_templates, 3))
+
+    def forward(self, inputs):
+        import math
+        from .modules import functional as PF
+        feats, one_hot = inputs['features'], inputs['one_hot_vectors']
+        mask_logits = self.inst_seg_net({'features': feats, 'one_hot_vectors': one_hot})
+        fg, fg_mean, _ = PF.logits_mask(coords=feats[:, :3, :], logits=mask_logits,
+                                        num_points_per_object=self.num_points_per_object)
+        delta = self.center_reg_net({'coords': fg, 'one_hot_vectors': one_hot})
+        fg = fg - delta.unsqueeze(-1)
+        est = self.box_est_net({'coords': fg, 'one_hot_vectors': one_hot})
+        nh, ns = self.num_heading_angle_bins, self.num_size_templates
+        centre, h_score, h_res, s_score, s_res = est.split([3, nh, nh, ns, ns * 3], dim=-1)
+        s_res = s_res.view(-1, ns, 3)
+        center_reg = fg_mean + delta
+        return {'mask_logits': mask_logits, 'center_reg': center_reg, 'center': centre + center_reg,
+                'heading_scores': h_score, 'heading_residuals_normalized': h_res,
+                'heading_residuals': h_res * (math.pi / nh), 'size_scores': s_score,
+                'size_residuals_normalized': s_res, 'size_residuals': s_res * self.size_templates}
+
+
 def make_s3dis_batch(batch, num_points, num_classes=13, device='cpu', seed=SEED, duplicates=0.05):
     """Synthetic S3DIS-like batch: features (B,9,N) fp32 and labels (B,N) int64."""
     g = torch.Generator().manual_seed(seed)
@@ -188,3 +320,54 @@ def make_s3dis_batch(batch, num_points, num_classes=13, device='cpu', seed=SEED,
             feats[b, :, dst[b]] = feats[b, :, src[b]]
     labels = torch.randint(0, num_classes, (batch, num_points), generator=g)
     return feats.contiguous().to(device), labels.to(device)
+
+
+def make_shapenet_batch(batch, num_points=2048, num_classes=50, num_shapes=16, device='cpu', seed=SEED):
+    """Synthetic ShapeNet-part batch (datasets/shapenet.py:62-101): inputs (B, 3+3+16, N) =
+    xyz (centred, scaled into the unit ball, jittered by N(0,0.01) clipped to +-0.05), unit normals, the shape
+    one-hot repeated over N; points drawn WITH replacement from a smaller pool, so exact duplicates are guaranteed.
+    Labels (B,N) int64."""
+    g = torch.Generator().manual_seed(seed)
+    pool = max(64, num_points * 3 // 4)
+    base = torch.randn(batch, 3, pool, generator=g) * torch.tensor([0.35, 0.2, 0.5]).view(1, 3, 1)
+    base = base - base.mean(dim=2, keepdim=True)
+    base = base / base.norm(dim=1, keepdim=True).amax(dim=2, keepdim=True)          # unit ball
+    pick = torch.randint(0, pool, (batch, num_points), generator=g)
+    xyz = torch.gather(base, 2, pick.unsqueeze(1).expand(-1, 3, -1))
+    xyz = xyz + (torch.randn(batch, 3, num_points, generator=g) * 0.01).clamp(-0.05, 0.05)
+    # keep ~6 % exact duplicates un-jittered (the loader's replace=True draws)
+    ndup = num_points // 16
+    src = torch.randint(0, num_points, (batch, ndup), generator=g)
+    dst = torch.randint(0, num_points, (batch, ndup), generator=g)
+    for b in range(batch):
+        xyz[b, :, dst[b]] = xyz[b, :, src[b]]
+    normals = torch.randn(batch, 3, num_points, generator=g)
+    normals = normals / normals.norm(dim=1, keepdim=True).clamp(min=1e-6)
+    shape_id = torch.randint(0, num_shapes, (batch,), generator=g)
+    one_hot = torch.zeros(batch, num_shapes, num_points)
+    one_hot[torch.arange(batch), shape_id, :] = 1.0
+    labels = torch.randint(0, num_classes, (batch, num_points), generator=g)
+    return torch.cat([xyz, normals, one_hot], dim=1).contiguous().to(device), labels.to(device)
+
+
+def make_frustum_batch(batch, num_points=1024, num_classes=3, device='cpu', seed=SEED):
+    """Synthetic KITTI frustum batch: {'features': (B,4,N) = frustum-like xyz (x, y ~ N(0,1.5),
+    depth z ~ U[5,40]) + intensity U[0,1], 'one_hot_vectors': (B,3)}, and per-point foreground labels (B,N)."""
+    g = torch.Generator().manual_seed(seed)
+    xy = torch.randn(batch, 2, num_points, generator=g) * 1.5
+    z = torch.rand(batch, 1, num_points, generator=g) * 35.0 + 5.0
+    inten = torch.rand(batch, 1, num_points, generator=g)
+    cls = torch.randint(0, num_classes, (batch,), generator=g)
+    one_hot = torch.zeros(batch, num_classes)
+    one_hot[torch.arange(batch), cls] = 1.0
+    labels = torch.randint(0, 2, (batch, num_points), generator=g)
+    return ({'features': torch.cat([xy, z, inten], dim=1).contiguous().to(device), 'one_hot_vectors': one_hot.to(device)},
+            labels.to(device))
+
+
+def frustum_size_templates(num_size_templates=8):
+    """Mean (l, w, h) box sizes per class; values only matter as a fixed buffer of the right shape here
+    (the reference reads them from its KITTI attributes, datasets/kitti/attributes.py)."""
+    base = torch.tensor([[3.9, 1.6, 1.56], [0.8, 0.6, 1.73], [1.76, 0.6, 1.73], [5.06, 1.9, 2.2],
+                         [10.1, 2.6, 3.0], [2.1, 1.2, 1.5], [16.2, 2.6, 3.5], [0.84, 0.66, 1.76]])
+    return base[:num_size_templates].clone()

@@ -216,28 +216,3 @@ def test_runs_on_the_current_stream(hip, oracle, gen):
     o_out = oracle.avg_voxelize_forward(feat, vox, 16)[0]
     assert torch.equal(out.cpu(), o_out)
     assert torch.equal(dev.cpu(), oracle.trilinear_devoxelize_forward(16, False, norm, o_out)[0])
-
-
-@pytest.mark.parametrize('b,n,r,normalize,eps', [(2, 4096, 32, True, 0.0), (3, 1000, 16, True, 1e-6), (1, 37, 12, False, 0.0),
-                                                   (16, 4096, 16, True, 0.0), (2, 8192, 8, False, 0.0)])
-def test_voxel_coords_prepass(hip, gen, b, n, r, normalize, eps):
-    """The fused coordinate pre-pass (modules/voxelization.py:16-25 in one kernel) vs the reference's torch
-    formulation evaluated in fp64: normalised coordinates to 1e-5 * R, voxel ids identical except where the
-    coordinate sits within that distance of a .5 rounding boundary (where torch-CPU and torch-GPU disagree too)."""
-    co = synth_cloud(gen, b, n, 's3dis')
-    if not normalize:
-        co = (co / co.amax()) * 1.6 - 0.8                  # "already in the unit ball" convention of that path
-    norm, vox = hip.voxel_coords(co.to(DEV), r, normalize, eps)
-    c = co.double()
-    c = c - c.mean(2, keepdim=True)
-    if normalize:
-        unit = c / (c.norm(dim=1, keepdim=True).max(dim=2, keepdim=True).values * 2.0 + eps) + 0.5
-    else:
-        unit = (c + 1) / 2.0
-    want = torch.clamp(unit * r, 0, r - 1)
-    assert norm.dtype == torch.float32 and vox.dtype == torch.int32 and norm.shape == vox.shape == (b, 3, n)
-    assert (norm.cpu().double() - want).abs().max().item() <= 1e-5 * r
-    assert torch.equal(vox.cpu(), torch.round(norm.cpu()).to(torch.int32)), 'vox must be round-half-even of the returned norm'
-    far = (want - torch.floor(want) - 0.5).abs() > 1e-4
-    assert torch.equal(vox.cpu()[far], torch.round(want).to(torch.int32)[far])
-    assert 0 <= int(vox.min()) and int(vox.max()) <= r - 1

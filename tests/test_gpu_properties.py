@@ -10,6 +10,9 @@ from conftest import synth_cloud
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 FULL = [(16, 64, 4096, 32), (16, 128, 4096, 16)]
+# BASELINE configs[3] (ShapeNet PVCNN, B=64 N=2048: 64 ch @ R=32, 128 ch @ R=16) and configs[4] (Frustum-PVCNN, B=32
+# N=1024, R=12 -- a non-power-of-two grid -- and R=16), SURVEY.md 8(d) op-level shapes
+FULL_OTHER = [(64, 128, 2048, 16), (64, 64, 2048, 32), (32, 64, 1024, 12), (32, 128, 1024, 12), (32, 64, 1024, 16)]
 
 
 def _inputs(b, c, n, r, kind, seed):
@@ -21,8 +24,8 @@ def _inputs(b, c, n, r, kind, seed):
     return g, norm, vox
 
 
-@pytest.mark.parametrize('b,c,n,r', FULL)
-@pytest.mark.parametrize('kind', ['cube', 'surface'])
+@pytest.mark.parametrize('b,c,n,r,kind', [(*f, k) for f in FULL for k in ('cube', 'surface')] +
+                         [(*f, 'cube') for f in FULL_OTHER] + [(32, 64, 1024, 12, 'surface')])
 def test_full_size_ops_equal_the_oracle(hip, oracle, b, c, n, r, kind):
     g, norm, vox = _inputs(b, c, n, r, kind, 1588147245)
     feat = torch.randn(b, c, n, generator=g)

@@ -98,11 +98,54 @@ def test_s3dis_networks_match_reference(ref, name, n):
         assert torch.equal(theirs(x), mine(x))
 
 
+def test_shapenet_and_frustum_networks_match_reference(ref):
+    """BASELINE configs[3] / configs[4] builders vs the reference's own classes (models/shapenet/pvcnn.py:9-42,
+    models/kitti/frustum/frustum_net.py:14-113): same state_dict keys / shapes, same outputs."""
+    import numpy as np
+    from pvcnn_amd import workload
+    sys.path.insert(0, REF)
+    try:
+        shapenet = importlib.import_module('models.shapenet')
+        frustum = importlib.import_module('models.kitti.frustum')
+    finally:
+        sys.path.remove(REF)
+    torch.manual_seed(4)
+    theirs, mine = shapenet.PVCNN(50, 16, 3, 0.125), workload.PVCNNShapeNet(50, 16, 3, 0.125)
+    _same_state(theirs, mine)
+    mine.load_state_dict(theirs.state_dict())
+    theirs.eval(); mine.eval()
+    x, _ = workload.make_shapenet_batch(2, 512)
+    assert x.shape == (2, 22, 512)
+    with torch.no_grad():
+        assert torch.equal(theirs(x), mine(x))
+    templates = workload.frustum_size_templates()
+    theirs = frustum.FrustumPVCNNE(3, 12, 8, 128, templates, 1, 0.25)
+    mine = workload.FrustumPVCNNE(3, 12, 8, 128, templates, 1, 0.25)
+    _same_state(theirs, mine)
+    mine.load_state_dict(theirs.state_dict())
+    theirs.eval(); mine.eval()
+    inputs, _ = workload.make_frustum_batch(2, 256)
+    with torch.no_grad():
+        np.random.seed(5); want = theirs(inputs)
+        np.random.seed(5); got = mine(inputs)
+    assert list(want.keys()) == list(got.keys())
+    for k in want:
+        assert torch.equal(want[k], got[k]), k
+    assert [m.resolution for m in mine.inst_seg_net.point_features[:4]] == [16, 16, 12, 12]
+
+
 def test_full_width_parameter_counts(ref):
     # SURVEY.md 2.1: PVCNN 1xC 2,572,493 parameters; PVCNN++ 13,709,837
     from pvcnn_amd import workload
     assert sum(p.numel() for p in workload.PVCNN(13, 6, 1).parameters()) == 2572493
     assert sum(p.numel() for p in workload.PVCNN2(13, 6, 1).parameters()) == 13709837
+    sys.path.insert(0, REF)
+    try:
+        shapenet = importlib.import_module('models.shapenet')
+    finally:
+        sys.path.remove(REF)
+    assert (sum(p.numel() for p in workload.PVCNNShapeNet(50, 16, 3, 1).parameters())
+            == sum(p.numel() for p in shapenet.PVCNN(50, 16, 3, 1).parameters()) == 4200434)
 
 
 def test_reference_models_run_unchanged_on_the_dropin(oracle_seam):
