@@ -148,6 +148,24 @@ class KernelClock:
         return out
 
 
+def pmc_traffic(kernel, shape):
+    """HBM bytes per launch of `kernel` at `shape` from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json,
+    written by tools/pmc_by_kernel.py from separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of THIS bench command;
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide streaming reads on gfx950).  Nothing is hard-coded:
+    no file, or no entry for this kernel and shape -> traffic null."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    try:
+        table = json.load(open(path))
+    except (OSError, ValueError):
+        return {'traffic': None}
+    for row in table.get('kernels', []):
+        if row.get('op') == kernel and list(row.get('shape_BCNR', [])) == list(shape):
+            return {'traffic': int((2 * row['FETCH_SIZE_KiB'] + row['WRITE_SIZE_KiB']) * 1024),
+                    'traffic_source': f"profiles/pmc_traffic.json: {row.get('kernel_name', '?')}, FETCH_SIZE {row['FETCH_SIZE_KiB']} KiB "
+                                      f"(x2, gfx950 correction) + WRITE_SIZE {row['WRITE_SIZE_KiB']} KiB; {table.get('command', '')}"}
+    return {'traffic': None}
+
+
 def cpu_baseline(args, sample_batch):
     """The same network + step on the host CPU with the oracle as native backend (kind "port")."""
     from oracle.oracle_backend import OracleBackend          # checker / baseline only
@@ -176,7 +194,7 @@ def cpu_baseline(args, sample_batch):
             step()
             n += 1
             el = time.perf_counter() - t0
-            if el > 12.0 or n >= 5:
+            if el > 20.0 or n >= 5:
                 break
     finally:
         seam._backend = hip
@@ -188,21 +206,29 @@ def cpu_baseline(args, sample_batch):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=16, help='clouds per GPU (BASELINE configs[1]: 16)')
     ap.add_argument('--points', type=int, default=4096)
     ap.add_argument('--width', type=float, default=1.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample-batch', type=int, default=2)
+    ap.add_argument('--cpu-sample-batch', type=int, default=0, help='clouds per CPU-baseline step (0 = the same batch as the GPU run)')
     ap.add_argument('--bucket-mb', type=float, default=8.0)
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: become the launcher -- one process per GPU under torch.distributed.run
+        import socket
+        with socket.socket() as sock:
+            sock.bind(('127.0.0.1', 0))
+            port = sock.getsockname()[1]
+        os.execv(sys.executable, [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+                                  '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__), *sys.argv[1:]])
     if world != args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: the launcher and the flag disagree')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the PVConv hot path has no CPU fallback')
     torch.cuda.set_device(local_rank)
@@ -277,12 +303,8 @@ def main():
                         'event_overhead_us': round(event_overhead_us, 2),
                         'timing': 'HIP events around every launch inside the timed steps, on the launch stream; '
                                   'avg_us = mean event-pair time - the time an empty event pair reads on a busy stream',
-                        'algorithmic_MB': head['algorithmic_MB'], 'traffic': None}
-            if head['shape_BCNR'] == [16, 64, 4096, 32]:
-                # HBM bytes per launch from rocprofv3 PMC passes on this kernel and shape (separate runs:
-                # FETCH_SIZE 68656 KiB, doubled per MI355X_MICROARCH.md for gfx950; WRITE_SIZE 20480 KiB)
-                roofline['traffic'] = (2 * 68656 + 20480) * 1024
-                roofline['traffic_source'] = 'profiles/r01_pmc_FETCH_SIZE_*.txt + r01_pmc_WRITE_SIZE_*.txt (rocprofv3 --pmc, separate passes)'
+                        'algorithmic_MB': head['algorithmic_MB']}
+            roofline.update(pmc_traffic('trilinear_devoxelize_fwd', head['shape_BCNR']))
         line = {
             'metric': 'point-clouds/sec fwd+bwd, PVCNN S3DIS N=4096 R=32',
             'value': round(global_batch * args.steps / elapsed, 2),
@@ -303,7 +325,7 @@ def main():
             'kernels': kernels,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(args, args.cpu_sample_batch)
+            line['cpu_baseline'] = cpu_baseline(args, args.cpu_sample_batch or args.batch)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -108,6 +108,29 @@ PVCNN_API int pvcnn_trilinear_devox_bwd(const float *grad_y, const int32_t *inds
                               int C, int N, int R, float *grad_x, void *workspace,
                               size_t workspace_bytes, void *stream);
 
+/* ---- scatter plans: the counting sort of a scatter depends on its entries only -----------------------------------
+ * Both scatters of the voxel branch are "plan, then apply".  The plan -- entries (source index, weight) grouped by
+ * target voxel in the reference's serial order, their prefix offsets, and a count-sorted lane assignment -- depends on
+ * (voxel coordinates, R) for avg_voxelize and on (inds, wgts) = (point coordinates, R) for the devoxelize backward, NOT
+ * on the features, their channel count or the layer: every PVConv that shares coords and R (PVCNN: three at R = 16)
+ * applies one plan, forward and backward.  pvcnn_avg_voxelize_fwd / pvcnn_trilinear_devox_bwd above are plan + apply in
+ * one call.  *_plan_bytes returns 0 when the grid is too large for a plan (R > 101): use the one-shot calls then.
+ * plan: caller-owned, 16-byte aligned, *_plan_bytes(...) bytes, opaque; scratch: *_plan_scratch_bytes(...) bytes, free
+ * to reuse once the plan call is enqueued on the same stream.  ind / cnt are avg_voxelize_forward's outputs.
+ */
+PVCNN_API size_t pvcnn_avg_voxelize_plan_bytes(int B, int N, int R);
+PVCNN_API size_t pvcnn_avg_voxelize_plan_scratch_bytes(int B, int N, int R);
+PVCNN_API int pvcnn_avg_voxelize_plan(const int32_t *coords, int B, int N, int R, int32_t *ind, int32_t *cnt, void *plan,
+                            size_t plan_bytes, void *scratch, size_t scratch_bytes, void *stream);
+PVCNN_API int pvcnn_avg_voxelize_apply(const float *feat, const void *plan, size_t plan_bytes, int B, int C, int N, int R,
+                             float *out, void *stream);
+PVCNN_API size_t pvcnn_trilinear_devox_bwd_plan_bytes(int B, int N, int R);
+PVCNN_API size_t pvcnn_trilinear_devox_bwd_plan_scratch_bytes(int B, int N, int R);
+PVCNN_API int pvcnn_trilinear_devox_bwd_plan(const int32_t *inds, const float *wgts, int B, int N, int R, void *plan,
+                                   size_t plan_bytes, void *scratch, size_t scratch_bytes, void *stream);
+PVCNN_API int pvcnn_trilinear_devox_bwd_apply(const float *grad_y, long grad_y_batch_stride, const void *plan, size_t plan_bytes,
+                                    int B, int C, int N, int R, float *grad_x, void *stream);
+
 /* ---- ball_query ---------------------------------------------------------------------------
  * replaces ball_query_forward (ball_query/ball_query.cpp:6-30, kernel ball_query.cu:19-50)
  * centers (B,3,M), points (B,3,N) -> out (B,M,U) i32: the first U points (ascending index)

@@ -31,6 +31,14 @@ SIGNATURES = {
     'pvcnn_trilinear_devox_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'pvcnn_trilinear_devox_bwd_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'pvcnn_trilinear_devox_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    'pvcnn_avg_voxelize_plan_bytes': (_sz, [_i, _i, _i]),
+    'pvcnn_avg_voxelize_plan_scratch_bytes': (_sz, [_i, _i, _i]),
+    'pvcnn_avg_voxelize_plan': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),
+    'pvcnn_avg_voxelize_apply': (_i, [_vp, _vp, _sz, _i, _i, _i, _i, _vp, _vp]),
+    'pvcnn_trilinear_devox_bwd_plan_bytes': (_sz, [_i, _i, _i]),
+    'pvcnn_trilinear_devox_bwd_plan_scratch_bytes': (_sz, [_i, _i, _i]),
+    'pvcnn_trilinear_devox_bwd_plan': (_i, [_vp, _vp, _i, _i, _i, _vp, _sz, _vp, _sz, _vp]),
+    'pvcnn_trilinear_devox_bwd_apply': (_i, [_vp, ctypes.c_long, _vp, _sz, _i, _i, _i, _i, _vp, _vp]),
     'pvcnn_ball_query': (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp]),
     'pvcnn_grouping_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     'pvcnn_grouping_bwd_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),

@@ -17,7 +17,7 @@ void set_error(const char *fmt, ...);
 // hipGetLastError() -> return code (+ error string); 0 when clean
 int check_launch(const char *what);
 
-inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+__host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 // log2(R) when R is a power of two >= 4 (grid rows can then be staged padded in LDS, slab.h), else 0
 inline int grid_pad_shift(int R) { int s = 0; while ((1 << s) < R) ++s; return ((1 << s) == R && R >= 4) ? s : 0; }
 __host__ __device__ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }

@@ -36,25 +36,39 @@ constexpr int kCsrMaxRange = 14336;      // (range + range/32 + 69 + 3*8192) * 4
 __host__ __device__ __forceinline__ int pad32(int v) { return v + (v >> 5); }          // conflict-free scan layout
 __host__ __device__ __forceinline__ int start_stride(int L) { return (L + 1 + 3) & ~3; }   // per-cloud stride of start[]
 
-inline int cl_channels(int C) { return (C + 63) & ~63; }   // channel stride of the transposed source
+constexpr int kTileTargets = 4096;          // targets per LDS output tile of segsum_tile_kernel (= one `order` range)
+constexpr int kTileThreads = 1024;
+__host__ __device__ inline int order_stride(int L) { return ceil_div(L, kTileTargets) * kTileTargets; }   // per-cloud stride of order[]
 
-struct CsrWorkspace {
-  int32_t *start;   // (B, start_stride(L))
-  int32_t *tmp;     // (B, E)   unordered placement (overflow path of csr_prep_kernel)
-  int2 *ent;        // (B, E)   {source index j, float bits of w}
-  float *srcT;      // (B, J, cl_channels(C))  channels-last copy of the source rows
+// The PLAN of a scatter: everything the owned sums need that depends only on the entries (keys, sources, weights) --
+// not on the feature tensor being scattered, its channel count, or the layer.  A plan built once per (coords, R) is
+// applied by every PVConv layer that shares them (PVCNN: three layers at R = 16), forward and backward.
+//   start (B, start_stride(L))  exclusive prefix of the per-target entry counts
+//   ent   (B, E)                {source index j, float bits of w} grouped by target, ascending entry id inside a target
+//   order (B, order_stride(L))  per range of kTileTargets targets: their LOCAL ids sorted by descending entry count
+//                               (0xFFFF pads the last range): lanes of a wave take neighbours of this list, so they
+//                               walk segments of (nearly) equal length whatever the key distribution
+struct CsrPlan {
+  int32_t *start;
+  int2 *ent;
+  uint16_t *order;
   static size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
-  static size_t bytes(int B, int C, int L, int J, long E) {
-    return align16((size_t)B * start_stride(L) * 4) + align16((size_t)B * E * 4) + align16((size_t)B * E * 8) +
-           align16((size_t)B * J * cl_channels(C) * 4) + 16;
+  static size_t bytes(int B, int L, long E) {
+    return align16((size_t)B * start_stride(L) * 4) + align16((size_t)B * E * 8) + align16((size_t)B * order_stride(L) * 2) + 16;
   }
-  void carve(void *ws, int B, int L, long E) {
-    char *p = static_cast<char *>(ws);
+  void carve(void *p_, int B, int L, long E) {
+    char *p = static_cast<char *>(p_);
     start = reinterpret_cast<int32_t *>(p); p += align16((size_t)B * start_stride(L) * 4);
-    tmp = reinterpret_cast<int32_t *>(p);   p += align16((size_t)B * E * 4);
     ent = reinterpret_cast<int2 *>(p);      p += align16((size_t)B * E * 8);
-    srcT = reinterpret_cast<float *>(p);
+    order = reinterpret_cast<uint16_t *>(p);
   }
+};
+// scratch of the prep step only (overflow path of csr_prep_kernel): tmp (B, E) int32
+inline size_t csr_prep_scratch_bytes(int B, long E) { return CsrPlan::align16((size_t)B * E * 4) + 16; }
+
+// combined-call workspace (plan followed by the prep scratch): what the one-shot entry points ask the caller for
+struct CsrWorkspace {
+  static size_t bytes(int B, int /*C*/, int L, int /*J*/, long E) { return CsrPlan::bytes(B, L, E) + csr_prep_scratch_bytes(B, E); }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -432,82 +446,169 @@ __global__ __launch_bounds__(THREADS) void segsum_kernel(const float *__restrict
 }
 
 // ---------------------------------------------------------------------------------------------
-// Channel-per-lane segmented sums (dense targets: E >= 2 L).  Lane-per-target walks are hostage to the key
-// distribution: real clouds fill ~1/5 of the grid, so at R = 16 an occupied voxel owns ~45 corner
-// entries while most lanes idle.  Here the work is spread over CHANNELS instead:
-//   transpose_cj_kernel : src (B,C,J) -> srcT (B,J,Cp) (Cp = C rounded up to 64), LDS-tiled, coalesced;
-//   segsum_cl_kernel    : a wave owns one target at a time, its 64 lanes are 64 channels; the
-//                         target's entries (j, w) are wave-uniform (scalar loads), every source read
-//                         srcT[j][c0 .. c0+63] is one coalesced 256-byte row, and each lane adds
-//                         its channel's addends in entry order (bit-exact, any distribution);
-//                         results go through a 64 x 64 LDS tile so dst (B,C,L) is written as
-//                         256-byte rows.  Work is proportional to E, independent of how the
-//                         entries are spread over the targets.
+// csr_order_kernel: grid = (ranges, B).  Counting sort of one range of kTileTargets targets by
+// min(count, 255), descending.  ~1 us; part of the plan (built once, reused by every apply).
 // ---------------------------------------------------------------------------------------------
-static __global__ __launch_bounds__(256) void transpose_cj_kernel(const float *__restrict__ src, float *__restrict__ dstT, int C,
-                                                           int J, int Cp, long src_bstride) {
-  __shared__ float tile[64][65];
-  const int b = blockIdx.z, j0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  for (int r = ty; r < 64; r += 4) {   // read rows of src: lanes along j
-    const int c = c0 + r, j = j0 + tx;
-    tile[r][tx] = (c < C && j < J) ? src[(size_t)b * src_bstride + (size_t)c * J + j] : 0.0f;
+static __global__ __launch_bounds__(kTileThreads) void csr_order_kernel(const int32_t *__restrict__ start, int L,
+                                                                        uint16_t *__restrict__ order) {
+  __shared__ int hist[256];
+  __shared__ int wtot[4];
+  const int r = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int t0 = r * kTileTargets, nt = min(kTileTargets, L - t0);
+  const int32_t *st = start + (size_t)b * start_stride(L) + t0;
+  uint16_t *out = order + (size_t)b * order_stride(L) + t0;
+  if (tid < 256) hist[tid] = 0;
+  __syncthreads();
+  int bucket[kTileTargets / kTileThreads];
+#pragma unroll
+  for (int k = 0; k < kTileTargets / kTileThreads; ++k) {
+    const int t = tid + k * kTileThreads;
+    bucket[k] = -1;
+    if (t < nt) {
+      bucket[k] = 255 - min(st[t + 1] - st[t], 255);      // bucket 0 = the longest segments
+      atomicAdd(&hist[bucket[k]], 1);
+    }
   }
   __syncthreads();
-  for (int r = ty; r < 64; r += 4) {   // write rows of srcT: lanes along c
-    const int j = j0 + r;
-    if (j < J) dstT[((size_t)b * J + j) * Cp + c0 + tx] = tile[tx][r];
+  int v = 0, incl = 0;
+  if (tid < 256) {                                        // exclusive prefix over the 256 buckets (waves 0..3)
+    v = hist[tid];
+    incl = v;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+      const int up = __shfl_up(incl, d);
+      if ((tid & 63) >= d) incl += up;
+    }
+    if ((tid & 63) == 63) wtot[tid >> 6] = incl;
   }
+  __syncthreads();
+  if (tid < 256) {
+    int base = incl - v;
+    for (int w = 0; w < (tid >> 6); ++w) base += wtot[w];
+    hist[tid] = base;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kTileTargets / kTileThreads; ++k)
+    if (bucket[k] >= 0) out[atomicAdd(&hist[bucket[k]], 1)] = (uint16_t)(tid + k * kTileThreads);
+  for (int t = nt + tid; t < kTileTargets; t += kTileThreads) out[t] = 0xFFFF;
 }
 
-static __global__ __launch_bounds__(1024) void segsum_cl_kernel(const float *__restrict__ srcT,
-                                                                 const int32_t *__restrict__ start,
-                                                                 const int2 *__restrict__ ent, float *__restrict__ dst,
-                                                                 int C, int Cp, int L, int J, int E) {
-  __shared__ float tile[64][65];   // [channel][target]
-  constexpr int kVox = 4;          // targets per wave: 16 waves x 4 = the 64-target tile
-  const int b = blockIdx.z, v0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+// ---------------------------------------------------------------------------------------------
+// segsum_tile_kernel: the owned sums, for any key distribution.  grid = (ceil(C/G), nsplit, B), 1024 threads.
+//   * the workgroup's G source rows (J floats each) are staged ONCE into LDS, channel-interleaved
+//     (srcI[j*G + c]): one ds_read of G floats serves all G channels of an entry;
+//   * targets are processed in ranges of kTileTargets; inside a range, thread t takes the targets at ranks
+//     t, t+1024, ... of the range's count-sorted `order` list, so the 64 lanes of a wave walk segments of nearly equal
+//     length (a lane-per-consecutive-target walk idles most lanes: real clouds fill a fifth of the grid, and the
+//     occupied voxels own ~45 corner entries each at R = 16);
+//   * each target's sum is acc = acc + w * src[j] over its entries in ascending entry id (the oracle's serial order:
+//     bit-exact), and lands in an LDS tile [G][range]; the tile leaves as coalesced 16-byte stores -- every target,
+//     empty or not, is written exactly once: no memset, no float atomics, no transposed copy of the source.
+//   nsplit > 1 spreads the ranges of one (cloud, channel slab) over several workgroups (few channels: voxelize C = 9).
+// ---------------------------------------------------------------------------------------------
+template <int G>
+__global__ __launch_bounds__(kTileThreads) void segsum_tile_kernel(const float *__restrict__ src, const int32_t *__restrict__ start,
+                                                                   const int2 *__restrict__ ent, const uint16_t *__restrict__ order,
+                                                                   float *__restrict__ dst, int C, int L, int J, int E,
+                                                                   long src_bstride, int nsplit, int JP) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  using vecG = __attribute__((ext_vector_type(G))) float;
+  const int b = blockIdx.z, split = blockIdx.y, c0 = blockIdx.x * G, tid = threadIdx.x;
+  const int g = min(G, C - c0);
+  float *srcI = lds;                    // JP * G floats (JP = J rounded up to 4)
+  float *tile = lds + (size_t)JP * G;   // G rows of kTileTargets floats
+  const float *rows = src + (size_t)b * src_bstride + (size_t)c0 * J;
+  // ---- stage the source rows, transposing to channel-interleaved ----
+  if ((J & 3) == 0 && aligned16(rows) && ((src_bstride & 3) == 0)) {
+    for (int j0 = tid * 4; j0 < J; j0 += kTileThreads * 4) {
+      float4 v[G];
+#pragma unroll
+      for (int c = 0; c < G; ++c) v[c] = ld4(rows + (size_t)min(c, g - 1) * J + j0);   // rows past g alias a valid row (discarded)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        vecG o;
+#pragma unroll
+        for (int c = 0; c < G; ++c) o[c] = (u == 0) ? v[c].x : (u == 1) ? v[c].y : (u == 2) ? v[c].z : v[c].w;
+        *reinterpret_cast<vecG *>(srcI + (size_t)(j0 + u) * G) = o;
+      }
+    }
+  } else {
+    for (int j = tid; j < J; j += kTileThreads) {
+      vecG o;
+#pragma unroll
+      for (int c = 0; c < G; ++c) o[c] = rows[(size_t)min(c, g - 1) * J + j];
+      *reinterpret_cast<vecG *>(srcI + (size_t)j * G) = o;
+    }
+  }
+  __syncthreads();
   const int32_t *st = start + (size_t)b * start_stride(L);
   const int2 *en = ent + (size_t)b * E;
-  const float *sT = srcT + (size_t)b * J * Cp + c0 + lane;
-  // the wave's kVox + 1 segment boundaries with ONE vector load (then lane -> scalar by readlane)
-  const int vb = v0 + wave * kVox;
-  const int sv = st[min(vb + min(lane, kVox), L)];
+  const uint16_t *ord = order + (size_t)b * order_stride(L);
+  const int nr = ceil_div(L, kTileTargets);
+  for (int r = split; r < nr; r += nsplit) {
+    const int t0 = r * kTileTargets, nt = min(kTileTargets, L - t0);
+#pragma unroll 1
+    for (int k = 0; k < kTileTargets / kTileThreads; ++k) {
+      const int lt = ord[t0 + k * kTileThreads + tid];
+      if (lt == 0xFFFF) continue;
+      int e = st[t0 + lt];
+      const int e1 = st[t0 + lt + 1];
+      vecG acc;
 #pragma unroll
-  for (int q = 0; q < kVox; ++q) {
-    const int s_lo = __builtin_amdgcn_readlane(sv, q);
-    const int s_hi = (vb + q < L) ? __builtin_amdgcn_readlane(sv, q + 1) : s_lo;
-    float acc = 0.0f;
-    int e = s_lo;
-    for (; e + 4 <= s_hi; e += 4) {   // 4 row loads in flight, adds in entry order
-      const int2 t0 = en[e], t1 = en[e + 1], t2 = en[e + 2], t3 = en[e + 3];
-      const float x0 = sT[(size_t)t0.x * Cp], x1 = sT[(size_t)t1.x * Cp], x2 = sT[(size_t)t2.x * Cp], x3 = sT[(size_t)t3.x * Cp];
-      acc = acc + __int_as_float(t0.y) * x0;
-      acc = acc + __int_as_float(t1.y) * x1;
-      acc = acc + __int_as_float(t2.y) * x2;
-      acc = acc + __int_as_float(t3.y) * x3;
+      for (int c = 0; c < G; ++c) acc[c] = 0.0f;
+      for (; e + 4 <= e1; e += 4) {      // 4 entries' loads in flight; the adds stay in entry order
+        int2 t[4];
+        vecG x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t[u] = en[e + u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const vecG *>(srcI + (size_t)t[u].x * G);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float w = __int_as_float(t[u].y);
+#pragma unroll
+          for (int c = 0; c < G; ++c) acc[c] = acc[c] + w * x[u][c];
+        }
+      }
+      for (; e < e1; ++e) {
+        const int2 t = en[e];
+        const vecG x = *reinterpret_cast<const vecG *>(srcI + (size_t)t.x * G);
+        const float w = __int_as_float(t.y);
+#pragma unroll
+        for (int c = 0; c < G; ++c) acc[c] = acc[c] + w * x[c];
+      }
+#pragma unroll
+      for (int c = 0; c < G; ++c) tile[c * kTileTargets + lt] = acc[c];
     }
-    for (; e < s_hi; ++e) {
-      const int2 t = en[e];
-      acc = acc + __int_as_float(t.y) * sT[(size_t)t.x * Cp];
+    __syncthreads();
+    float *out = dst + ((size_t)b * C + c0) * L + t0;
+    if ((L & 3) == 0 && aligned16(dst)) {
+      const int q_per_row = nt >> 2;      // nt % 4 == 0 since L % 4 == 0 and kTileTargets % 4 == 0
+      for (int q = tid; q < g * q_per_row; q += kTileThreads) {
+        const int c = q / q_per_row, i = (q - c * q_per_row) * 4;
+        const float4 v = *reinterpret_cast<const float4 *>(tile + c * kTileTargets + i);
+        using v4f = __attribute__((ext_vector_type(4))) float;
+        v4f o = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(o, reinterpret_cast<v4f *>(out + (size_t)c * L + i));
+      }
+    } else {
+      for (int q = tid; q < g * nt; q += kTileThreads) {
+        const int c = q / nt, i = q - c * nt;
+        out[(size_t)c * L + i] = tile[c * kTileTargets + i];
+      }
     }
-    tile[lane][wave * kVox + q] = acc;
-  }
-  __syncthreads();
-  for (int r = wave; r < 64; r += 16) {   // one 256-byte row of dst per wave-store
-    const int c = c0 + r, v = v0 + lane;
-    if (c < C && v < L) dst[((size_t)b * C + c) * L + v] = tile[r][lane];
+    __syncthreads();   // the tile is rewritten by the next range
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// Host-side launch.
+// Host-side launch: plan (prep) and apply are separate steps so that a plan can be reused.
 // ---------------------------------------------------------------------------------------------
 inline bool csr_supported(int L, long E) { return L <= kCsrMaxTargets && E <= 0x7fffffffL / 8; }
 
 template <int G, bool STAGE>
-int launch_segsum_g(const float *src, const CsrWorkspace &ws, float *dst, int B, int C, int L, int J, int E,
+int launch_segsum_g(const float *src, const CsrPlan &ws, float *dst, int B, int C, int L, int J, int E,
                     bool vec, int threads, hipStream_t s, const char *what, long src_bstride) {
   const size_t lds = STAGE ? (size_t)G * J * sizeof(float) : 0;
   const dim3 grid(ceil_div(C, G), B);
@@ -523,62 +624,93 @@ int launch_segsum_g(const float *src, const CsrWorkspace &ws, float *dst, int B,
   return check_launch(what);
 }
 
-// dst (B,C,L) = segmented sums of src (B,C,J) over the entries of `ep` (E per cloud).
-// cnt_out: optional (B,L) per-target counts (avg_voxelize's `cnt`).
+// Step 1: build the plan of the scatter described by `ep` (E entries per cloud onto L targets).
+// cnt_out: optional (B,L) per-target counts (avg_voxelize's `cnt`).  scratch: csr_prep_scratch_bytes(B, E).
 template <class EP>
-int launch_csr_scatter(const EP &ep, const float *src, float *dst, int B, int C, int L, int J, long E_,
-                       int32_t *cnt_out, void *workspace, size_t workspace_bytes, hipStream_t s, const char *what,
-                       long src_bstride = 0) {
-  if (src_bstride <= 0) src_bstride = (long)C * J;          // default: src is a contiguous (B,C,J) tensor
+int launch_csr_prep(const EP &ep, int B, int L, long E_, int32_t *cnt_out, void *plan, size_t plan_bytes, void *scratch,
+                    size_t scratch_bytes, hipStream_t s, const char *what) {
   const int E = (int)E_;
   if (B == 0) return 0;
-  if (!workspace || workspace_bytes < CsrWorkspace::bytes(B, C, L, J, E) || !aligned16(workspace)) {
-    set_error("%s: workspace missing, misaligned or too small (%zu bytes needed)", what, CsrWorkspace::bytes(B, C, L, J, E));
+  if (!plan || plan_bytes < CsrPlan::bytes(B, L, E) || !aligned16(plan) || !scratch || !aligned16(scratch) ||
+      scratch_bytes < csr_prep_scratch_bytes(B, E)) {
+    set_error("%s: plan / scratch missing, misaligned or too small (%zu + %zu bytes needed)", what, CsrPlan::bytes(B, L, E),
+              csr_prep_scratch_bytes(B, E));
     return PVCNN_ERR_INVALID_ARGUMENT;
   }
-  CsrWorkspace ws;
-  ws.carve(workspace, B, L, E);
-  // 1. per-cloud counting sort of the entries, targets split into entry-balanced ranges (one workgroup each)
+  CsrPlan pl;
+  pl.carve(plan, B, L, E);
+  // per-cloud counting sort of the entries, targets split into entry-balanced ranges (one workgroup each)
   const CsrSplit sp = csr_split(B, L, E);
   const size_t prep_lds = ((size_t)kCsrCoarse * 2 + 4 + 32 + 4 + 3 * kCsrList + sp.HP) * sizeof(int);
-  {
-    auto k = csr_prep_kernel<EP>;
-    if (int e = enable_big_lds(k, prep_lds)) { set_error("%s: LDS attribute: %d", what, e); return e; }
-    hipLaunchKernelGGL(k, dim3(sp.P, B), dim3(kCsrThreads), prep_lds, s, ep, E, L, sp, cnt_out, ws.start, ws.tmp, ws.ent);
-  }
+  auto k = csr_prep_kernel<EP>;
+  if (int e = enable_big_lds(k, prep_lds)) { set_error("%s: LDS attribute: %d", what, e); return e; }
+  hipLaunchKernelGGL(k, dim3(sp.P, B), dim3(kCsrThreads), prep_lds, s, ep, E, L, sp, cnt_out, pl.start,
+                     static_cast<int32_t *>(scratch), pl.ent);
   if (int e = check_launch(what)) return e;
-  if (C == 0) return 0;
-  if ((long)E >= 2L * L) {
-    // dense targets: channels-last copy of the source rows + channel-per-lane segmented sums
-    const int Cp = cl_channels(C);
-    if (J > 0) {
-      hipLaunchKernelGGL(transpose_cj_kernel, dim3(ceil_div(J, 64), Cp / 64, B), dim3(256), 0, s, src, ws.srcT, C, J, Cp, src_bstride);
-      if (int e = check_launch(what)) return e;
-    }
-    hipLaunchKernelGGL(segsum_cl_kernel, dim3(ceil_div(L, 64), Cp / 64, B), dim3(1024), 0, s, ws.srcT, ws.start, ws.ent, dst,
-                       C, Cp, L, J, E);
+  hipLaunchKernelGGL(csr_order_kernel, dim3(ceil_div(L, kTileTargets), B), dim3(kTileThreads), 0, s, pl.start, L, pl.order);
+  return check_launch(what);
+}
+
+// Step 2: dst (B,C,L) = segmented sums of src (B,C,J) over the plan's entries.  src: rows of a cloud contiguous, clouds
+// src_bstride floats apart.
+inline int launch_csr_apply(const float *src, const void *plan, size_t plan_bytes, float *dst, int B, int C, int L, int J, long E_,
+                            hipStream_t s, const char *what, long src_bstride = 0) {
+  if (src_bstride <= 0) src_bstride = (long)C * J;
+  const int E = (int)E_;
+  if (B == 0 || C == 0) return 0;
+  if (!plan || plan_bytes < CsrPlan::bytes(B, L, E) || !aligned16(plan)) {
+    set_error("%s: plan missing, misaligned or too small (%zu bytes needed)", what, CsrPlan::bytes(B, L, E));
+    return PVCNN_ERR_INVALID_ARGUMENT;
+  }
+  CsrPlan pl;
+  pl.carve(const_cast<void *>(plan), B, L, E);
+  // tile kernel: G source rows channel-interleaved + a G x kTileTargets output tile in LDS
+  const int JP = (J + 3) & ~3;
+  int G = 0;
+  for (int cand = 4; cand >= 1; cand >>= 1)
+    if ((size_t)cand * (JP + kTileTargets) * sizeof(float) <= (size_t)kLdsBytesPerCU) { G = cand; break; }
+  if (G > 0 && J > 0) {
+    while (G > 1 && G / 2 >= C) G >>= 1;                                   // C = 1, 2: no wider than needed
+    const int nr = ceil_div(L, kTileTargets), slabs = ceil_div(C, G);
+    int nsplit = 1;
+    while (nsplit < nr && (long)B * slabs * nsplit < kNumCU) nsplit <<= 1;   // few channels: spread the ranges too
+    nsplit = std::min(nsplit, nr);
+    const size_t lds = (size_t)G * (JP + kTileTargets) * sizeof(float);
+    const dim3 grid(slabs, nsplit, B);
+#define PVCNN_TILE(GV)                                                                                                   \
+  do {                                                                                                                   \
+    auto k = segsum_tile_kernel<GV>;                                                                                     \
+    if (int e = enable_big_lds(k, lds)) { set_error("%s: LDS attribute: %d", what, e); return e; }                       \
+    hipLaunchKernelGGL(k, grid, dim3(kTileThreads), lds, s, src, pl.start, pl.ent, pl.order, dst, C, L, J, E, src_bstride, \
+                       nsplit, JP);                                                                                      \
+  } while (0)
+    if (G == 4) PVCNN_TILE(4); else if (G == 2) PVCNN_TILE(2); else PVCNN_TILE(1);
+#undef PVCNN_TILE
     return check_launch(what);
   }
-  // sparse targets (most are empty, e.g. voxelize at R = 32): lane-per-target sums, source rows in LDS.
-  // G rows per workgroup: as many as keep the slab <= 64 KiB and the grid >= 2 workgroups per CU.
+  // source rows too long for LDS next to a tile: lane-per-target sums (correct for any distribution, slow when dense)
   const size_t row = (size_t)J * sizeof(float);
   const bool stage = row > 0 && row <= (size_t)kLdsBytesPerCU;
-  int G = 1;
-  if (stage && row <= 64 * 1024) {
-    G = (int)((64 * 1024) / row);
-    if (G > 8) G = 8;
-    while (G > 1 && (long)B * ceil_div(C, G) < 2L * kNumCU) G >>= 1;
-    if (G >= 8) G = 8; else if (G >= 4) G = 4; else if (G >= 2) G = 2; else G = 1;
-  }
   const bool vec = (L % 4 == 0) && aligned16(dst);
-  const int threads = (L >= 8192 || (size_t)G * row > 48 * 1024) ? 1024 : 256;
-  if (!stage) return launch_segsum_g<1, false>(src, ws, dst, B, C, L, J, E, vec, threads, s, what, src_bstride);
-  switch (G) {
-    case 8: return launch_segsum_g<8, true>(src, ws, dst, B, C, L, J, E, vec, threads, s, what, src_bstride);
-    case 4: return launch_segsum_g<4, true>(src, ws, dst, B, C, L, J, E, vec, threads, s, what, src_bstride);
-    case 2: return launch_segsum_g<2, true>(src, ws, dst, B, C, L, J, E, vec, threads, s, what, src_bstride);
-    default: return launch_segsum_g<1, true>(src, ws, dst, B, C, L, J, E, vec, threads, s, what, src_bstride);
+  const int threads = (L >= 8192 || row > 48 * 1024) ? 1024 : 256;
+  if (!stage) return launch_segsum_g<1, false>(src, pl, dst, B, C, L, J, E, vec, threads, s, what, src_bstride);
+  return launch_segsum_g<1, true>(src, pl, dst, B, C, L, J, E, vec, threads, s, what, src_bstride);
+}
+
+// one-shot: plan + apply in caller-owned workspace (CsrWorkspace::bytes)
+template <class EP>
+int launch_csr_scatter(const EP &ep, const float *src, float *dst, int B, int C, int L, int J, long E,
+                       int32_t *cnt_out, void *workspace, size_t workspace_bytes, hipStream_t s, const char *what,
+                       long src_bstride = 0) {
+  if (B == 0) return 0;
+  const size_t pb = CsrPlan::bytes(B, L, E);
+  if (!workspace || workspace_bytes < pb + csr_prep_scratch_bytes(B, E) || !aligned16(workspace)) {
+    set_error("%s: workspace missing, misaligned or too small (%zu bytes needed)", what, pb + csr_prep_scratch_bytes(B, E));
+    return PVCNN_ERR_INVALID_ARGUMENT;
   }
+  char *w = static_cast<char *>(workspace);
+  if (int e = launch_csr_prep(ep, B, L, E, cnt_out, w, pb, w + pb, workspace_bytes - pb, s, what)) return e;
+  return launch_csr_apply(src, w, pb, dst, B, C, L, J, E, s, what, src_bstride);
 }
 
 }  // namespace pvcnn

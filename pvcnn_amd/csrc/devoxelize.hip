@@ -103,3 +103,44 @@ extern "C" int pvcnn_trilinear_devox_bwd_strided(const float *grad_y, long grad_
                                                  void *workspace, size_t workspace_bytes, void *stream) {
   return devox_bwd_impl(grad_y, grad_y_batch_stride, inds, wgts, B, C, N, R, grad_x, workspace, workspace_bytes, stream);
 }
+
+// ---- plan / apply split: the corner entries (inds, wgts) depend on (coords, R) only -- one counting sort serves every
+// layer that devoxelizes at these coordinates ----
+extern "C" size_t pvcnn_trilinear_devox_bwd_plan_bytes(int B, int N, int R) {
+  if (B <= 0 || N < 0 || R <= 0) return 0;
+  const long S = (long)R * R * R;
+  if (S > 0x7fffffffL / 4 || !csr_supported((int)S, 8L * N)) return 0;
+  return CsrPlan::bytes(B, (int)S, 8L * N);
+}
+
+extern "C" size_t pvcnn_trilinear_devox_bwd_plan_scratch_bytes(int B, int N, int R) {
+  if (B <= 0 || N < 0 || R <= 0) return 0;
+  return csr_prep_scratch_bytes(B, 8L * N);
+}
+
+extern "C" int pvcnn_trilinear_devox_bwd_plan(const int32_t *inds, const float *wgts, int B, int N, int R, void *plan,
+                                              size_t plan_bytes, void *scratch, size_t scratch_bytes, void *stream) {
+  PVCNN_REQUIRE(B >= 0 && N >= 0 && R > 0, "negative size");
+  PVCNN_REQUIRE((long)R * R * R <= 0x7fffffffL / 4, "resolution too large");
+  if (B == 0) return 0;
+  const int S = R * R * R;
+  PVCNN_REQUIRE(csr_supported(S, 8L * N), "grid too large for a plan: use pvcnn_trilinear_devox_bwd");
+  PVCNN_REQUIRE(N == 0 || (inds && wgts), "null pointer");
+  PVCNN_REQUIRE(B <= 65535, "batch > 65535");
+  TapEntries<8> ep{inds, wgts, N, S};
+  return launch_csr_prep(ep, B, /*L=*/S, /*E=*/8L * N, nullptr, plan, plan_bytes, scratch, scratch_bytes,
+                         static_cast<hipStream_t>(stream), "trilinear_devox_bwd_plan");
+}
+
+extern "C" int pvcnn_trilinear_devox_bwd_apply(const float *grad_y, long grad_y_batch_stride, const void *plan, size_t plan_bytes,
+                                               int B, int C, int N, int R, float *grad_x, void *stream) {
+  PVCNN_REQUIRE(B >= 0 && C >= 0 && N >= 0 && R > 0, "negative size");
+  PVCNN_REQUIRE((long)R * R * R <= 0x7fffffffL / 4, "resolution too large");
+  if (B == 0 || C == 0) return 0;
+  PVCNN_REQUIRE(grad_x && (N == 0 || grad_y), "null pointer");
+  PVCNN_REQUIRE(B <= 65535, "batch > 65535");
+  PVCNN_REQUIRE(grad_y_batch_stride >= (long)C * N, "grad_y batch stride smaller than one cloud");
+  const int S = R * R * R;
+  return launch_csr_apply(grad_y, plan, plan_bytes, grad_x, B, C, /*L=*/S, /*J=*/N, /*E=*/8L * N, static_cast<hipStream_t>(stream),
+                          "trilinear_devox_bwd_apply", grad_y_batch_stride);
+}

@@ -242,3 +242,42 @@ extern "C" int pvcnn_avg_voxelize_bwd(const float *grad_y, const int32_t *ind, c
   return launch_gather(p, grad_y, grad_x, B, C, /*L=*/S, /*J=*/N, vec, static_cast<hipStream_t>(stream),
                        "avg_voxelize_bwd", XfNone{}, pshift);
 }
+
+// ---- plan / apply split: one counting sort per (voxel coordinates, R), shared by every layer that voxelizes with them ----
+extern "C" size_t pvcnn_avg_voxelize_plan_bytes(int B, int N, int R) {
+  if (B <= 0 || N < 0 || R <= 0) return 0;
+  const long S = (long)R * R * R;
+  if (S > 0x7fffffffL / 4 || !csr_supported((int)S, N)) return 0;      // 0: no plan for this size (use the one-shot call)
+  return CsrPlan::bytes(B, (int)S, N);
+}
+
+extern "C" size_t pvcnn_avg_voxelize_plan_scratch_bytes(int B, int N, int R) {
+  if (B <= 0 || N < 0 || R <= 0) return 0;
+  return csr_prep_scratch_bytes(B, N);
+}
+
+extern "C" int pvcnn_avg_voxelize_plan(const int32_t *coords, int B, int N, int R, int32_t *ind, int32_t *cnt, void *plan,
+                                       size_t plan_bytes, void *scratch, size_t scratch_bytes, void *stream) {
+  PVCNN_REQUIRE(B >= 0 && N >= 0 && R > 0, "negative size");
+  PVCNN_REQUIRE((long)R * R * R <= 0x7fffffffL / 4, "resolution too large");
+  const int S = R * R * R;
+  if (B == 0) return 0;
+  PVCNN_REQUIRE(csr_supported(S, N), "grid too large for a plan: use pvcnn_avg_voxelize_fwd");
+  PVCNN_REQUIRE(cnt && (ind || N == 0) && (coords || N == 0), "null pointer");
+  PVCNN_REQUIRE(B <= 65535, "batch > 65535");
+  VoxelEntries ep{coords, ind, N, R, S};
+  return launch_csr_prep(ep, B, /*L=*/S, /*E=*/N, cnt, plan, plan_bytes, scratch, scratch_bytes, static_cast<hipStream_t>(stream),
+                         "avg_voxelize_plan");
+}
+
+extern "C" int pvcnn_avg_voxelize_apply(const float *feat, const void *plan, size_t plan_bytes, int B, int C, int N, int R,
+                                        float *out, void *stream) {
+  PVCNN_REQUIRE(B >= 0 && C >= 0 && N >= 0 && R > 0, "negative size");
+  PVCNN_REQUIRE((long)R * R * R <= 0x7fffffffL / 4, "resolution too large");
+  if (B == 0 || C == 0) return 0;
+  PVCNN_REQUIRE(out && (feat || N == 0), "null pointer");
+  PVCNN_REQUIRE(B <= 65535, "batch > 65535");
+  const int S = R * R * R;
+  return launch_csr_apply(feat, plan, plan_bytes, out, B, C, /*L=*/S, /*J=*/N, /*E=*/N, static_cast<hipStream_t>(stream),
+                          "avg_voxelize_apply");
+}

@@ -320,6 +320,71 @@ class HipBackend:
         return grad_x
 
 
+    # ---- scatter plans (include/pvcnn_hip.h "scatter plans"): one counting sort per (coords, R), applied by every layer ----
+    has_scatter_plans = True
+
+    class VoxelPlan:
+        """avg_voxelize's plan for one (voxel coordinates, R): ind (B,N), cnt (B,R^3) and the opaque sort plan."""
+        __slots__ = ('ind', 'cnt', 'plan', 'r', 'n', 'b')
+
+    def avg_voxelize_plan(self, coords, resolution):
+        """coords (B,3,N) int32 -> VoxelPlan, or None when the grid is too large for a plan (one-shot path then)."""
+        _i32(coords, 'coords')
+        _shape(coords.dim() == 3 and coords.shape[1] == 3, 'avg_voxelize: coords (B,3,N) expected')
+        b, _, n = coords.shape
+        r = int(resolution)
+        nbytes = self.lib.pvcnn_avg_voxelize_plan_bytes(b, n, r)
+        if nbytes == 0:
+            return None
+        dev = coords.device
+        vp = self.VoxelPlan()
+        vp.r, vp.n, vp.b = r, n, b
+        vp.ind = torch.empty((b, n), dtype=torch.int32, device=dev)
+        vp.cnt = torch.empty((b, r * r * r), dtype=torch.int32, device=dev)
+        vp.plan = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+        scratch = self._scratch(self.lib.pvcnn_avg_voxelize_plan_scratch_bytes(b, n, r), dev)
+        with _Launch(coords) as s:
+            _lib.check(self.lib.pvcnn_avg_voxelize_plan(_p(coords), b, n, r, _p(vp.ind), _p(vp.cnt), _p(vp.plan), vp.plan.numel(),
+                                                        _p(scratch), scratch.numel(), s), 'avg_voxelize_plan')
+        return vp
+
+    def avg_voxelize_apply(self, features, vp):
+        """features (B,C,N) -> out (B,C,R^3) with the plan of avg_voxelize_plan (same B, N, R)."""
+        _f32(features, 'features')
+        _shape(features.dim() == 3 and features.shape[0] == vp.b and features.shape[2] == vp.n, 'avg_voxelize: features do not match the plan')
+        b, c, n = features.shape
+        out = torch.empty((b, c, vp.r ** 3), dtype=torch.float32, device=features.device)
+        with _Launch(features) as s:
+            _lib.check(self.lib.pvcnn_avg_voxelize_apply(_p(features), _p(vp.plan), vp.plan.numel(), b, c, n, vp.r, _p(out), s),
+                       'avg_voxelize_apply')
+        return out
+
+    def trilinear_devoxelize_backward_plan(self, indices, weights, r):
+        """(inds, wgts) (B,8,N) -> opaque plan tensor of the backward scatter, or None when R is too large for one."""
+        _i32(indices, 'indices'); _f32(weights, 'weights')
+        _shape(indices.dim() == 3 and indices.shape[1] == 8 and indices.shape == weights.shape, 'inds / wgts (B,8,N) expected')
+        b, _, n = indices.shape
+        r = int(r)
+        nbytes = self.lib.pvcnn_trilinear_devox_bwd_plan_bytes(b, n, r)
+        if nbytes == 0:
+            return None
+        plan = torch.empty((nbytes,), dtype=torch.uint8, device=indices.device)
+        scratch = self._scratch(self.lib.pvcnn_trilinear_devox_bwd_plan_scratch_bytes(b, n, r), indices.device)
+        with _Launch(indices) as s:
+            _lib.check(self.lib.pvcnn_trilinear_devox_bwd_plan(_p(indices), _p(weights), b, n, r, _p(plan), plan.numel(),
+                                                               _p(scratch), scratch.numel(), s), 'trilinear_devoxelize_backward_plan')
+        return plan
+
+    def trilinear_devoxelize_backward_apply(self, grad_y, plan, r):
+        gy_bstride = _f32_rows(grad_y, 'grad_y')
+        b, c, n = grad_y.shape
+        r = int(r)
+        grad_x = torch.empty((b, c, r * r * r), dtype=torch.float32, device=grad_y.device)
+        with _Launch(grad_y) as s:
+            _lib.check(self.lib.pvcnn_trilinear_devox_bwd_apply(_p(grad_y), gy_bstride, _p(plan), plan.numel(), b, c, n, r,
+                                                                _p(grad_x), s), 'trilinear_devoxelize_backward_apply')
+        return grad_x
+
     # ---- voxel_layers Conv3d (k=3, stride 1, pad 1): modules/pvconv.py:20-27 (cuDNN in the reference) ----
     has_conv3d = True
 

@@ -11,6 +11,7 @@ import torch.nn as nn
 from torch.autograd import Function
 
 from ._autograd import native, amp_fwd, amp_bwd
+from .devoxelization import CornerTaps
 
 
 def _rows(t, shape):
@@ -95,18 +96,22 @@ class BatchNormActDevoxelize(Function):
             mean, rstd = native().bn_stats(x3, running_mean, running_var, momentum, eps)
         else:
             mean, rstd = running_mean.contiguous(), torch.rsqrt(running_var + eps)
-        out, inds, wgts = native().trilinear_devoxelize_bnact_forward(int(resolution), is_training, coords.contiguous(), x3,
-                                                                      w, b, mean, rstd, slope)
-        if is_training:
-            ctx.save_for_backward(x3, w, b, mean, rstd, inds, wgts)
-            ctx.slope, ctx.use_batch_stats, ctx.shape, ctx.r = slope, use_batch_stats, shape, int(resolution)
+        r = int(resolution)
+        pts = coords.contiguous()
+        if not is_training:
+            return native().trilinear_devoxelize_bnact_forward(r, False, pts, x3, w, b, mean, rstd, slope)[0]
+        taps = CornerTaps.of(coords, r)
+        out = taps.forward(lambda emit: native().trilinear_devoxelize_bnact_forward(r, emit, pts, x3, w, b, mean, rstd, slope))
+        ctx.save_for_backward(x3, w, b, mean, rstd, taps.inds, taps.wgts)
+        ctx.taps = taps
+        ctx.slope, ctx.use_batch_stats, ctx.shape = slope, use_batch_stats, shape
         return out
 
     @staticmethod
     @amp_bwd
     def backward(ctx, grad_out):
-        x3, w, b, mean, rstd, inds, wgts = ctx.saved_tensors
-        g_act = native().trilinear_devoxelize_backward(_rows(grad_out, grad_out.shape), inds, wgts, ctx.r)
+        x3, w, b, mean, rstd, _, _ = ctx.saved_tensors
+        g_act = ctx.taps.backward(_rows(grad_out, grad_out.shape))
         gx, gw, gb = native().bnact_backward(x3, g_act.view(x3.shape), w, b, mean, rstd, ctx.slope, ctx.use_batch_stats)
         return (gx.view(ctx.shape), None, gw if w is not None else None, gb if b is not None else None,
                 None, None, None, None, None, None, None, None, None)

@@ -42,7 +42,11 @@ def test_binding_table_matches_header():
     lib = _lib.load()
     assert lib.pvcnn_version() == _lib.ABI_VERSION
     assert lib.pvcnn_last_error_string() is not None
-    assert lib.pvcnn_avg_voxelize_fwd_workspace_bytes(16, 64, 4096, 32) >= 16 * 32768 * 4 + 16 * 4096 * 12 + 16 * 4096 * 64 * 4
+    # one-shot workspace = the plan (prefix offsets, sorted entries, count-sorted lane order) + the sort's scratch
+    plan = lib.pvcnn_avg_voxelize_plan_bytes(16, 4096, 32)
+    assert plan >= 16 * 32768 * 4 + 16 * 4096 * 8 + 16 * 32768 * 2
+    assert lib.pvcnn_avg_voxelize_fwd_workspace_bytes(16, 64, 4096, 32) >= plan + lib.pvcnn_avg_voxelize_plan_scratch_bytes(16, 4096, 32) - 16
+    assert lib.pvcnn_avg_voxelize_plan_bytes(1, 4096, 128) == 0          # beyond 2^20 targets: no plan, one-shot atomic fallback
 
 
 def test_product_path_refuses_cpu_tensors():
