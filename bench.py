@@ -74,6 +74,20 @@ class KernelClock:
                                                          (a[0].shape[0], a[0].shape[1], a[0].shape[2], int(a[3]))),
     }
 
+    # the scatters run as plan (once per (coords, R), shared by the layers) + apply (per layer): both are timed; the
+    # algorithmic bytes of SURVEY 8(d) are charged to the apply, the plan is listed with the bytes it must touch
+    WATCH.update({
+        'avg_voxelize_apply': lambda a, out: ('avg_voxelize_fwd', bytes_vox_fwd(a[0].shape[0], a[0].shape[1], a[0].shape[2], a[1].r ** 3),
+                                              (a[0].shape[0], a[0].shape[1], a[0].shape[2], a[1].r)),
+        'avg_voxelize_plan': lambda a, out: ('avg_voxelize_plan (counting sort, shared by the layers at this R)',
+                                             4 * a[0].shape[0] * (4 * a[0].shape[2] + int(a[1]) ** 3), (a[0].shape[0], 0, a[0].shape[2], int(a[1]))),
+        'trilinear_devoxelize_backward_apply': lambda a, out: ('trilinear_devoxelize_bwd',
+                                                               bytes_devox_bwd(a[0].shape[0], a[0].shape[1], a[0].shape[2], int(a[2]) ** 3),
+                                                               (a[0].shape[0], a[0].shape[1], a[0].shape[2], int(a[2]))),
+        'trilinear_devoxelize_backward_plan': lambda a, out: ('trilinear_devoxelize_bwd_plan (counting sort, shared by the layers at this R)',
+                                                              4 * a[0].shape[0] * 16 * a[0].shape[2], (a[0].shape[0], 0, a[0].shape[2], int(a[2]))),
+    })
+
     # MFMA-bound family: Conv3d forward (x (B,Ci,R,R,R), weight (Co,Ci,3,3,3)); "bytes" slot carries FLOPs here
     WATCH_FLOPS = {
         'conv3d_forward': lambda a, out: ('conv3d_forward', 2.0 * a[0].shape[0] * a[0].shape[2] ** 3 * 27 * a[0].shape[1] * a[1].shape[0],

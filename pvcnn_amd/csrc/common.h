@@ -23,6 +23,12 @@ inline int grid_pad_shift(int R) { int s = 0; while ((1 << s) < R) ++s; return (
 __host__ __device__ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 #ifdef __HIPCC__
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding GLOBAL store of the
+// wave (s_waitcnt vmcnt(0): its release fence), which serialises "store a tile, barrier, load the next one" loops on the
+// full write latency; kernels whose global stores are never read back in the same launch use this instead, so the stores
+// drain while the next phase runs.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // Sum each of 16 per-lane values over the 32 lanes of a half-wave (lanes that differ in bits 0..4) with a
 // transposing butterfly: every step halves the number of values a lane carries (the lane keeps one half and
 // ships the other), so it takes 8+4+2+1+1 = 16 shuffles instead of 16*5.  Returns, in lane j, the total of

@@ -376,7 +376,7 @@ __global__ __launch_bounds__(THREADS) void gather_lds_kernel(P p, XF xf, const f
     const int c0 = (blockIdx.x * SEQ + sq) * G;
     if (c0 >= C) break;
     const int g = min(G, C - c0);
-    if (sq > 0) __syncthreads();                       // all reads of the previous slab are done
+    if (sq > 0) lds_barrier();                         // all LDS reads of the previous slab are done (its output stores keep draining)
     const int Lp = PAD ? L + (L >> pshift) : L;            // LDS row length
     slab_stage<THREADS, PAD>(lds, src + ((size_t)b * C + c0) * L, g, L, Lp, pshift, xf, c0);
     __syncthreads();

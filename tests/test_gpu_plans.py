@@ -1,0 +1,113 @@
+"""Scatter plans (include/pvcnn_hip.h "scatter plans"): plan once per (coords, R), apply per layer.
+
+Bit-exact bar as everywhere: apply(plan) == the one-shot entry point == the CPU oracle, for every channel count that
+shares the plan, on uniform, planar and degenerate clouds, odd sizes and non-power-of-two grids; and the autograd layer
+really shares one plan / one set of corner taps between the layers of a network.
+"""
+import pytest
+import torch
+
+from conftest import synth_cloud
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _inputs(gen, b, n, r, kind):
+    co = synth_cloud(gen, b, n, kind)
+    co = co / co.amax(dim=(1, 2), keepdim=True).clamp(min=1e-6)
+    norm = torch.clamp(co * r, 0, r - 1).contiguous()
+    return norm, torch.round(norm).to(torch.int32).contiguous()
+
+
+@pytest.mark.parametrize('b,n,r', [(16, 4096, 16), (4, 4096, 32), (3, 1000, 12), (2, 37, 5), (8, 8192, 32), (2, 64, 8), (1, 1, 2), (2, 12000, 16)])
+@pytest.mark.parametrize('kind', ['cube', 'surface'])
+def test_one_plan_serves_every_channel_count(hip, oracle, gen, b, n, r, kind):
+    norm, vox = _inputs(gen, b, n, r, kind)
+    vplan = hip.avg_voxelize_plan(vox.to(DEV), r)
+    _, inds, wgts = oracle.trilinear_devoxelize_forward(r, True, norm, torch.zeros(b, 1, r ** 3))
+    dplan = hip.trilinear_devoxelize_backward_plan(inds.to(DEV), wgts.to(DEV), r)
+    assert vplan is not None and dplan is not None
+    for c in (1, 3, 9, 64, 130):
+        if b * c * max(n, r ** 3) > 40e6:
+            continue
+        feat = torch.randn(b, c, n, generator=gen)
+        want, o_ind, o_cnt = oracle.avg_voxelize_forward(feat, vox, r)
+        assert torch.equal(hip.avg_voxelize_apply(feat.to(DEV), vplan).cpu(), want), (c, 'voxelize apply')
+        assert torch.equal(vplan.ind.cpu(), o_ind) and torch.equal(vplan.cnt.cpu(), o_cnt)
+        assert torch.equal(hip.trilinear_devoxelize_backward_apply(feat.to(DEV), dplan, r).cpu(),
+                           oracle.trilinear_devoxelize_backward(feat, inds, wgts, r)), (c, 'devoxelize backward apply')
+
+
+def test_plans_on_a_degenerate_cloud_and_strided_gradients(hip, oracle, gen):
+    b, n, r, c = 2, 4096, 16, 8
+    vox = torch.full((b, 3, n), 7, dtype=torch.int32)               # every point in one voxel
+    feat = torch.randn(b, c, n, generator=gen)
+    vplan = hip.avg_voxelize_plan(vox.to(DEV), r)
+    assert torch.equal(hip.avg_voxelize_apply(feat.to(DEV), vplan).cpu(), oracle.avg_voxelize_forward(feat, vox, r)[0])
+    norm = torch.full((b, 3, n), 7.25)
+    _, inds, wgts = oracle.trilinear_devoxelize_forward(r, True, norm, torch.zeros(b, 1, r ** 3))
+    dplan = hip.trilinear_devoxelize_backward_plan(inds.to(DEV), wgts.to(DEV), r)
+    wide = torch.randn(b, 3 * c, n, generator=gen).to(DEV)          # gradient arriving as a channel slice (torch.cat's backward)
+    view = wide[:, c:2 * c, :]
+    assert torch.equal(hip.trilinear_devoxelize_backward_apply(view, dplan, r).cpu(),
+                       oracle.trilinear_devoxelize_backward(view.contiguous().cpu(), inds, wgts, r))
+
+
+def test_layers_share_one_plan_and_one_set_of_taps(hip, oracle):
+    """Three PVConvs on the same coords at R = 16 (PVCNN's middle stages): one voxel-coordinate pre-pass, one voxelize plan,
+    one inds / wgts emission, one backward plan -- observed by counting the native calls -- and the same result as
+    running each layer with its own (memo disabled)."""
+    from pvcnn_amd.modules import PVConv
+    from pvcnn_amd.modules.functional import _cache
+    from pvcnn_amd.modules.functional import backend as seam
+    from pvcnn_amd import workload
+    torch.manual_seed(5)
+    layers = [PVConv(9 if i == 0 else 16, 16, 3, 16).to(DEV).train() for i in range(3)]
+    x, _ = workload.make_s3dis_batch(4, 2048, device=DEV)
+
+    calls = {}
+    be = seam._backend
+    originals = {}
+    for name in ('voxel_coords_tail', 'avg_voxelize_plan', 'avg_voxelize_apply', 'trilinear_devoxelize_backward_plan',
+                 'trilinear_devoxelize_backward_apply', 'trilinear_devoxelize_bnact_forward'):
+        orig = getattr(be, name)
+        originals[name] = orig
+
+        def counted(*a, _orig=orig, _name=name, **k):
+            key = _name + ('/emit' if _name == 'trilinear_devoxelize_bnact_forward' and a[1] else '')
+            calls[key] = calls.get(key, 0) + 1
+            return _orig(*a, **k)
+        setattr(be, name, counted)
+
+    def run():
+        for layer in layers:
+            layer.zero_grad(set_to_none=True)
+        xin = x.clone().requires_grad_()
+        coords = xin[:, :3, :]
+        f = xin
+        for layer in layers:
+            f, _ = layer((f, coords))
+        f.square().mean().backward()
+        return f.detach().clone(), xin.grad.clone(), [p.grad.clone() for layer in layers for p in layer.parameters()]
+
+    try:
+        calls.clear()
+        shared = run()
+        counts = dict(calls)
+        _cache.enabled = False
+        for layer in layers:                      # BatchNorm running statistics: same starting point for the second run
+            for m in layer.modules():
+                if hasattr(m, 'reset_running_stats'):
+                    m.reset_running_stats()
+        separate = run()
+    finally:
+        _cache.enabled = True
+        for name in originals:
+            delattr(be, name)
+    assert counts['voxel_coords_tail'] == 1 and counts['avg_voxelize_plan'] == 1 and counts['avg_voxelize_apply'] == 3
+    assert counts['trilinear_devoxelize_bnact_forward/emit'] == 1 and counts['trilinear_devoxelize_bnact_forward'] == 2
+    assert counts['trilinear_devoxelize_backward_plan'] == 1 and counts['trilinear_devoxelize_backward_apply'] == 3
+    assert torch.equal(shared[0], separate[0]) and torch.equal(shared[1], separate[1])
+    for a, b_ in zip(shared[2], separate[2]):
+        assert torch.equal(a, b_)

@@ -50,7 +50,7 @@ def timeit(fn, iters, warm=3, reps=10):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--iters', type=int, default=20)
-    ap.add_argument('--ops', default='vox_fwd,vox_bwd,devox_fwd,devox_bwd')
+    ap.add_argument('--ops', default='vox_fwd,vox_apply,vox_plan,vox_bwd,devox_fwd,devox_bwd,devox_bwd_apply,devox_bwd_plan')
     ap.add_argument('--shapes', default='')
     ap.add_argument('--kind', default='cube', choices=['cube', 'surface'])
     args = ap.parse_args()
@@ -72,7 +72,14 @@ def main():
         out, ind, cnt = hip.avg_voxelize_forward(feat, vox, r)
         outs, inds, wgts = hip.trilinear_devoxelize_forward(r, True, norm, grid)
         gy_pts = torch.randn(b, c, n, generator=g).to(dev)
+        vplan = hip.avg_voxelize_plan(vox, r)
+        dplan = hip.trilinear_devoxelize_backward_plan(inds, wgts, r)
         runs = {
+            # plan / apply split (what a network runs: one plan per (coords, R), one apply per layer)
+            'vox_plan': (lambda: hip.avg_voxelize_plan(vox, r), 4 * b * (3 * n + n + s)),
+            'vox_apply': (lambda: hip.avg_voxelize_apply(feat, vplan), B.bytes_vox_fwd(b, c, n, s)),
+            'devox_bwd_plan': (lambda: hip.trilinear_devoxelize_backward_plan(inds, wgts, r), 4 * b * 16 * n),
+            'devox_bwd_apply': (lambda: hip.trilinear_devoxelize_backward_apply(gy_pts, dplan, r), B.bytes_devox_bwd(b, c, n, s)),
             'vox_fwd': (lambda: hip.avg_voxelize_forward(feat, vox, r), B.bytes_vox_fwd(b, c, n, s)),
             'vox_bwd': (lambda: hip.avg_voxelize_backward(grid, ind, cnt), B.bytes_vox_bwd(b, c, n, s)),
             'devox_fwd': (lambda: hip.trilinear_devoxelize_forward(r, True, norm, grid), B.bytes_devox_fwd(b, c, n, s, True)),
