@@ -47,7 +47,7 @@ extern "C" {
 #define PVCNN_API
 #endif
 
-#define PVCNN_ABI_VERSION 1
+#define PVCNN_ABI_VERSION 2
 #define PVCNN_OK 0
 #define PVCNN_ERR_INVALID_ARGUMENT (-1)
 
@@ -259,7 +259,9 @@ PVCNN_API int pvcnn_conv3d_fwd_stats(const float *x, const float *wt, const floa
 PVCNN_API size_t pvcnn_pwconv_fwd_stats_parts(int B, int N);
 PVCNN_API int pvcnn_pwconv_fwd_stats(const float *x, const float *wt, int wt_rows, const float *bias, int B, int K, int M,
                            int N, float *y, float *stats_part, void *stream);
-PVCNN_API int pvcnn_bn_finalize(const float *part, int C, long nparts, double count, float eps, float momentum,
+/* The epilogue partials are sums of (y - bias) and (y - bias)^2: pass the convolution's bias as `shift` (NULL = no bias) and
+ * bn_finalize adds it back to the mean -- a variance from E[a^2] - E[a]^2 stays accurate when the bias dwarfs the spread. */
+PVCNN_API int pvcnn_bn_finalize(const float *part, int C, long nparts, double count, float eps, float momentum, const float *shift,
                       float *running_mean, float *running_var, float *mean, float *rstd, void *stream);
 PVCNN_API int pvcnn_bn_stats(const float *x, float *running_mean, float *running_var, int B, int C, int S,
                    float eps, float momentum, float *mean, float *rstd, void *workspace,

@@ -36,30 +36,37 @@ __device__ __forceinline__ void block_sum2(float &a, float &b, float *sm) {
   }
 }
 
-// grid = (slices, B, C): partial (sum, sum of squares) of one slice of row (b, c)
+// Variance as E[(x-K)^2] - E[x-K]^2 with a per-channel shift K close to the mean: the plain E[x^2] - E[x]^2 loses
+// all digits in fp32 partial sums once |mean| / std reaches ~1e3 (sum of squares rounded at 6e-8 * n * mean^2).
+// K = the channel's first element here; = the convolution's bias for the epilogue statistics (conv3d.hip, pointwise.hip).
+// grid = (slices, B, C): partial (sum, sum of squares) of (x - K) over one slice of row (b, c)
 __global__ __launch_bounds__(kBnThreads) void bn_stats_kernel(const float *__restrict__ x, int C, int S, int slices,
-                                                             float2 *__restrict__ part) {
+                                                             float2 *__restrict__ part, float *__restrict__ shift) {
   __shared__ float sm[16];
   const int sl = blockIdx.x, b = blockIdx.y, c = blockIdx.z;
   const float *row = x + ((size_t)b * C + c) * S;
+  const float K = x[(size_t)c * S];                      // first element of the channel (cloud 0): same K in every workgroup
+  if (sl == 0 && b == 0 && threadIdx.x == 0) shift[c] = K;
   const int lo = sl * kBnSlice, hi = min(S, lo + kBnSlice);
   float s = 0.f, q = 0.f;
   if ((S & 3) == 0 && aligned16(row)) {
     for (int i = lo + threadIdx.x * 4; i < hi; i += kBnThreads * 4) {
-      const float4 v = *reinterpret_cast<const float4 *>(row + i);
+      float4 v = *reinterpret_cast<const float4 *>(row + i);
+      v.x -= K; v.y -= K; v.z -= K; v.w -= K;
       s += (v.x + v.y) + (v.z + v.w);
       q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
     }
   } else {
-    for (int i = lo + threadIdx.x; i < hi; i += kBnThreads) { const float v = row[i]; s += v; q += v * v; }
+    for (int i = lo + threadIdx.x; i < hi; i += kBnThreads) { const float v = row[i] - K; s += v; q += v * v; }
   }
   block_sum2(s, q, sm);
   if (threadIdx.x == 0) part[((size_t)c * gridDim.y + b) * slices + sl] = make_float2(s, q);
 }
 
-// grid = C: combine the partials in fp64 -> mean, rstd; update the running statistics (unbiased var)
+// grid = C: combine the partials (of x - shift[c]; shift may be null = 0) in fp64 -> mean, rstd; update the running
+// statistics (unbiased var)
 __global__ __launch_bounds__(64) void bn_finalize_kernel(const float2 *__restrict__ part, int nparts, double count, float eps,
-                                                        float momentum, float *__restrict__ mean,
+                                                        float momentum, const float *__restrict__ shift, float *__restrict__ mean,
                                                         float *__restrict__ rstd, float *__restrict__ running_mean,
                                                         float *__restrict__ running_var) {
   const int c = blockIdx.x;
@@ -68,8 +75,9 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(const float2 *__restric
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) { s += __shfl_xor(s, d); q += __shfl_xor(q, d); }
   if (threadIdx.x == 0) {
-    const double m = s / count;
-    double var = q / count - m * m;
+    const double ms = s / count;                          // mean of (x - shift)
+    const double m = ms + (shift ? (double)shift[c] : 0.0);
+    double var = q / count - ms * ms;
     var = var < 0.0 ? 0.0 : var;
     mean[c] = (float)m;
     rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -218,7 +226,7 @@ using namespace pvcnn;
 
 extern "C" size_t pvcnn_bnact_workspace_bytes(int B, int C, int S) {
   if (B <= 0 || C <= 0 || S <= 0) return 16;
-  return (size_t)C * B * ceil_div(S, kBnSlice) * sizeof(float2) + 16;
+  return (size_t)C * B * ceil_div(S, kBnSlice) * sizeof(float2) + (size_t)C * sizeof(float) + 16;   // partials + per-channel shift
 }
 
 extern "C" int pvcnn_bnact_fwd(const float *x, const float *gamma, const float *beta, float *running_mean,
@@ -232,9 +240,10 @@ extern "C" int pvcnn_bnact_fwd(const float *x, const float *gamma, const float *
   if (training) {
     PVCNN_REQUIRE(workspace && workspace_bytes >= pvcnn_bnact_workspace_bytes(B, C, S), "workspace too small");
     float2 *part = static_cast<float2 *>(workspace);
-    hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(kBnThreads), 0, s, x, C, S, slices, part);
+    float *shift = reinterpret_cast<float *>(part + (size_t)C * B * slices);
+    hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(kBnThreads), 0, s, x, C, S, slices, part, shift);
     if (int e = check_launch("bn_stats")) return e;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, s, part, B * slices, (double)B * S, eps, momentum, mean, rstd,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, s, part, B * slices, (double)B * S, eps, momentum, shift, mean, rstd,
                        running_mean, running_var);
     if (int e = check_launch("bn_finalize")) return e;
   }
@@ -245,11 +254,11 @@ extern "C" int pvcnn_bnact_fwd(const float *x, const float *gamma, const float *
 
 // mean / rstd (+ running statistics) from per-workgroup partials produced by a convolution epilogue
 // (pvcnn_conv3d_fwd_stats, pvcnn_pwconv_fwd_stats): part is (C, nparts) float2 {sum, sum of squares}.
-extern "C" int pvcnn_bn_finalize(const float *part, int C, long nparts, double count, float eps, float momentum,
+extern "C" int pvcnn_bn_finalize(const float *part, int C, long nparts, double count, float eps, float momentum, const float *shift,
                                  float *running_mean, float *running_var, float *mean, float *rstd, void *stream) {
   PVCNN_REQUIRE(C > 0 && nparts > 0 && nparts <= 0x7fffffffL && count > 0 && part && mean && rstd, "bad argument");
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, static_cast<hipStream_t>(stream),
-                     reinterpret_cast<const float2 *>(part), (int)nparts, count, eps, momentum, mean, rstd, running_mean,
+                     reinterpret_cast<const float2 *>(part), (int)nparts, count, eps, momentum, shift, mean, rstd, running_mean,
                      running_var);
   return check_launch("bn_finalize");
 }
@@ -262,9 +271,10 @@ extern "C" int pvcnn_bn_stats(const float *x, float *running_mean, float *runnin
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int slices = ceil_div(S, kBnSlice);
   float2 *part = static_cast<float2 *>(workspace);
-  hipLaunchKernelGGL(bn_stats_kernel, dim3(slices, B, C), dim3(kBnThreads), 0, s, x, C, S, slices, part);
+  float *shift = reinterpret_cast<float *>(part + (size_t)C * B * slices);
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(slices, B, C), dim3(kBnThreads), 0, s, x, C, S, slices, part, shift);
   if (int e = check_launch("bn_stats")) return e;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, s, part, B * slices, (double)B * S, eps, momentum, mean, rstd,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, s, part, B * slices, (double)B * S, eps, momentum, shift, mean, rstd,
                      running_mean, running_var);
   return check_launch("bn_finalize");
 }

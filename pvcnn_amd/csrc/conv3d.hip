@@ -251,13 +251,13 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(const float *__restri
         const int co = co0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
         float v;
         asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(acc[mb][nb][r]));
-        v += bv[r];
-        if (vok[nb] && co < Co) yb[(size_t)co * R * RR + voff[nb]] = v;
-        if (want_stats) {
-          const float m = vok[nb] ? v : 0.0f;
+        if (want_stats) {                                   // statistics of (y - bias): the shift keeps E[a^2] - E[a]^2 well
+          const float m = vok[nb] ? v : 0.0f;               // conditioned when the bias dwarfs the spread (bn_finalize adds it back)
           ss[r] += m;
           qq[r] += m * m;
         }
+        v += bv[r];
+        if (vok[nb] && co < Co) yb[(size_t)co * R * RR + voff[nb]] = v;
       }
     if (want_stats) {
       // lane j ends up with the totals of register (j >> 1) & 15 over its 32 voxels / points

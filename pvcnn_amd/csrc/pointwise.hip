@@ -193,13 +193,13 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const float *__restrict__ 
         // VGPRs in one block at the loop exit (+128 VGPRs for MB = 4: one wave per SIMD instead of two)
         float v;
         asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(acc[mb][nb][r]));
-        v += bv[r];
-        if (FAST || (n < N && m < M)) yb[(size_t)m * N + n] = v;
-        if (want_stats) {
+        if (want_stats) {                                   // statistics of (y - bias), see bn_finalize_kernel
           const float mv = (FAST || n < N) ? v : 0.0f;
           ss[r] += mv;
           qq[r] += mv * mv;
         }
+        v += bv[r];
+        if (FAST || (n < N && m < M)) yb[(size_t)m * N + n] = v;
       }
     }
     if (want_stats) {

@@ -53,6 +53,12 @@ class GradBucketReducer:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         # always_reduce: issue the collectives even in a 1-rank group (exercises the RCCL path on one GPU)
         self.collective = dist.is_initialized() and (self.world > 1 or always_reduce)
+        self._accumulate = False
+        # hook-launched (backward-overlapped) all-reduces are issued in the order the buckets fill; that order is the same
+        # on every rank as long as every rank uses the same parameters in backward (true for the static graphs of this
+        # path).  Set launch_from_hooks = False for models with data-dependent unused parameters: finish() then issues
+        # every collective in fixed bucket order (no overlap, no ordering hazard).
+        self.launch_from_hooks = True
         self.params = [p for p in model.parameters() if p.requires_grad]
         if self.collective and broadcast:
             with torch.no_grad():
@@ -84,14 +90,37 @@ class GradBucketReducer:
 
     def _on_grad(self, p):
         b = self._owner[p]
+        if self.collective and (b.work is not None or b.pending <= 0):
+            # a second backward() before finish(): its local gradients would land on top of an already reduced (or
+            # in-flight) bucket and the result would silently be wrong on every rank
+            raise RuntimeError('GradBucketReducer: a gradient arrived for a bucket that was already all-reduced in this step; '
+                               'call finish() after every backward(), or accumulate under no_sync()')
+        if self._accumulate:
+            return
         b.pending -= 1
-        if b.pending == 0 and self.collective:
+        if b.pending == 0 and self.collective and self.launch_from_hooks:
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def no_sync(self):
+        """Context manager for gradient accumulation: backward() passes inside it only accumulate into the buckets; the
+        all-reduces are issued by the first backward() outside it (or by finish())."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            prev, self._accumulate = self._accumulate, True
+            try:
+                yield
+            finally:
+                self._accumulate = prev
+        return ctx()
 
     def finish(self):
         """Wait for the in-flight all-reduces, launch those of buckets that never filled (unused
         parameters) and turn sums into means.  Call after backward, before optimizer.step()."""
         if self.collective:
+            # buckets that never filled (parameters unused in this backward): always in fixed bucket order, after the
+            # hook-launched ones -- identical on every rank provided the SET of filled buckets is (see launch_from_hooks)
             for b in self.buckets:
                 if b.work is None:
                     b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)

@@ -506,7 +506,7 @@ class HipBackend:
             mean = torch.empty((c,), dtype=torch.float32, device=dev)
             rstd = torch.empty((c,), dtype=torch.float32, device=dev)
         else:
-            mean = running_mean.contiguous()
+            mean = running_mean.clone()          # saved for backward: must not alias the live buffer
             rstd = torch.rsqrt(running_var + eps)
         ws = self._scratch(self.lib.pvcnn_bnact_workspace_bytes(b, c, s3), dev)
         nul = ctypes.c_void_p(None)
@@ -520,8 +520,9 @@ class HipBackend:
 
     has_devox_bnact = True
 
-    def bn_finalize(self, part, count, running_mean, running_var, momentum, eps):
-        """(C, nparts, 2) partial sums from a convolution epilogue -> (mean, rstd); running stats updated in place."""
+    def bn_finalize(self, part, count, running_mean, running_var, momentum, eps, shift=None):
+        """(C, nparts, 2) partial sums of (y - shift) from a convolution epilogue (shift = that convolution's bias, or None)
+        -> (mean, rstd) of y; running stats updated in place."""
         c, nparts = part.shape[0], part.shape[1]
         dev = part.device
         mean = torch.empty((c,), dtype=torch.float32, device=dev)
@@ -529,6 +530,7 @@ class HipBackend:
         nul = ctypes.c_void_p(None)
         with _Launch(part) as s:
             _lib.check(self.lib.pvcnn_bn_finalize(_p(part), c, nparts, float(count), float(eps), float(momentum),
+                                                  _p(shift) if shift is not None else nul,
                                                   _p(running_mean) if running_mean is not None else nul,
                                                   _p(running_var) if running_var is not None else nul, _p(mean), _p(rstd), s),
                        'bn_finalize')

@@ -33,14 +33,14 @@ __all__ = ['batch_norm_act', 'batch_norm_act_devoxelize', 'fusable_tail', 'run_l
 class BatchNormAct(Function):
     @staticmethod
     @amp_fwd
-    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, slope, stats_part=None):
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, slope, stats_part=None, stats_shift=None):
         shape = x.shape
         x3 = x.contiguous().view(shape[0], shape[1], -1)
         w = weight.contiguous() if weight is not None else None
         b = bias.contiguous() if bias is not None else None
         stats = None
         if training and stats_part is not None:   # partial sums from the producing convolution's epilogue
-            stats = native().bn_finalize(stats_part, x3.shape[0] * x3.shape[2], running_mean, running_var, momentum, eps)
+            stats = native().bn_finalize(stats_part, x3.shape[0] * x3.shape[2], running_mean, running_var, momentum, eps, stats_shift)
         y, mean, rstd = native().bnact_forward(x3, w, b, running_mean, running_var, training, momentum, eps, slope, stats=stats)
         ctx.save_for_backward(x3, w, b, mean, rstd)
         ctx.slope, ctx.training, ctx.shape = slope, training, shape
@@ -53,7 +53,7 @@ class BatchNormAct(Function):
         g3 = _rows(grad_y, ctx.shape)
         gx, gw, gb = native().bnact_backward(x3, g3, w, b, mean, rstd, ctx.slope, ctx.training)
         return (gx.view(ctx.shape), gw if w is not None else None, gb if b is not None else None,
-                None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None)
 
 
 def _bn_mode(bn):
@@ -70,11 +70,20 @@ def _bn_mode(bn):
     return use_batch_stats, momentum, rm, rv
 
 
+def _split(stats):
+    """stats: None | (partial sums, shift) as produced by run_layers -> (part, shift)."""
+    if stats is None:
+        return None, None
+    part, shift = stats
+    return part, (shift.detach().contiguous() if shift is not None else None)
+
+
 def batch_norm_act(x, bn, slope, stats_part=None):
     """Apply BatchNorm module `bn` followed by LeakyReLU(slope) (slope = 0: ReLU) to x (B, C, ...).
-    stats_part: per-workgroup partial sums of x written by the convolution that produced it."""
+    stats_part: (per-workgroup partial sums of x - shift written by the convolution that produced x, shift = its bias)."""
     use_batch_stats, momentum, rm, rv = _bn_mode(bn)
-    return BatchNormAct.apply(x, bn.weight, bn.bias, rm, rv, use_batch_stats, momentum, bn.eps, slope, stats_part)
+    part, shift = _split(stats_part)
+    return BatchNormAct.apply(x, bn.weight, bn.bias, rm, rv, use_batch_stats, momentum, bn.eps, slope, part, shift)
 
 
 class BatchNormActDevoxelize(Function):
@@ -85,13 +94,13 @@ class BatchNormActDevoxelize(Function):
     @staticmethod
     @amp_fwd
     def forward(ctx, grid, coords, weight, bias, running_mean, running_var, use_batch_stats, momentum, eps, slope,
-                resolution, is_training, stats_part=None):
+                resolution, is_training, stats_part=None, stats_shift=None):
         shape = grid.shape
         x3 = grid.contiguous().view(shape[0], shape[1], -1)
         w = weight.contiguous() if weight is not None else None
         b = bias.contiguous() if bias is not None else None
         if use_batch_stats and stats_part is not None:
-            mean, rstd = native().bn_finalize(stats_part, x3.shape[0] * x3.shape[2], running_mean, running_var, momentum, eps)
+            mean, rstd = native().bn_finalize(stats_part, x3.shape[0] * x3.shape[2], running_mean, running_var, momentum, eps, stats_shift)
         elif use_batch_stats:
             mean, rstd = native().bn_stats(x3, running_mean, running_var, momentum, eps)
         else:
@@ -114,13 +123,14 @@ class BatchNormActDevoxelize(Function):
         g_act = ctx.taps.backward(_rows(grad_out, grad_out.shape))
         gx, gw, gb = native().bnact_backward(x3, g_act.view(x3.shape), w, b, mean, rstd, ctx.slope, ctx.use_batch_stats)
         return (gx.view(ctx.shape), None, gw if w is not None else None, gb if b is not None else None,
-                None, None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None, None)
 
 
 def batch_norm_act_devoxelize(grid, coords, bn, slope, resolution, is_training, stats_part=None):
     use_batch_stats, momentum, rm, rv = _bn_mode(bn)
+    part, shift = _split(stats_part)
     return BatchNormActDevoxelize.apply(grid, coords, bn.weight, bn.bias, rm, rv, use_batch_stats, momentum, bn.eps, slope,
-                                        resolution, is_training, stats_part)
+                                        resolution, is_training, part, shift)
 
 
 def fusable_tail(layers, x):
@@ -142,6 +152,10 @@ def _slope(act):
     return None
 
 
+def _has_hooks(m):
+    return bool(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or getattr(m, '_backward_pre_hooks', None))
+
+
 def _is_pointwise(m):
     """kernel-size-1, stride-1, unpadded, ungrouped Conv1d / Conv2d: the SharedMLP convolutions."""
     return (isinstance(m, (nn.Conv1d, nn.Conv2d)) and all(k == 1 for k in m.kernel_size) and all(v == 1 for v in m.stride)
@@ -161,8 +175,11 @@ def run_layers(layers, x, stop=None, tail_stats=False):
     to the BatchNorm at position `stop` if the last module run was such a convolution (else None)."""
     all_mods = list(layers)
     mods = all_mods[:stop]
-    fuse = x.is_cuda and getattr(native(), 'has_bnact', False)
-    pw = x.is_cuda and getattr(native(), 'has_pwconv', False)
+    # forward / backward hooks on a sub-module (FLOP counters, feature extractors, pruning) only fire through its
+    # __call__: a hooked Sequential runs module by module like nn.Sequential does
+    hooked = any(_has_hooks(m) for m in all_mods)
+    fuse = x.is_cuda and getattr(native(), 'has_bnact', False) and not hooked
+    pw = x.is_cuda and getattr(native(), 'has_pwconv', False) and not hooked
     part = carried = None
     i = 0
     while i < len(mods):
@@ -175,13 +192,15 @@ def run_layers(layers, x, stop=None, tail_stats=False):
             from .pwconv import pointwise_conv
             if want:
                 x, part = pointwise_conv(x, m.weight, m.bias, True)
+                part = (part, m.bias)
             else:
                 x = pointwise_conv(x, m.weight, m.bias)
             i += 1
-        elif want and hasattr(m, 'forward_with_stats') and x.numel() > 0:
+        elif want and hasattr(m, 'forward_with_stats') and x.numel() > 0 and not hooked:
             res = m.forward_with_stats(x)
             if isinstance(res, tuple):
                 x, part = res
+                part = (part, m.bias)
             else:
                 x = res
             i += 1

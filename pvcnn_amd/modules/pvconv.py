@@ -30,9 +30,9 @@ class _VoxelConv3d(nn.Conv3d):
         fast = (x.is_cuda and getattr(native(), 'has_conv3d', False) and self.kernel_size == (3, 3, 3)
                 and self.stride == (1, 1, 1) and self.padding == (1, 1, 1) and self.dilation == (1, 1, 1)
                 and self.groups == 1 and self.padding_mode == 'zeros' and x.dim() == 5
-                and x.shape[2] == x.shape[3] == x.shape[4])
+                and x.shape[2] == x.shape[3] == x.shape[4] and x.dtype == torch.float32 and self.weight.dtype == torch.float32)
         if not fast:
-            return super().forward(x)
+            return super().forward(x)            # other dtypes / shapes: the vendor library
         return voxel_conv3d(x, self.weight, self.bias)
 
     def forward_with_stats(self, x):

@@ -104,3 +104,38 @@ def test_shard_batch_requires_equal_shards():
     assert shard_batch(16, 4, 1) == slice(4, 8)
     with pytest.raises(ValueError):
         shard_batch(10, 4, 0)
+
+
+def test_reducer_refuses_a_second_backward_and_supports_no_sync():
+    """A second backward() before finish() used to add local gradients on top of an already reduced bucket (silently
+    wrong); now it raises, and accumulation goes through no_sync()."""
+    import torch.distributed as dist
+    from pvcnn_amd.dp import GradBucketReducer
+    import tempfile
+    store = os.path.join(tempfile.mkdtemp(), 'store')
+    if True:
+        dist.init_process_group('gloo', init_method=f'file://{store}', rank=0, world_size=1)
+        try:
+            torch.manual_seed(0)
+            net = torch.nn.Sequential(torch.nn.Linear(4, 8), torch.nn.ReLU(), torch.nn.Linear(8, 2))
+            red = GradBucketReducer(net, always_reduce=True)
+            x = torch.randn(6, 4)
+            red.zero_grad()
+            net(x).sum().backward()
+            with pytest.raises(RuntimeError, match='already all-reduced'):
+                net(x).sum().backward()
+            red.finish()
+            # accumulation: two micro-batches == one double batch
+            red.zero_grad()
+            with red.no_sync():
+                net(x[:3]).sum().backward()
+            net(x[3:]).sum().backward()
+            red.finish()
+            acc = [p.grad.clone() for p in net.parameters()]
+            red.zero_grad()
+            net(x).sum().backward()
+            red.finish()
+            for a, p in zip(acc, net.parameters()):
+                assert torch.allclose(a, p.grad, atol=1e-6)
+        finally:
+            dist.destroy_process_group()

@@ -111,3 +111,39 @@ def test_backward_kernels_take_batch_strided_gradients(hip):
     _, inds2, wgts2 = hip.trilinear_devoxelize_forward(4, True, coords2, torch.randn(b, c, 64, device=dev))
     assert torch.equal(hip.trilinear_devoxelize_backward(g_view, inds2, wgts2, 4),
                        hip.trilinear_devoxelize_backward(g_copy, inds2, wgts2, 4))
+
+
+@pytest.mark.parametrize('path', ['stats-pass', 'conv3d-epilogue', 'pwconv-epilogue'])
+def test_batch_statistics_when_the_mean_dwarfs_the_spread(hip, path):
+    """mean = 1e3, std = 1e-2: a variance from fp32 sums as E[x^2] - E[x]^2 has no correct digit left (it clamps to 0 and
+    rstd becomes 1/sqrt(eps)); torch's BatchNorm gets it right.  The kernels accumulate SHIFTED sums -- around the
+    channel's first element in the statistics pass, around the convolution's bias in the epilogue statistics -- and must
+    agree with an fp64 evaluation: output to 1e-3 of its scale (the input itself carries only ~4 digits of the spread),
+    running_var to 1e-2 relative."""
+    from pvcnn_amd.modules.functional.bnact import run_layers
+    torch.manual_seed(3)
+    if path == 'stats-pass':
+        net = nn.Sequential(nn.BatchNorm1d(16), nn.ReLU(True)).to(DEV).train()
+        x = (torch.randn(4, 16, 2048, device=DEV, dtype=torch.float64) * 1e-2 + 1e3).float()
+    elif path == 'pwconv-epilogue':
+        net = nn.Sequential(nn.Conv1d(8, 16, 1), nn.BatchNorm1d(16), nn.ReLU(True)).to(DEV).train()
+        with torch.no_grad():
+            net[0].weight.mul_(1e-2); net[0].bias.fill_(1e3)
+        x = torch.randn(4, 8, 2048, device=DEV)
+    else:
+        from pvcnn_amd.modules.pvconv import _VoxelConv3d
+        net = nn.Sequential(_VoxelConv3d(4, 64, 3, stride=1, padding=1), nn.BatchNorm3d(64, eps=1e-4), nn.LeakyReLU(0.1, True)).to(DEV).train()
+        with torch.no_grad():
+            net[0].weight.mul_(1e-2); net[0].bias.fill_(1e3)
+        x = torch.randn(2, 4, 8, 8, 8, device=DEV)
+    import copy
+    ref = copy.deepcopy(net).double()
+    if path == 'conv3d-epilogue':
+        ref[0] = nn.Conv3d(4, 64, 3, stride=1, padding=1).to(DEV).double()
+        ref[0].load_state_dict({k: v.double() for k, v in net[0].state_dict().items()})
+    got = run_layers(net, x)
+    want = ref(x.double())
+    bn, bn_ref = [m for m in net if isinstance(m, nn.modules.batchnorm._BatchNorm)][0], [m for m in ref if isinstance(m, nn.modules.batchnorm._BatchNorm)][0]
+    assert _rel(bn.running_mean, bn_ref.running_mean) < 1e-6
+    assert _rel(bn.running_var, bn_ref.running_var) < 1e-2, (bn.running_var[:4], bn_ref.running_var[:4])
+    assert (got.double() - want).abs().max().item() < 1e-3 * want.abs().max().item() + (5e-2 if path == 'stats-pass' else 0)

@@ -84,7 +84,8 @@ def test_conv_epilogue_statistics_match_a_pass_over_the_output(hip):
             w = torch.randn(co, ci, device=DEV) * 0.1
             bias = torch.randn(co, device=DEV)
             y, part = hip.pwconv_forward(x, w, bias, want_stats=True)
-        yc = y.double().transpose(0, 1).reshape(co, -1)
+        # the partials are sums of (y - bias) and (y - bias)^2: the shift keeps the variance well conditioned
+        yc = (y.double() - bias.double().view(1, co, *([1] * (y.dim() - 2)))).transpose(0, 1).reshape(co, -1)
         sums = part.double().sum(dim=1)
         assert _rel(sums[:, 0], yc.sum(dim=1)) < 1e-5, f'case {case}'
         assert _rel(sums[:, 1], (yc * yc).sum(dim=1)) < 1e-5, f'case {case}'

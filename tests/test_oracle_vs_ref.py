@@ -155,3 +155,31 @@ def test_contraction_sensitivity_is_reported(oracle, ref, ref_nofma, gen):
     pts = synth_cloud(gen, 1, 500, 's3dis')
     ctr = pts[:, :, :40].contiguous()
     assert torch.equal(ref.ball_query(ctr, pts, 0.2, 16), ref_nofma.ball_query(ctr, pts, 0.2, 16))
+
+
+def test_contraction_exposure_of_the_index_ops_is_bounded(ref, ref_nofma):
+    """ASSUMPTION, stated as such: oracle/_ref is the reference source AS CONTRACTED BY GCC
+    (-ffp-contract=fast).  Whether nvcc's NVVM fuses the same products cannot be checked here (no nvcc).  What can be
+    bounded is the exposure: the same source built with and without contraction brackets nvcc's choice (any other
+    association of fused / unfused products lies between), so the index-producing ops -- ball_query (d^2 < r^2),
+    furthest point sampling (arg-max of squared distances) and 3-NN (three smallest squared distances) -- are swept
+    over both builds on S3DIS-like clouds at the PVCNN++ level sizes and the number of differing indices is REPORTED.
+    The test fails only if the two builds stop agreeing on essentially everything (which would mean index parity hangs
+    on the compiler): a d^2 within one ulp of r^2, or two candidates within one ulp of each other, is the only way a
+    contraction choice can flip an index."""
+    g = torch.Generator().manual_seed(20240924)
+    total = {'ball_query': [0, 0], 'fps': [0, 0], 'three_nn': [0, 0]}
+    for (n, m, radius) in [(8192, 1024, 0.1), (1024, 256, 0.2), (256, 64, 0.4), (64, 16, 0.8)]:      # cfg3 levels
+        pts = synth_cloud(g, 2, n, 's3dis')
+        f_a, f_z = ref.furthest_point_sampling(pts, m), ref_nofma.furthest_point_sampling(pts, m)
+        total['fps'][0] += (f_a != f_z).sum().item(); total['fps'][1] += f_a.numel()
+        ctr = torch.gather(pts, 2, f_a.long().unsqueeze(1).expand(-1, 3, -1)).contiguous()
+        b_a, b_z = ref.ball_query(ctr, pts, radius, 32), ref_nofma.ball_query(ctr, pts, radius, 32)
+        total['ball_query'][0] += (b_a != b_z).sum().item(); total['ball_query'][1] += b_a.numel()
+        feats = torch.randn(2, 4, m, generator=g)
+        t_a = ref.three_nearest_neighbors_interpolate_forward(pts, ctr, feats)
+        t_z = ref_nofma.three_nearest_neighbors_interpolate_forward(pts, ctr, feats)
+        total['three_nn'][0] += (t_a[1] != t_z[1]).sum().item(); total['three_nn'][1] += t_a[1].numel()
+    for op, (diff, count) in total.items():
+        print(f'[contraction exposure] {op}: {diff} of {count} indices differ between the fma and the no-fma build of the reference source')
+        assert diff <= max(2, count // 10000), (op, diff, count)
