@@ -66,8 +66,10 @@ class KernelClock:
                                                         bytes_devox_fwd(a[3].shape[0], a[3].shape[1], a[2].shape[2], int(a[0]) ** 3, bool(a[1])),
                                                         (a[3].shape[0], a[3].shape[1], a[2].shape[2], int(a[0]))),
         # the same gather with BatchNorm + LeakyReLU applied while the grid is staged (same argument positions)
+        # (+ the point-branch addend read when PVConv's sum rides on the store: 4*B*C*N more compulsory bytes)
         'trilinear_devoxelize_bnact_forward': lambda a, out: ('trilinear_devoxelize_fwd',
-                                                              bytes_devox_fwd(a[3].shape[0], a[3].shape[1], a[2].shape[2], int(a[0]) ** 3, bool(a[1])),
+                                                              bytes_devox_fwd(a[3].shape[0], a[3].shape[1], a[2].shape[2], int(a[0]) ** 3, bool(a[1]))
+                                                              + (4 * a[9].numel() if len(a) > 9 and a[9] is not None else 0),
                                                               (a[3].shape[0], a[3].shape[1], a[2].shape[2], int(a[0]))),
         'trilinear_devoxelize_backward': lambda a, out: ('trilinear_devoxelize_bwd',
                                                          bytes_devox_bwd(a[0].shape[0], a[0].shape[1], a[0].shape[2], int(a[3]) ** 3),

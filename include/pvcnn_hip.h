@@ -171,6 +171,19 @@ PVCNN_API int pvcnn_gather_bwd(const float *grad_y, const int32_t *indices, int 
 PVCNN_API int pvcnn_fps(const float *coords, int B, int N, int M, float *distances, int32_t *indices,
               void *stream);
 
+/* ---- foreground selection of logits_mask (Frustum-PVCNN) --------------------------------------------------------
+ * replaces the per-cloud Python loop of modules/functional/sampling.py:69-82 (nonzero() sync + numpy draws per cloud).
+ * mask (B,N) bytes (non-zero = foreground) -> selected (B,M) int32 point ids:
+ *   k = foreground count; k >= M: M distinct foreground points in random order; 0 < k < M: every one M/k times plus M%k
+ *   distinct extra ones, shuffled; k == 0: all 0 -- the reference's three cases.
+ * Randomness: `choices` (B,M) int32 = positions into the ascending foreground list, supplied by the caller (PARITY MODE:
+ * with numpy's own draws the result is bit-identical to the reference), or, when choices is NULL, a Philox4x32-10 stream
+ * keyed by `seed` (two int64 in DEVICE memory: key, stream id) -- no host round trip.  count (B) optional: receives k.
+ * N, M <= 8192.
+ */
+PVCNN_API int pvcnn_mask_select(const uint8_t *mask, int B, int N, int M, const int32_t *choices, const int64_t *seed,
+                      int32_t *selected, int32_t *count, void *stream);
+
 /* ---- 3-nearest-neighbour interpolation ----------------------------------------------------
  * replaces three_nearest_neighbors_interpolate_forward/backward
  *          (interpolate/neighbor_interpolate.cpp:6-65, neighbor_interpolate.cu:20-170)
@@ -248,7 +261,9 @@ PVCNN_API int pvcnn_bnact_fwd(const float *x, const float *gamma, const float *b
  * Used with pvcnn_trilinear_devox_bnact_fwd, which applies BatchNorm + LeakyReLU while it stages the voxel
  * grid into LDS -- out = trilinear_devoxelize(leaky_relu(bn(feat))) without writing the activated grid
  * (PVConv: the last BatchNorm3d + LeakyReLU of voxel_layers followed by the devoxelization, modules/pvconv.py:
- * 25-27,36).  Bit-identical to bnact_fwd followed by trilinear_devox_fwd.  Requires R^3 * 4 bytes <= 160 KiB. */
+ * 25-27,36).  Bit-identical to bnact_fwd followed by trilinear_devox_fwd.  Requires R^3 * 4 bytes <= 160 KiB.
+ * addend (B,C,N) or NULL: outs = devoxelized + addend in the gather's store -- PVConv's "voxel branch + point branch"
+ * (modules/pvconv.py:38) without a separate read-modify-write pass; one rounded fp32 addition, as in the reference. */
 /* Convolution forward WITH BatchNorm statistics: as pvcnn_conv3d_fwd / pvcnn_pwconv_fwd, and the epilogue also
  * writes per-workgroup partial (sum, sum of squares) of every output channel to stats_part -- (C, nparts) pairs of
  * floats, nparts = *_fwd_stats_parts(...) -- so the BatchNorm that follows needs no pass over y:
@@ -269,7 +284,7 @@ PVCNN_API int pvcnn_bn_stats(const float *x, float *running_mean, float *running
 PVCNN_API int pvcnn_trilinear_devox_bnact_fwd(const float *coords, const float *feat, const float *gamma,
                                     const float *beta, const float *mean, const float *rstd, float slope,
                                     int B, int C, int N, int R, int is_training, int32_t *inds, float *wgts,
-                                    float *outs, void *stream);
+                                    const float *addend, float *outs, void *stream);
 PVCNN_API int pvcnn_bnact_bwd(const float *x, const float *grad_y, const float *gamma, const float *beta,
                               const float *mean, const float *rstd, int B, int C, int S, float slope, int training,
                               float *grad_x, float *grad_gamma, float *grad_beta, void *workspace,

@@ -47,6 +47,7 @@ SIGNATURES = {
     'pvcnn_gather_bwd_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'pvcnn_gather_bwd': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     'pvcnn_fps': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
+    'pvcnn_mask_select': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'pvcnn_three_nn_interp_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'pvcnn_three_nn_interp_bwd_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'pvcnn_three_nn_interp_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
@@ -66,7 +67,7 @@ SIGNATURES = {
     'pvcnn_pwconv_fwd_stats': (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     'pvcnn_bn_finalize': (_i, [_vp, _i, ctypes.c_long, ctypes.c_double, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     'pvcnn_bn_stats': (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp, _sz, _vp]),
-    'pvcnn_trilinear_devox_bnact_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    'pvcnn_trilinear_devox_bnact_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'pvcnn_bnact_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     'pvcnn_bnact_bwd_strided': (_i, [_vp, _vp, ctypes.c_long, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     'pvcnn_trilinear_devox_bwd_strided': (_i, [_vp, ctypes.c_long, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),

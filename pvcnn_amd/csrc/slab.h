@@ -355,7 +355,8 @@ __device__ __forceinline__ void slab_stage(float *lds, const float *src, int g, 
 template <class P, int VEC, int THREADS, bool RESIDENT, class XF, bool PAD>
 __global__ __launch_bounds__(THREADS) void gather_lds_kernel(P p, XF xf, const float *__restrict__ src,
                                                              float *__restrict__ dst, int C, int L,
-                                                             int J, int G, int SEQ, int pshift) {
+                                                             int J, int G, int SEQ, int pshift,
+                                                             const float *__restrict__ addend = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int NC = P::NC;
   const int b = blockIdx.y;
@@ -381,6 +382,9 @@ __global__ __launch_bounds__(THREADS) void gather_lds_kernel(P p, XF xf, const f
     slab_stage<THREADS, PAD>(lds, src + ((size_t)b * C + c0) * L, g, L, Lp, pshift, xf, c0);
     __syncthreads();
     float *out = dst + ((size_t)b * C + c0) * J;
+    // optional epilogue: out = gather + addend (PVConv's "devoxelized voxel branch + point branch", modules/pvconv.py:38,
+    // one rounded fp32 addition like the reference's separate kernel) -- saves a full read-modify-write pass over (B,C,J)
+    const float *add = addend ? addend + ((size_t)b * C + c0) * J : nullptr;
     for (int j0 = jf; j0 < J; j0 += THREADS * VEC) {
       Taps<NC> t[VEC];
       if constexpr (resident) {
@@ -397,10 +401,14 @@ __global__ __launch_bounds__(THREADS) void gather_lds_kernel(P p, XF xf, const f
         const float *row = lds + c * Lp;
         if constexpr (VEC == 4) {
           const float r0 = combine<NC, P::kMaySkip, PAD>(t[0], row, pshift), r1 = combine<NC, P::kMaySkip, PAD>(t[1], row, pshift);
-          const float r2 = combine<NC, P::kMaySkip, PAD>(t[2], row, pshift), r3 = combine<NC, P::kMaySkip, PAD>(t[3], row, pshift);
-          st4(out + (size_t)c * J + j0, r0, r1, r2, r3);
+          float r2 = combine<NC, P::kMaySkip, PAD>(t[2], row, pshift), r3 = combine<NC, P::kMaySkip, PAD>(t[3], row, pshift);
+          float q0 = r0, q1 = r1;
+          if (add) { const float4 a = ld4(add + (size_t)c * J + j0); q0 = q0 + a.x; q1 = q1 + a.y; r2 = r2 + a.z; r3 = r3 + a.w; }
+          st4(out + (size_t)c * J + j0, q0, q1, r2, r3);
         } else {
-          out[(size_t)c * J + j0] = combine<NC, P::kMaySkip, PAD>(t[0], row, pshift);
+          float r = combine<NC, P::kMaySkip, PAD>(t[0], row, pshift);
+          if (add) r = r + add[(size_t)c * J + j0];
+          out[(size_t)c * J + j0] = r;
         }
       }
     }
@@ -494,15 +502,15 @@ inline int enable_big_lds(K kernel, size_t bytes) {
 // pshift > 0: rows are voxel grids of resolution 2^pshift; stage them padded (see combine()).
 template <class P, class XF = XfNone>
 int launch_gather(const P &p, const float *src, float *dst, int B, int C, int L, int J, bool vec_ok,
-                  hipStream_t s, const char *what, const XF &xf = XF{}, int pshift = 0) {
+                  hipStream_t s, const char *what, const XF &xf = XF{}, int pshift = 0, const float *addend = nullptr) {
   if (B == 0 || C == 0 || J == 0) return 0;
   if (pshift > 0 && (size_t)(L + (L >> pshift)) * sizeof(float) > (size_t)kLdsBytesPerCU) pshift = 0;   // padding must not cost the LDS path
   const SlabPlan pl = plan_slab(B, C, L, pshift);
   if (!pl.lds) {
-    if constexpr (!XF::kIdentity) {
-      set_error("%s: row does not fit LDS; the fused transform needs the LDS path", what);
+    if (!XF::kIdentity || addend) {
+      set_error("%s: row does not fit LDS; the fused transform / addend needs the LDS path", what);
       return PVCNN_ERR_INVALID_ARGUMENT;
-    } else {
+    } else if constexpr (XF::kIdentity) {
       const int CT = 16;
       hipLaunchKernelGGL((gather_direct_kernel<P>), dim3(ceil_div(J, 256), ceil_div(C, CT), B), dim3(256), 0, s,
                          p, src, dst, C, L, J, CT);
@@ -514,7 +522,7 @@ int launch_gather(const P &p, const float *src, float *dst, int B, int C, int L,
   do {                                                                                           \
     auto k = (J <= T * VEC) ? gather_lds_kernel<P, VEC, T, true, XF, PADV> : gather_lds_kernel<P, VEC, T, false, XF, PADV>; \
     if (int e = enable_big_lds(k, pl.bytes)) { set_error("%s: LDS attribute: %d", what, e); return e; } \
-    hipLaunchKernelGGL(k, grid, dim3(T), pl.bytes, s, p, xf, src, dst, C, L, J, pl.G, pl.seq, pshift); \
+    hipLaunchKernelGGL(k, grid, dim3(T), pl.bytes, s, p, xf, src, dst, C, L, J, pl.G, pl.seq, pshift, addend); \
   } while (0)
 #define PVCNN_LAUNCH_GATHER(VEC, T)                                                              \
   do {                                                                                           \

@@ -142,6 +142,28 @@ class HipBackend:
             _lib.check(self.lib.pvcnn_fps(_p(coords), b, n, m, _p(distances), _p(indices), s), 'furthest_point_sampling')
         return indices
 
+    # ---- the index selection of logits_mask (modules/functional/sampling.py:69-82) on the device ----------------
+    has_mask_select = True
+
+    def mask_select(self, mask, num_samples, choices=None, seed=None):
+        """mask (B,N) bool -> selected (B,M) int32 foreground point ids (see include/pvcnn_hip.h).  choices (B,M) int32:
+        parity mode (the caller's draws); else seed: int64 device tensor (key, stream id) for the Philox stream."""
+        _dev(mask, 'mask')
+        _shape(mask.dim() == 2 and mask.dtype in (torch.bool, torch.uint8) and mask.is_contiguous(), 'mask_select: mask (B,N) bool expected')
+        b, n = mask.shape
+        m = int(num_samples)
+        if choices is not None:
+            _i32(choices, 'choices')
+            _shape(tuple(choices.shape) == (b, m), 'mask_select: choices (B,M) expected')
+        else:
+            _dev(seed, 'seed')
+            _shape(seed.dtype == torch.int64 and seed.numel() >= 2 and seed.is_contiguous(), 'mask_select: seed = 2 x int64 on the device')
+        selected = torch.empty((b, m), dtype=torch.int32, device=mask.device)
+        with _Launch(mask) as s:
+            _lib.check(self.lib.pvcnn_mask_select(_p(mask.view(torch.uint8)), b, n, m, _p(choices) if choices is not None else None,
+                                                  _p(seed) if choices is None else None, _p(selected), None, s), 'mask_select')
+        return selected
+
     # ---- ball_query.cpp:6-30 ----------------------------------------------------------------
     def ball_query(self, centers_coords, points_coords, radius, num_neighbors):
         _f32(centers_coords, 'centers_coords'); _f32(points_coords, 'points_coords')
@@ -551,7 +573,7 @@ class HipBackend:
                                                float(momentum), _p(mean), _p(rstd), _p(ws), ws.numel(), s), 'bn_stats')
         return mean, rstd
 
-    def trilinear_devoxelize_bnact_forward(self, r, is_training, coords, features, gamma, beta, mean, rstd, slope):
+    def trilinear_devoxelize_bnact_forward(self, r, is_training, coords, features, gamma, beta, mean, rstd, slope, addend=None):
         """trilinear_devoxelize_forward of leaky_relu(bn(features)) without materialising that tensor:
         features (B,C,R^3) is the PRE-BatchNorm grid, mean / rstd (C) its statistics."""
         _f32(features, 'features'); _f32(coords, 'coords')
@@ -562,6 +584,9 @@ class HipBackend:
         b, c = features.shape[:2]
         n = coords.shape[2]
         dev = features.device
+        if addend is not None:
+            _f32(addend, 'addend')
+            _shape(tuple(addend.shape) == (b, c, n), 'trilinear_devoxelize: addend (B,C,N) expected')
         outs = torch.empty((b, c, n), dtype=torch.float32, device=dev)
         if is_training:
             inds = torch.empty((b, 8, n), dtype=torch.int32, device=dev)
@@ -574,7 +599,8 @@ class HipBackend:
             _lib.check(self.lib.pvcnn_trilinear_devox_bnact_fwd(
                 _p(coords), _p(features), _p(gamma) if gamma is not None else nul, _p(beta) if beta is not None else nul,
                 _p(mean), _p(rstd), float(slope), b, c, n, r, int(bool(is_training)),
-                _p(inds) if is_training else None, _p(wgts) if is_training else None, _p(outs), s),
+                _p(inds) if is_training else None, _p(wgts) if is_training else None,
+                _p(addend) if addend is not None else None, _p(outs), s),
                 'trilinear_devoxelize_bnact_forward')
         return [outs, inds, wgts]
 

@@ -94,7 +94,7 @@ class BatchNormActDevoxelize(Function):
     @staticmethod
     @amp_fwd
     def forward(ctx, grid, coords, weight, bias, running_mean, running_var, use_batch_stats, momentum, eps, slope,
-                resolution, is_training, stats_part=None, stats_shift=None):
+                resolution, is_training, stats_part=None, stats_shift=None, addend=None):
         shape = grid.shape
         x3 = grid.contiguous().view(shape[0], shape[1], -1)
         w = weight.contiguous() if weight is not None else None
@@ -107,10 +107,12 @@ class BatchNormActDevoxelize(Function):
             mean, rstd = running_mean.contiguous(), torch.rsqrt(running_var + eps)
         r = int(resolution)
         pts = coords.contiguous()
+        add = addend.contiguous() if addend is not None else None      # the point branch: added in the gather's store
+        ctx.has_addend = add is not None
         if not is_training:
-            return native().trilinear_devoxelize_bnact_forward(r, False, pts, x3, w, b, mean, rstd, slope)[0]
+            return native().trilinear_devoxelize_bnact_forward(r, False, pts, x3, w, b, mean, rstd, slope, add)[0]
         taps = CornerTaps.of(coords, r)
-        out = taps.forward(lambda emit: native().trilinear_devoxelize_bnact_forward(r, emit, pts, x3, w, b, mean, rstd, slope))
+        out = taps.forward(lambda emit: native().trilinear_devoxelize_bnact_forward(r, emit, pts, x3, w, b, mean, rstd, slope, add))
         ctx.save_for_backward(x3, w, b, mean, rstd, taps.inds, taps.wgts)
         ctx.taps = taps
         ctx.slope, ctx.use_batch_stats, ctx.shape = slope, use_batch_stats, shape
@@ -123,14 +125,15 @@ class BatchNormActDevoxelize(Function):
         g_act = ctx.taps.backward(_rows(grad_out, grad_out.shape))
         gx, gw, gb = native().bnact_backward(x3, g_act.view(x3.shape), w, b, mean, rstd, ctx.slope, ctx.use_batch_stats)
         return (gx.view(ctx.shape), None, gw if w is not None else None, gb if b is not None else None,
-                None, None, None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None, None, grad_out if ctx.has_addend else None)
 
 
-def batch_norm_act_devoxelize(grid, coords, bn, slope, resolution, is_training, stats_part=None):
+def batch_norm_act_devoxelize(grid, coords, bn, slope, resolution, is_training, stats_part=None, addend=None):
+    """trilinear_devoxelize(act(bn(grid)), coords) [+ addend]: PVConv's tail (modules/pvconv.py:25-27,36-38) in one gather."""
     use_batch_stats, momentum, rm, rv = _bn_mode(bn)
     part, shift = _split(stats_part)
     return BatchNormActDevoxelize.apply(grid, coords, bn.weight, bn.bias, rm, rv, use_batch_stats, momentum, bn.eps, slope,
-                                        resolution, is_training, part, shift)
+                                        resolution, is_training, part, shift, addend)
 
 
 def fusable_tail(layers, x):

@@ -78,7 +78,11 @@ class PVConv(nn.Module):
             bn, slope = tail
             grid, stats_part = run_layers(self.voxel_layers, grid, stop=len(self.voxel_layers) - 2, tail_stats=True)
             per_point = self.point_features(features)
-            from_voxels = batch_norm_act_devoxelize(grid, grid_coords, bn, slope, self.resolution, self.training, stats_part)
+            # ... and so does the sum with the point branch: added in the gather's store (one rounded addition, like the
+            # reference's `voxel_features + point_features`, modules/pvconv.py:38)
+            fused = batch_norm_act_devoxelize(grid, grid_coords, bn, slope, self.resolution, self.training, stats_part,
+                                              addend=per_point)
+            return fused, coords
         else:
             grid = run_layers(self.voxel_layers, grid)     # = self.voxel_layers(grid), BN + LeakyReLU fused
             per_point = self.point_features(features)
