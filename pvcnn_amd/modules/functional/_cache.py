@@ -15,7 +15,9 @@ import weakref
 
 __all__ = ['memo', 'clear', 'enabled']
 
-_lock = threading.Lock()
+# re-entrant: a weak-reference callback (_drop) can fire from the garbage collector at any allocation, including inside
+# memo()'s own critical section on the same thread -- a plain Lock deadlocks there (seen in the GPU test-suite)
+_lock = threading.RLock()
 _entries = {}          # id(tensor) -> (weakref, version, dict)
 enabled = True
 

@@ -70,3 +70,36 @@ def test_shard_batch():
     assert [shard_batch(16, 4, r) for r in range(4)] == [slice(0, 4), slice(4, 8), slice(8, 12), slice(12, 16)]
     with pytest.raises(ValueError):
         shard_batch(10, 4, 0)
+
+
+def test_coordinate_memo_survives_a_weakref_callback_inside_its_own_critical_section():
+    """The memo's weak-reference callback takes the same lock as memo(): a garbage collection that frees a keyed tensor
+    while memo() holds the lock must not deadlock (it did with a non-reentrant lock: a hang in training)."""
+    import gc
+    import threading
+    import torch
+    from pvcnn_amd.modules.functional import _cache
+
+    done = threading.Event()
+
+    def work():
+        for i in range(200):
+            t = torch.zeros(3)
+            _cache.memo(t, 'k', lambda: i)
+            cyc = [t]
+            cyc.append(cyc)                     # the tensor dies only through the cycle collector ...
+            del t, cyc
+
+            def make():
+                gc.collect()                    # ... which runs here, inside memo() of another tensor
+                return 1
+            u = torch.zeros(3)
+            with _cache._lock:                  # the callback fires while this thread holds the lock
+                gc.collect()
+            assert _cache.memo(u, 'k', make) == 1
+        done.set()
+
+    th = threading.Thread(target=work, daemon=True)
+    th.start()
+    th.join(30)
+    assert done.is_set(), 'memo() deadlocked against its own weak-reference callback'
