@@ -223,6 +223,22 @@ PVCNN_API int pvcnn_conv3d_bwd_weight(const float *x, const float *grad_y, int B
                                       float *grad_w, float *grad_bias, void *workspace, size_t workspace_bytes,
                                       void *stream);
 
+/* ---- the same convolution on the bf16 matrix cores (csrc/conv3d_bf16.hip) ---------------------------------------
+ * nsplit = 1: bf16 operands, fp32 accumulate (BASELINE configs[4], "bf16 with MFMA 3D conv"; ~4e-3 relative).
+ * nsplit = 3: "bf16x3" -- both fp32 operands split exactly into three bf16 pieces, the six significant partial products
+ *             accumulated in fp32: fp32-class accuracy (<= 1e-5 vs fp64, like pvcnn_conv3d_fwd) at up to 16/6 = 2.7x
+ *             the fp32-MFMA rate.
+ * weight_split: w (Co,Ci,3,3,3) fp32 -> the kernels' pre-split, pre-swizzled LDS image (opaque, *_split_bytes bytes,
+ *             16-byte aligned); for_bwd_data = 1 builds the flipped / channel-transposed image with which
+ *             grad_x = conv3d_fwd_split(grad_y, wts, NULL, B, Ci = Co_fwd, Co = Ci_fwd, ...).
+ * stats_part: NULL, or (Co, *_split_stats_parts) float pairs of per-workgroup (sum, sum of squares) of (y - bias).
+ */
+PVCNN_API size_t pvcnn_conv3d_weight_split_bytes(int Co, int Ci, int for_bwd_data, int nsplit);
+PVCNN_API int pvcnn_conv3d_weight_split(const float *w, int Co, int Ci, int for_bwd_data, int nsplit, void *wts, void *stream);
+PVCNN_API size_t pvcnn_conv3d_fwd_split_stats_parts(int B, int Co, int R);
+PVCNN_API int pvcnn_conv3d_fwd_split(const float *x, const void *wts, const float *bias, int B, int Ci, int Co, int R, int nsplit,
+                           float *y, float *stats_part, void *stream);
+
 /* ---- 1x1 convolutions of SharedMLP (point branch, classifier) ------------------------------------
  * replaces the nn.Conv1d / nn.Conv2d (kernel 1) calls of modules/shared_mlp.py:9-25 (cuDNN / cuBLAS in the
  * reference) with fp32-MFMA GEMMs that work on the reference's channel-major layout directly:

@@ -13,6 +13,7 @@ Here the same object shape is implemented over the C ABI in include/pvcnn_hip.h:
   * there is no CPU path: a CPU tensor or a missing library is an error, never a fallback.
 """
 import ctypes
+import os
 
 import torch
 
@@ -460,6 +461,51 @@ class HipBackend:
                                                         _p(ws), ws.numel(), s), 'conv3d_backward_weight')
         return (gw, gb) if with_bias else gw
 
+
+    # ---- the same convolution on the bf16 matrix cores (csrc/conv3d_bf16.hip): nsplit = 3 "bf16x3" (fp32-class accuracy, up to
+    # 2.7x the fp32-MFMA rate) or nsplit = 1 (plain bf16 operands: the autocast / BASELINE configs[4] path) ----
+    has_conv3d_split = True
+    # default arithmetic of the voxel convolutions' forward / backward-data products:
+    #   'bf16x3' : exact three-way bf16 split of both fp32 operands, 6 partial products, fp32 accumulate (<= 1e-5 vs fp64)
+    #   'fp32'   : v_mfma_f32_32x32x2_f32, one rounding per product (conv3d.hip)
+    conv_math = os.environ.get('PVCNN_CONV_MATH', 'bf16x3')
+
+    def _conv_wsplit(self, weight, for_bwd_data, nsplit):
+        co, ci = weight.shape[0], weight.shape[1]
+        nbytes = self.lib.pvcnn_conv3d_weight_split_bytes(co, ci, int(for_bwd_data), int(nsplit))
+        wts = torch.empty((nbytes,), dtype=torch.uint8, device=weight.device)
+        with _Launch(weight) as s:
+            _lib.check(self.lib.pvcnn_conv3d_weight_split(_p(weight), co, ci, int(for_bwd_data), int(nsplit), _p(wts), s), 'conv3d_weight_split')
+        return wts
+
+    def conv3d_forward_split(self, x, weight, bias, nsplit, want_stats=False):
+        _f32(x, 'x'); _f32(weight, 'weight')
+        _shape(x.dim() == 5 and weight.dim() == 5 and tuple(weight.shape[2:]) == (3, 3, 3) and weight.shape[1] == x.shape[1]
+               and x.shape[2] == x.shape[3] == x.shape[4], 'conv3d: x (B,Ci,R,R,R), weight (Co,Ci,3,3,3) expected')
+        if bias is not None:
+            _f32(bias, 'bias')
+        b, ci, r = x.shape[0], x.shape[1], x.shape[2]
+        co = weight.shape[0]
+        wts = self._conv_wsplit(weight, False, nsplit)
+        y = torch.empty((b, co, r, r, r), dtype=torch.float32, device=x.device)
+        part = None
+        if want_stats:
+            part = torch.empty((co, self.lib.pvcnn_conv3d_fwd_split_stats_parts(b, co, r), 2), dtype=torch.float32, device=x.device)
+        with _Launch(x) as s:
+            _lib.check(self.lib.pvcnn_conv3d_fwd_split(_p(x), _p(wts), _p(bias) if bias is not None else None, b, ci, co, r, int(nsplit),
+                                                       _p(y), _p(part) if want_stats else None, s), 'conv3d_forward_split')
+        return (y, part) if want_stats else y
+
+    def conv3d_backward_data_split(self, grad_y, weight, nsplit):
+        _f32(grad_y, 'grad_y'); _f32(weight, 'weight')
+        b, co, r = grad_y.shape[0], grad_y.shape[1], grad_y.shape[2]
+        ci = weight.shape[1]
+        wts = self._conv_wsplit(weight, True, nsplit)
+        gx = torch.empty((b, ci, r, r, r), dtype=torch.float32, device=grad_y.device)
+        with _Launch(grad_y) as s:   # a convolution with Ci and Co exchanged on the flipped weights
+            _lib.check(self.lib.pvcnn_conv3d_fwd_split(_p(grad_y), _p(wts), None, b, co, ci, r, int(nsplit), _p(gx), None, s),
+                       'conv3d_backward_data_split')
+        return gx
 
     # ---- SharedMLP 1x1 convolutions as channel-major MFMA GEMMs (csrc/pointwise.hip) --------------------
     has_pwconv = True

@@ -3,37 +3,56 @@
 The reference calls nn.Conv3d (cuDNN) here (modules/pvconv.py:20-27).  On gfx950 the three GEMMs
 (forward, backward-data, backward-weight) run on the fp32-MFMA implicit-GEMM kernels of
 csrc/conv3d.hip; gradients w.r.t. the bias are a plain reduction."""
+import torch
 from torch.autograd import Function
 
 from ._autograd import native, amp_fwd, amp_bwd
 
-__all__ = ['voxel_conv3d']
+__all__ = ['voxel_conv3d', 'conv_nsplit']
+
+
+def conv_nsplit():
+    """Arithmetic of the forward / backward-data products, decided where the convolution is CALLED (inside the autograd
+    function autocast is already switched off): 1 = bf16 operands under torch.autocast(bfloat16) (BASELINE configs[4]),
+    3 = bf16x3 split (fp32-class accuracy on the bf16 matrix cores, the default), 0 = exact fp32 MFMA."""
+    be = native()
+    if not getattr(be, 'has_conv3d_split', False):
+        return 0
+    if torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16:
+        return 1
+    return 3 if getattr(be, 'conv_math', 'fp32') == 'bf16x3' else 0
 
 
 class VoxelConv3d(Function):
     @staticmethod
     @amp_fwd
-    def forward(ctx, x, weight, bias, want_stats=False):
+    def forward(ctx, x, weight, bias, want_stats=False, nsplit=0):
         x = x.contiguous()
         weight = weight.contiguous()
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        ctx.nsplit = int(nsplit)
         b = bias.contiguous() if bias is not None else None
+        be = native()
         if want_stats:   # second output: BatchNorm partial sums from the epilogue (not differentiable)
-            y, part = native().conv3d_forward(x, weight, b, want_stats=True)
+            y, part = (be.conv3d_forward_split(x, weight, b, ctx.nsplit, want_stats=True) if ctx.nsplit
+                       else be.conv3d_forward(x, weight, b, want_stats=True))
             ctx.mark_non_differentiable(part)
             ctx.set_materialize_grads(False)     # no zero tensor for the (non-existent) gradient of `part`
             return y, part
-        return native().conv3d_forward(x, weight, b)
+        return be.conv3d_forward_split(x, weight, b, ctx.nsplit) if ctx.nsplit else be.conv3d_forward(x, weight, b)
 
     @staticmethod
     @amp_bwd
     def backward(ctx, grad_y, grad_part=None):
         x, weight = ctx.saved_tensors
         if grad_y is None:
-            return None, None, None, None
+            return None, None, None, None, None
         grad_y = grad_y.contiguous()
-        gx = native().conv3d_backward_data(grad_y, weight) if ctx.needs_input_grad[0] else None
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = (native().conv3d_backward_data_split(grad_y, weight, ctx.nsplit) if ctx.nsplit
+                  else native().conv3d_backward_data(grad_y, weight))
         want_bias = ctx.has_bias and ctx.needs_input_grad[2]
         gw = gb = None
         if ctx.needs_input_grad[1]:
@@ -42,7 +61,7 @@ class VoxelConv3d(Function):
             gw, gb = res if want_bias else (res, None)
         elif want_bias:
             gb = grad_y.sum(dim=(0, 2, 3, 4))
-        return gx, gw, gb, None
+        return gx, gw, gb, None, None
 
 
 voxel_conv3d = VoxelConv3d.apply

@@ -14,7 +14,7 @@ import torch.nn as nn
 from . import functional as F
 from .functional._autograd import native
 from .functional.bnact import batch_norm_act_devoxelize, fusable_tail, run_layers
-from .functional.conv3d import voxel_conv3d
+from .functional.conv3d import conv_nsplit, voxel_conv3d
 from .se import SE3d
 from .shared_mlp import SharedMLP
 from .voxelization import Voxelization
@@ -30,10 +30,11 @@ class _VoxelConv3d(nn.Conv3d):
         fast = (x.is_cuda and getattr(native(), 'has_conv3d', False) and self.kernel_size == (3, 3, 3)
                 and self.stride == (1, 1, 1) and self.padding == (1, 1, 1) and self.dilation == (1, 1, 1)
                 and self.groups == 1 and self.padding_mode == 'zeros' and x.dim() == 5
-                and x.shape[2] == x.shape[3] == x.shape[4] and x.dtype == torch.float32 and self.weight.dtype == torch.float32)
+                and x.shape[2] == x.shape[3] == x.shape[4] and self.weight.dtype == torch.float32
+                and (x.dtype == torch.float32 or (torch.is_autocast_enabled() and x.dtype in (torch.bfloat16, torch.float16))))
         if not fast:
             return super().forward(x)            # other dtypes / shapes: the vendor library
-        return voxel_conv3d(x, self.weight, self.bias)
+        return voxel_conv3d(x, self.weight, self.bias, False, conv_nsplit())
 
     def forward_with_stats(self, x):
         """-> (y, stats_part) on the fast path: the epilogue also emits the per-channel partial sums the
@@ -44,7 +45,7 @@ class _VoxelConv3d(nn.Conv3d):
                 and x.shape[2] == x.shape[3] == x.shape[4] and x.dtype == torch.float32)
         if not fast:
             return self.forward(x)
-        return voxel_conv3d(x, self.weight, self.bias, True)
+        return voxel_conv3d(x, self.weight, self.bias, True, conv_nsplit())
 
 
 class PVConv(nn.Module):

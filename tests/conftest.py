@@ -23,6 +23,9 @@ SEED = 1588147245   # the reference's seed (configs/__init__.py:3)
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X GPU (deselected on the CPU box)')
+    # a hung test must FAIL, not stall the GPU box for its whole time limit (pytest-timeout, when installed)
+    if config.pluginmanager.hasplugin('timeout') and not getattr(config.option, 'timeout', None):
+        config.option.timeout = 600
 
 
 def pytest_collection_modifyitems(config, items):

@@ -40,6 +40,63 @@ def test_conv3d_forward_backward(hip, b, ci, co, r):
     assert _rel(gw2, wd.grad) < TOL and _rel(gb2, bd.grad) < TOL
 
 
+@pytest.mark.parametrize('b,ci,co,r', CASES)
+def test_conv3d_on_the_bf16_matrix_cores(hip, b, ci, co, r):
+    """csrc/conv3d_bf16.hip.  bf16x3 (exact three-way bf16 split of both fp32 operands, six partial products, fp32
+    accumulate) must meet the SAME 1e-5 bar as the exact-fp32 MFMA kernel -- forward, backward-data, with the BatchNorm
+    epilogue statistics -- and is deterministic; plain bf16 operands (the autocast / BASELINE configs[4] path): 4e-3."""
+    g = torch.Generator().manual_seed(1588147245)
+    x = torch.randn(b, ci, r, r, r, generator=g).to(DEV)
+    w = (torch.randn(co, ci, 3, 3, 3, generator=g) * 0.1).to(DEV)
+    bias = torch.randn(co, generator=g).to(DEV)
+    gy = torch.randn(b, co, r, r, r, generator=g).to(DEV)
+    xd, wd, bd = x.double().requires_grad_(), w.double(), bias.double()
+    ref = F.conv3d(xd, wd, bd, padding=1)
+    ref.backward(gy.double())
+    y3, part = hip.conv3d_forward_split(x, w, bias, 3, want_stats=True)
+    assert _rel(y3, ref.detach()) < TOL
+    assert torch.equal(hip.conv3d_forward_split(x, w, bias, 3), y3)
+    assert _rel(hip.conv3d_forward_split(x, w, None, 3), ref.detach() - bd.view(1, -1, 1, 1, 1)) < TOL
+    assert _rel(hip.conv3d_backward_data_split(gy, w, 3), xd.grad) < TOL
+    centred = (y3.double() - bd.view(1, -1, 1, 1, 1)).transpose(0, 1).reshape(co, -1)
+    sums = part.double().sum(dim=1)
+    assert _rel(sums[:, 0], centred.sum(dim=1)) < 1e-5 and _rel(sums[:, 1], (centred * centred).sum(dim=1)) < 1e-5
+    assert _rel(hip.conv3d_forward_split(x, w, bias, 1), ref.detach()) < 4e-3
+    assert _rel(hip.conv3d_backward_data_split(gy, w, 1), xd.grad) < 4e-3
+
+
+def test_bf16x3_is_as_accurate_as_the_fp32_mfma_kernel(hip):
+    """Same inputs through both kernels vs fp64: the split's error must stay within 4x of the exact-fp32 kernel's on a
+    deep reduction (K = 27 * 128), i.e. it is fp32-class, not 'a bit better than bf16'."""
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 128, 16, 16, 16, generator=g).to(DEV)
+    w = (torch.randn(128, 128, 3, 3, 3, generator=g) * 0.05).to(DEV)
+    ref = F.conv3d(x.double(), w.double(), padding=1)
+    e32, e3, e1 = (_rel(hip.conv3d_forward(x, w, None), ref), _rel(hip.conv3d_forward_split(x, w, None, 3), ref),
+                   _rel(hip.conv3d_forward_split(x, w, None, 1), ref))
+    print(f'[conv3d accuracy vs fp64, K = 3456] fp32 MFMA {e32:.2e}   bf16x3 {e3:.2e}   bf16 {e1:.2e}')
+    assert e3 < 1e-5 and e3 < 4 * e32 + 1e-7 and e1 > 100 * e3
+
+
+def test_voxel_conv_under_autocast_uses_bf16_operands(hip):
+    """BASELINE configs[4]: under torch.autocast(bfloat16) the voxel convolution runs on bf16 operands with fp32
+    accumulation (fp32 tensors in and out): ~4e-3 of the fp32 result, gradients included."""
+    from pvcnn_amd.modules.pvconv import _VoxelConv3d
+    torch.manual_seed(0)
+    conv = _VoxelConv3d(64, 64, 3, stride=1, padding=1).to(DEV)
+    x = torch.randn(2, 64, 12, 12, 12, device=DEV)
+    xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+    full = conv(xa)
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        low = conv(xb)
+    assert low.dtype == torch.float32
+    assert 1e-4 < _rel(low, full.detach().double()) < 4e-3            # really bf16 operands, and within bf16 tolerance
+    full.square().sum().backward()
+    gw_full = conv.weight.grad.clone(); conv.weight.grad = None
+    low.square().sum().backward()
+    assert _rel(xb.grad, xa.grad.double()) < 1e-2 and _rel(conv.weight.grad, gw_full.double()) < 1e-2
+
+
 def test_voxel_conv_module_matches_torch_autograd(hip):
     from pvcnn_amd.modules.pvconv import _VoxelConv3d
     torch.manual_seed(0)

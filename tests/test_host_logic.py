@@ -83,7 +83,7 @@ def test_coordinate_memo_survives_a_weakref_callback_inside_its_own_critical_sec
     done = threading.Event()
 
     def work():
-        for i in range(200):
+        for i in range(25):
             t = torch.zeros(3)
             _cache.memo(t, 'k', lambda: i)
             cyc = [t]

@@ -44,6 +44,30 @@ def bwd_data(gy, w):
     return gx
 
 
+def split_wts(w, for_bwd, ns):
+    co, ci = w.shape[0], w.shape[1]
+    nb = lib.pvcnn_conv3d_weight_split_bytes(co, ci, for_bwd, ns)
+    wts = torch.empty(nb, dtype=torch.uint8, device=dev)
+    _lib.check(lib.pvcnn_conv3d_weight_split(P(w), co, ci, for_bwd, ns, P(wts), S()), 'split')
+    return wts
+
+
+def fwd_split(x, w, bias, ns):
+    b, ci, r = x.shape[0], x.shape[1], x.shape[2]
+    co = w.shape[0]
+    y = torch.empty(b, co, r, r, r, device=dev)
+    _lib.check(lib.pvcnn_conv3d_fwd_split(P(x), P(split_wts(w, 0, ns)), P(bias), b, ci, co, r, ns, P(y), None, S()), 'fwd_split')
+    return y
+
+
+def bwd_data_split(gy, w, ns):
+    b, co, r = gy.shape[0], gy.shape[1], gy.shape[2]
+    ci = w.shape[1]
+    gx = torch.empty(b, ci, r, r, r, device=dev)
+    _lib.check(lib.pvcnn_conv3d_fwd_split(P(gy), P(split_wts(w, 1, ns)), None, b, co, ci, r, ns, P(gx), None, S()), 'bwd_data_split')
+    return gx
+
+
 def graph_time(fn, reps=5, iters=5):
     fn()
     torch.cuda.synchronize()
@@ -90,6 +114,11 @@ def main():
         errw = (gw.double() - wd.grad).abs().max().item() / wd.grad.abs().max().item()
         print(json.dumps({'check_BCiCoR': [b, ci, co, r], 'fwd_rel_err': err, 'bwd_data_rel_err': errd, 'bwd_weight_rel_err': errw,
                           'ok': max(err, errd, errw) < 1e-5}), flush=True)
+        for ns in (3, 1):
+            e1 = (fwd_split(x, w, bias, ns).double() - ref).abs().max().item() / ref.abs().max().item()
+            e2 = (bwd_data_split(gy, w, ns).double() - xd.grad).abs().max().item() / xd.grad.abs().max().item()
+            print(json.dumps({'check_split_BCiCoR': [b, ci, co, r], 'nsplit': ns, 'fwd_rel_err': e1, 'bwd_data_rel_err': e2,
+                              'ok': max(e1, e2) < (1e-5 if ns == 3 else 2e-2)}), flush=True)
     if '--time' in sys.argv:
         shapes = [(16, 9, 64, 32), (16, 64, 64, 32), (16, 64, 64, 16), (16, 64, 128, 16), (16, 128, 128, 16)]
         if '--shapes' in sys.argv:   # e.g. --shapes 16x64x64x16,16x128x128x16
@@ -108,6 +137,12 @@ def main():
             nb = lib.pvcnn_conv3d_bwd_weight_workspace_bytes(b, ci, co, r)
             wsb = torch.empty(nb, dtype=torch.uint8, device=dev)
             msw = graph_time(lambda: lib.pvcnn_conv3d_bwd_weight(P(x), P(gy), b, ci, co, r, P(gw), None, P(wsb), nb, S()))
+            for ns in (3, 1):
+                wts = split_wts(w, 0, ns)
+                mss = graph_time(lambda: lib.pvcnn_conv3d_fwd_split(P(x), P(wts), P(bias), b, ci, co, r, ns, P(y), None, S()))
+                print(json.dumps({'time_split_BCiCoR': [b, ci, co, r], 'nsplit': ns, 'fwd_ms': round(mss, 4),
+                                  'effective_TFLOPs': round(fl / mss / 1e9, 1), 'bf16_mfma_TFLOPs': round((6 if ns == 3 else 1) * fl / mss / 1e9, 1),
+                                  'frac_2500TF': round((6 if ns == 3 else 1) * fl / mss / 1e9 / 2500, 3)}), flush=True)
             print(json.dumps({'time_BCiCoR': [b, ci, co, r], 'fwd_ms': round(ms, 4), 'TFLOPs': round(fl / ms / 1e9, 1),
                               'frac_157TF': round(fl / ms / 1e9 / 157.3, 3), 'bwd_weight_ms': round(msw, 4),
                               'bwd_weight_TFLOPs': round(fl / msw / 1e9, 1), 'wgrad_ws_MB': round(nb / 1e6, 1)}), flush=True)
