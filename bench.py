@@ -19,6 +19,7 @@ Extra objects on the JSON line:
                  (kind "port": the reference has no CPU implementation), bounded sample.
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -33,6 +34,7 @@ import torch.distributed as dist
 import torch.nn.functional as tf
 
 MFMA_FP32_PEAK_TF = 157.3      # v_mfma_f32_32x32x2_f32, dense, MI355X_MICROARCH.md
+MFMA_BF16_PEAK_TF = 2500.0     # v_mfma_f32_32x32x16_bf16, dense (not the 2:1-sparsity headline), MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable copy)
 
 
@@ -90,10 +92,16 @@ class KernelClock:
                                                               4 * a[0].shape[0] * 16 * a[0].shape[2], (a[0].shape[0], 0, a[0].shape[2], int(a[2]))),
     })
 
-    # MFMA-bound family: Conv3d forward (x (B,Ci,R,R,R), weight (Co,Ci,3,3,3)); "bytes" slot carries FLOPs here
+    # MFMA-bound family: the Conv3d implicit-GEMM launches (forward and backward-data are the same kernel); the "bytes" slot
+    # carries the ALGORITHMIC FLOPs 2*B*R^3*27*Ci*Co.  conv3d_igemm_split(x, wts, bias, co, nsplit): the launch alone (the
+    # weight image is prepared outside the timed call); nsplit = 3 executes 6 bf16 MFMA products per algorithmic one.
     WATCH_FLOPS = {
-        'conv3d_forward': lambda a, out: ('conv3d_forward', 2.0 * a[0].shape[0] * a[0].shape[2] ** 3 * 27 * a[0].shape[1] * a[1].shape[0],
+        'conv3d_forward': lambda a, out: ('conv3d_igemm fp32-MFMA (incl. weight transform)',
+                                          2.0 * a[0].shape[0] * a[0].shape[2] ** 3 * 27 * a[0].shape[1] * a[1].shape[0],
                                           (a[0].shape[0], a[0].shape[1], a[1].shape[0], a[0].shape[2])),
+        'conv3d_igemm_split': lambda a, out: ('conv3d_igemm_bf16 ' + ('bf16x3' if int(a[4]) == 3 else 'bf16'),
+                                              2.0 * a[0].shape[0] * a[0].shape[2] ** 3 * 27 * a[0].shape[1] * int(a[3]),
+                                              (a[0].shape[0], a[0].shape[1], int(a[3]), a[0].shape[2])),
     }
 
     def __init__(self, backend):
@@ -150,11 +158,15 @@ class KernelClock:
         for (kernel, shape), (calls, ms, nbytes) in sorted(agg.items()):
             raw_us = ms * 1e3 / calls
             us = max(raw_us - overhead_us, 1e-3)
-            if kernel in self.WATCH_FLOPS:       # MFMA-bound: TFLOP/s against the fp32-MFMA peak
-                tf_s = nbytes / (us * 1e-6) / 1e12
+            if kernel.startswith('conv3d_igemm'):       # MFMA-bound
+                tf_s = nbytes / (us * 1e-6) / 1e12              # algorithmic ("effective fp32") rate
+                mult = 6 if 'bf16x3' in kernel else 1           # MFMA products executed per algorithmic product
+                peak = MFMA_FP32_PEAK_TF if 'fp32' in kernel else MFMA_BF16_PEAK_TF
                 out.append({'kernel': kernel, 'shape_BCiCoR': list(shape), 'calls': calls, 'avg_us': round(us, 2),
                             'event_pair_us': round(raw_us, 2), 'GFLOP': round(nbytes / 1e9, 2),
-                            'achieved_TFLOPs': round(tf_s, 1), 'frac_of_157TF': round(tf_s / MFMA_FP32_PEAK_TF, 4)})
+                            'effective_TFLOPs': round(tf_s, 1), 'executed_mfma_TFLOPs': round(tf_s * mult, 1), 'peak_TFLOPs': peak,
+                            'frac_of_peak': round(tf_s * mult / peak, 4),
+                            'x_fp32_mfma_peak': round(tf_s / MFMA_FP32_PEAK_TF, 3)})
                 continue
             gbs = nbytes / (us * 1e-6) / 1e9
             out.append({'kernel': kernel, 'shape_BCNR': list(shape), 'calls': calls, 'avg_us': round(us, 2),
@@ -162,6 +174,14 @@ class KernelClock:
                         'algorithmic_MB': round(nbytes / 1e6, 3), 'achieved_GBs': round(gbs, 1),
                         'frac_of_8TBs': round(gbs / HBM_PEAK_GBS, 4)})
         return out
+
+
+def dtype_label(backend):
+    """fp32 tensors and fp32 accumulation everywhere; what differs is how the dense-convolution PRODUCTS are formed."""
+    if getattr(backend, 'conv_math', 'fp32') == 'bf16x3':
+        return ('f32 (fp32 tensors, fp32 accumulate; Conv3d fwd/bwd-data products as exact 3-way bf16 splits on bf16 MFMA, '
+                'max rel err vs fp64 2e-6 = the fp32-MFMA kernel\'s; PVCNN_CONV_MATH=fp32 selects single-rounding fp32 MFMA)')
+    return 'f32'
 
 
 def pmc_traffic(kernel, shape):
@@ -224,9 +244,12 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--batch', type=int, default=16, help='clouds per GPU (BASELINE configs[1]: 16)')
-    ap.add_argument('--points', type=int, default=4096)
+    ap.add_argument('--batch', type=int, default=0, help='clouds per GPU (default: cfg2 16, cfg3 8, cfg4 8, cfg5 32)')
+    ap.add_argument('--points', type=int, default=0)
     ap.add_argument('--width', type=float, default=1.0)
+    ap.add_argument('--config', default='cfg2', choices=['cfg2', 'cfg3', 'cfg4', 'cfg5'],
+                    help='BASELINE.json configs: cfg2 PVCNN S3DIS (the headline, default); cfg3 PVCNN++ S3DIS B=8 N=8192; cfg4 PVCNN ShapeNet '
+                         'B=8/GPU N=2048; cfg5 Frustum-PVCNN KITTI B=4/GPU... (per-GPU batches of the 8-GPU runs unless --batch is given)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-batch', type=int, default=0, help='clouds per CPU-baseline step (0 = the same batch as the GPU run)')
     ap.add_argument('--bucket-mb', type=float, default=8.0)
@@ -263,17 +286,51 @@ def main():
     # search for the remaining 1x1 convolutions would cost minutes of start-up for nothing.
     torch.backends.cudnn.benchmark = False
     torch.manual_seed(workload.SEED)
-    model = workload.PVCNN(13, 6, width_multiplier=args.width).to(dev).train()
+    defaults = {'cfg2': (16, 4096), 'cfg3': (8, 8192), 'cfg4': (8, 2048), 'cfg5': (32, 1024)}[args.config]
+    args.batch = args.batch or defaults[0]
+    args.points = args.points or defaults[1]
+    autocast = contextlib.nullcontext
+    if args.config == 'cfg2':      # BASELINE configs[1]: the headline
+        model = workload.PVCNN(13, 6, width_multiplier=args.width)
+        x, y = workload.make_s3dis_batch(args.batch, args.points, device=dev, seed=workload.SEED + rank)
+        loss_of = lambda out: tf.cross_entropy(out, y)
+        label = f'PVCNN ({args.width:g}xC) S3DIS fwd+bwd+Adam, B={args.batch}/GPU N={args.points} R=32/16 fp32'
+        metric = 'point-clouds/sec fwd+bwd, PVCNN S3DIS N=4096 R=32'
+    elif args.config == 'cfg3':    # configs[2]: ball_query + grouping + FPS + 3-NN path
+        model = workload.PVCNN2(13, 6, width_multiplier=args.width)
+        x, y = workload.make_s3dis_batch(args.batch, args.points, device=dev, seed=workload.SEED + rank)
+        loss_of = lambda out: tf.cross_entropy(out, y)
+        label = f'PVCNN++ ({args.width:g}xC) S3DIS fwd+bwd+Adam, B={args.batch}/GPU N={args.points} fp32'
+        metric = 'point-clouds/sec fwd+bwd, PVCNN++ S3DIS N=8192'
+    elif args.config == 'cfg4':    # configs[3]: SE blocks, normalize=False, one-hot concat
+        model = workload.PVCNNShapeNet(50, 16, 3, width_multiplier=args.width)
+        x, y = workload.make_shapenet_batch(args.batch, args.points, device=dev, seed=workload.SEED + rank)
+        loss_of = lambda out: tf.cross_entropy(out, y)
+        label = f'PVCNN ({args.width:g}xC) ShapeNet part-seg fwd+bwd+Adam, B={args.batch}/GPU N={args.points} R=32/16 fp32'
+        metric = 'point-clouds/sec fwd+bwd, PVCNN ShapeNet N=2048 R=32'
+    else:                          # configs[4]: Frustum-PVCNN, voxel convolutions on bf16 operands (torch.autocast)
+        from pvcnn_amd.modules import FrustumPointNetLoss
+        templates = workload.frustum_size_templates()
+        model = workload.FrustumPVCNNE(3, 12, 8, 512, templates, 1, args.width)
+        x, _ = workload.make_frustum_batch(args.batch, args.points, device=dev, seed=workload.SEED + rank)
+        targets = workload.make_frustum_targets(args.batch, args.points, device=dev, seed=workload.SEED + rank)
+        criterion = FrustumPointNetLoss(12, 8, templates).to(dev)
+        loss_of = lambda out: criterion(out, targets)
+        autocast = lambda: torch.autocast('cuda', dtype=torch.bfloat16)
+        label = (f'Frustum-PVCNN ({args.width:g}xC) KITTI fwd+bwd+Adam, B={args.batch}/GPU N={args.points} R=16/12, torch.autocast(bf16): '
+                 'Conv3d on bf16 MFMA operands, fp32 accumulate; device-side logits_mask')
+        metric = 'frustums/sec fwd+bwd, Frustum-PVCNN KITTI N=1024'
+    model = model.to(dev).train()
     reducer = GradBucketReducer(model, bucket_mb=args.bucket_mb)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5, fused=True)   # one multi-tensor kernel per step
-    x, y = workload.make_s3dis_batch(args.batch, args.points, device=dev, seed=workload.SEED + rank)
 
     clock = KernelClock(seam._backend)
     clock.install()
 
     def step():
         reducer.zero_grad()
-        loss = tf.cross_entropy(model(x), y)
+        with autocast():
+            loss = loss_of(model(x))
         loss.backward()
         reducer.finish()
         opt.step()
@@ -298,7 +355,7 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
     event_overhead_us = KernelClock.event_pair_overhead_us()
     kernels = clock.summary(event_overhead_us)
     clock.uninstall()
@@ -307,8 +364,8 @@ def main():
         global_batch = args.batch * world
         head = next((k for k in kernels if k['kernel'] == 'trilinear_devoxelize_fwd' and k['shape_BCNR'][3] == max(
             kk['shape_BCNR'][3] for kk in kernels if kk['kernel'] == 'trilinear_devoxelize_fwd')), None)
-        convs = [k for k in kernels if k['kernel'] == 'conv3d_forward']
-        mfma = max(convs, key=lambda k: k['GFLOP']) if convs else None
+        convs = [k for k in kernels if k['kernel'].startswith('conv3d_igemm')]
+        mfma = max(convs, key=lambda k: (k['GFLOP'], k['calls'])) if convs else None
         roofline = None
         if head:
             roofline = {'bound': 'hbm', 'kernel': 'trilinear_devoxelize_fwd (gather_lds_kernel<TrilinearFromCoords>; BatchNorm+LeakyReLU fused into its LDS staging inside PVConv)',
@@ -322,25 +379,29 @@ def main():
                         'algorithmic_MB': head['algorithmic_MB']}
             roofline.update(pmc_traffic('trilinear_devoxelize_fwd', head['shape_BCNR']))
         line = {
-            'metric': 'point-clouds/sec fwd+bwd, PVCNN S3DIS N=4096 R=32',
+            'metric': metric,
             'value': round(global_batch * args.steps / elapsed, 2),
-            'unit': 'point-clouds/s',
+            'unit': 'frustums/s' if args.config == 'cfg5' else 'point-clouds/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'PVCNN ({args.width:g}xC) S3DIS fwd+bwd+Adam, B={args.batch}/GPU N={args.points} R=32/16 fp32',
+            'dtype': ('bf16 Conv3d operands (fp32 accumulate), fp32 elsewhere' if args.config == 'cfg5' else dtype_label(seam._backend)),
+            'data': 'synthetic',
+            'config': {'workload': label, 'baseline_config': args.config,
                        'global_batch': global_batch, 'points': args.points, 'parallelism': f'dp{world}',
                        'gradient_bytes': reducer.gradient_bytes, 'final_loss': round(final_loss, 4)},
             'roofline': roofline,
             # the step's largest MFMA-bound launch (Conv3d forward of the R=32 stage), same live event timing
             'roofline_mfma': None if mfma is None else {
-                'bound': 'mfma', 'kernel': 'conv3d_igemm_kernel (Conv3d 3x3x3 forward)', 'shape_BCiCoR': mfma['shape_BCiCoR'],
-                'achieved': mfma['achieved_TFLOPs'], 'peak': MFMA_FP32_PEAK_TF, 'unit': 'TFLOP/s', 'frac': mfma['frac_of_157TF'],
-                'avg_us': mfma['avg_us'], 'GFLOP': mfma['GFLOP']},
+                'bound': 'mfma', 'kernel': mfma['kernel'] + ' (Conv3d 3x3x3 forward / backward-data of the R=32 stage)',
+                'shape_BCiCoR': mfma['shape_BCiCoR'], 'achieved': mfma['executed_mfma_TFLOPs'], 'peak': mfma['peak_TFLOPs'],
+                'unit': 'TFLOP/s', 'frac': mfma['frac_of_peak'], 'avg_us': mfma['avg_us'], 'algorithmic_GFLOP': mfma['GFLOP'],
+                'effective_fp32_TFLOPs': mfma['effective_TFLOPs'], 'x_fp32_mfma_peak_157TF': mfma['x_fp32_mfma_peak'],
+                'note': 'achieved = MFMA flops actually executed (bf16x3: 6 bf16 partial products per fp32 product) / launch time; '
+                        'effective = algorithmic 2*B*R^3*27*Ci*Co / launch time'},
             'kernels': kernels,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.config == 'cfg2':
             line['cpu_baseline'] = cpu_baseline(args, args.cpu_sample_batch or args.batch)
         print(json.dumps(line), flush=True)
     if world > 1:

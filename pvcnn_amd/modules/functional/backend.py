@@ -484,9 +484,11 @@ class HipBackend:
                and x.shape[2] == x.shape[3] == x.shape[4], 'conv3d: x (B,Ci,R,R,R), weight (Co,Ci,3,3,3) expected')
         if bias is not None:
             _f32(bias, 'bias')
+        return self.conv3d_igemm_split(x, self._conv_wsplit(weight, False, nsplit), bias, weight.shape[0], nsplit, want_stats)
+
+    def conv3d_igemm_split(self, x, wts, bias, co, nsplit, want_stats=False):
+        """The implicit-GEMM launch alone (pre-split weight image `wts`): x (B,Ci,R,R,R) -> y (B,co,R,R,R) [, stats partials]."""
         b, ci, r = x.shape[0], x.shape[1], x.shape[2]
-        co = weight.shape[0]
-        wts = self._conv_wsplit(weight, False, nsplit)
         y = torch.empty((b, co, r, r, r), dtype=torch.float32, device=x.device)
         part = None
         if want_stats:
@@ -500,12 +502,8 @@ class HipBackend:
         _f32(grad_y, 'grad_y'); _f32(weight, 'weight')
         b, co, r = grad_y.shape[0], grad_y.shape[1], grad_y.shape[2]
         ci = weight.shape[1]
-        wts = self._conv_wsplit(weight, True, nsplit)
-        gx = torch.empty((b, ci, r, r, r), dtype=torch.float32, device=grad_y.device)
-        with _Launch(grad_y) as s:   # a convolution with Ci and Co exchanged on the flipped weights
-            _lib.check(self.lib.pvcnn_conv3d_fwd_split(_p(grad_y), _p(wts), None, b, co, ci, r, int(nsplit), _p(gx), None, s),
-                       'conv3d_backward_data_split')
-        return gx
+        # a convolution with Ci and Co exchanged on the flipped weights
+        return self.conv3d_igemm_split(grad_y, self._conv_wsplit(weight, True, nsplit), None, ci, nsplit)
 
     # ---- SharedMLP 1x1 convolutions as channel-major MFMA GEMMs (csrc/pointwise.hip) --------------------
     has_pwconv = True

@@ -22,7 +22,7 @@ from .modules import PVConv, PointNetAModule, PointNetFPModule, PointNetSAModule
 SEED = 1588147245
 
 __all__ = ['PVCNN', 'PVCNN2', 'PVCNNShapeNet', 'FrustumPVCNNE', 'make_s3dis_batch', 'make_shapenet_batch',
-           'make_frustum_batch', 'frustum_size_templates', 'SEED']
+           'make_frustum_batch', 'make_frustum_targets', 'frustum_size_templates', 'SEED']
 
 
 def _scaled(width, k):
@@ -371,3 +371,17 @@ def frustum_size_templates(num_size_templates=8):
     base = torch.tensor([[3.9, 1.6, 1.56], [0.8, 0.6, 1.73], [1.76, 0.6, 1.73], [5.06, 1.9, 2.2],
                          [10.1, 2.6, 3.0], [2.1, 1.2, 1.5], [16.2, 2.6, 3.5], [0.84, 0.66, 1.76]])
     return base[:num_size_templates].clone()
+
+
+def make_frustum_targets(batch, num_points=1024, num_heading_angle_bins=12, num_size_templates=8, device='cpu', seed=SEED):
+    """Synthetic targets for FrustumPointNetLoss (modules/frustum.py:43-124): foreground labels, box centre, heading bin +
+    residual, size template + residual."""
+    import math
+    g = torch.Generator().manual_seed(seed + 17)
+    t = {'mask_logits': torch.randint(0, 2, (batch, num_points), generator=g),
+         'center': torch.randn(batch, 3, generator=g) * 2 + torch.tensor([0.0, 0.0, 20.0]),
+         'heading_bin_id': torch.randint(0, num_heading_angle_bins, (batch,), generator=g),
+         'heading_residual': (torch.rand(batch, generator=g) - 0.5) * (2 * math.pi / num_heading_angle_bins),
+         'size_template_id': torch.randint(0, num_size_templates, (batch,), generator=g),
+         'size_residual': torch.randn(batch, 3, generator=g) * 0.1}
+    return {k: v.to(device) for k, v in t.items()}
