@@ -243,7 +243,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=100)
-    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=30)
     ap.add_argument('--batch', type=int, default=0, help='clouds per GPU (default: cfg2 16, cfg3 8, cfg4 8, cfg5 32)')
     ap.add_argument('--points', type=int, default=0)
     ap.add_argument('--width', type=float, default=1.0)

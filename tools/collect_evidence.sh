@@ -1,17 +1,32 @@
-R=$PWD; O=$R/gpurun_out/r1f; mkdir -p $O
+#!/bin/bash
+# Round-2 evidence set, one gpurun call:  tools/collect_evidence.sh   (outputs -> gpurun_out/r02/, copy what is judged to profiles/)
+R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/r02; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-# 1. un-profiled bench line (includes cpu_baseline)
-(cd $R && timeout 900 python bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/bench.json)
-# 2. kernel trace of the same command (no cpu baseline) -> stats + steady-state reduction
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_under_rocprof.log 2>&1
+BENCH="python $R/bench.py"
+# 1. the bench line (default flags: 1 GPU, 100 steps, 30 warm-up; includes cpu_baseline at the full batch)
+(cd $R && timeout 600 $BENCH 2>$O/bench.err | tail -1 > $O/bench.json)
+# 2. rocprofv3 kernel trace + stats of the same command (no CPU baseline) -> kernel stats, steady-state reduction
+rm -rf /tmp/kt; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- $BENCH --no-cpu-baseline > $O/bench_under_rocprof.log 2>&1
 grep "^{\"metric\"" $O/bench_under_rocprof.log | tail -1 > $O/bench_under_rocprof.json
-f=$(find /tmp/kt -name "*kernel_stats.csv" | head -1); head -60 $f > $O/bench_kernel_stats.csv
-t=$(find /tmp/kt -name "*kernel_trace.csv" | head -1); python $R/tools/trace_steady.py $t 20 60 > $O/bench_steady_state.txt
-# 3. PMC passes (separate), op-level shape of the headline kernel
+f=$(find /tmp/kt -name "*kernel_stats.csv" | head -1); head -80 $f > $O/bench_kernel_stats.csv
+t=$(find /tmp/kt -name "*kernel_trace.csv" | head -1); python $R/tools/trace_steady.py $t 100 70 > $O/bench_steady_state.txt
+# 3. HBM traffic counters, separate passes, ON THE BENCH COMMAND ITSELF (the fused gather as it runs in the step) ...
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -- python $R/tools/opbench.py --ops devox_fwd,vox_fwd,devox_bwd,vox_bwd --shapes 16x64x4096x32 > /dev/null 2>&1
-  python $R/tools/pmc_by_kernel.py /tmp/pmc_$c pvcnn > $O/pmc_${c}_opbench_16x64x4096x32.txt
+  rm -rf /tmp/pmc_$c; timeout 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -- $BENCH --steps 10 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
+  python $R/tools/pmc_by_kernel.py /tmp/pmc_$c pvcnn --json > $O/pmc_${c}_bench.json
+  python $R/tools/pmc_by_kernel.py /tmp/pmc_$c pvcnn > $O/pmc_${c}_bench.txt
 done
-# 4. op-level table
-(cd $R && python tools/opbench.py 2>/dev/null | grep median > $O/opbench.jsonl; python tools/opbench.py --kind surface 2>/dev/null | grep median >> $O/opbench.jsonl; python tools/convcheck.py --time --no-check 2>/dev/null | grep time_ > $O/convbench.jsonl)
+# ... and per op at the devoxelize-backward shapes (one shape per run so that launches of one kernel template are one shape)
+for shp in 16x64x4096x16 16x128x4096x16 16x64x4096x32; do
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rm -rf /tmp/pmco; timeout 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmco -- python $R/tools/opbench.py --ops devox_bwd_apply,devox_fwd --shapes $shp --iters 3 > /dev/null 2>&1
+    python $R/tools/pmc_by_kernel.py /tmp/pmco pvcnn --json > $O/pmc_${c}_opbench_$shp.json
+  done
+done
+python $R/tools/make_pmc_traffic.py $O > $O/pmc_traffic.json
+# 4. op-level and convolution tables, the other BASELINE configs
+(cd $R && python tools/opbench.py 2>/dev/null | grep median > $O/opbench.jsonl; python tools/opbench.py --kind surface 2>/dev/null | grep median >> $O/opbench.jsonl
+ python tools/convcheck.py --time --no-check --shapes 16x9x64x32,16x64x64x32,16x64x64x16,16x64x128x16,16x128x128x16,32x64x64x12,32x64x64x16,32x64x128x12 2>/dev/null | grep time_ > $O/convbench.jsonl
+ PVCNN_CONV_MATH=fp32 timeout 300 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_fp32_mfma.json
+ for c in cfg3 cfg4 cfg5; do timeout 300 python bench.py --config $c --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_$c.json; done)
 ls -la $O
