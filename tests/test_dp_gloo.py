@@ -139,3 +139,75 @@ def test_reducer_refuses_a_second_backward_and_supports_no_sync():
                 assert torch.allclose(a, p.grad, atol=1e-6)
         finally:
             dist.destroy_process_group()
+
+
+def _pvcnn_worker(rank, world, port, q):
+    """The real model on the data-parallel path: PVCNN (0.125xC, BatchNorm and all) on the CPU oracle backend."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from oracle.oracle_backend import OracleBackend
+        from pvcnn_amd import workload
+        from pvcnn_amd.modules.functional import backend as seam
+        seam._backend = OracleBackend()
+        torch.manual_seed(50 + rank)
+        model = workload.PVCNN(13, 6, width_multiplier=0.125).train()
+        for m in model.modules():
+            if isinstance(m, nn.Dropout):
+                m.p = 0.0
+        reducer = GradBucketReducer(model, bucket_mb=0.05)
+        x, y = workload.make_s3dis_batch(4, 256)
+        sl = shard_batch(4, world, rank)
+        reducer.zero_grad()
+        nn.functional.cross_entropy(model(x[sl]), y[sl]).backward()
+        reducer.finish()
+        q.put((rank, {k: v.detach().numpy().copy() for k, v in model.state_dict().items() if 'running' not in k and 'num_batches' not in k},
+               [p.grad.numpy().copy() for p in model.parameters()], len(reducer.buckets)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_pvcnn_gradients_are_the_mean_of_the_shard_gradients():
+    """With BatchNorm the big-batch identity does not hold (statistics are per replica, in the reference's DataParallel as
+    well); what must hold: after the all-reduce every rank has the MEAN of the two shards' gradients, each computed with
+    that shard's own batch statistics."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pvcnn_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, state0, grads0, nb0), (_, state1, grads1, nb1) = results
+    assert nb0 == nb1 and nb0 > 1
+    for k in state0:
+        assert (state0[k] == state1[k]).all(), k          # broadcast from rank 0
+    for ga, gb in zip(grads0, grads1):
+        assert (ga == gb).all()                           # every rank holds the same reduced gradient
+    from oracle.oracle_backend import OracleBackend
+    from pvcnn_amd import workload
+    from pvcnn_amd.modules.functional import backend as seam
+    prev = seam._backend
+    seam._backend = OracleBackend()
+    try:
+        x, y = workload.make_s3dis_batch(4, 256)
+        per_shard = []
+        for r in range(world):
+            model = workload.PVCNN(13, 6, width_multiplier=0.125).train()
+            for m in model.modules():
+                if isinstance(m, nn.Dropout):
+                    m.p = 0.0
+            model.load_state_dict({k: torch.from_numpy(v) for k, v in state0.items()}, strict=False)
+            sl = shard_batch(4, world, r)
+            nn.functional.cross_entropy(model(x[sl]), y[sl]).backward()
+            per_shard.append([p.grad.clone() for p in model.parameters()])
+    finally:
+        seam._backend = prev
+    for g0, a, b in zip(grads0, *per_shard):
+        want = (a + b) / 2
+        # (the workers run torch-CPU with 2 threads, this process with its default: fp32 summation order differs)
+        assert (torch.from_numpy(g0) - want).abs().max().item() <= 1e-4 * max(want.abs().max().item(), 1e-3)

@@ -47,3 +47,42 @@ def test_bucket_reducer_over_rccl_single_rank(hip):
             assert torch.allclose(p.grad, ref, rtol=1e-4, atol=1e-7)
     finally:
         dist.destroy_process_group()
+
+
+def _rccl_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    dev = torch.device('cuda', rank)
+    torch.cuda.set_device(dev)
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    try:
+        from pvcnn_amd import workload
+        from pvcnn_amd.dp import GradBucketReducer, shard_batch
+        torch.manual_seed(9 + rank)
+        net = workload.PVCNN(13, 6, width_multiplier=0.25).to(dev).train()
+        reducer = GradBucketReducer(net, bucket_mb=0.25)
+        x, y = workload.make_s3dis_batch(4, 1024, device=dev)
+        sl = shard_batch(4, world, rank)
+        reducer.zero_grad()
+        torch.nn.functional.cross_entropy(net(x[sl]), y[sl]).backward()
+        reducer.finish()
+        torch.cuda.synchronize()
+        q.put((rank, [p.grad.float().cpu().numpy().copy() for p in net.parameters()]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs 2 GPUs (the 1-GPU test box runs the 1-rank RCCL test above)')
+def test_two_rank_rccl_all_reduce_agrees_across_ranks(hip):
+    """World size 2 over RCCL / xGMI: after finish() both ranks hold the same gradients (runs on any multi-GPU box)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q, port = ctx.Queue(), _free_port()
+    procs = [ctx.Process(target=_rccl_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for a, b in zip(res[0][1], res[1][1]):
+        assert (a == b).all()
