@@ -207,7 +207,9 @@ def test_two_rank_pvcnn_gradients_are_the_mean_of_the_shard_gradients():
             per_shard.append([p.grad.clone() for p in model.parameters()])
     finally:
         seam._backend = prev
+    scale = max(((a + b) / 2).abs().max().item() for a, b in zip(*per_shard))   # biases in front of a BatchNorm have a zero
+    #                                                                               true gradient: judged against the global scale
     for g0, a, b in zip(grads0, *per_shard):
         want = (a + b) / 2
         # (the workers run torch-CPU with 2 threads, this process with its default: fp32 summation order differs)
-        assert (torch.from_numpy(g0) - want).abs().max().item() <= 1e-4 * max(want.abs().max().item(), 1e-3)
+        assert (torch.from_numpy(g0) - want).abs().max().item() <= 1e-4 * max(want.abs().max().item(), 0.01 * scale)
