@@ -212,4 +212,4 @@ def test_two_rank_pvcnn_gradients_are_the_mean_of_the_shard_gradients():
     for g0, a, b in zip(grads0, *per_shard):
         want = (a + b) / 2
         # (the workers run torch-CPU with 2 threads, this process with its default: fp32 summation order differs)
-        assert (torch.from_numpy(g0) - want).abs().max().item() <= 1e-4 * max(want.abs().max().item(), 0.01 * scale)
+        assert (torch.from_numpy(g0) - want).abs().max().item() <= 1e-4 * want.abs().max().item() + 1e-5 * scale
