@@ -258,6 +258,16 @@ PVCNN_API int pvcnn_pwconv_bwd_weight(const float *x, const float *grad_y, int B
                             float *grad_w, float *grad_bias, void *workspace, size_t workspace_bytes,
                             void *stream);
 
+/* ---- the same 1x1 GEMMs on the bf16 matrix cores (csrc/pointwise_bf16.hip): nsplit = 3 "bf16x3" (fp32-class accuracy, <= 1e-5
+ * vs fp64) or nsplit = 1 (bf16 operands); see the Conv3d split entry points for the arithmetic.  weight_split: w (Co,Ci) fp32 -> the
+ * kernel's pre-split, pre-swizzled image (opaque, *_split_bytes bytes, 16-byte aligned); for_bwd_data = 1 builds the transposed image
+ * with which grad_x = pwconv_fwd_split(grad_y, wts, NULL, B, K = Co, M = Ci, ...). */
+PVCNN_API size_t pvcnn_pwconv_weight_split_bytes(int Co, int Ci, int for_bwd_data, int nsplit);
+PVCNN_API int pvcnn_pwconv_weight_split(const float *w, int Co, int Ci, int for_bwd_data, int nsplit, void *wts, void *stream);
+PVCNN_API size_t pvcnn_pwconv_fwd_split_stats_parts(int B, int N);
+PVCNN_API int pvcnn_pwconv_fwd_split(const float *x, const void *wts, const float *bias, int B, int K, int M, int N, int nsplit,
+                           float *y, float *stats_part, void *stream);
+
 /* ---- BatchNorm fused with the following ReLU / LeakyReLU -----------------------------------------
  * replaces the (nn.BatchNorm{1,2,3}d, nn.ReLU | nn.LeakyReLU) module pairs of modules/pvconv.py:20-27
  * and modules/shared_mlp.py:20-25 (cuDNN BN + one more elementwise pass each way in the reference).

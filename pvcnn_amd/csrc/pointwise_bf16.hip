@@ -1,0 +1,311 @@
+// pointwise_bf16.hip -- the SharedMLP 1x1 convolutions (forward / backward-data) on the bf16 matrix cores of gfx950.
+//
+//   y[b,m,n] = sum_k W[m,k] x[b,k,n] + bias[m]          (m = output channels, k = reduction channels, n = points)
+//
+// Same arithmetic as conv3d_bf16.hip: NS = 3 "bf16x3" -- both fp32 operands split exactly into three bf16 pieces, the six
+// partial products of weight >= 2^-16 accumulated in fp32 (fp32-class accuracy, <= 1e-5 vs fp64 like the fp32-MFMA kernels
+// of pointwise.hip) at up to 2.7x the fp32-MFMA rate -- or NS = 1, plain bf16 operands.  It is the implicit GEMM of
+// conv3d_bf16.hip with a single tap and no halo:
+//   * a workgroup owns 256 consecutive points x 32*MB output channels (MB = 4: x is the big operand, every staged and
+//     converted element should feed as many output channels as the register file allows);
+//   * per chunk of 16 reduction channels the 256 x 16 input tile is staged once, fp32 -> NS bf16 planes, as packed channel
+//     PAIRS with points contiguous: xs[plane][channel pair][point] (coalesced 16-byte loads in, 16-byte LDS writes, and the
+//     operand reads are conflict-free);
+//   * the weights come from a pre-split, pre-swizzled image in global memory (pw_weight_split_kernel; L2-resident), each
+//     lane fetching its own 16-byte A fragments, requested BEFORE the tile is staged so they land behind the staging;
+//   * C/D rows are 32 consecutive points of one channel = 128-byte rows of the channel-major (B, M, N) output; bias and the
+//     optional BatchNorm partial sums of (y - bias) ride on the epilogue.
+// Backward-data is the same kernel on the transposed weights (for_bwd_data image), x = grad_y.
+//
+// STATUS: correct (<= 1e-5 vs fp64, tests/test_gpu_pwconv.py) but NOT the default: at PVCNN's layer shapes it is 0.9-1.14x the
+// fp32-MFMA kernels of pointwise.hip (classifier 1472->512 over 65 536 points: 0.69 vs 0.77 ms forward).  Unlike the 3x3x3
+// convolution, where every staged and converted element is reused by 27 taps x 64 channels, a 1x1 GEMM reuses it by the M tile
+// only (128), and the per-chunk phase "convert + LDS + barrier" (0.29 ms in total at this shape, measured with NS = 1) does not
+// overlap the MFMA phase (0.37 ms at the sustained 1.6 PF) of the co-resident workgroup -- the two add up.  Tried without effect:
+// one-chunk-ahead register prefetch of x and of the weight fragments, 32-channel stages (spills at 2 waves per SIMD, slower at 1),
+// XCD-aware tile order (L2 hit rate 75 %: x is fetched from HBM once), issue priority for the multiplying wave.  Selected with
+// `backend.pw_math = 'bf16x3'`.
+#include <algorithm>
+
+#include "common.h"
+
+namespace pvcnn {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kPbN = 256;          // points per workgroup
+constexpr int kPbK = 16;           // reduction channels per chunk = MFMA K
+
+__device__ __forceinline__ uint32_t pb_bf16_bits(float v) {
+  const uint32_t u = __float_as_uint(v);
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+template <int NS>
+__device__ __forceinline__ void pb_split(float v, uint32_t (&p)[NS]) {
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    p[s] = pb_bf16_bits(v);
+    if (s + 1 < NS) v = v - __uint_as_float(p[s] << 16);      // exact residual
+  }
+}
+
+// W (Mo, Ko) fp32 [forward: Mo = Co, Ko = Ci;  for_bwd_data: the GEMM's output channels are Ci and it reduces over Co, W'[ci][co] =
+// W[co][ci]] -> image [chunk][mtile][plane][TM rows][16 k (halves swizzled by bit 3 of the row)] bf16, TM = 32 * MB
+template <int NS>
+__global__ __launch_bounds__(256) void pw_weight_split_kernel(const float *__restrict__ w, int Co, int Ci, int for_bwd_data, int TM,
+                                                              uint16_t *__restrict__ wts) {
+  const int KE = for_bwd_data ? Co : Ci, ME = for_bwd_data ? Ci : Co;
+  const int chunks = ceil_div(KE, kPbK), mtiles = ceil_div(ME, TM);
+  const long total = (long)chunks * mtiles * TM * kPbK;
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int k_l = (int)(e % kPbK), row = (int)((e / kPbK) % TM);
+  const long rest = e / ((long)kPbK * TM);
+  const int mt = (int)(rest % mtiles), chunk = (int)(rest / mtiles);
+  const int k = chunk * kPbK + k_l, m = mt * TM + row;
+  float v = 0.0f;
+  if (k < KE && m < ME) v = for_bwd_data ? w[(size_t)k * Ci + m] : w[(size_t)m * Ci + k];
+  uint32_t p[NS];
+  pb_split<NS>(v, p);
+  const int pos = ((k_l >> 3) ^ ((row >> 3) & 1)) * 8 + (k_l & 7);
+  const size_t blk = ((size_t)chunk * mtiles + mt) * ((size_t)NS * TM * kPbK);
+#pragma unroll
+  for (int s = 0; s < NS; ++s) wts[blk + ((size_t)s * TM + row) * kPbK + pos] = (uint16_t)p[s];
+}
+
+template <int NS, int MB>
+__global__ __launch_bounds__(256, 2) void pw_gemm_bf16_kernel(const float *__restrict__ x, const uint16_t *__restrict__ wts,
+                                                              const float *__restrict__ bias, float *__restrict__ y, int K, int M,
+                                                              int N, int tiles_n, int tiles_total, float2 *__restrict__ stats_part) {
+  constexpr int TM = 32 * MB, NBW = 2;
+  constexpr int WBLK = NS * TM * kPbK;                          // bf16 elements of one (chunk, mtile) weight block
+  __shared__ __attribute__((aligned(16))) uint32_t xs[NS * 8 * kPbN];       // [NS][8 channel pairs][256 points] words
+
+  // XCD-aware tile order: workgroup ids go round-robin over the 8 XCDs (each with its own L2).  The mtiles workgroups that
+  // share one 256-point tile of x get ids that are congruent mod 8 and adjacent in an XCD's queue, so x is fetched from HBM
+  // once and re-read from that XCD's L2 (otherwise the big GEMM moves x mtiles = 4 times: 1.5 GB, and is bandwidth-bound).
+  const int mtiles = ceil_div(M, TM);
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int tile = (slot / mtiles) * 8 + xcd, mt = slot - (slot / mtiles) * mtiles;
+  if (tile >= tiles_total) return;
+  const int b = tile / tiles_n, n0 = (tile - b * tiles_n) * kPbN, m0 = mt * TM;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, kh = lane >> 5;
+  const float *xb = x + (size_t)b * K * N;
+  const int chunks = ceil_div(K, kPbK);
+
+  int a_off[MB];                                                // A fragment uint4 offsets inside one plane slab
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const int row = mb * 32 + j;
+    a_off[mb] = (row * 8 + ((kh ^ ((row >> 3) & 1)) * 4)) >> 2;
+  }
+  int b_pt[NBW];                                                // this lane's point inside the tile, per column block
+#pragma unroll
+  for (int nb = 0; nb < NBW; ++nb) b_pt[nb] = wave * 64 + nb * 32 + j;
+  f32x16 acc[MB][NBW];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.0f;
+
+  // Staging: an item = (channel pair kp, point quad q): two fully coalesced float4 loads (4 consecutive points of channels
+  // 2kp and 2kp+1: a wave reads one whole 1 KiB channel row per instruction), split into NS bf16 pieces, packed pairwise and
+  // stored with ONE 16-byte LDS write per plane into xs[plane][kp][point] (points contiguous: conflict-free).  A lane's B
+  // fragment (8 consecutive channels of its point) is then 4 ds_read_b32 at stride 256 words (bank = point: conflict-free).
+  // (First version: scalar loads with (channel pair, point) items -- 16 cache lines per wave instruction; the kernel spent its
+  // time in the texture addresser and was no faster than fp32 MFMA.)
+  // Pipeline: the next chunk's rows are requested right after the barrier that publishes this chunk's tile (they land during
+  // its MFMAs); the next chunk's weight fragments as soon as this chunk's MFMAs have been issued.
+  constexpr int ITEMS = (kPbK / 2) * (kPbN / 4) / 256;          // 2 items per thread and chunk
+  float4 va[ITEMS], vb[ITEMS];
+  const bool vec = (N % 4 == 0) && aligned16(xb) && (n0 + kPbN <= N);
+  auto load_x = [&](int chunk) {
+    const int c0 = chunk * kPbK;
+#pragma unroll
+    for (int u = 0; u < ITEMS; ++u) {
+      const int e = u * 256 + tid;
+      const int q = e & 63, kp = e >> 6;                        // 64 point quads x 8 channel pairs
+      const int c = c0 + 2 * kp, n = n0 + 4 * q;
+      va[u] = vb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (vec) {
+        if (c < K) va[u] = *reinterpret_cast<const float4 *>(xb + (size_t)c * N + n);
+        if (c + 1 < K) vb[u] = *reinterpret_cast<const float4 *>(xb + (size_t)(c + 1) * N + n);
+      } else {
+        float a[4] = {0.f, 0.f, 0.f, 0.f}, bq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          if (n + t < N) {
+            if (c < K) a[t] = xb[(size_t)c * N + n + t];
+            if (c + 1 < K) bq[t] = xb[(size_t)(c + 1) * N + n + t];
+          }
+        va[u] = make_float4(a[0], a[1], a[2], a[3]);
+        vb[u] = make_float4(bq[0], bq[1], bq[2], bq[3]);
+      }
+    }
+  };
+  uint4 af[MB][NS];
+  auto load_a = [&](int chunk) {
+    const uint4 *wq = reinterpret_cast<const uint4 *>(wts + ((size_t)chunk * mtiles + mt) * WBLK);
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int s = 0; s < NS; ++s) af[mb][s] = wq[s * (TM * kPbK / 8) + a_off[mb]];
+  };
+  load_x(0);
+  load_a(0);
+  for (int chunk = 0; chunk < chunks; ++chunk) {
+    __syncthreads();                                            // previous chunk's fragment reads are done
+#pragma unroll
+    for (int u = 0; u < ITEMS; ++u) {
+      const int e = u * 256 + tid;
+      const int q = e & 63, kp = e >> 6;
+      const float a[4] = {va[u].x, va[u].y, va[u].z, va[u].w}, bq[4] = {vb[u].x, vb[u].y, vb[u].z, vb[u].w};
+      uint32_t w[NS][4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        uint32_t pa[NS], pb[NS];
+        pb_split<NS>(a[t], pa);
+        pb_split<NS>(bq[t], pb);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) w[s][t] = pa[s] | (pb[s] << 16);
+      }
+#pragma unroll
+      for (int s = 0; s < NS; ++s)
+        *reinterpret_cast<uint4 *>(xs + (s * 8 + kp) * kPbN + 4 * q) = make_uint4(w[s][0], w[s][1], w[s][2], w[s][3]);
+    }
+    __syncthreads();
+    if (chunk + 1 < chunks) load_x(chunk + 1);                  // in flight during this chunk's MFMAs
+    uint4 bf[NBW][NS];
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const uint32_t *col = xs + (s * 8 + 4 * kh) * kPbN + b_pt[nb];
+        bf[nb][s] = make_uint4(col[0], col[kPbN], col[2 * kPbN], col[3 * kPbN]);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+#define PVCNN_PB_MFMA(SA, SB)                                                                                            \
+    _Pragma("unroll") for (int nb = 0; nb < NBW; ++nb)                                                                   \
+    _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                                                                    \
+      acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[mb][SA]),                      \
+                                                            __builtin_bit_cast(bf16x8, bf[nb][SB]), acc[mb][nb], 0, 0, 0)
+    if constexpr (NS == 1) {
+      PVCNN_PB_MFMA(0, 0);
+    } else {
+      PVCNN_PB_MFMA(2, 0); PVCNN_PB_MFMA(1, 1); PVCNN_PB_MFMA(0, 2);    // smallest partial products first
+      PVCNN_PB_MFMA(1, 0); PVCNN_PB_MFMA(0, 1);
+      PVCNN_PB_MFMA(0, 0);
+    }
+#undef PVCNN_PB_MFMA
+    __builtin_amdgcn_sched_barrier(0);
+    if (chunk + 1 < chunks) load_a(chunk + 1);                  // overwrites af once this chunk's MFMAs have been issued
+  }
+
+  // ---- epilogue: D[i = m][j = point]; lanes = consecutive points (128-byte rows) ----
+  const bool want_stats = stats_part != nullptr;
+  float2 *stat_lds = reinterpret_cast<float2 *>(xs);            // [4 waves][TM]
+  if (want_stats) __syncthreads();
+  float *yb = y + (size_t)b * M * N;
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    float bv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+      bv[r] = (bias != nullptr && m < M) ? bias[m] : 0.0f;
+    }
+    float ss[16], qq[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ss[r] = qq[r] = 0.0f;
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb) {
+      const int n = n0 + wave * 64 + nb * 32 + j;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        float v = acc[mb][nb][r];
+        if (want_stats) {                                       // statistics of (y - bias), see bn_finalize_kernel
+          const float mv = n < N ? v : 0.0f;
+          ss[r] += mv;
+          qq[r] += mv * mv;
+        }
+        v += bv[r];
+        if (n < N && m < M) yb[(size_t)m * N + n] = v;
+      }
+    }
+    if (want_stats) {
+      const float st = half_wave_sum16(ss, j), qt = half_wave_sum16(qq, j);
+      const int rr = (j >> 1) & 15;
+      if ((j & 1) == 0) stat_lds[wave * TM + mb * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * kh] = make_float2(st, qt);
+    }
+  }
+  if (want_stats) {
+    __syncthreads();
+    if (tid < TM && m0 + tid < M) {
+      float2 t = stat_lds[tid];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) { t.x += stat_lds[w * TM + tid].x; t.y += stat_lds[w * TM + tid].y; }
+      stats_part[(size_t)(m0 + tid) * tiles_total + tile] = t;
+    }
+  }
+}
+
+static int pb_mb(int M) { return M > 64 ? 4 : 2; }
+
+}  // namespace pvcnn
+
+using namespace pvcnn;
+
+extern "C" size_t pvcnn_pwconv_weight_split_bytes(int Co, int Ci, int for_bwd_data, int nsplit) {
+  if (Co <= 0 || Ci <= 0 || (nsplit != 1 && nsplit != 3)) return 0;
+  const int KE = for_bwd_data ? Co : Ci, ME = for_bwd_data ? Ci : Co;
+  const int TM = 32 * pb_mb(ME);
+  return (size_t)ceil_div(KE, kPbK) * ceil_div(ME, TM) * nsplit * TM * kPbK * sizeof(uint16_t);
+}
+
+extern "C" int pvcnn_pwconv_weight_split(const float *w, int Co, int Ci, int for_bwd_data, int nsplit, void *wts, void *stream) {
+  PVCNN_REQUIRE(w && wts && Co > 0 && Ci > 0, "bad argument");
+  PVCNN_REQUIRE(nsplit == 1 || nsplit == 3, "nsplit must be 1 (bf16) or 3 (bf16x3)");
+  PVCNN_REQUIRE(aligned16(wts), "wts must be 16-byte aligned");
+  const int KE = for_bwd_data ? Co : Ci, ME = for_bwd_data ? Ci : Co;
+  const int TM = 32 * pb_mb(ME);
+  const long total = (long)ceil_div(KE, kPbK) * ceil_div(ME, TM) * TM * kPbK;
+  const dim3 grid((unsigned)((total + 255) / 256));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (nsplit == 1) hipLaunchKernelGGL(pw_weight_split_kernel<1>, grid, dim3(256), 0, s, w, Co, Ci, for_bwd_data, TM, static_cast<uint16_t *>(wts));
+  else             hipLaunchKernelGGL(pw_weight_split_kernel<3>, grid, dim3(256), 0, s, w, Co, Ci, for_bwd_data, TM, static_cast<uint16_t *>(wts));
+  return check_launch("pwconv_weight_split");
+}
+
+extern "C" size_t pvcnn_pwconv_fwd_split_stats_parts(int B, int N) {
+  if (B <= 0 || N <= 0) return 0;
+  return (size_t)B * ceil_div(N, kPbN);
+}
+
+// y (B,M,N) = W x + bias with the pre-split weights (forward: K = Ci, M = Co; backward-data: x = grad_y, K = Co, M = Ci, bias NULL,
+// for_bwd_data = 1 image).  stats_part: NULL or (M, *_split_stats_parts) float pairs of (sum, sum of squares) of (y - bias).
+extern "C" int pvcnn_pwconv_fwd_split(const float *x, const void *wts, const float *bias, int B, int K, int M, int N, int nsplit,
+                                      float *y, float *stats_part, void *stream) {
+  PVCNN_REQUIRE(B >= 0 && K > 0 && M > 0 && N >= 0, "bad size");
+  PVCNN_REQUIRE(nsplit == 1 || nsplit == 3, "nsplit must be 1 (bf16) or 3 (bf16x3)");
+  if (B == 0 || N == 0) return 0;
+  PVCNN_REQUIRE(x && wts && y && aligned16(wts), "null or misaligned pointer");
+  PVCNN_REQUIRE(!stats_part || (reinterpret_cast<uintptr_t>(stats_part) & 7) == 0, "stats_part must be 8-byte aligned");
+  PVCNN_REQUIRE((long)N * std::max(K, M) <= 0x7fffffffL, "cloud too large");
+  const int tiles_n = ceil_div(N, kPbN), MB = pb_mb(M);
+  const long tiles_total = (long)B * tiles_n;
+  const long wgs = ((tiles_total + 7) / 8) * 8 * ceil_div(M, 32 * MB);       // tiles padded to the 8 XCDs
+  PVCNN_REQUIRE(wgs <= 0x7fffffffL, "grid too large");
+  const dim3 grid((unsigned)wgs);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const uint16_t *w16 = static_cast<const uint16_t *>(wts);
+  float2 *sp = reinterpret_cast<float2 *>(stats_part);
+#define PVCNN_PB_LAUNCH(NSV, MBV) hipLaunchKernelGGL((pw_gemm_bf16_kernel<NSV, MBV>), grid, dim3(256), 0, s, x, w16, bias, y, K, M, N, tiles_n, (int)tiles_total, sp)
+  if (nsplit == 3) { if (MB == 4) PVCNN_PB_LAUNCH(3, 4); else PVCNN_PB_LAUNCH(3, 2); }
+  else             { if (MB == 4) PVCNN_PB_LAUNCH(1, 4); else PVCNN_PB_LAUNCH(1, 2); }
+#undef PVCNN_PB_LAUNCH
+  return check_launch("pwconv_fwd_split");
+}

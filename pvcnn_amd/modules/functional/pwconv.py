@@ -20,12 +20,16 @@ class PointwiseConv(Function):
         ctx.save_for_backward(x3, w2)
         ctx.has_bias, ctx.x_shape, ctx.w_shape = bias is not None, shape, weight.shape
         b = bias.contiguous() if bias is not None else None
+        be = native()
+        # opt-in: the three-way bf16 split on the bf16 matrix cores (csrc/pointwise_bf16.hip; 0.9-1.14x here, see its header)
+        ctx.split = 3 if (getattr(be, 'has_pwconv_split', False) and getattr(be, 'pw_math', 'fp32') == 'bf16x3') else 0
+        run = (lambda **kw: be.pwconv_forward_split(x3, w2, b, ctx.split, **kw)) if ctx.split else (lambda **kw: be.pwconv_forward(x3, w2, b, **kw))
         if want_stats:   # second output: BatchNorm partial sums from the epilogue (not differentiable)
-            y, part = native().pwconv_forward(x3, w2, b, want_stats=True)
+            y, part = run(want_stats=True)
             ctx.mark_non_differentiable(part)
             ctx.set_materialize_grads(False)     # no zero tensor for the (non-existent) gradient of `part`
             return y.view(shape[0], w2.shape[0], *shape[2:]), part
-        return native().pwconv_forward(x3, w2, b).view(shape[0], w2.shape[0], *shape[2:])
+        return run().view(shape[0], w2.shape[0], *shape[2:])
 
     @staticmethod
     @amp_bwd
@@ -34,7 +38,9 @@ class PointwiseConv(Function):
         if grad_y is None:
             return None, None, None, None
         g3 = grad_y.contiguous().view(x3.shape[0], w2.shape[0], -1)
-        gx = native().pwconv_backward_data(g3, w2).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = (native().pwconv_backward_data_split(g3, w2, ctx.split) if ctx.split else native().pwconv_backward_data(g3, w2)).view(ctx.x_shape)
         want_bias = ctx.has_bias and ctx.needs_input_grad[2]
         gw = gb = None
         if ctx.needs_input_grad[1]:

@@ -99,3 +99,23 @@ def test_pointwise_conv_is_deterministic(hip):
         outs.append((y.detach().clone(), x.grad.clone(), w.grad.clone(), bias.grad.clone()))
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('b,ci,co,n', [(2, 9, 64, 4096), (3, 64, 128, 1000), (1, 130, 70, 513), (2, 1472, 512, 2048), (1, 16, 13, 7), (2, 128, 1024, 1024)])
+def test_pointwise_gemm_on_the_bf16_matrix_cores(hip, b, ci, co, n):
+    """csrc/pointwise_bf16.hip (opt-in, `pw_math = 'bf16x3'`): the exact three-way bf16 split meets the same 1e-5 bar as the
+    fp32-MFMA kernels -- forward with bias and BatchNorm epilogue statistics, backward-data -- for ragged K, M and N;
+    plain bf16 operands: 4e-3."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(b, ci, n, generator=g).to(DEV)
+    w = (torch.randn(co, ci, generator=g) * 0.1).to(DEV)
+    bias = torch.randn(co, generator=g).to(DEV)
+    gy = torch.randn(b, co, n, generator=g).to(DEV)
+    ref = torch.einsum('oc,bcn->bon', w.double(), x.double()) + bias.double().view(1, -1, 1)
+    y, part = hip.pwconv_forward_split(x, w, bias, 3, want_stats=True)
+    assert _rel(y, ref) < 1e-5
+    centred = (y.double() - bias.double().view(1, -1, 1)).transpose(0, 1).reshape(co, -1)
+    sums = part.double().sum(dim=1)
+    assert _rel(sums[:, 0], centred.sum(dim=1)) < 1e-5 and _rel(sums[:, 1], (centred * centred).sum(dim=1)) < 1e-5
+    assert _rel(hip.pwconv_backward_data_split(gy, w, 3), torch.einsum('oc,bon->bcn', w.double(), gy.double())) < 1e-5
+    assert _rel(hip.pwconv_forward_split(x, w, bias, 1), ref) < 4e-3

@@ -33,6 +33,17 @@ for (b, ci, co, n) in shapes:
     bias = torch.randn(co, device=dev)
     gy = torch.randn(b, co, n, device=dev)
     fl = 2.0 * b * n * ci * co
+    f3 = t(lambda: be.pwconv_forward_split(x, w, bias, 3))
+    d3 = t(lambda: be.pwconv_backward_data_split(gy, w, 3))
+    f1 = t(lambda: be.pwconv_forward_split(x, w, bias, 1))
+    ref = F.conv1d(x.double(), w.double().view(co, ci, 1), bias.double())
+    e3 = ((be.pwconv_forward_split(x, w, bias, 3).double() - ref).abs().max() / ref.abs().max()).item()
+    e1 = ((be.pwconv_forward_split(x, w, bias, 1).double() - ref).abs().max() / ref.abs().max()).item()
+    e0 = ((be.pwconv_forward(x, w, bias).double() - ref).abs().max() / ref.abs().max()).item()
+    gxr = torch.einsum('oc,bon->bcn', w.double(), gy.double())
+    ed3 = ((be.pwconv_backward_data_split(gy, w, 3).double() - gxr).abs().max() / gxr.abs().max()).item()
+    print(json.dumps({'split_BCiCoN': [b, ci, co, n], 'bf16x3_fwd_ms': round(f3, 4), 'bf16x3_fwd_eff_TF': round(fl / f3 / 1e9, 1), 'bf16x3_bwd_data_ms': round(d3, 4),
+                      'bf16_fwd_ms': round(f1, 4), 'err_fp32mfma': e0, 'err_bf16x3': e3, 'err_bf16x3_bwd_data': ed3, 'err_bf16': e1}), flush=True)
     f = t(lambda: be.pwconv_forward(x, w, bias))
     d = t(lambda: be.pwconv_backward_data(gy, w))
     g = t(lambda: be.pwconv_backward_weight(x, gy, with_bias=True))
