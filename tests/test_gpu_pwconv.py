@@ -8,6 +8,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
 
 SHAPES = [  # (B, Ci, Co, spatial)
     (2, 9, 64, (4096,)),        # PVConv point branch, first layer (fast path)
