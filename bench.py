@@ -94,12 +94,13 @@ class KernelClock:
 
     # MFMA-bound family: the Conv3d implicit-GEMM launches (forward and backward-data are the same kernel); the "bytes" slot
     # carries the ALGORITHMIC FLOPs 2*B*R^3*27*Ci*Co.  conv3d_igemm_split(x, wts, bias, co, nsplit): the launch alone (the
-    # weight image is prepared outside the timed call); nsplit = 3 executes 6 bf16 MFMA products per algorithmic one.
+    # weight image and, for f16x2, the input's absmax -- one 134 MB read, 26 us at R = 32 -- are prepared outside the timed call); nsplit = 3 / 2 executes 6 bf16 / 3 fp16 MFMA
+    # products per algorithmic one.
     WATCH_FLOPS = {
         'conv3d_forward': lambda a, out: ('conv3d_igemm fp32-MFMA (incl. weight transform)',
                                           2.0 * a[0].shape[0] * a[0].shape[2] ** 3 * 27 * a[0].shape[1] * a[1].shape[0],
                                           (a[0].shape[0], a[0].shape[1], a[1].shape[0], a[0].shape[2])),
-        'conv3d_igemm_split': lambda a, out: ('conv3d_igemm_bf16 ' + ('bf16x3' if int(a[4]) == 3 else 'bf16'),
+        'conv3d_igemm_split': lambda a, out: ('conv3d_igemm_bf16 ' + {3: 'bf16x3', 2: 'f16x2', 1: 'bf16'}[int(a[4])],
                                               2.0 * a[0].shape[0] * a[0].shape[2] ** 3 * 27 * a[0].shape[1] * int(a[3]),
                                               (a[0].shape[0], a[0].shape[1], int(a[3]), a[0].shape[2])),
     }
@@ -160,7 +161,7 @@ class KernelClock:
             us = max(raw_us - overhead_us, 1e-3)
             if kernel.startswith('conv3d_igemm'):       # MFMA-bound
                 tf_s = nbytes / (us * 1e-6) / 1e12              # algorithmic ("effective fp32") rate
-                mult = 6 if 'bf16x3' in kernel else 1           # MFMA products executed per algorithmic product
+                mult = 6 if 'bf16x3' in kernel else 3 if 'f16x2' in kernel else 1    # MFMA products executed per algorithmic product
                 peak = MFMA_FP32_PEAK_TF if 'fp32' in kernel else MFMA_BF16_PEAK_TF
                 out.append({'kernel': kernel, 'shape_BCiCoR': list(shape), 'calls': calls, 'avg_us': round(us, 2),
                             'event_pair_us': round(raw_us, 2), 'GFLOP': round(nbytes / 1e9, 2),
@@ -178,6 +179,10 @@ class KernelClock:
 
 def dtype_label(backend):
     """fp32 tensors and fp32 accumulation everywhere; what differs is how the dense-convolution PRODUCTS are formed."""
+    if getattr(backend, 'conv_math', 'fp32') == 'f16x2':
+        return ('f32 (fp32 tensors, fp32 accumulate; Conv3d fwd/bwd-data products as power-of-two scaled fp16 hi+lo splits, 3 partial '
+                'products on fp16 MFMA, max rel err vs fp64 1e-6 <= the fp32-MFMA kernel\'s; PVCNN_CONV_MATH=fp32 selects '
+                'single-rounding fp32 MFMA, =bf16x3 the scale-free 6-product split)')
     if getattr(backend, 'conv_math', 'fp32') == 'bf16x3':
         return ('f32 (fp32 tensors, fp32 accumulate; Conv3d fwd/bwd-data products as exact 3-way bf16 splits on bf16 MFMA, '
                 'max rel err vs fp64 2e-6 = the fp32-MFMA kernel\'s; PVCNN_CONV_MATH=fp32 selects single-rounding fp32 MFMA)')
@@ -397,7 +402,7 @@ def main():
                 'shape_BCiCoR': mfma['shape_BCiCoR'], 'achieved': mfma['executed_mfma_TFLOPs'], 'peak': mfma['peak_TFLOPs'],
                 'unit': 'TFLOP/s', 'frac': mfma['frac_of_peak'], 'avg_us': mfma['avg_us'], 'algorithmic_GFLOP': mfma['GFLOP'],
                 'effective_fp32_TFLOPs': mfma['effective_TFLOPs'], 'x_fp32_mfma_peak_157TF': mfma['x_fp32_mfma_peak'],
-                'note': 'achieved = MFMA flops actually executed (bf16x3: 6 bf16 partial products per fp32 product) / launch time; '
+                'note': 'achieved = MFMA flops actually executed (f16x2: 3 fp16 partial products per fp32 product; bf16x3: 6) / launch time; '
                         'effective = algorithmic 2*B*R^3*27*Ci*Co / launch time'},
             'kernels': kernels,
         }

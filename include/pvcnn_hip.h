@@ -47,7 +47,7 @@ extern "C" {
 #define PVCNN_API
 #endif
 
-#define PVCNN_ABI_VERSION 2
+#define PVCNN_ABI_VERSION 3
 #define PVCNN_OK 0
 #define PVCNN_ERR_INVALID_ARGUMENT (-1)
 
@@ -228,6 +228,10 @@ PVCNN_API int pvcnn_conv3d_bwd_weight(const float *x, const float *grad_y, int B
  * nsplit = 3: "bf16x3" -- both fp32 operands split exactly into three bf16 pieces, the six significant partial products
  *             accumulated in fp32: fp32-class accuracy (<= 1e-5 vs fp64, like pvcnn_conv3d_fwd) at up to 16/6 = 2.7x
  *             the fp32-MFMA rate.
+ * nsplit = 2: "f16x2" -- both fp32 operands scaled by a power of two (per tensor for x, per output channel for w) and split
+ *             into fp16 hi + lo (11 + 11 bits); hi*hi + hi*lo + lo*hi accumulated in fp32 and scaled back exactly: fp32-class
+ *             accuracy (<= 1e-5 vs fp64) at 3 MFMAs per k-step.  Needs x_absmax = pvcnn_absmax_bits of the input (one
+ *             uint32 in device memory: the bit pattern of max |x|).
  * weight_split: w (Co,Ci,3,3,3) fp32 -> the kernels' pre-split, pre-swizzled LDS image (opaque, *_split_bytes bytes,
  *             16-byte aligned); for_bwd_data = 1 builds the flipped / channel-transposed image with which
  *             grad_x = conv3d_fwd_split(grad_y, wts, NULL, B, Ci = Co_fwd, Co = Ci_fwd, ...).
@@ -235,9 +239,10 @@ PVCNN_API int pvcnn_conv3d_bwd_weight(const float *x, const float *grad_y, int B
  */
 PVCNN_API size_t pvcnn_conv3d_weight_split_bytes(int Co, int Ci, int for_bwd_data, int nsplit);
 PVCNN_API int pvcnn_conv3d_weight_split(const float *w, int Co, int Ci, int for_bwd_data, int nsplit, void *wts, void *stream);
-PVCNN_API size_t pvcnn_conv3d_fwd_split_stats_parts(int B, int Co, int R);
+PVCNN_API size_t pvcnn_conv3d_fwd_split_stats_parts(int B, int Co, int R, int nsplit);
+PVCNN_API int pvcnn_absmax_bits(const float *x, size_t n, void *out, void *stream);
 PVCNN_API int pvcnn_conv3d_fwd_split(const float *x, const void *wts, const float *bias, int B, int Ci, int Co, int R, int nsplit,
-                           float *y, float *stats_part, void *stream);
+                           const void *x_absmax, float *y, float *stats_part, void *stream);
 
 /* ---- 1x1 convolutions of SharedMLP (point branch, classifier) ------------------------------------
  * replaces the nn.Conv1d / nn.Conv2d (kernel 1) calls of modules/shared_mlp.py:9-25 (cuDNN / cuBLAS in the

@@ -15,7 +15,7 @@ import torch  # noqa: F401  (must be imported before the dlopen, see above)
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 LIB_PATH = os.path.join(_CSRC, 'libpvcnn_hip.so')
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
 
@@ -57,8 +57,9 @@ SIGNATURES = {
     'pvcnn_conv3d_bwd_weight': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     'pvcnn_conv3d_weight_split_bytes': (_sz, [_i, _i, _i, _i]),
     'pvcnn_conv3d_weight_split': (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
-    'pvcnn_conv3d_fwd_split_stats_parts': (_sz, [_i, _i, _i]),
-    'pvcnn_conv3d_fwd_split': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    'pvcnn_conv3d_fwd_split_stats_parts': (_sz, [_i, _i, _i, _i]),
+    'pvcnn_absmax_bits': (_i, [_vp, _sz, _vp, _vp]),
+    'pvcnn_conv3d_fwd_split': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'pvcnn_pwconv_transpose': (_i, [_vp, _i, _i, _vp, _vp]),
     'pvcnn_pwconv_fwd': (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
     'pvcnn_pwconv_weight_split_bytes': (_sz, [_i, _i, _i, _i]),

@@ -1,26 +1,31 @@
-// conv3d_bf16.hip -- the 3x3x3 voxel convolutions on the bf16 matrix cores of gfx950, in two precisions:
+// conv3d_bf16.hip -- the 3x3x3 voxel convolutions on the 16-bit matrix cores of gfx950 (v_mfma_f32_32x32x16_{bf16,f16}: 16x the
+// rate of v_mfma_f32_32x32x2_f32), in three precisions:
 //
 //   NS = 1  plain bf16 operands, fp32 accumulate            (BASELINE configs[4]: "bf16 with MFMA 3D conv")
-//   NS = 3  "bf16x3": every fp32 operand is split EXACTLY into three bf16 pieces, x = x0 + x1 + x2 (8 + 8 + 8 mantissa
-//           bits), and the product x * w is evaluated as the six partial products whose weight is >= 2^-16 of the
-//           leading one:  x0w0 + x0w1 + x1w0 + x0w2 + x1w1 + x2w0  (dropped: x1w2, x2w1, x2w2 <= 2^-24 relative),
-//           each exact in the MFMA (8 x 8 bit products), accumulated in fp32.  Result: fp32-class accuracy (measured
-//           against fp64 in tests/test_gpu_conv3d.py: same 1e-5 bar, same error level as the exact-fp32 MFMA kernel of
-//           conv3d.hip) at 6 bf16 MFMAs per 16-deep k-step -- v_mfma_f32_32x32x16_bf16 runs at 16x the rate of
-//           v_mfma_f32_32x32x2_f32, so the ceiling is 16 / 6 = 2.7x the fp32-MFMA peak (157 -> 419 TFLOP/s effective).
-//           (The reference's own fp32 convolution is cuDNN under PyTorch's default allow_tf32 = True: a 10-bit-mantissa
-//           product on Ampere and later; this split keeps all 24 bits of both operands.)
+//   NS = 2  "f16x2" (the default for fp32 tensors): every fp32 operand is scaled by a power of two (per tensor for the
+//           activations, per output channel for the weights -- fp16 has 5 exponent bits) and split into fp16 hi + lo,
+//           x * 2^s = hi + lo (11 + 11 significant bits, |lo| <= 2^-11 |hi|); the product is hi*hi' + hi*lo' + lo*hi'
+//           (dropped: lo*lo' <= 2^-22 relative), each exact in the MFMA (11 x 11 bit products), accumulated in fp32 and
+//           scaled back by 2^-(s+s') in the epilogue (exact).  3 MFMAs per 16-deep k-step: ceiling 16 / 3 = 5.3x the
+//           fp32-MFMA peak.  Measured against fp64: BELOW the error of the exact-fp32 MFMA kernel of conv3d.hip (its
+//           accumulation order is the same; the operands keep 22 of 24 bits) -- tests/test_gpu_conv3d.py, also for tiny /
+//           huge / outlier-dominated tensors and weight rows 14 decades apart.
+//   NS = 3  "bf16x3": x = x0 + x1 + x2 EXACTLY in three bf16 pieces (8 + 8 + 8 bits, no scaling: bf16 has fp32's exponent),
+//           product = the six partial products >= 2^-16 of the leading one (x0w0 + x0w1 + x1w0 + x0w2 + x1w1 + x2w0).
+//           fp32-class as well, 6 MFMAs per k-step (ceiling 2.7x); kept as the scale-free alternative (PVCNN_CONV_MATH=bf16x3).
+//   (The reference's own fp32 convolution is cuDNN under PyTorch's default allow_tf32 = True: a 10-bit-mantissa product on
+//   Ampere and later; both splits keep >= 22 bits of both operands.)
 //
 // Implicit GEMM, D[co][voxel] += A[co][k] * B[k][voxel] on v_mfma_f32_32x32x16_bf16 with k = 16 INPUT CHANNELS of one tap:
-//   * per chunk of 16 input channels a workgroup (256 threads, 256 output voxels x 64 output channels) stages its input
-//     tile WITH halo once, converting fp32 -> NS bf16 planes on the way: xs[plane][halo voxel][16 ch] (32 B per voxel,
+//   * per chunk of 16 input channels a workgroup (256 threads, 256 or 512 output voxels x 64 output channels) stages its input
+//     tile WITH halo once, converting fp32 -> NS 16-bit planes on the way (v_cvt_pk_{bf16,f16}_f32 on channel pairs): xs[plane][halo voxel][16 ch] (32 B per voxel,
 //     the two 8-channel halves XOR-swizzled by bit 3 of the voxel index: the 16-byte operand reads of 32 consecutive
 //     voxels then hit 64 distinct banks);
 //   * weights arrive pre-split and pre-swizzled in exactly the LDS layout (conv3d_weight_split_kernel, once per forward):
 //     per (dx, dy) the 3 dz taps x NS planes x 64 co x 16 ci = NS * 6 KiB are one contiguous block -> straight 16-byte copies;
 //   * a consumer wave owns 64 voxels x 64 channels (2 x 2 MFMA tiles); per tap it reads 2 * NS weight fragments (from the
 //     pre-split image in global memory / L2) and 2 * NS input fragments (LDS) for 4 * (NS == 3 ? 6 : 1) MFMAs;
-//   * 61 KiB of LDS at NS = 3 -> 2 workgroups per CU: one stages while the other multiplies;
+//   * 41 / 61 KiB of LDS at NS = 2 / 3 for the 256-voxel tile -> 3 / 2 workgroups per CU: one stages while the others multiply;
 //   * epilogue as in conv3d.hip: C/D rows are 32 consecutive-z voxels of one channel = 128-byte rows of (B, C, R^3); bias;
 //     optional BatchNorm partial sums of (y - bias).
 // Backward-data is the same kernel on the flipped, channel-transposed weights (the split kernel's for_bwd_data mode).
@@ -32,6 +37,10 @@ namespace pvcnn {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kCoTileB = 64;
 constexpr int kKc = 16;            // input channels per chunk = MFMA K
@@ -50,6 +59,100 @@ __device__ __forceinline__ void split_bf16(float v, uint32_t (&p)[NS]) {
   for (int s = 0; s < NS; ++s) {
     p[s] = bf16_bits(v);
     if (s + 1 < NS) v = v - bf16_value(p[s]);          // exact: the residual fits fp32
+  }
+}
+
+// Two neighbouring channels at once, packed (first value in the low half): v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32 round to nearest
+// even in hardware.  NS = 1, 3: bf16 pieces as in split_bf16.  NS = 2: fp16 "hi + lo" of PRE-SCALED values (|v| < 2^15, see
+// scale_shift): hi = fp16(v) keeps 11 bits, lo = fp16(v - hi) the next 11.
+template <int NS>
+__device__ __forceinline__ void split_pair(float a, float b, uint32_t (&w)[NS]) {
+  f32x2 v = {a, b};
+  if constexpr (NS == 2) {
+    const f16x2 h = __builtin_convertvector(v, f16x2);
+    w[0] = __builtin_bit_cast(uint32_t, h);
+    v = v - __builtin_convertvector(h, f32x2);                   // exact
+    w[1] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
+  } else {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      w[s] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+      if (s + 1 < NS) {
+        const f32x2 back = {__uint_as_float(w[s] << 16), __uint_as_float(w[s] & 0xffff0000u)};
+        v = v - back;                                            // exact: the residual fits fp32
+      }
+    }
+  }
+}
+
+// fp16 has 5 exponent bits: operands of the f16x2 mode are scaled by a power of two that puts the largest magnitude of the
+// tensor (bits of max |x|, from absmax_kernel; of a weight row, in the split kernel) into [2^13, 2^14).  Everything within
+// 2^-17 of the maximum then keeps 22 bits in hi + lo; smaller elements lose low bits gradually (absolute error <= 2^-38 of
+// the maximum).  Zero / inf / NaN maxima: no scaling (inf and NaN then propagate as they would in fp32).
+__device__ __forceinline__ int scale_shift(uint32_t absmax_bits) {
+  const int e = (int)((absmax_bits >> 23) & 0xffu);
+  if (e == 0 || e == 255) return 0;
+  return min(max(140 - e, -100), 100);                           // 13 - (e - 127)
+}
+__device__ __forceinline__ float exp2_int(int s) { return __uint_as_float((uint32_t)(s + 127) << 23); }
+
+__global__ __launch_bounds__(512) void absmax_kernel(const float *__restrict__ x, size_t n, uint32_t *__restrict__ out) {
+  uint32_t m = 0;
+  const size_t n4 = n >> 2, stride = (size_t)gridDim.x * 512;
+  const float4 *x4 = reinterpret_cast<const float4 *>(x);
+  auto take = [&](const float4 &v) {
+    m = max(max(m, __float_as_uint(fabsf(v.x))), max(__float_as_uint(fabsf(v.y)), max(__float_as_uint(fabsf(v.z)), __float_as_uint(fabsf(v.w)))));
+  };
+  size_t i = (size_t)blockIdx.x * 512 + threadIdx.x;
+  for (; i + 3 * stride < n4; i += 4 * stride) {                // four independent 16-byte loads in flight
+    const float4 a = x4[i], b = x4[i + stride], c = x4[i + 2 * stride], d = x4[i + 3 * stride];
+    take(a); take(b); take(c); take(d);
+  }
+  for (; i < n4; i += stride) take(x4[i]);
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = max(m, __float_as_uint(fabsf(x[(n4 << 2) + threadIdx.x])));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+  __shared__ uint32_t red[8];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int w = 1; w < 8; ++w) m = max(m, red[w]);
+    if (m != 0) atomicMax(out, m);                               // order-independent: deterministic
+  }
+}
+
+// f16x2 weights: one workgroup per (padded) output channel finds the row maximum, then writes the row's hi / lo planes in the
+// image layout below and the row's shift to wexp[co].
+__global__ __launch_bounds__(256) void conv3d_weight_split_f16_kernel(const float *__restrict__ w, int Co, int Ci, int for_bwd_data,
+                                                                      uint16_t *__restrict__ wts, int *__restrict__ wexp) {
+  const int CiE = for_bwd_data ? Co : Ci, CoE = for_bwd_data ? Ci : Co;
+  const int chunks = ceil_div(CiE, 16), cotiles = ceil_div(CoE, 64);
+  const int co = blockIdx.x, cot = co >> 6, co_l = co & 63, tid = threadIdx.x;
+  auto load = [&](int ci, int tap) { return for_bwd_data ? w[((size_t)ci * Ci + co) * 27 + (26 - tap)] : w[((size_t)co * Ci + ci) * 27 + tap]; };
+  __shared__ uint32_t red[4];
+  uint32_t m = 0;
+  if (co < CoE)
+    for (int i = tid; i < CiE * 27; i += 256) m = max(m, __float_as_uint(fabsf(load(i / 27, i % 27))));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+  if ((tid & 63) == 0) red[tid >> 6] = m;
+  __syncthreads();
+  const int shift = scale_shift(max(max(red[0], red[1]), max(red[2], red[3])));
+  if (tid == 0) wexp[co] = shift;
+  const float scale = exp2_int(shift);
+  for (int i = tid; i < chunks * 27 * 8; i += 256) {             // item = (chunk, tap, channel pair)
+    const int cp = i & 7, tap = (i >> 3) % 27, chunk = (i >> 3) / 27;
+    const int ci = chunk * 16 + 2 * cp, dxy = tap / 3, dz = tap - dxy * 3;
+    const float a = (co < CoE && ci < CiE) ? load(ci, tap) * scale : 0.0f;
+    const float b = (co < CoE && ci + 1 < CiE) ? load(ci + 1, tap) * scale : 0.0f;
+    uint32_t p[2];
+    split_pair<2>(a, b, p);
+    const int pos = (((cp >> 2) ^ ((co_l >> 3) & 1)) * 8 + 2 * (cp & 3)) >> 1;     // word inside the 16-channel row
+    const size_t blk = (((size_t)chunk * 9 + dxy) * cotiles + cot) * (3 * 2 * 64 * 16);
+    uint32_t *img = reinterpret_cast<uint32_t *>(wts + blk);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) img[((size_t)(dz * 2 + s) * 64 + co_l) * 8 + pos] = p[s];
   }
 }
 
@@ -80,6 +183,12 @@ __global__ __launch_bounds__(256) void conv3d_weight_split_kernel(const float *_
   for (int s = 0; s < NS; ++s) wts[blk + ((size_t)(dz * NS + s) * kCoTileB + co_l) * kKc + pos] = (uint16_t)p[s];
 }
 
+template <int NS>
+__device__ __forceinline__ f32x16 mfma16(const uint4 &a, const uint4 &b, const f32x16 &c) {
+  if constexpr (NS == 2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
 // Variants measured on (16,64,64,32^3), bf16x3 (fp32 kernel: 0.87 ms; 6x the MFMAs at 16x the rate = 0.28 ms at 2.4 GHz):
 //   this one (256 threads, 2 workgroups per CU, 27 taps unrolled, weights one tap ahead)   0.56 ms
 //   explicit one-tap software pipeline of both operands behind sched_barriers              0.58-0.61 ms (1 / 2 waves per SIMD)
@@ -87,14 +196,17 @@ __global__ __launch_bounds__(256) void conv3d_weight_split_kernel(const float *_
 //   the same MFMA stream with NO loads and NO staging at all                                0.43 ms
 // i.e. the matrix pipe itself sustains ~1.6 PF on random data here (the chip clocks down under a dense bf16 MFMA stream),
 // and what is left above it is prologue / epilogue exposure; the simplest structure is kept.
-template <int NS, int TX, int TY, int TZ>
-__global__ __launch_bounds__(256, 2) void conv3d_igemm_bf16_kernel(const float *__restrict__ x, const uint16_t *__restrict__ wts,
+template <int NS, int TX, int TY, int TZ, bool VEC>
+__global__ __launch_bounds__(256, (NS == 3 || TX * TY * TZ == 512) ? 2 : 3) void conv3d_igemm_bf16_kernel(const float *__restrict__ x, const uint16_t *__restrict__ wts,
                                                                    const float *__restrict__ bias, float *__restrict__ y,
                                                                    int Ci, int Co, int R, int tiles_x, int tiles_y, int tiles_z,
-                                                                   float2 *__restrict__ stats_part) {
-  static_assert(TX * TY * TZ == 256, "a workgroup tile is 4 waves x 2 x 32 voxels");
+                                                                   float2 *__restrict__ stats_part,
+                                                                   const uint32_t *__restrict__ x_absmax, const int *__restrict__ wexp) {
+  static_assert(TX * TY * TZ == 256 || TX * TY * TZ == 512, "a workgroup tile is 4 waves x NBW x 32 voxels");
+  const int x_shift = NS == 2 ? scale_shift(*x_absmax) : 0;
+  const float x_scale = exp2_int(x_shift);
   constexpr int HX = TX + 2, HY = TY + 2, HZ = TZ + 2, HS = HX * HY * HZ;
-  constexpr int NBW = 2;
+  constexpr int NBW = TX * TY * TZ / 128;                       // 32-voxel MFMA column blocks per wave
   constexpr int WBLK = 3 * NS * kCoTileB * kKc;                 // bf16 elements of one (chunk, dxy, cotile) weight block
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
   uint32_t *xs = lds_u;                                         // [NS][HS][8] words (16 bf16 per voxel)
@@ -114,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_bf16_kernel(const float *
   int hb[NBW];                                                  // halo index of this lane's output voxel (tap 0,0,0 corner)
 #pragma unroll
   for (int nb = 0; nb < NBW; ++nb) {
-    const int m = wave * 64 + nb * 32 + j;
+    const int m = wave * (32 * NBW) + nb * 32 + j;
     const int zt = m % TZ, yt = (m / TZ) % TY, xt = m / (TZ * TY);
     hb[nb] = (xt * HY + yt) * HZ + zt;
   }
@@ -132,11 +244,58 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_bf16_kernel(const float *
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.0f;
 
+  if constexpr (VEC) {                                          // the z halo (hz = 0 and hz = HZ - 1) is padding for every chunk
+    for (int e = tid; e < NS * HX * HY * 2 * 8; e += 256) {
+      const int w = e & 7, side = (e >> 3) & 1, row = (e >> 4) % (HX * HY), pl = (e >> 4) / (HX * HY);
+      xs[pl * HS * 8 + (row * HZ + side * (HZ - 1)) * 8 + w] = 0u;
+    }
+  }
   for (int chunk = 0; chunk < chunks; ++chunk) {
     const int c0 = chunk * kKc;
     __syncthreads();                                            // previous chunk's fragment reads are done
-    // ---- stage the halo tile: item = (halo voxel, channel pair); fp32 -> NS bf16 planes, channels-last, swizzled ----
-    {
+    // ---- stage the halo tile, fp32 -> NS 16-bit planes, channels-last, swizzled ----
+    if constexpr (VEC) {
+      // R % 4 == 0 and the tile spans the whole z extent (z0 = 0, R <= TZ): a z row of one channel is R contiguous, 16-byte
+      // aligned floats and its two halo voxels are padding (zeroed once, above).  item = (channel pair, hx, hy, z quad) with the
+      // quad fastest across lanes: a wave reads whole 128-byte lines (the scalar path below touches 32 bytes of each line it
+      // requests, and four times as many requests -- the L1's outstanding-request slots were what bounded this kernel).
+      constexpr int QZ = TZ / 4, ITEMS = 8 * HX * HY * QZ, PER = (ITEMS + 255) / 256, ITER = PER > 4 ? 3 : PER, BATCHES = (PER + ITER - 1) / ITER;
+#pragma unroll 1
+      for (int batch = 0; batch < BATCHES; ++batch) {
+        float4 va[ITER], vb[ITER];
+#pragma unroll
+        for (int u = 0; u < ITER; ++u) {
+          const int e = (batch * ITER + u) * 256 + tid;
+          const int q = e % QZ, hy = (e / QZ) % HY, hx = (e / (QZ * HY)) % HX, cp = e / (QZ * HY * HX);
+          const int gx = x0 + hx - 1, gy = y0 + hy - 1, c = c0 + 2 * cp;
+          va[u] = vb[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+          if (e < ITEMS && (unsigned)gx < (unsigned)R && (unsigned)gy < (unsigned)R && 4 * q < R) {
+            const size_t off = (size_t)gx * RR + (size_t)gy * R + 4 * q;
+            if (c < Ci) va[u] = *reinterpret_cast<const float4 *>(xb + (size_t)c * S + off);
+            if (c + 1 < Ci) vb[u] = *reinterpret_cast<const float4 *>(xb + (size_t)(c + 1) * S + off);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < ITER; ++u) {
+          const int e = (batch * ITER + u) * 256 + tid;
+          if (e < ITEMS) {
+            const int q = e % QZ, hy = (e / QZ) % HY, hx = (e / (QZ * HY)) % HX, cp = e / (QZ * HY * HX);
+            const int v0 = (hx * HY + hy) * HZ + 1 + 4 * q;
+            const float fa[4] = {va[u].x, va[u].y, va[u].z, va[u].w}, fb[4] = {vb[u].x, vb[u].y, vb[u].z, vb[u].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int v = v0 + i;
+              uint32_t pw[NS];
+              if constexpr (NS == 2) split_pair<NS>(fa[i] * x_scale, fb[i] * x_scale, pw);
+              else split_pair<NS>(fa[i], fb[i], pw);
+              const int word = v * 8 + (((cp >> 2) ^ ((v >> 3) & 1)) * 4) + (cp & 3);
+#pragma unroll
+              for (int s = 0; s < NS; ++s) xs[s * HS * 8 + word] = pw[s];
+            }
+          }
+        }
+      }
+    } else {   // any R: item = (halo voxel, channel pair), one float per channel
       constexpr int ITER_ALL = (HS * 8 + 255) / 256, ITER = (ITER_ALL + 1) / 2;   // two batches: ~22 loads in flight each
 #pragma unroll 1
       for (int half = 0; half < 2; ++half) {
@@ -160,12 +319,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_bf16_kernel(const float *
           const int e = (half * ITER + u) * 256 + tid;
           if (e < HS * 8) {
             const int cp = e & 7, v = e >> 3;
-            uint32_t pa[NS], pb[NS];
-            split_bf16<NS>(va[u], pa);
-            split_bf16<NS>(vb[u], pb);
+            uint32_t pw[NS];
+            if constexpr (NS == 2) split_pair<NS>(va[u] * x_scale, vb[u] * x_scale, pw);
+            else split_pair<NS>(va[u], vb[u], pw);
             const int word = v * 8 + (((cp >> 2) ^ ((v >> 3) & 1)) * 4) + (cp & 3);
 #pragma unroll
-            for (int s = 0; s < NS; ++s) xs[s * HS * 8 + word] = pa[s] | (pb[s] << 16);
+            for (int s = 0; s < NS; ++s) xs[s * HS * 8 + word] = pw[s];
           }
         }
       }
@@ -207,9 +366,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_bf16_kernel(const float *
 #define PVCNN_MFMA4(SA, SB)                                                                                              \
       _Pragma("unroll") for (int nb = 0; nb < NBW; ++nb)                                                                 \
       _Pragma("unroll") for (int mb = 0; mb < 2; ++mb)                                                                   \
-        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[mb][SA]),                    \
-                                                              __builtin_bit_cast(bf16x8, bf[nb][SB]), acc[mb][nb], 0, 0, 0)
+        acc[mb][nb] = mfma16<NS>(af[mb][SA], bf[nb][SB], acc[mb][nb])
       if constexpr (NS == 1) {
+        PVCNN_MFMA4(0, 0);
+      } else if constexpr (NS == 2) {
+        PVCNN_MFMA4(1, 0); PVCNN_MFMA4(0, 1);                         // lo x hi, hi x lo, then hi x hi
         PVCNN_MFMA4(0, 0);
       } else {
         PVCNN_MFMA4(2, 0); PVCNN_MFMA4(1, 1); PVCNN_MFMA4(0, 2);      // smallest partial products first
@@ -227,7 +388,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_bf16_kernel(const float *
   bool vok[NBW];
 #pragma unroll
   for (int nb = 0; nb < NBW; ++nb) {
-    const int m = wave * 64 + nb * 32 + j;
+    const int m = wave * (32 * NBW) + nb * 32 + j;
     const int zt = m % TZ, yt = (m / TZ) % TY, xt = m / (TZ * TY);
     const int gx = x0 + xt, gy = y0 + yt, gz = z0 + zt;
     vok[nb] = gx < R && gy < R && gz < R;
@@ -237,12 +398,14 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_bf16_kernel(const float *
   float2 *stat_lds = reinterpret_cast<float2 *>(lds_u);        // [4 waves][64 channels]
 #pragma unroll
   for (int mb = 0; mb < 2; ++mb) {
-    float bv[16];
+    float bv[16], unscale[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = co0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
       bv[r] = (bias != nullptr && co < Co) ? bias[co] : 0.0f;
+      if constexpr (NS == 2) unscale[r] = exp2_int(-wexp[co]);   // wexp covers the padded rows of the tile
     }
+    const float x_unscale = exp2_int(-x_shift);
     float ss[16], qq[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) ss[r] = qq[r] = 0.0f;
@@ -252,6 +415,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_bf16_kernel(const float *
       for (int r = 0; r < 16; ++r) {
         const int co = co0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
         float v = acc[mb][nb][r];
+        if constexpr (NS == 2) v = v * unscale[r] * x_unscale;  // powers of two: exact
         if (want_stats) {                                       // statistics of (y - bias), see bn_finalize_kernel
           const float m = vok[nb] ? v : 0.0f;
           ss[r] += m;
@@ -277,23 +441,33 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_bf16_kernel(const float *
   }
 }
 
-static void split_tiles(int R, int &tx, int &ty, int &tz) {
-  if (R > 8) { tx = 4; ty = 4; tz = 16; } else { tx = 4; ty = 8; tz = 8; }
+// Workgroup tile and staging path.  Vector staging (whole z rows as 16-byte loads) needs R % 4 == 0 and a tile that spans z:
+// tz = 8 / 16 / 32 for R <= 8 / 16 / 32.  At 16 < R <= 32 a 512-voxel tile (a wave owns 64 channels x 128 voxels: every weight
+// fragment feeds four MFMA column blocks, the halo overhead drops from 3.0x to 2.25x) when that still leaves two workgroups for
+// every CU; the six-product bf16x3 mode has neither the registers nor the LDS for it.  (Measured, (16,64,64,32^3), f16x2:
+// scalar staging 0.354 ms, vector 0.320 ms, vector + 512-voxel tile 0.309 ms; a (4,8,16) tile at R = 16 spills and loses.)
+struct SplitTile { int tx, ty, tz; bool vec; };
+static SplitTile split_tiles(int B, int Co, int R, int nsplit) {
+  const bool vec = R % 4 == 0 && R <= 32;
+  if (R <= 8) return {4, 8, 8, vec};
+  if (!vec || R <= 16) return {4, 4, 16, vec};
+  const bool big = nsplit != 3 && (long)B * ceil_div(R, 4) * ceil_div(R, 4) * ceil_div(Co, kCoTileB) >= 512;
+  return big ? SplitTile{4, 4, 32, true} : SplitTile{2, 4, 32, true};
 }
 
-template <int NS, int TX, int TY, int TZ>
+template <int NS, int TX, int TY, int TZ, bool VEC>
 static int launch_igemm_bf16(const float *x, const uint16_t *wts, const float *bias, float *y, int B, int Ci, int Co, int R,
-                             hipStream_t s, float2 *stats_part) {
+                             hipStream_t s, float2 *stats_part, const uint32_t *x_absmax = nullptr, const int *wexp = nullptr) {
   constexpr int HS = (TX + 2) * (TY + 2) * (TZ + 2);
   const size_t lds = std::max((size_t)NS * HS * 8 * sizeof(uint32_t), (size_t)4 * kCoTileB * sizeof(float2));
   const int tx = ceil_div(R, TX), ty = ceil_div(R, TY), tz = ceil_div(R, TZ);
-  auto k = conv3d_igemm_bf16_kernel<NS, TX, TY, TZ>;
+  auto k = conv3d_igemm_bf16_kernel<NS, TX, TY, TZ, VEC>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { set_error("conv3d(bf16): LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
   }
   hipLaunchKernelGGL(k, dim3((unsigned)((long)B * tx * ty * tz), ceil_div(Co, kCoTileB)), dim3(256), lds, s, x, wts, bias, y,
-                     Ci, Co, R, tx, ty, tz, stats_part);
+                     Ci, Co, R, tx, ty, tz, stats_part, x_absmax, wexp);
   return check_launch("conv3d_igemm_bf16");
 }
 
@@ -301,17 +475,41 @@ static int launch_igemm_bf16(const float *x, const uint16_t *wts, const float *b
 
 using namespace pvcnn;
 
-extern "C" size_t pvcnn_conv3d_weight_split_bytes(int Co, int Ci, int for_bwd_data, int nsplit) {
-  if (Co <= 0 || Ci <= 0 || (nsplit != 1 && nsplit != 3)) return 0;
-  const int CiE = for_bwd_data ? Co : Ci, CoE = for_bwd_data ? Ci : Co;
+static size_t weight_image_bytes(int CiE, int CoE, int nsplit) {
   return (size_t)ceil_div(CiE, kKc) * 9 * ceil_div(CoE, kCoTileB) * 3 * nsplit * kCoTileB * kKc * sizeof(uint16_t);
+}
+
+// nsplit: 1 = bf16, 3 = bf16x3, 2 = f16x2 (image followed by one int32 shift per padded output channel)
+extern "C" size_t pvcnn_conv3d_weight_split_bytes(int Co, int Ci, int for_bwd_data, int nsplit) {
+  if (Co <= 0 || Ci <= 0 || nsplit < 1 || nsplit > 3) return 0;
+  const int CiE = for_bwd_data ? Co : Ci, CoE = for_bwd_data ? Ci : Co;
+  return weight_image_bytes(CiE, CoE, nsplit) + (nsplit == 2 ? (size_t)ceil_div(CoE, kCoTileB) * kCoTileB * sizeof(int) : 0);
+}
+
+// out[0] = max over x of the bit pattern of |x| (0 for an empty tensor); the f16x2 convolution derives its input scale from it
+extern "C" int pvcnn_absmax_bits(const float *x, size_t n, void *out, void *stream) {
+  PVCNN_REQUIRE(out && (x || n == 0), "null pointer");
+  PVCNN_REQUIRE(n == 0 || aligned16(x), "x must be 16-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipError_t e = hipMemsetAsync(out, 0, sizeof(uint32_t), s);
+  if (e != hipSuccess) { set_error("absmax: memset: %s", hipGetErrorString(e)); return (int)e; }
+  if (n == 0) return 0;
+  const unsigned grid = (unsigned)std::min<size_t>(512, (n / 4 + 2047) / 2048 + 1);
+  hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(512), 0, s, x, n, static_cast<uint32_t *>(out));
+  return check_launch("absmax");
 }
 
 extern "C" int pvcnn_conv3d_weight_split(const float *w, int Co, int Ci, int for_bwd_data, int nsplit, void *wts, void *stream) {
   PVCNN_REQUIRE(w && wts && Co > 0 && Ci > 0, "bad argument");
-  PVCNN_REQUIRE(nsplit == 1 || nsplit == 3, "nsplit must be 1 (bf16) or 3 (bf16x3)");
+  PVCNN_REQUIRE(nsplit >= 1 && nsplit <= 3, "nsplit must be 1 (bf16), 2 (f16x2) or 3 (bf16x3)");
   PVCNN_REQUIRE(aligned16(wts), "wts must be 16-byte aligned");
   const int CiE = for_bwd_data ? Co : Ci, CoE = for_bwd_data ? Ci : Co;
+  if (nsplit == 2) {
+    int *wexp = reinterpret_cast<int *>(static_cast<char *>(wts) + weight_image_bytes(CiE, CoE, 2));
+    hipLaunchKernelGGL(conv3d_weight_split_f16_kernel, dim3(ceil_div(CoE, kCoTileB) * kCoTileB), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       w, Co, Ci, for_bwd_data, static_cast<uint16_t *>(wts), wexp);
+    return check_launch("conv3d_weight_split_f16");
+  }
   const long total = (long)ceil_div(CiE, kKc) * 9 * ceil_div(CoE, kCoTileB) * 3 * kCoTileB * kKc;
   const dim3 grid((unsigned)((total + 255) / 256));
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -320,19 +518,19 @@ extern "C" int pvcnn_conv3d_weight_split(const float *w, int Co, int Ci, int for
   return check_launch("conv3d_weight_split");
 }
 
-extern "C" size_t pvcnn_conv3d_fwd_split_stats_parts(int B, int Co, int R) {
+extern "C" size_t pvcnn_conv3d_fwd_split_stats_parts(int B, int Co, int R, int nsplit) {
   if (B <= 0 || Co <= 0 || R <= 0) return 0;
-  int tx, ty, tz;
-  split_tiles(R, tx, ty, tz);
-  return (size_t)B * ceil_div(R, tx) * ceil_div(R, ty) * ceil_div(R, tz);
+  const SplitTile t = split_tiles(B, Co, R, nsplit);
+  return (size_t)B * ceil_div(R, t.tx) * ceil_div(R, t.ty) * ceil_div(R, t.tz);
 }
 
 // y = conv3d(x, w) + bias with the pre-split weights of pvcnn_conv3d_weight_split (forward layout: Ci, Co as given; backward-data:
 // call with x = grad_y, Ci = the forward Co, Co = the forward Ci, bias = NULL and the for_bwd_data = 1 weights).
 extern "C" int pvcnn_conv3d_fwd_split(const float *x, const void *wts, const float *bias, int B, int Ci, int Co, int R, int nsplit,
-                                      float *y, float *stats_part, void *stream) {
+                                      const void *x_absmax, float *y, float *stats_part, void *stream) {
   PVCNN_REQUIRE(B >= 0 && Ci > 0 && Co > 0 && R > 0, "bad size");
-  PVCNN_REQUIRE(nsplit == 1 || nsplit == 3, "nsplit must be 1 (bf16) or 3 (bf16x3)");
+  PVCNN_REQUIRE(nsplit >= 1 && nsplit <= 3, "nsplit must be 1 (bf16), 2 (f16x2) or 3 (bf16x3)");
+  PVCNN_REQUIRE(nsplit != 2 || x_absmax, "f16x2 needs the input's pvcnn_absmax_bits");
   if (B == 0) return 0;
   PVCNN_REQUIRE(x && wts && y && aligned16(wts), "null or misaligned pointer");
   PVCNN_REQUIRE(!stats_part || (reinterpret_cast<uintptr_t>(stats_part) & 7) == 0, "stats_part must be 8-byte aligned");
@@ -340,8 +538,18 @@ extern "C" int pvcnn_conv3d_fwd_split(const float *x, const void *wts, const flo
   hipStream_t s = static_cast<hipStream_t>(stream);
   const uint16_t *w16 = static_cast<const uint16_t *>(wts);
   float2 *sp = reinterpret_cast<float2 *>(stats_part);
-  if (R > 8) return nsplit == 3 ? launch_igemm_bf16<3, 4, 4, 16>(x, w16, bias, y, B, Ci, Co, R, s, sp)
-                                : launch_igemm_bf16<1, 4, 4, 16>(x, w16, bias, y, B, Ci, Co, R, s, sp);
-  return nsplit == 3 ? launch_igemm_bf16<3, 4, 8, 8>(x, w16, bias, y, B, Ci, Co, R, s, sp)
-                     : launch_igemm_bf16<1, 4, 8, 8>(x, w16, bias, y, B, Ci, Co, R, s, sp);
+  const SplitTile t = split_tiles(B, Co, R, nsplit);
+  PVCNN_REQUIRE(!t.vec || aligned16(x), "x must be 16-byte aligned");
+  const uint32_t *am = static_cast<const uint32_t *>(x_absmax);
+  const int *wexp = nsplit == 2 ? reinterpret_cast<const int *>(static_cast<const char *>(wts) + weight_image_bytes(Ci, Co, 2)) : nullptr;
+#define PVCNN_IGEMM(NS, TX, TY, TZ, VEC) launch_igemm_bf16<NS, TX, TY, TZ, VEC>(x, w16, bias, y, B, Ci, Co, R, s, sp, am, wexp)
+#define PVCNN_IGEMM_NS(TX, TY, TZ, VEC) (nsplit == 3 ? PVCNN_IGEMM(3, TX, TY, TZ, VEC) : nsplit == 2 ? PVCNN_IGEMM(2, TX, TY, TZ, VEC) : PVCNN_IGEMM(1, TX, TY, TZ, VEC))
+#define PVCNN_IGEMM_BIG(TX, TY, TZ) (nsplit == 2 ? PVCNN_IGEMM(2, TX, TY, TZ, true) : PVCNN_IGEMM(1, TX, TY, TZ, true))
+  if (t.tz == 8) return t.vec ? PVCNN_IGEMM_NS(4, 8, 8, true) : PVCNN_IGEMM_NS(4, 8, 8, false);
+  if (!t.vec) return PVCNN_IGEMM_NS(4, 4, 16, false);
+  if (t.tz == 16) return PVCNN_IGEMM_NS(4, 4, 16, true);
+  return t.tx == 4 ? PVCNN_IGEMM_BIG(4, 4, 32) : PVCNN_IGEMM_NS(2, 4, 32, true);
+#undef PVCNN_IGEMM_BIG
+#undef PVCNN_IGEMM_NS
+#undef PVCNN_IGEMM
 }

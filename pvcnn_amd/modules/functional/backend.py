@@ -466,9 +466,19 @@ class HipBackend:
     # 2.7x the fp32-MFMA rate) or nsplit = 1 (plain bf16 operands: the autocast / BASELINE configs[4] path) ----
     has_conv3d_split = True
     # default arithmetic of the voxel convolutions' forward / backward-data products:
+    #   'f16x2'  : power-of-two scaled fp16 hi + lo split of both fp32 operands, 3 partial products, fp32 accumulate (<= 1e-5 vs fp64)
     #   'bf16x3' : exact three-way bf16 split of both fp32 operands, 6 partial products, fp32 accumulate (<= 1e-5 vs fp64)
     #   'fp32'   : v_mfma_f32_32x32x2_f32, one rounding per product (conv3d.hip)
-    conv_math = os.environ.get('PVCNN_CONV_MATH', 'bf16x3')
+    conv_math = os.environ.get('PVCNN_CONV_MATH', 'f16x2')
+    CONV_NSPLIT = {'f16x2': 2, 'bf16x3': 3, 'fp32': 0}
+
+    def absmax_bits(self, x):
+        """One uint32 on the device: the bit pattern of max |x| (the f16x2 kernels derive their power-of-two input scale from it)."""
+        _f32(x, 'x')
+        out = torch.empty((1,), dtype=torch.int32, device=x.device)
+        with _Launch(x) as s:
+            _lib.check(self.lib.pvcnn_absmax_bits(_p(x), x.numel(), _p(out), s), 'absmax_bits')
+        return out
 
     def _conv_wsplit(self, weight, for_bwd_data, nsplit):
         co, ci = weight.shape[0], weight.shape[1]
@@ -484,17 +494,22 @@ class HipBackend:
                and x.shape[2] == x.shape[3] == x.shape[4], 'conv3d: x (B,Ci,R,R,R), weight (Co,Ci,3,3,3) expected')
         if bias is not None:
             _f32(bias, 'bias')
-        return self.conv3d_igemm_split(x, self._conv_wsplit(weight, False, nsplit), bias, weight.shape[0], nsplit, want_stats)
+        return self.conv3d_igemm_split(x, self._conv_wsplit(weight, False, nsplit), bias, weight.shape[0], nsplit, want_stats,
+                                       self.absmax_bits(x) if int(nsplit) == 2 else None)
 
-    def conv3d_igemm_split(self, x, wts, bias, co, nsplit, want_stats=False):
-        """The implicit-GEMM launch alone (pre-split weight image `wts`): x (B,Ci,R,R,R) -> y (B,co,R,R,R) [, stats partials]."""
+    def conv3d_igemm_split(self, x, wts, bias, co, nsplit, want_stats=False, amax=None):
+        """The implicit-GEMM launch alone (pre-split weight image `wts`; f16x2: `amax` = absmax_bits(x)): x (B,Ci,R,R,R) ->
+        y (B,co,R,R,R) [, stats partials]."""
         b, ci, r = x.shape[0], x.shape[1], x.shape[2]
         y = torch.empty((b, co, r, r, r), dtype=torch.float32, device=x.device)
         part = None
         if want_stats:
-            part = torch.empty((co, self.lib.pvcnn_conv3d_fwd_split_stats_parts(b, co, r), 2), dtype=torch.float32, device=x.device)
+            part = torch.empty((co, self.lib.pvcnn_conv3d_fwd_split_stats_parts(b, co, r, int(nsplit)), 2), dtype=torch.float32, device=x.device)
+        if int(nsplit) == 2 and amax is None:
+            amax = self.absmax_bits(x)
         with _Launch(x) as s:
             _lib.check(self.lib.pvcnn_conv3d_fwd_split(_p(x), _p(wts), _p(bias) if bias is not None else None, b, ci, co, r, int(nsplit),
+                                                       _p(amax) if amax is not None else None,
                                                        _p(y), _p(part) if want_stats else None, s), 'conv3d_forward_split')
         return (y, part) if want_stats else y
 
@@ -503,7 +518,8 @@ class HipBackend:
         b, co, r = grad_y.shape[0], grad_y.shape[1], grad_y.shape[2]
         ci = weight.shape[1]
         # a convolution with Ci and Co exchanged on the flipped weights
-        return self.conv3d_igemm_split(grad_y, self._conv_wsplit(weight, True, nsplit), None, ci, nsplit)
+        return self.conv3d_igemm_split(grad_y, self._conv_wsplit(weight, True, nsplit), None, ci, nsplit, False,
+                                       self.absmax_bits(grad_y) if int(nsplit) == 2 else None)
 
     # ---- SharedMLP 1x1 convolutions as channel-major MFMA GEMMs (csrc/pointwise.hip) --------------------
     has_pwconv = True

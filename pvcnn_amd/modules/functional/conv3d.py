@@ -14,13 +14,14 @@ __all__ = ['voxel_conv3d', 'conv_nsplit']
 def conv_nsplit():
     """Arithmetic of the forward / backward-data products, decided where the convolution is CALLED (inside the autograd
     function autocast is already switched off): 1 = bf16 operands under torch.autocast(bfloat16) (BASELINE configs[4]),
-    3 = bf16x3 split (fp32-class accuracy on the bf16 matrix cores, the default), 0 = exact fp32 MFMA."""
+    2 = f16x2 (scaled fp16 hi + lo split: fp32-class accuracy at 3 MFMAs per k-step, the default), 3 = bf16x3 split
+    (fp32-class, 6 MFMAs), 0 = exact fp32 MFMA."""
     be = native()
     if not getattr(be, 'has_conv3d_split', False):
         return 0
     if torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16:
         return 1
-    return 3 if getattr(be, 'conv_math', 'fp32') == 'bf16x3' else 0
+    return getattr(be, 'CONV_NSPLIT', {}).get(getattr(be, 'conv_math', 'fp32'), 0)
 
 
 class VoxelConv3d(Function):

@@ -63,6 +63,13 @@ def test_conv3d_on_the_bf16_matrix_cores(hip, b, ci, co, r):
     assert _rel(sums[:, 0], centred.sum(dim=1)) < 1e-5 and _rel(sums[:, 1], (centred * centred).sum(dim=1)) < 1e-5
     assert _rel(hip.conv3d_forward_split(x, w, bias, 1), ref.detach()) < 4e-3
     assert _rel(hip.conv3d_backward_data_split(gy, w, 1), xd.grad) < 4e-3
+    # f16x2: scaled fp16 hi + lo split, three partial products -- the same bar, deterministic, statistics included
+    y2, part2 = hip.conv3d_forward_split(x, w, bias, 2, want_stats=True)
+    assert _rel(y2, ref.detach()) < TOL and torch.equal(hip.conv3d_forward_split(x, w, bias, 2), y2)
+    assert _rel(hip.conv3d_backward_data_split(gy, w, 2), xd.grad) < TOL
+    centred = (y2.double() - bd.view(1, -1, 1, 1, 1)).transpose(0, 1).reshape(co, -1)
+    sums = part2.double().sum(dim=1)
+    assert _rel(sums[:, 0], centred.sum(dim=1)) < 1e-5 and _rel(sums[:, 1], (centred * centred).sum(dim=1)) < 1e-5
 
 
 def test_bf16x3_is_as_accurate_as_the_fp32_mfma_kernel(hip):
@@ -72,10 +79,56 @@ def test_bf16x3_is_as_accurate_as_the_fp32_mfma_kernel(hip):
     x = torch.randn(2, 128, 16, 16, 16, generator=g).to(DEV)
     w = (torch.randn(128, 128, 3, 3, 3, generator=g) * 0.05).to(DEV)
     ref = F.conv3d(x.double(), w.double(), padding=1)
-    e32, e3, e1 = (_rel(hip.conv3d_forward(x, w, None), ref), _rel(hip.conv3d_forward_split(x, w, None, 3), ref),
-                   _rel(hip.conv3d_forward_split(x, w, None, 1), ref))
-    print(f'[conv3d accuracy vs fp64, K = 3456] fp32 MFMA {e32:.2e}   bf16x3 {e3:.2e}   bf16 {e1:.2e}')
+    e32, e3, e1, e2 = (_rel(hip.conv3d_forward(x, w, None), ref), _rel(hip.conv3d_forward_split(x, w, None, 3), ref),
+                       _rel(hip.conv3d_forward_split(x, w, None, 1), ref), _rel(hip.conv3d_forward_split(x, w, None, 2), ref))
+    print(f'[conv3d accuracy vs fp64, K = 3456] fp32 MFMA {e32:.2e}   f16x2 {e2:.2e}   bf16x3 {e3:.2e}   bf16 {e1:.2e}')
     assert e3 < 1e-5 and e3 < 4 * e32 + 1e-7 and e1 > 100 * e3
+    assert e2 < 1e-5 and e2 < 4 * e32 + 1e-7
+
+
+@pytest.mark.parametrize('case', ['tiny', 'huge', 'outlier', 'rows', 'zero', 'inf'])
+def test_f16x2_scaling_over_the_fp32_range(hip, case):
+    """fp16 has five exponent bits; the f16x2 mode scales activations per tensor and weights per output channel by powers of
+    two before splitting.  Per OUTPUT CHANNEL (each has its own weight scale) the error must stay fp32-class for tensors at
+    1e-20 and 1e12, for a tensor dominated by one outlier, for weight rows 14 decades apart; zeros stay zeros; inf propagates."""
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 64, 16, 16, 16, generator=g).to(DEV)
+    w = (torch.randn(64, 64, 3, 3, 3, generator=g) * 0.05).to(DEV)
+    if case == 'tiny':
+        x, w = x * 1e-20, w * 1e-6
+    elif case == 'huge':
+        x, w = x * 1e12, w * 1e3
+    elif case == 'outlier':
+        x.view(-1)[12345] = 3.0e4
+    elif case == 'rows':
+        w = w * torch.logspace(-8, 6, 64, device=DEV).view(-1, 1, 1, 1, 1)
+    elif case == 'zero':
+        x = torch.zeros_like(x)
+    elif case == 'inf':
+        x.view(-1)[777] = float('inf')
+    y = hip.conv3d_forward_split(x, w, None, 2)
+    if case == 'inf':
+        ref = F.conv3d(x, w, padding=1)
+        assert not torch.isfinite(y).all() and torch.equal(torch.isfinite(y), torch.isfinite(ref))
+        return
+    ref = F.conv3d(x.double(), w.double(), padding=1)
+    if case == 'zero':
+        assert torch.equal(y, torch.zeros_like(y))
+        return
+    scale = ref.abs().amax(dim=(0, 2, 3, 4), keepdim=True)
+    err = ((y.double() - ref).abs() / scale).max().item()
+    err32 = ((hip.conv3d_forward(x, w, None).double() - ref).abs() / scale).max().item()
+    print(f'[f16x2 range case {case}] per-channel error {err:.2e} (exact-fp32 MFMA kernel: {err32:.2e})')
+    assert err < 1e-5 and err < 2 * err32 + 1e-7
+
+
+def test_absmax_bits(hip):
+    for n in (1, 3, 4, 1023, 4096 * 33 + 2):
+        x = torch.randn(n, device=DEV)
+        x[n // 2] = -77.5
+        assert hip.absmax_bits(x).item() == torch.tensor(77.5).view(torch.int32).item()
+    assert hip.absmax_bits(torch.zeros(100, device=DEV)).item() == 0
+    assert hip.absmax_bits(torch.empty(0, device=DEV)).item() == 0
 
 
 def test_voxel_conv_under_autocast_uses_bf16_operands(hip):
