@@ -59,6 +59,8 @@ SIGNATURES = {
     'pvcnn_conv3d_weight_split': (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     'pvcnn_conv3d_fwd_split_stats_parts': (_sz, [_i, _i, _i, _i]),
     'pvcnn_absmax_bits': (_i, [_vp, _sz, _vp, _vp]),
+    'pvcnn_conv3d_bwd_weight_f16_workspace_bytes': (_sz, [_i, _i, _i, _i]),
+    'pvcnn_conv3d_bwd_weight_f16': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     'pvcnn_conv3d_fwd_split': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'pvcnn_pwconv_transpose': (_i, [_vp, _i, _i, _vp, _vp]),
     'pvcnn_pwconv_fwd': (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp]),

@@ -32,15 +32,9 @@
 #include <algorithm>
 
 #include "common.h"
+#include "split16.h"
 
 namespace pvcnn {
-
-using f32x16 = __attribute__((ext_vector_type(16))) float;
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kCoTileB = 64;
 constexpr int kKc = 16;            // input channels per chunk = MFMA K
@@ -61,40 +55,6 @@ __device__ __forceinline__ void split_bf16(float v, uint32_t (&p)[NS]) {
     if (s + 1 < NS) v = v - bf16_value(p[s]);          // exact: the residual fits fp32
   }
 }
-
-// Two neighbouring channels at once, packed (first value in the low half): v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32 round to nearest
-// even in hardware.  NS = 1, 3: bf16 pieces as in split_bf16.  NS = 2: fp16 "hi + lo" of PRE-SCALED values (|v| < 2^15, see
-// scale_shift): hi = fp16(v) keeps 11 bits, lo = fp16(v - hi) the next 11.
-template <int NS>
-__device__ __forceinline__ void split_pair(float a, float b, uint32_t (&w)[NS]) {
-  f32x2 v = {a, b};
-  if constexpr (NS == 2) {
-    const f16x2 h = __builtin_convertvector(v, f16x2);
-    w[0] = __builtin_bit_cast(uint32_t, h);
-    v = v - __builtin_convertvector(h, f32x2);                   // exact
-    w[1] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
-  } else {
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      w[s] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-      if (s + 1 < NS) {
-        const f32x2 back = {__uint_as_float(w[s] << 16), __uint_as_float(w[s] & 0xffff0000u)};
-        v = v - back;                                            // exact: the residual fits fp32
-      }
-    }
-  }
-}
-
-// fp16 has 5 exponent bits: operands of the f16x2 mode are scaled by a power of two that puts the largest magnitude of the
-// tensor (bits of max |x|, from absmax_kernel; of a weight row, in the split kernel) into [2^13, 2^14).  Everything within
-// 2^-17 of the maximum then keeps 22 bits in hi + lo; smaller elements lose low bits gradually (absolute error <= 2^-38 of
-// the maximum).  Zero / inf / NaN maxima: no scaling (inf and NaN then propagate as they would in fp32).
-__device__ __forceinline__ int scale_shift(uint32_t absmax_bits) {
-  const int e = (int)((absmax_bits >> 23) & 0xffu);
-  if (e == 0 || e == 255) return 0;
-  return min(max(140 - e, -100), 100);                           // 13 - (e - 127)
-}
-__device__ __forceinline__ float exp2_int(int s) { return __uint_as_float((uint32_t)(s + 127) << 23); }
 
 __global__ __launch_bounds__(512) void absmax_kernel(const float *__restrict__ x, size_t n, uint32_t *__restrict__ out) {
   uint32_t m = 0;
@@ -183,12 +143,6 @@ __global__ __launch_bounds__(256) void conv3d_weight_split_kernel(const float *_
   for (int s = 0; s < NS; ++s) wts[blk + ((size_t)(dz * NS + s) * kCoTileB + co_l) * kKc + pos] = (uint16_t)p[s];
 }
 
-template <int NS>
-__device__ __forceinline__ f32x16 mfma16(const uint4 &a, const uint4 &b, const f32x16 &c) {
-  if constexpr (NS == 2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-
 // Variants measured on (16,64,64,32^3), bf16x3 (fp32 kernel: 0.87 ms; 6x the MFMAs at 16x the rate = 0.28 ms at 2.4 GHz):
 //   this one (256 threads, 2 workgroups per CU, 27 taps unrolled, weights one tap ahead)   0.56 ms
 //   explicit one-tap software pipeline of both operands behind sched_barriers              0.58-0.61 ms (1 / 2 waves per SIMD)
@@ -197,12 +151,12 @@ __device__ __forceinline__ f32x16 mfma16(const uint4 &a, const uint4 &b, const f
 // i.e. the matrix pipe itself sustains ~1.6 PF on random data here (the chip clocks down under a dense bf16 MFMA stream),
 // and what is left above it is prologue / epilogue exposure; the simplest structure is kept.
 template <int NS, int TX, int TY, int TZ, bool VEC>
-__global__ __launch_bounds__(256, (NS == 3 || TX * TY * TZ == 512) ? 2 : 3) void conv3d_igemm_bf16_kernel(const float *__restrict__ x, const uint16_t *__restrict__ wts,
+__global__ __launch_bounds__(256, TX * TY * TZ == 128 ? 4 : (NS == 3 || TX * TY * TZ == 512) ? 2 : 3) void conv3d_igemm_bf16_kernel(const float *__restrict__ x, const uint16_t *__restrict__ wts,
                                                                    const float *__restrict__ bias, float *__restrict__ y,
                                                                    int Ci, int Co, int R, int tiles_x, int tiles_y, int tiles_z,
                                                                    float2 *__restrict__ stats_part,
                                                                    const uint32_t *__restrict__ x_absmax, const int *__restrict__ wexp) {
-  static_assert(TX * TY * TZ == 256 || TX * TY * TZ == 512, "a workgroup tile is 4 waves x NBW x 32 voxels");
+  static_assert(TX * TY * TZ == 128 || TX * TY * TZ == 256 || TX * TY * TZ == 512, "a workgroup tile is 4 waves x NBW x 32 voxels");
   const int x_shift = NS == 2 ? scale_shift(*x_absmax) : 0;
   const float x_scale = exp2_int(x_shift);
   constexpr int HX = TX + 2, HY = TY + 2, HZ = TZ + 2, HS = HX * HY * HZ;
@@ -450,7 +404,9 @@ struct SplitTile { int tx, ty, tz; bool vec; };
 static SplitTile split_tiles(int B, int Co, int R, int nsplit) {
   const bool vec = R % 4 == 0 && R <= 32;
   if (R <= 8) return {4, 8, 8, vec};
-  if (!vec || R <= 16) return {4, 4, 16, vec};
+  if (!vec) return {4, 4, 16, false};
+  if (R <= 16)   // too few 256-voxel tiles to give every SIMD two waves (R = 16, B = 16: 256 per 64 channels): halve them
+    return (long)B * ceil_div(R, 4) * ceil_div(R, 4) * ceil_div(Co, kCoTileB) < 768 ? SplitTile{2, 4, 16, true} : SplitTile{4, 4, 16, true};
   const bool big = nsplit != 3 && (long)B * ceil_div(R, 4) * ceil_div(R, 4) * ceil_div(Co, kCoTileB) >= 512;
   return big ? SplitTile{4, 4, 32, true} : SplitTile{2, 4, 32, true};
 }
@@ -547,7 +503,7 @@ extern "C" int pvcnn_conv3d_fwd_split(const float *x, const void *wts, const flo
 #define PVCNN_IGEMM_BIG(TX, TY, TZ) (nsplit == 2 ? PVCNN_IGEMM(2, TX, TY, TZ, true) : PVCNN_IGEMM(1, TX, TY, TZ, true))
   if (t.tz == 8) return t.vec ? PVCNN_IGEMM_NS(4, 8, 8, true) : PVCNN_IGEMM_NS(4, 8, 8, false);
   if (!t.vec) return PVCNN_IGEMM_NS(4, 4, 16, false);
-  if (t.tz == 16) return PVCNN_IGEMM_NS(4, 4, 16, true);
+  if (t.tz == 16) return t.tx == 2 ? PVCNN_IGEMM_NS(2, 4, 16, true) : PVCNN_IGEMM_NS(4, 4, 16, true);
   return t.tx == 4 ? PVCNN_IGEMM_BIG(4, 4, 32) : PVCNN_IGEMM_NS(2, 4, 32, true);
 #undef PVCNN_IGEMM_BIG
 #undef PVCNN_IGEMM_NS

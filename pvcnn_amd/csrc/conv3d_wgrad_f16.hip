@@ -1,0 +1,282 @@
+// conv3d_wgrad_f16.hip -- backward-weight of the 3x3x3 voxel convolution on the fp16 matrix cores, "f16x2" arithmetic
+// (split16.h / top of conv3d_bf16.hip: both fp32 operands scaled by a power of two and split into fp16 hi + lo, three exact
+// partial products per fp32 product, fp32 accumulation -- fp32-class accuracy at 3 MFMAs per 16-deep k-step).
+//
+//   grad_w[co][ci][tap] = sum over (b, voxel) of grad_y[b][co][voxel] * x[b][ci][voxel + offset(tap)]
+//
+// is a GEMM with M = co, N = (ci, tap) and K = every voxel of the batch: the output is tiny (Co x Ci x 27), K is huge, both
+// operands are activations (nothing can be pre-split) and the 27 taps read the SAME x values at shifted positions.  Structure:
+//   * D[co][ci] += A[co][k] * B[k][ci] on v_mfma_f32_32x32x16_f16 with k = 16 consecutive z voxels of one (x, y) output row:
+//     A = grad_y row segments, B = x row segments of the (dx, dy) neighbour row, shifted by dz along z;
+//   * a workgroup owns a 64 (co) x 32 (ci) x 27 (tap) block of grad_w -- 54 accumulator tiles -- as 18 units (dx, dy; 32-row co
+//     block) of three dz tiles; its 8 waves take 3, 3, 2, 2, 2, 2, 2, 2 units, i.e. 5, 5, 4, 4 per SIMD;
+//   * the three dz taps of a unit come from ONE LDS window of the x row (a 16-byte read plus the dword on either side): dz = 1 is
+//     the aligned middle, dz = 0 / 2 are v_alignbit funnel shifts by one fp16 -- no shifted copies of x in LDS;
+//   * K runs over "strips" (b, x plane): the workgroup walks y, keeping a ring of four y rows of the three x planes and a
+//     double-buffered grad_y row in LDS (fp16 hi and lo planes); per step it loads ONE new row of each (whole 128-byte lines),
+//     multiplies the current one, then converts and stores -- one barrier per output row;
+//   * split-K over P partitions of the strips; every workgroup writes its block to part[p] ([tap][co][ci]: 128-byte rows) and
+//     conv3d_wgrad_f16_reduce_kernel sums the partitions in a fixed order (deterministic, no atomics), scales back by
+//     2^-(sx + sgy) and transposes to (Co, Ci, 27).  grad_bias falls out of the grad_y rows a thread stages.
+// R must be a multiple of 16 (R = 16 and 32 are instantiated); anything else stays on the fp32-MFMA kernel of conv3d.hip.
+#include <algorithm>
+
+#include "common.h"
+#include "split16.h"
+
+namespace pvcnn {
+
+constexpr int kWgCo = 64, kWgCi = 32;
+
+template <int R>
+struct WgradLds {
+  static constexpr int RS = R + 24;                 // fp16 elements per LDS row: [8 pad | R data | 16 pad]; z = i - 8.  RS * 2 bytes
+  static constexpr int ROWB = RS * 2;               //   = 28 / 20 dwords (R = 32 / 16): 16-byte reads of 16 rows hit 64 distinct banks
+  static constexpr int XPL = 4 * 3 * kWgCi * ROWB;  // one fp16 plane of the x ring  [slot 4][dx 3][ci 32][row]
+  static constexpr int GPL = 2 * kWgCo * ROWB;      // one fp16 plane of grad_y      [buffer 2][co 64][row]
+  static constexpr int BYTES = 2 * XPL + 2 * GPL;
+};
+
+template <int R>
+__global__ __launch_bounds__(512, 2) void conv3d_wgrad_f16_kernel(const float *__restrict__ x, const float *__restrict__ gy,
+                                                                  const uint32_t *__restrict__ x_absmax,
+                                                                  const uint32_t *__restrict__ gy_absmax, int B, int Ci, int Co, int P,
+                                                                  int citiles, float *__restrict__ part, float *__restrict__ gb_part) {
+  using L = WgradLds<R>;
+  constexpr int QZ = R / 4, KS = R / 16, ROWB = L::ROWB;
+  constexpr int XITEMS = 3 * kWgCi * QZ, GITEMS = kWgCo * QZ;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  unsigned char *xl = lds, *gl = lds + 2 * L::XPL;
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, kh = lane >> 5;
+  int bid = blockIdx.x;
+  const int p = bid % P; bid /= P;
+  const int cit = bid % citiles, cot = bid / citiles;
+  const int ci0 = cit * kWgCi, co0 = cot * kWgCo;
+  const size_t RR = (size_t)R * R, S = RR * R;
+  const float x_scale = exp2_int(scale_shift(*x_absmax)), gy_scale = exp2_int(scale_shift(*gy_absmax));
+
+  for (int e = tid; e < L::BYTES / 4; e += 512) reinterpret_cast<uint32_t *>(lds)[e] = 0u;    // z halos stay zero for good
+  __syncthreads();
+
+  // units of this wave: u = wave, wave + 8, wave + 16 (< 18);  u -> (dxy = u % 9, mb = u / 9)
+  const int nunits = wave < 2 ? 3 : 2;
+  f32x16 acc[3][3];
+#pragma unroll
+  for (int u = 0; u < 3; ++u)
+#pragma unroll
+    for (int dz = 0; dz < 3; ++dz)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[u][dz][r] = 0.0f;
+
+  // staging roles: x item = (dx, ci, z quad), grad_y item = (co, z quad); a thread keeps its items for the whole kernel
+  const int xq0 = tid % QZ, xci0 = (tid / QZ) % kWgCi, xdx0 = tid / (QZ * kWgCi);
+  const int t1 = tid + 512;
+  const int xq1 = t1 % QZ, xci1 = (t1 / QZ) % kWgCi, xdx1 = t1 / (QZ * kWgCi);
+  const bool has_x0 = tid < XITEMS, has_x1 = t1 < XITEMS;
+  const int gq = tid % QZ, gco = tid / QZ;
+  const bool has_g = tid < GITEMS;
+  float gsum = 0.0f;
+
+  auto store_row = [&](unsigned char *plane0, int plane_bytes, int row_byte, int q, const float4 &v, float scale) {
+    uint32_t w0[2], w1[2];
+    split_pair<2>(v.x * scale, v.y * scale, w0);
+    split_pair<2>(v.z * scale, v.w * scale, w1);
+    const int off = row_byte + (8 + 4 * q) * 2;
+    *reinterpret_cast<uint2 *>(plane0 + off) = make_uint2(w0[0], w1[0]);                 // hi
+    *reinterpret_cast<uint2 *>(plane0 + plane_bytes + off) = make_uint2(w0[1], w1[1]);   // lo
+  };
+
+  const int nstrips = B * R;
+  for (int strip = p; strip < nstrips; strip += P) {
+    const int b = strip / R, xo = strip - b * R;
+    const float *xb = x + (size_t)b * Ci * S, *gb_ = gy + (size_t)b * Co * S;
+    for (int t = -2; t < R; ++t) {
+      // ---- loads for the rows that enter the window: x rows y = t + 2 (three x planes), grad_y row y = t + 1 ----
+      const int y2 = t + 2, y1 = t + 1;
+      const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      float4 vx0 = zero4, vx1 = zero4, vg = zero4;
+      if (y2 < R) {
+        const int gx0 = xo + xdx0 - 1, gx1 = xo + xdx1 - 1;
+        if (has_x0 && (unsigned)gx0 < (unsigned)R && ci0 + xci0 < Ci)
+          vx0 = *reinterpret_cast<const float4 *>(xb + (size_t)(ci0 + xci0) * S + (size_t)gx0 * RR + (size_t)y2 * R + 4 * xq0);
+        if (has_x1 && (unsigned)gx1 < (unsigned)R && ci0 + xci1 < Ci)
+          vx1 = *reinterpret_cast<const float4 *>(xb + (size_t)(ci0 + xci1) * S + (size_t)gx1 * RR + (size_t)y2 * R + 4 * xq1);
+      }
+      if (y1 >= 0 && y1 < R && has_g && co0 + gco < Co)
+        vg = *reinterpret_cast<const float4 *>(gb_ + (size_t)(co0 + gco) * S + (size_t)xo * RR + (size_t)y1 * R + 4 * gq);
+
+      // ---- multiply output row y = t ----
+      if (t >= 0) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const int z8 = ks * 16 + kh * 8;
+          uint4 a[2][2];                                         // [mb][hi, lo]
+#pragma unroll
+          for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+              a[mb][pl] = *reinterpret_cast<const uint4 *>(gl + pl * L::GPL + (((t & 1) * kWgCo + mb * 32 + j) * ROWB) + (z8 + 8) * 2);
+#pragma unroll
+          for (int u = 0; u < 3; ++u) {
+            if (u < nunits) {
+              const int unit = wave + 8 * u, dxy = unit % 9, mb = unit / 9, dx = dxy / 3, dy = dxy - dx * 3;
+              const int slot = (t + dy - 1) & 3;
+              uint4 bw[2][3];                                    // [hi, lo][dz]
+#pragma unroll
+              for (int pl = 0; pl < 2; ++pl) {
+                const unsigned char *row = xl + pl * L::XPL + ((slot * 3 + dx) * kWgCi + j) * ROWB + (z8 + 6) * 2;
+                const uint32_t d0 = *reinterpret_cast<const uint32_t *>(row);
+                const uint4 m = *reinterpret_cast<const uint4 *>(row + 4);
+                const uint32_t d5 = *reinterpret_cast<const uint32_t *>(row + 20);
+                bw[pl][1] = m;                                   // dz = 1: x[z]     = fp16 elements 8 .. 15 of the window
+                bw[pl][0] = make_uint4(__builtin_amdgcn_alignbit(m.x, d0, 16), __builtin_amdgcn_alignbit(m.y, m.x, 16),
+                                       __builtin_amdgcn_alignbit(m.z, m.y, 16), __builtin_amdgcn_alignbit(m.w, m.z, 16));   // x[z - 1]
+                bw[pl][2] = make_uint4(__builtin_amdgcn_alignbit(m.y, m.x, 16), __builtin_amdgcn_alignbit(m.z, m.y, 16),
+                                       __builtin_amdgcn_alignbit(m.w, m.z, 16), __builtin_amdgcn_alignbit(d5, m.w, 16));    // x[z + 1]
+              }
+              const uint4 ah = mb ? a[1][0] : a[0][0], al = mb ? a[1][1] : a[0][1];
+#pragma unroll
+              for (int dz = 0; dz < 3; ++dz) acc[u][dz] = mfma16<2>(al, bw[0][dz], acc[u][dz]);     // lo x hi
+#pragma unroll
+              for (int dz = 0; dz < 3; ++dz) acc[u][dz] = mfma16<2>(ah, bw[1][dz], acc[u][dz]);     // hi x lo
+#pragma unroll
+              for (int dz = 0; dz < 3; ++dz) acc[u][dz] = mfma16<2>(ah, bw[0][dz], acc[u][dz]);     // hi x hi
+            }
+          }
+        }
+      }
+
+      // ---- convert and store the new rows (out-of-range rows are stored as zeros: they are the y / x halo) ----
+      if (t == -2) {                                            // row y = -1 of the new strip lives in slot 3
+        if (has_x0) store_row(xl, L::XPL, ((3 * 3 + xdx0) * kWgCi + xci0) * ROWB, xq0, zero4, 1.0f);
+        if (has_x1) store_row(xl, L::XPL, ((3 * 3 + xdx1) * kWgCi + xci1) * ROWB, xq1, zero4, 1.0f);
+      }
+      if (has_x0) store_row(xl, L::XPL, (((y2 & 3) * 3 + xdx0) * kWgCi + xci0) * ROWB, xq0, vx0, x_scale);
+      if (has_x1) store_row(xl, L::XPL, (((y2 & 3) * 3 + xdx1) * kWgCi + xci1) * ROWB, xq1, vx1, x_scale);
+      if (has_g && y1 >= 0) {
+        store_row(gl, L::GPL, ((y1 & 1) * kWgCo + gco) * ROWB, gq, vg, gy_scale);
+        gsum += (vg.x + vg.y) + (vg.z + vg.w);
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: part[p][tap][co][ci] (CoP x CiP padded block grid), lanes along ci ----
+  const int CoP = (int)gridDim.x / (P * citiles) * kWgCo, CiP = citiles * kWgCi;
+  float *pp = part + (size_t)p * 27 * CoP * CiP;
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    if (u < nunits) {
+      const int unit = wave + 8 * u, dxy = unit % 9, mb = unit / 9;
+#pragma unroll
+      for (int dz = 0; dz < 3; ++dz) {
+        const int tap = dxy * 3 + dz;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = co0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+          pp[((size_t)tap * CoP + co) * CiP + ci0 + j] = acc[u][dz][r];
+        }
+      }
+    }
+  }
+  if (gb_part != nullptr && cit == 0) {                         // grad_bias partial: the QZ quads of a channel, fixed order
+    __syncthreads();
+    float *red = reinterpret_cast<float *>(lds);
+    if (has_g) red[tid] = gsum;
+    __syncthreads();
+    if (tid < kWgCo) {
+      float s = 0.0f;
+#pragma unroll
+      for (int q = 0; q < QZ; ++q) s += red[tid * QZ + q];
+      gb_part[(size_t)p * CoP + co0 + tid] = s;
+    }
+  }
+}
+
+// gw[co][ci][tap] = 2^-(sx + sgy) * sum_p part[p][tap][co][ci];  gb[co] = sum_p gb_part[p][co]
+__global__ __launch_bounds__(256) void conv3d_wgrad_f16_reduce_kernel(const float *__restrict__ part, const float *__restrict__ gb_part,
+                                                                      const uint32_t *__restrict__ x_absmax,
+                                                                      const uint32_t *__restrict__ gy_absmax, int P, int CoP, int CiP,
+                                                                      int Co, int Ci, float *__restrict__ gw, float *__restrict__ gb) {
+  const size_t block = (size_t)27 * CoP * CiP;
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e < block) {
+    const int ci = (int)(e % CiP), co = (int)((e / CiP) % CoP), tap = (int)(e / ((size_t)CiP * CoP));
+    if (co < Co && ci < Ci) {
+      float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+      int q = 0;
+      for (; q + 3 < P; q += 4) {
+        s0 += part[(size_t)q * block + e];
+        s1 += part[(size_t)(q + 1) * block + e];
+        s2 += part[(size_t)(q + 2) * block + e];
+        s3 += part[(size_t)(q + 3) * block + e];
+      }
+      for (; q < P; ++q) s0 += part[(size_t)q * block + e];
+      const float s = (s0 + s1) + (s2 + s3);
+      gw[((size_t)co * Ci + ci) * 27 + tap] = s * exp2_int(-scale_shift(*x_absmax)) * exp2_int(-scale_shift(*gy_absmax));
+    }
+  }
+  if (gb != nullptr && e < (size_t)Co) {
+    float s = 0.0f;
+    for (int q = 0; q < P; ++q) s += gb_part[(size_t)q * CoP + e];
+    gb[e] = s;
+  }
+}
+
+struct WgradPlan { int cotiles, citiles, P; size_t part_floats, gb_floats; };
+
+static WgradPlan wgrad_f16_plan(int B, int Ci, int Co, int R) {
+  WgradPlan w;
+  w.cotiles = ceil_div(Co, kWgCo);
+  w.citiles = ceil_div(Ci, kWgCi);
+  const int blocks = w.cotiles * w.citiles;
+  w.P = std::max(1, std::min(B * R, 256 / blocks));             // one workgroup per CU (112 KiB of LDS each)
+  w.part_floats = (size_t)w.P * 27 * w.cotiles * kWgCo * w.citiles * kWgCi;
+  w.gb_floats = (size_t)w.P * w.cotiles * kWgCo;
+  return w;
+}
+
+template <int R>
+static int launch_wgrad_f16(const float *x, const float *gy, const uint32_t *xa, const uint32_t *ga, int B, int Ci, int Co, float *gw,
+                            float *gb, float *ws, hipStream_t s) {
+  const WgradPlan w = wgrad_f16_plan(B, Ci, Co, R);
+  float *part = ws, *gb_part = ws + w.part_floats;
+  auto k = conv3d_wgrad_f16_kernel<R>;
+  const int lds = WgradLds<R>::BYTES;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (e != hipSuccess) { set_error("conv3d_wgrad_f16: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
+  hipLaunchKernelGGL(k, dim3((unsigned)(w.P * w.citiles * w.cotiles)), dim3(512), lds, s, x, gy, xa, ga, B, Ci, Co, w.P, w.citiles, part,
+                     gb ? gb_part : nullptr);
+  if (int rc = check_launch("conv3d_wgrad_f16")) return rc;
+  const int CoP = w.cotiles * kWgCo, CiP = w.citiles * kWgCi;
+  hipLaunchKernelGGL(conv3d_wgrad_f16_reduce_kernel, dim3((unsigned)ceil_div(27 * CoP * CiP, 256)), dim3(256), 0, s, part, gb_part, xa, ga, w.P,
+                     CoP, CiP, Co, Ci, gw, gb);
+  return check_launch("conv3d_wgrad_f16_reduce");
+}
+
+}  // namespace pvcnn
+
+using namespace pvcnn;
+
+// 0 when this shape is not served by the f16x2 kernel (R not 16 or 32): use pvcnn_conv3d_bwd_weight
+extern "C" size_t pvcnn_conv3d_bwd_weight_f16_workspace_bytes(int B, int Ci, int Co, int R) {
+  if (B <= 0 || Ci <= 0 || Co <= 0 || (R != 16 && R != 32)) return 0;
+  const WgradPlan w = wgrad_f16_plan(B, Ci, Co, R);
+  return (w.part_floats + w.gb_floats) * sizeof(float);
+}
+
+extern "C" int pvcnn_conv3d_bwd_weight_f16(const float *x, const float *grad_y, const void *x_absmax, const void *gy_absmax, int B, int Ci,
+                                           int Co, int R, float *grad_w, float *grad_bias, void *workspace, size_t workspace_bytes,
+                                           void *stream) {
+  PVCNN_REQUIRE(B > 0 && Ci > 0 && Co > 0 && (R == 16 || R == 32), "bad size (R must be 16 or 32)");
+  PVCNN_REQUIRE(x && grad_y && grad_w && x_absmax && gy_absmax, "null pointer");
+  PVCNN_REQUIRE(aligned16(x) && aligned16(grad_y), "x and grad_y must be 16-byte aligned");
+  PVCNN_REQUIRE(workspace && aligned16(workspace) && workspace_bytes >= pvcnn_conv3d_bwd_weight_f16_workspace_bytes(B, Ci, Co, R),
+                "workspace missing, misaligned or too small (see pvcnn_conv3d_bwd_weight_f16_workspace_bytes)");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const uint32_t *xa = static_cast<const uint32_t *>(x_absmax), *ga = static_cast<const uint32_t *>(gy_absmax);
+  float *ws = static_cast<float *>(workspace);
+  return R == 32 ? launch_wgrad_f16<32>(x, grad_y, xa, ga, B, Ci, Co, grad_w, grad_bias, ws, s)
+                 : launch_wgrad_f16<16>(x, grad_y, xa, ga, B, Ci, Co, grad_w, grad_bias, ws, s);
+}

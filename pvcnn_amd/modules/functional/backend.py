@@ -488,14 +488,14 @@ class HipBackend:
             _lib.check(self.lib.pvcnn_conv3d_weight_split(_p(weight), co, ci, int(for_bwd_data), int(nsplit), _p(wts), s), 'conv3d_weight_split')
         return wts
 
-    def conv3d_forward_split(self, x, weight, bias, nsplit, want_stats=False):
+    def conv3d_forward_split(self, x, weight, bias, nsplit, want_stats=False, amax=None):
         _f32(x, 'x'); _f32(weight, 'weight')
         _shape(x.dim() == 5 and weight.dim() == 5 and tuple(weight.shape[2:]) == (3, 3, 3) and weight.shape[1] == x.shape[1]
                and x.shape[2] == x.shape[3] == x.shape[4], 'conv3d: x (B,Ci,R,R,R), weight (Co,Ci,3,3,3) expected')
         if bias is not None:
             _f32(bias, 'bias')
         return self.conv3d_igemm_split(x, self._conv_wsplit(weight, False, nsplit), bias, weight.shape[0], nsplit, want_stats,
-                                       self.absmax_bits(x) if int(nsplit) == 2 else None)
+                                       amax if amax is not None else (self.absmax_bits(x) if int(nsplit) == 2 else None))
 
     def conv3d_igemm_split(self, x, wts, bias, co, nsplit, want_stats=False, amax=None):
         """The implicit-GEMM launch alone (pre-split weight image `wts`; f16x2: `amax` = absmax_bits(x)): x (B,Ci,R,R,R) ->
@@ -513,13 +513,33 @@ class HipBackend:
                                                        _p(y), _p(part) if want_stats else None, s), 'conv3d_forward_split')
         return (y, part) if want_stats else y
 
-    def conv3d_backward_data_split(self, grad_y, weight, nsplit):
+    def conv3d_backward_data_split(self, grad_y, weight, nsplit, amax=None):
         _f32(grad_y, 'grad_y'); _f32(weight, 'weight')
         b, co, r = grad_y.shape[0], grad_y.shape[1], grad_y.shape[2]
         ci = weight.shape[1]
         # a convolution with Ci and Co exchanged on the flipped weights
         return self.conv3d_igemm_split(grad_y, self._conv_wsplit(weight, True, nsplit), None, ci, nsplit, False,
-                                       self.absmax_bits(grad_y) if int(nsplit) == 2 else None)
+                                       amax if amax is not None else (self.absmax_bits(grad_y) if int(nsplit) == 2 else None))
+
+    # ---- backward-weight in f16x2 (csrc/conv3d_wgrad_f16.hip): R = 16 and 32; other grids stay on the fp32-MFMA kernel ----
+    def conv3d_backward_weight_f16_serves(self, x):
+        return x.dim() == 5 and x.shape[2] in (16, 32)
+
+    def conv3d_backward_weight_f16(self, x, grad_y, x_amax=None, gy_amax=None, with_bias=False):
+        """grad_w (Co,Ci,3,3,3) [, grad_bias]: x (B,Ci,R,R,R), grad_y (B,Co,R,R,R); *_amax = absmax_bits of the two tensors."""
+        _f32(x, 'x'); _f32(grad_y, 'grad_y')
+        b, ci, r = x.shape[0], x.shape[1], x.shape[2]
+        co = grad_y.shape[1]
+        _shape(self.conv3d_backward_weight_f16_serves(x) and tuple(grad_y.shape) == (b, co, r, r, r), 'conv3d_backward_weight_f16: R must be 16 or 32')
+        x_amax = x_amax if x_amax is not None else self.absmax_bits(x)
+        gy_amax = gy_amax if gy_amax is not None else self.absmax_bits(grad_y)
+        gw = torch.empty((co, ci, 3, 3, 3), dtype=torch.float32, device=x.device)
+        gb = torch.empty((co,), dtype=torch.float32, device=x.device) if with_bias else None
+        ws = self._scratch(self.lib.pvcnn_conv3d_bwd_weight_f16_workspace_bytes(b, ci, co, r), x.device)
+        with _Launch(x) as s:
+            _lib.check(self.lib.pvcnn_conv3d_bwd_weight_f16(_p(x), _p(grad_y), _p(x_amax), _p(gy_amax), b, ci, co, r, _p(gw),
+                                                            _p(gb) if with_bias else None, _p(ws), ws.numel(), s), 'conv3d_backward_weight_f16')
+        return (gw, gb) if with_bias else gw
 
     # ---- SharedMLP 1x1 convolutions as channel-major MFMA GEMMs (csrc/pointwise.hip) --------------------
     has_pwconv = True

@@ -35,13 +35,16 @@ class VoxelConv3d(Function):
         ctx.nsplit = int(nsplit)
         b = bias.contiguous() if bias is not None else None
         be = native()
+        # f16x2: the input's max |x| (its power-of-two scale) is measured once and reused by backward-weight
+        ctx.x_amax = be.absmax_bits(x) if ctx.nsplit == 2 else None
+        kw = {'amax': ctx.x_amax} if ctx.nsplit == 2 else {}
         if want_stats:   # second output: BatchNorm partial sums from the epilogue (not differentiable)
-            y, part = (be.conv3d_forward_split(x, weight, b, ctx.nsplit, want_stats=True) if ctx.nsplit
+            y, part = (be.conv3d_forward_split(x, weight, b, ctx.nsplit, want_stats=True, **kw) if ctx.nsplit
                        else be.conv3d_forward(x, weight, b, want_stats=True))
             ctx.mark_non_differentiable(part)
             ctx.set_materialize_grads(False)     # no zero tensor for the (non-existent) gradient of `part`
             return y, part
-        return be.conv3d_forward_split(x, weight, b, ctx.nsplit) if ctx.nsplit else be.conv3d_forward(x, weight, b)
+        return be.conv3d_forward_split(x, weight, b, ctx.nsplit, **kw) if ctx.nsplit else be.conv3d_forward(x, weight, b)
 
     @staticmethod
     @amp_bwd
@@ -50,15 +53,20 @@ class VoxelConv3d(Function):
         if grad_y is None:
             return None, None, None, None, None
         grad_y = grad_y.contiguous()
+        be = native()
+        f16 = ctx.nsplit == 2
+        wgrad_f16 = f16 and ctx.needs_input_grad[1] and be.conv3d_backward_weight_f16_serves(x)
+        g_amax = be.absmax_bits(grad_y) if f16 and (ctx.needs_input_grad[0] or wgrad_f16) else None    # shared by both products
         gx = None
         if ctx.needs_input_grad[0]:
-            gx = (native().conv3d_backward_data_split(grad_y, weight, ctx.nsplit) if ctx.nsplit
-                  else native().conv3d_backward_data(grad_y, weight))
+            gx = (be.conv3d_backward_data_split(grad_y, weight, ctx.nsplit, **({'amax': g_amax} if f16 else {})) if ctx.nsplit
+                  else be.conv3d_backward_data(grad_y, weight))
         want_bias = ctx.has_bias and ctx.needs_input_grad[2]
         gw = gb = None
         if ctx.needs_input_grad[1]:
             # the bias gradient is accumulated by the same kernel from the grad_y tiles it stages anyway
-            res = native().conv3d_backward_weight(x, grad_y, with_bias=want_bias)
+            res = (be.conv3d_backward_weight_f16(x, grad_y, ctx.x_amax, g_amax, with_bias=want_bias) if wgrad_f16
+                   else be.conv3d_backward_weight(x, grad_y, with_bias=want_bias))
             gw, gb = res if want_bias else (res, None)
         elif want_bias:
             gb = grad_y.sum(dim=(0, 2, 3, 4))

@@ -74,6 +74,18 @@ def bwd_data_split(gy, w, ns):
     return gx
 
 
+def wgrad_f16(x, gy, with_bias=False):
+    b, ci, r = x.shape[0], x.shape[1], x.shape[2]
+    co = gy.shape[1]
+    gw = torch.empty(co, ci, 3, 3, 3, device=dev)
+    gb = torch.empty(co, device=dev) if with_bias else None
+    nb = lib.pvcnn_conv3d_bwd_weight_f16_workspace_bytes(b, ci, co, r)
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    ax, ag = absmax(x), absmax(gy)      # both alive until the launch is enqueued (a freed temporary would be reused by the second)
+    _lib.check(lib.pvcnn_conv3d_bwd_weight_f16(P(x), P(gy), P(ax), P(ag), b, ci, co, r, P(gw), P(gb), P(ws), nb, S()), 'wgrad_f16')
+    return (gw, gb) if with_bias else gw
+
+
 def graph_time(fn, reps=5, iters=5):
     fn()
     torch.cuda.synchronize()
@@ -125,6 +137,17 @@ def main():
             e2 = (bwd_data_split(gy, w, ns).double() - xd.grad).abs().max().item() / xd.grad.abs().max().item()
             print(json.dumps({'check_split_BCiCoR': [b, ci, co, r], 'nsplit': ns, 'fwd_rel_err': e1, 'bwd_data_rel_err': e2,
                               'ok': max(e1, e2) < (1e-5 if ns != 1 else 2e-2)}), flush=True)
+    for (b, ci, co, r) in [] if '--no-check' in sys.argv else [(2, 9, 64, 32), (2, 64, 64, 16), (3, 40, 70, 16), (1, 33, 130, 32), (1, 1, 1, 16)]:
+        x = torch.randn(b, ci, r, r, r, device=dev)
+        gy = torch.randn(b, co, r, r, r, device=dev) * 1e-3
+        wd = torch.zeros(co, ci, 3, 3, 3, device=dev, dtype=torch.float64, requires_grad=True)
+        F.conv3d(x.double(), wd, torch.zeros(co, device=dev, dtype=torch.float64), padding=1).backward(gy.double())
+        gw, gb = wgrad_f16(x, gy, True)
+        gw2, _ = wgrad_f16(x, gy, True)
+        e1 = (gw.double() - wd.grad).abs().max().item() / wd.grad.abs().max().item()
+        e2 = (gb.double() - gy.double().sum(dim=(0, 2, 3, 4))).abs().max().item() / gy.double().sum(dim=(0, 2, 3, 4)).abs().max().item()
+        print(json.dumps({'check_wgrad_f16_BCiCoR': [b, ci, co, r], 'gw_rel_err': e1, 'gb_rel_err': e2, 'deterministic': bool(torch.equal(gw, gw2)),
+                          'ok': e1 < 1e-5 and e2 < 1e-5}), flush=True)
     if '--no-check' not in sys.argv:   # f16x2 under awkward magnitudes: tiny / huge tensors, outliers, per-row weight scales, zeros
         g = torch.Generator(device=dev).manual_seed(1)
         for name, xs, wsc in [('tiny', 1e-20, 1e-6), ('huge', 1e12, 1e3), ('outlier', 1.0, 1.0), ('rows', 1.0, None), ('zero', 0.0, 1.0)]:
@@ -161,6 +184,13 @@ def main():
             am = absmax(x)
             msa = graph_time(lambda: lib.pvcnn_absmax_bits(P(x), x.numel(), P(am), S()))
             print(json.dumps({'absmax_BCR': [b, ci, r], 'ms': round(msa, 4), 'GBps': round(x.numel() * 4 / msa / 1e6, 0)}), flush=True)
+            if r in (16, 32):
+                nb16 = lib.pvcnn_conv3d_bwd_weight_f16_workspace_bytes(b, ci, co, r)
+                ws16 = torch.empty(nb16, dtype=torch.uint8, device=dev)
+                ax, ag = absmax(x), absmax(gy)
+                ms16 = graph_time(lambda: lib.pvcnn_conv3d_bwd_weight_f16(P(x), P(gy), P(ax), P(ag), b, ci, co, r, P(gw), None, P(ws16), nb16, S()))
+                print(json.dumps({'time_wgrad_f16_BCiCoR': [b, ci, co, r], 'ms': round(ms16, 4), 'effective_TFLOPs': round(fl / ms16 / 1e9, 1),
+                                  'fp32_mfma_kernel_ms': round(msw, 4), 'ws_MB': round(nb16 / 1e6, 1)}), flush=True)
             for ns, dbg in [(2, 0), (3, 0), (1, 0)]:
                 wts = split_wts(w, 0, ns)
                 mss = graph_time(lambda: lib.pvcnn_conv3d_fwd_split(P(x), P(wts), P(bias), b, ci, co, r, ns, P(am), P(y), None, S()))
