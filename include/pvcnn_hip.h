@@ -279,7 +279,7 @@ PVCNN_API size_t pvcnn_pwconv_weight_split_bytes(int Co, int Ci, int for_bwd_dat
 PVCNN_API int pvcnn_pwconv_weight_split(const float *w, int Co, int Ci, int for_bwd_data, int nsplit, void *wts, void *stream);
 PVCNN_API size_t pvcnn_pwconv_fwd_split_stats_parts(int B, int N);
 PVCNN_API int pvcnn_pwconv_fwd_split(const float *x, const void *wts, const float *bias, int B, int K, int M, int N, int nsplit,
-                           float *y, float *stats_part, void *stream);
+                           const void *x_absmax, float *y, float *stats_part, void *stream);
 
 /* ---- BatchNorm fused with the following ReLU / LeakyReLU -----------------------------------------
  * replaces the (nn.BatchNorm{1,2,3}d, nn.ReLU | nn.LeakyReLU) module pairs of modules/pvconv.py:20-27

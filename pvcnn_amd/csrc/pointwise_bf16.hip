@@ -28,11 +28,9 @@
 #include <algorithm>
 
 #include "common.h"
+#include "split16.h"
 
 namespace pvcnn {
-
-using f32x16 = __attribute__((ext_vector_type(16))) float;
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kPbN = 256;          // points per workgroup
 constexpr int kPbK = 16;           // reduction channels per chunk = MFMA K
@@ -74,11 +72,45 @@ __global__ __launch_bounds__(256) void pw_weight_split_kernel(const float *__res
   for (int s = 0; s < NS; ++s) wts[blk + ((size_t)s * TM + row) * kPbK + pos] = (uint16_t)p[s];
 }
 
+// f16x2 image: one workgroup per (padded) output row finds the row's max |w|, scales by the power of two of scale_shift and writes the
+// fp16 hi / lo planes; wexp[row] = the shift (the epilogue scales back per output channel).
+__global__ __launch_bounds__(256) void pw_weight_split_f16_kernel(const float *__restrict__ w, int Co, int Ci, int for_bwd_data, int TM,
+                                                                  uint16_t *__restrict__ wts, int *__restrict__ wexp) {
+  const int KE = for_bwd_data ? Co : Ci, ME = for_bwd_data ? Ci : Co;
+  const int chunks = ceil_div(KE, kPbK), mtiles = ceil_div(ME, TM);
+  const int m = blockIdx.x, mt = m / TM, row = m - mt * TM, tid = threadIdx.x;
+  auto load = [&](int k) { return for_bwd_data ? w[(size_t)k * Ci + m] : w[(size_t)m * Ci + k]; };
+  __shared__ uint32_t red[4];
+  uint32_t mx = 0;
+  if (m < ME)
+    for (int k = tid; k < KE; k += 256) mx = max(mx, __float_as_uint(fabsf(load(k))));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  __syncthreads();
+  const int shift = scale_shift(max(max(red[0], red[1]), max(red[2], red[3])));
+  if (tid == 0) wexp[m] = shift;
+  const float scale = exp2_int(shift);
+  for (int i = tid; i < chunks * 8; i += 256) {                 // item = (chunk, channel pair)
+    const int cp = i & 7, chunk = i >> 3, k = chunk * kPbK + 2 * cp;
+    const float a = (m < ME && k < KE) ? load(k) * scale : 0.0f, b = (m < ME && k + 1 < KE) ? load(k + 1) * scale : 0.0f;
+    uint32_t p[2];
+    split_pair<2>(a, b, p);
+    const int word = ((cp >> 2) ^ ((row >> 3) & 1)) * 4 + (cp & 3);
+    uint32_t *img = reinterpret_cast<uint32_t *>(wts + ((size_t)chunk * mtiles + mt) * ((size_t)2 * TM * kPbK));
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) img[((size_t)s2 * TM + row) * 8 + word] = p[s2];
+  }
+}
+
 template <int NS, int MB>
 __global__ __launch_bounds__(256, 2) void pw_gemm_bf16_kernel(const float *__restrict__ x, const uint16_t *__restrict__ wts,
                                                               const float *__restrict__ bias, float *__restrict__ y, int K, int M,
-                                                              int N, int tiles_n, int tiles_total, float2 *__restrict__ stats_part) {
+                                                              int N, int tiles_n, int tiles_total, float2 *__restrict__ stats_part,
+                                                              const uint32_t *__restrict__ x_absmax, const int *__restrict__ wexp) {
   constexpr int TM = 32 * MB, NBW = 2;
+  const int x_shift = NS == 2 ? scale_shift(*x_absmax) : 0;
+  const float x_scale = exp2_int(x_shift);
   constexpr int WBLK = NS * TM * kPbK;                          // bf16 elements of one (chunk, mtile) weight block
   __shared__ __attribute__((aligned(16))) uint32_t xs[NS * 8 * kPbN];       // [NS][8 channel pairs][256 points] words
 
@@ -166,11 +198,11 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_bf16_kernel(const float *__res
       uint32_t w[NS][4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        uint32_t pa[NS], pb[NS];
-        pb_split<NS>(a[t], pa);
-        pb_split<NS>(bq[t], pb);
+        uint32_t pw[NS];
+        if constexpr (NS == 2) split_pair<NS>(a[t] * x_scale, bq[t] * x_scale, pw);
+        else split_pair<NS>(a[t], bq[t], pw);
 #pragma unroll
-        for (int s = 0; s < NS; ++s) w[s][t] = pa[s] | (pb[s] << 16);
+        for (int s = 0; s < NS; ++s) w[s][t] = pw[s];
       }
 #pragma unroll
       for (int s = 0; s < NS; ++s)
@@ -190,9 +222,11 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_bf16_kernel(const float *__res
 #define PVCNN_PB_MFMA(SA, SB)                                                                                            \
     _Pragma("unroll") for (int nb = 0; nb < NBW; ++nb)                                                                   \
     _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                                                                    \
-      acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[mb][SA]),                      \
-                                                            __builtin_bit_cast(bf16x8, bf[nb][SB]), acc[mb][nb], 0, 0, 0)
+      acc[mb][nb] = mfma16<NS>(af[mb][SA], bf[nb][SB], acc[mb][nb])
     if constexpr (NS == 1) {
+      PVCNN_PB_MFMA(0, 0);
+    } else if constexpr (NS == 2) {
+      PVCNN_PB_MFMA(1, 0); PVCNN_PB_MFMA(0, 1);                         // lo x hi, hi x lo, then hi x hi
       PVCNN_PB_MFMA(0, 0);
     } else {
       PVCNN_PB_MFMA(2, 0); PVCNN_PB_MFMA(1, 1); PVCNN_PB_MFMA(0, 2);    // smallest partial products first
@@ -211,12 +245,14 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_bf16_kernel(const float *__res
   float *yb = y + (size_t)b * M * N;
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
-    float bv[16];
+    float bv[16], unscale[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = m0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
       bv[r] = (bias != nullptr && m < M) ? bias[m] : 0.0f;
+      if constexpr (NS == 2) unscale[r] = exp2_int(-wexp[m]);   // wexp covers the padded rows of the tile
     }
+    const float x_unscale = exp2_int(-x_shift);
     float ss[16], qq[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) ss[r] = qq[r] = 0.0f;
@@ -227,6 +263,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_bf16_kernel(const float *__res
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
         float v = acc[mb][nb][r];
+        if constexpr (NS == 2) v = v * unscale[r] * x_unscale;  // powers of two: exact
         if (want_stats) {                                       // statistics of (y - bias), see bn_finalize_kernel
           const float mv = n < N ? v : 0.0f;
           ss[r] += mv;
@@ -259,19 +296,31 @@ static int pb_mb(int M) { return M > 64 ? 4 : 2; }
 
 using namespace pvcnn;
 
-extern "C" size_t pvcnn_pwconv_weight_split_bytes(int Co, int Ci, int for_bwd_data, int nsplit) {
-  if (Co <= 0 || Ci <= 0 || (nsplit != 1 && nsplit != 3)) return 0;
-  const int KE = for_bwd_data ? Co : Ci, ME = for_bwd_data ? Ci : Co;
+static size_t pb_image_bytes(int KE, int ME, int nsplit) {
   const int TM = 32 * pb_mb(ME);
   return (size_t)ceil_div(KE, kPbK) * ceil_div(ME, TM) * nsplit * TM * kPbK * sizeof(uint16_t);
 }
 
+// nsplit: 1 = bf16, 3 = bf16x3, 2 = f16x2 (image followed by one int32 shift per padded output channel)
+extern "C" size_t pvcnn_pwconv_weight_split_bytes(int Co, int Ci, int for_bwd_data, int nsplit) {
+  if (Co <= 0 || Ci <= 0 || nsplit < 1 || nsplit > 3) return 0;
+  const int KE = for_bwd_data ? Co : Ci, ME = for_bwd_data ? Ci : Co;
+  const int TM = 32 * pb_mb(ME);
+  return pb_image_bytes(KE, ME, nsplit) + (nsplit == 2 ? (size_t)ceil_div(ME, TM) * TM * sizeof(int) : 0);
+}
+
 extern "C" int pvcnn_pwconv_weight_split(const float *w, int Co, int Ci, int for_bwd_data, int nsplit, void *wts, void *stream) {
   PVCNN_REQUIRE(w && wts && Co > 0 && Ci > 0, "bad argument");
-  PVCNN_REQUIRE(nsplit == 1 || nsplit == 3, "nsplit must be 1 (bf16) or 3 (bf16x3)");
+  PVCNN_REQUIRE(nsplit >= 1 && nsplit <= 3, "nsplit must be 1 (bf16), 2 (f16x2) or 3 (bf16x3)");
   PVCNN_REQUIRE(aligned16(wts), "wts must be 16-byte aligned");
   const int KE = for_bwd_data ? Co : Ci, ME = for_bwd_data ? Ci : Co;
   const int TM = 32 * pb_mb(ME);
+  if (nsplit == 2) {
+    int *wexp = reinterpret_cast<int *>(static_cast<char *>(wts) + pb_image_bytes(KE, ME, 2));
+    hipLaunchKernelGGL(pw_weight_split_f16_kernel, dim3(ceil_div(ME, TM) * TM), dim3(256), 0, static_cast<hipStream_t>(stream), w, Co, Ci,
+                       for_bwd_data, TM, static_cast<uint16_t *>(wts), wexp);
+    return check_launch("pwconv_weight_split_f16");
+  }
   const long total = (long)ceil_div(KE, kPbK) * ceil_div(ME, TM) * TM * kPbK;
   const dim3 grid((unsigned)((total + 255) / 256));
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -288,9 +337,10 @@ extern "C" size_t pvcnn_pwconv_fwd_split_stats_parts(int B, int N) {
 // y (B,M,N) = W x + bias with the pre-split weights (forward: K = Ci, M = Co; backward-data: x = grad_y, K = Co, M = Ci, bias NULL,
 // for_bwd_data = 1 image).  stats_part: NULL or (M, *_split_stats_parts) float pairs of (sum, sum of squares) of (y - bias).
 extern "C" int pvcnn_pwconv_fwd_split(const float *x, const void *wts, const float *bias, int B, int K, int M, int N, int nsplit,
-                                      float *y, float *stats_part, void *stream) {
+                                      const void *x_absmax, float *y, float *stats_part, void *stream) {
   PVCNN_REQUIRE(B >= 0 && K > 0 && M > 0 && N >= 0, "bad size");
-  PVCNN_REQUIRE(nsplit == 1 || nsplit == 3, "nsplit must be 1 (bf16) or 3 (bf16x3)");
+  PVCNN_REQUIRE(nsplit >= 1 && nsplit <= 3, "nsplit must be 1 (bf16), 2 (f16x2) or 3 (bf16x3)");
+  PVCNN_REQUIRE(nsplit != 2 || x_absmax, "f16x2 needs the input's pvcnn_absmax_bits");
   if (B == 0 || N == 0) return 0;
   PVCNN_REQUIRE(x && wts && y && aligned16(wts), "null or misaligned pointer");
   PVCNN_REQUIRE(!stats_part || (reinterpret_cast<uintptr_t>(stats_part) & 7) == 0, "stats_part must be 8-byte aligned");
@@ -303,9 +353,12 @@ extern "C" int pvcnn_pwconv_fwd_split(const float *x, const void *wts, const flo
   hipStream_t s = static_cast<hipStream_t>(stream);
   const uint16_t *w16 = static_cast<const uint16_t *>(wts);
   float2 *sp = reinterpret_cast<float2 *>(stats_part);
-#define PVCNN_PB_LAUNCH(NSV, MBV) hipLaunchKernelGGL((pw_gemm_bf16_kernel<NSV, MBV>), grid, dim3(256), 0, s, x, w16, bias, y, K, M, N, tiles_n, (int)tiles_total, sp)
-  if (nsplit == 3) { if (MB == 4) PVCNN_PB_LAUNCH(3, 4); else PVCNN_PB_LAUNCH(3, 2); }
-  else             { if (MB == 4) PVCNN_PB_LAUNCH(1, 4); else PVCNN_PB_LAUNCH(1, 2); }
+  const uint32_t *am = static_cast<const uint32_t *>(x_absmax);
+  const int *wexp = nsplit == 2 ? reinterpret_cast<const int *>(static_cast<const char *>(wts) + pb_image_bytes(K, M, 2)) : nullptr;
+#define PVCNN_PB_LAUNCH(NSV, MBV) hipLaunchKernelGGL((pw_gemm_bf16_kernel<NSV, MBV>), grid, dim3(256), 0, s, x, w16, bias, y, K, M, N, tiles_n, (int)tiles_total, sp, am, wexp)
+  if (nsplit == 3)      { if (MB == 4) PVCNN_PB_LAUNCH(3, 4); else PVCNN_PB_LAUNCH(3, 2); }
+  else if (nsplit == 2) { if (MB == 4) PVCNN_PB_LAUNCH(2, 4); else PVCNN_PB_LAUNCH(2, 2); }
+  else                  { if (MB == 4) PVCNN_PB_LAUNCH(1, 4); else PVCNN_PB_LAUNCH(1, 2); }
 #undef PVCNN_PB_LAUNCH
   return check_launch("pwconv_fwd_split");
 }

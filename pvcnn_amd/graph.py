@@ -1,0 +1,70 @@
+"""One training step as a hipGraph.
+
+A PVCNN step is ~380 kernel launches of 5-400 us.  Since the dense convolutions moved to the 16-bit matrix cores the GPU finishes
+them faster than one Python thread can issue them (ctypes call + torch dispatch: ~25 us per launch), i.e. the eager step is
+host-bound.  The step has static shapes and no host synchronisation (the per-coords plans, the device-side logits_mask and the
+BatchNorm statistics all stay on the device), so it is captured once -- zero the gradient buckets, forward, loss, backward and,
+on one GPU, the fused Adam update -- and replayed with a single launch per step.
+
+Multi-GPU: only forward + backward are captured; the bucket all-reduces (RCCL) and the optimizer run eagerly after the replay
+(`GradBucketReducer.finish()` issues them in fixed bucket order).  PVCNN's gradients are a few MB, so nothing is lost by not
+overlapping them with backward, and no collective has to live inside a captured graph.
+
+New input data goes INTO the static tensors the step was captured with (`tensor.copy_(batch)`), as with any captured graph.
+"""
+import contextlib
+
+import torch
+
+from .modules.functional import _cache
+
+__all__ = ['GraphedTrainStep']
+
+
+class GraphedTrainStep:
+    """step = GraphedTrainStep(model, loss_fn, optimizer, reducer); loss = step()
+
+    loss_fn() -> scalar loss tensor, reading the model's inputs / targets from static device tensors.
+    optimizer: built with capturable=True when it is to be captured (single GPU).
+    """
+
+    def __init__(self, model, loss_fn, optimizer, reducer, autocast=contextlib.nullcontext, warmup=3):
+        self.model, self.loss_fn, self.optimizer, self.reducer, self.autocast = model, loss_fn, optimizer, reducer, autocast
+        self.collective = bool(reducer.collective)
+        if self.collective:
+            reducer.launch_from_hooks = False            # collectives are issued by finish(), outside the graph
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                    # warm up on the capture stream's side: lazy inits, allocator pools
+            for _ in range(max(1, warmup)):
+                self.eager_step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        _cache.clear()                                   # the per-coords plans must be rebuilt INSIDE the graph
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = self._forward_backward()
+            if not self.collective:
+                self.reducer.finish()
+                self.optimizer.step()
+        _cache.clear()                                   # nothing outside may alias tensors of the graph's private pool
+
+    def _forward_backward(self):
+        self.reducer.zero_grad()
+        with self.autocast():
+            loss = self.loss_fn()
+        loss.backward()
+        return loss
+
+    def eager_step(self):
+        loss = self._forward_backward()
+        self.reducer.finish()
+        self.optimizer.step()
+        return loss
+
+    def __call__(self):
+        self.graph.replay()
+        if self.collective:
+            self.reducer.finish()
+            self.optimizer.step()
+        return self.loss

@@ -579,7 +579,10 @@ class HipBackend:
 
     # ---- the same GEMMs on the bf16 matrix cores (csrc/pointwise_bf16.hip), nsplit = 3 (bf16x3) or 1 (bf16) ----
     has_pwconv_split = True
-    pw_math = os.environ.get('PVCNN_PW_MATH', 'fp32')     # 'bf16x3' routes SharedMLP fwd / bwd-data through pointwise_bf16.hip (see its header)
+    # arithmetic of the SharedMLP forward / backward-data products: 'fp32' (pointwise.hip), 'f16x2' or 'bf16x3' (pointwise_bf16.hip)
+    pw_math = os.environ.get('PVCNN_PW_MATH', 'f16x2')
+    PW_NSPLIT = {'f16x2': 2, 'bf16x3': 3, 'fp32': 0}
+    pw_split_min_macs = 1 << 32     # K * M * B * N below which the split path is not worth its two extra launches (4.3 G multiply-adds)
 
     def _pw_wsplit(self, weight, for_bwd_data, nsplit):
         co, ci = weight.shape
@@ -589,28 +592,31 @@ class HipBackend:
             _lib.check(self.lib.pvcnn_pwconv_weight_split(_p(weight), co, ci, int(for_bwd_data), int(nsplit), _p(wts), s), 'pwconv_weight_split')
         return wts
 
-    def pwconv_gemm_split(self, x, wts, bias, m, nsplit, want_stats=False):
-        """The GEMM launch alone: x (B,K,N), pre-split weight image -> y (B,m,N) [, stats partials]."""
+    def pwconv_gemm_split(self, x, wts, bias, m, nsplit, want_stats=False, amax=None):
+        """The GEMM launch alone: x (B,K,N), pre-split weight image (f16x2: amax = absmax_bits(x)) -> y (B,m,N) [, stats partials]."""
         b, k, n = x.shape
         y = torch.empty((b, m, n), dtype=torch.float32, device=x.device)
         part = None
         if want_stats:
             part = torch.empty((m, self.lib.pvcnn_pwconv_fwd_split_stats_parts(b, n), 2), dtype=torch.float32, device=x.device)
+        if int(nsplit) == 2 and amax is None:
+            amax = self.absmax_bits(x)
         with _Launch(x) as s:
             _lib.check(self.lib.pvcnn_pwconv_fwd_split(_p(x), _p(wts), _p(bias) if bias is not None else None, b, k, m, n, int(nsplit),
+                                                       _p(amax) if amax is not None else None,
                                                        _p(y), _p(part) if want_stats else None, s), 'pwconv_forward_split')
         return (y, part) if want_stats else y
 
-    def pwconv_forward_split(self, x, weight, bias, nsplit, want_stats=False):
+    def pwconv_forward_split(self, x, weight, bias, nsplit, want_stats=False, amax=None):
         _f32(x, 'x'); _f32(weight, 'weight')
         _shape(x.dim() == 3 and weight.dim() == 2 and weight.shape[1] == x.shape[1], 'pwconv: x (B,Ci,N), weight (Co,Ci) expected')
         if bias is not None:
             _f32(bias, 'bias')
-        return self.pwconv_gemm_split(x, self._pw_wsplit(weight, False, nsplit), bias, weight.shape[0], nsplit, want_stats)
+        return self.pwconv_gemm_split(x, self._pw_wsplit(weight, False, nsplit), bias, weight.shape[0], nsplit, want_stats, amax)
 
-    def pwconv_backward_data_split(self, grad_y, weight, nsplit):
+    def pwconv_backward_data_split(self, grad_y, weight, nsplit, amax=None):
         _f32(grad_y, 'grad_y'); _f32(weight, 'weight')
-        return self.pwconv_gemm_split(grad_y, self._pw_wsplit(weight, True, nsplit), None, weight.shape[1], nsplit)
+        return self.pwconv_gemm_split(grad_y, self._pw_wsplit(weight, True, nsplit), None, weight.shape[1], nsplit, False, amax)
 
     def pwconv_backward_weight(self, x, grad_y, with_bias=False):
         """-> grad_weight (Co,Ci), or (grad_weight, grad_bias) when with_bias."""

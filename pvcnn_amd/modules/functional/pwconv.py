@@ -21,9 +21,13 @@ class PointwiseConv(Function):
         ctx.has_bias, ctx.x_shape, ctx.w_shape = bias is not None, shape, weight.shape
         b = bias.contiguous() if bias is not None else None
         be = native()
-        # opt-in: the three-way bf16 split on the bf16 matrix cores (csrc/pointwise_bf16.hip; 0.9-1.14x here, see its header)
-        ctx.split = 3 if (getattr(be, 'has_pwconv_split', False) and getattr(be, 'pw_math', 'fp32') == 'bf16x3') else 0
-        run = (lambda **kw: be.pwconv_forward_split(x3, w2, b, ctx.split, **kw)) if ctx.split else (lambda **kw: be.pwconv_forward(x3, w2, b, **kw))
+        # the split products on the 16-bit matrix cores (csrc/pointwise_bf16.hip): 2 = f16x2, 3 = bf16x3, 0 = fp32 MFMA
+        ctx.split = getattr(be, 'PW_NSPLIT', {}).get(getattr(be, 'pw_math', 'fp32'), 0) if getattr(be, 'has_pwconv_split', False) else 0
+        if ctx.split and w2.shape[0] * w2.shape[1] * x3.shape[0] * x3.shape[2] < getattr(be, 'pw_split_min_macs', 0):
+            ctx.split = 0      # small GEMMs are launch-bound: the weight split and the absmax pass would cost more than they save
+        ctx.x_amax = be.absmax_bits(x3) if ctx.split == 2 else None
+        akw = {'amax': ctx.x_amax} if ctx.split == 2 else {}
+        run = (lambda **kw: be.pwconv_forward_split(x3, w2, b, ctx.split, **akw, **kw)) if ctx.split else (lambda **kw: be.pwconv_forward(x3, w2, b, **kw))
         if want_stats:   # second output: BatchNorm partial sums from the epilogue (not differentiable)
             y, part = run(want_stats=True)
             ctx.mark_non_differentiable(part)

@@ -120,3 +120,10 @@ def test_pointwise_gemm_on_the_bf16_matrix_cores(hip, b, ci, co, n):
     assert _rel(sums[:, 0], centred.sum(dim=1)) < 1e-5 and _rel(sums[:, 1], (centred * centred).sum(dim=1)) < 1e-5
     assert _rel(hip.pwconv_backward_data_split(gy, w, 3), torch.einsum('oc,bon->bcn', w.double(), gy.double())) < 1e-5
     assert _rel(hip.pwconv_forward_split(x, w, bias, 1), ref) < 4e-3
+    # f16x2: scaled fp16 hi + lo, three partial products
+    y2, part2 = hip.pwconv_forward_split(x, w, bias, 2, want_stats=True)
+    assert _rel(y2, ref) < 1e-5 and torch.equal(hip.pwconv_forward_split(x, w, bias, 2), y2)
+    centred = (y2.double() - bias.double().view(1, -1, 1)).transpose(0, 1).reshape(co, -1)
+    sums = part2.double().sum(dim=1)
+    assert _rel(sums[:, 0], centred.sum(dim=1)) < 1e-5 and _rel(sums[:, 1], (centred * centred).sum(dim=1)) < 1e-5
+    assert _rel(hip.pwconv_backward_data_split(gy * 1e-9, w * 1e3, 2), torch.einsum('oc,bon->bcn', w.double() * 1e3, gy.double() * 1e-9)) < 1e-5

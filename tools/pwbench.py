@@ -33,6 +33,15 @@ for (b, ci, co, n) in shapes:
     bias = torch.randn(co, device=dev)
     gy = torch.randn(b, co, n, device=dev)
     fl = 2.0 * b * n * ci * co
+    ax, ag = be.absmax_bits(x), be.absmax_bits(gy)
+    wf, wb = be._pw_wsplit(w, False, 2), be._pw_wsplit(w, True, 2)
+    f2 = t(lambda: be.pwconv_gemm_split(x, wf, bias, co, 2, False, ax))        # the GEMM launch alone
+    d2 = t(lambda: be.pwconv_gemm_split(gy, wb, None, ci, 2, False, ag))
+    f2all = t(lambda: be.pwconv_forward_split(x, w, bias, 2))                  # + weight split + absmax
+    e2 = ((be.pwconv_forward_split(x, w, bias, 2).double() - F.conv1d(x.double(), w.double().view(co, ci, 1), bias.double())).abs().max()
+          / F.conv1d(x.double(), w.double().view(co, ci, 1), bias.double()).abs().max()).item()
+    print(json.dumps({'f16x2_BCiCoN': [b, ci, co, n], 'fwd_ms': round(f2, 4), 'fwd_eff_TF': round(fl / f2 / 1e9, 1), 'bwd_data_ms': round(d2, 4),
+                      'fwd_with_split_and_absmax_ms': round(f2all, 4), 'err_f16x2': e2}), flush=True)
     f3 = t(lambda: be.pwconv_forward_split(x, w, bias, 3))
     d3 = t(lambda: be.pwconv_backward_data_split(gy, w, 3))
     f1 = t(lambda: be.pwconv_forward_split(x, w, bias, 1))
