@@ -280,6 +280,12 @@ PVCNN_API int pvcnn_pwconv_weight_split(const float *w, int Co, int Ci, int for_
 PVCNN_API size_t pvcnn_pwconv_fwd_split_stats_parts(int B, int N);
 PVCNN_API int pvcnn_pwconv_fwd_split(const float *x, const void *wts, const float *bias, int B, int K, int M, int N, int nsplit,
                            const void *x_absmax, float *y, float *stats_part, void *stream);
+/* Backward-weight of the 1x1 convolution in f16x2 (csrc/pointwise_wgrad_f16.hip), N % 4 == 0 (workspace_bytes returns 0 otherwise:
+ * use pvcnn_pwconv_bwd_weight).  x (B,K,N), grad_y (B,M,N) -> grad_w (M,K) [, grad_bias (M)]; *_absmax: pvcnn_absmax_bits of the two
+ * tensors.  Deterministic split-K, <= 1e-5 vs fp64. */
+PVCNN_API size_t pvcnn_pwconv_bwd_weight_f16_workspace_bytes(int B, int K, int M, int N);
+PVCNN_API int pvcnn_pwconv_bwd_weight_f16(const float *x, const float *grad_y, const void *x_absmax, const void *gy_absmax, int B, int K,
+                                int M, int N, float *grad_w, float *grad_bias, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- BatchNorm fused with the following ReLU / LeakyReLU -----------------------------------------
  * replaces the (nn.BatchNorm{1,2,3}d, nn.ReLU | nn.LeakyReLU) module pairs of modules/pvconv.py:20-27

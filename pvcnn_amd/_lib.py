@@ -68,6 +68,8 @@ SIGNATURES = {
     'pvcnn_pwconv_weight_split': (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     'pvcnn_pwconv_fwd_split_stats_parts': (_sz, [_i, _i]),
     'pvcnn_pwconv_fwd_split': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    'pvcnn_pwconv_bwd_weight_f16_workspace_bytes': (_sz, [_i, _i, _i, _i]),
+    'pvcnn_pwconv_bwd_weight_f16': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     'pvcnn_pwconv_bwd_weight_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'pvcnn_pwconv_bwd_weight': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     'pvcnn_bnact_workspace_bytes': (_sz, [_i, _i, _i]),

@@ -631,6 +631,25 @@ class HipBackend:
                                                         _p(ws), ws.numel(), s), 'pwconv_backward_weight')
         return (gw, gb) if with_bias else gw
 
+    def pwconv_backward_weight_f16_serves(self, x):
+        return x.dim() == 3 and x.shape[2] % 4 == 0
+
+    def pwconv_backward_weight_f16(self, x, grad_y, x_amax=None, gy_amax=None, with_bias=False):
+        """f16x2 on the fp16 matrix cores (csrc/pointwise_wgrad_f16.hip): -> grad_weight (Co,Ci) [, grad_bias]."""
+        _f32(x, 'x'); _f32(grad_y, 'grad_y')
+        b, ci, n = x.shape
+        co = grad_y.shape[1]
+        _shape(self.pwconv_backward_weight_f16_serves(x) and tuple(grad_y.shape) == (b, co, n), 'pwconv_backward_weight_f16: N must be a multiple of 4')
+        x_amax = x_amax if x_amax is not None else self.absmax_bits(x)
+        gy_amax = gy_amax if gy_amax is not None else self.absmax_bits(grad_y)
+        gw = torch.empty((co, ci), dtype=torch.float32, device=x.device)
+        gb = torch.empty((co,), dtype=torch.float32, device=x.device) if with_bias else None
+        ws = self._scratch(self.lib.pvcnn_pwconv_bwd_weight_f16_workspace_bytes(b, ci, co, n), x.device)
+        with _Launch(x) as s:
+            _lib.check(self.lib.pvcnn_pwconv_bwd_weight_f16(_p(x), _p(grad_y), _p(x_amax), _p(gy_amax), b, ci, co, n, _p(gw),
+                                                            _p(gb) if with_bias else None, _p(ws), ws.numel(), s), 'pwconv_backward_weight_f16')
+        return (gw, gb) if with_bias else gw
+
     # ---- BatchNorm + ReLU/LeakyReLU in two passes each way (csrc/bnact.hip) ---------------------------
     has_bnact = True
 

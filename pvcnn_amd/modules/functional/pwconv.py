@@ -42,13 +42,19 @@ class PointwiseConv(Function):
         if grad_y is None:
             return None, None, None, None
         g3 = grad_y.contiguous().view(x3.shape[0], w2.shape[0], -1)
+        be = native()
+        f16 = ctx.split == 2
+        wgrad_f16 = f16 and ctx.needs_input_grad[1] and be.pwconv_backward_weight_f16_serves(x3)
+        g_amax = be.absmax_bits(g3) if f16 and (ctx.needs_input_grad[0] or wgrad_f16) else None      # shared by both products
         gx = None
         if ctx.needs_input_grad[0]:
-            gx = (native().pwconv_backward_data_split(g3, w2, ctx.split) if ctx.split else native().pwconv_backward_data(g3, w2)).view(ctx.x_shape)
+            gx = (be.pwconv_backward_data_split(g3, w2, ctx.split, **({'amax': g_amax} if f16 else {})) if ctx.split
+                  else be.pwconv_backward_data(g3, w2)).view(ctx.x_shape)
         want_bias = ctx.has_bias and ctx.needs_input_grad[2]
         gw = gb = None
         if ctx.needs_input_grad[1]:
-            res = native().pwconv_backward_weight(x3, g3, with_bias=want_bias)
+            res = (be.pwconv_backward_weight_f16(x3, g3, ctx.x_amax, g_amax, with_bias=want_bias) if wgrad_f16
+                   else be.pwconv_backward_weight(x3, g3, with_bias=want_bias))
             gw, gb = res if want_bias else (res, None)
             gw = gw.view(ctx.w_shape)
         elif want_bias:

@@ -127,3 +127,17 @@ def test_pointwise_gemm_on_the_bf16_matrix_cores(hip, b, ci, co, n):
     sums = part2.double().sum(dim=1)
     assert _rel(sums[:, 0], centred.sum(dim=1)) < 1e-5 and _rel(sums[:, 1], (centred * centred).sum(dim=1)) < 1e-5
     assert _rel(hip.pwconv_backward_data_split(gy * 1e-9, w * 1e3, 2), torch.einsum('oc,bon->bcn', w.double() * 1e3, gy.double() * 1e-9)) < 1e-5
+
+
+@pytest.mark.parametrize('b,ci,co,n', [(2, 9, 64, 4096), (3, 64, 128, 1000), (1, 130, 70, 516), (2, 1472, 512, 1024), (1, 16, 13, 8), (16, 128, 1024, 512)])
+def test_pointwise_backward_weight_f16x2(hip, b, ci, co, n):
+    """csrc/pointwise_wgrad_f16.hip: grad_w and grad_bias at the 1e-5 bar (vs fp64), bit-reproducible, ragged M / K / N tails,
+    gradients far below fp16's range."""
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(b, ci, n, generator=g).to(DEV)
+    gy = (torch.randn(b, co, n, generator=g) * 1e-8).to(DEV)
+    ref = torch.einsum('bon,bcn->oc', gy.double(), x.double())
+    gw, gb = hip.pwconv_backward_weight_f16(x, gy, with_bias=True)
+    assert _rel(gw, ref) < 1e-5 and _rel(gb, gy.double().sum(dim=(0, 2))) < 1e-5
+    assert torch.equal(hip.pwconv_backward_weight_f16(x, gy, hip.absmax_bits(x), hip.absmax_bits(gy)), gw)
+    assert _rel(gw, ref) < 4 * _rel(hip.pwconv_backward_weight(x, gy), ref) + 1e-7

@@ -40,6 +40,10 @@ for (b, ci, co, n) in shapes:
     f2all = t(lambda: be.pwconv_forward_split(x, w, bias, 2))                  # + weight split + absmax
     e2 = ((be.pwconv_forward_split(x, w, bias, 2).double() - F.conv1d(x.double(), w.double().view(co, ci, 1), bias.double())).abs().max()
           / F.conv1d(x.double(), w.double().view(co, ci, 1), bias.double()).abs().max()).item()
+    g2 = t(lambda: be.pwconv_backward_weight_f16(x, gy, ax, ag, with_bias=True))
+    gwr = torch.einsum('bon,bcn->oc', gy.double(), x.double())
+    eg = ((be.pwconv_backward_weight_f16(x, gy, ax, ag).double() - gwr).abs().max() / gwr.abs().max()).item()
+    print(json.dumps({'f16x2_wgrad_BCiCoN': [b, ci, co, n], 'bwd_w_ms': round(g2, 4), 'eff_TF': round(fl / g2 / 1e9, 1), 'err': eg}), flush=True)
     print(json.dumps({'f16x2_BCiCoN': [b, ci, co, n], 'fwd_ms': round(f2, 4), 'fwd_eff_TF': round(fl / f2 / 1e9, 1), 'bwd_data_ms': round(d2, 4),
                       'fwd_with_split_and_absmax_ms': round(f2all, 4), 'err_f16x2': e2}), flush=True)
     f3 = t(lambda: be.pwconv_forward_split(x, w, bias, 3))
