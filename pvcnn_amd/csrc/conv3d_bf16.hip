@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void conv3d_weight_split_kernel(const float *_
 // i.e. the matrix pipe itself sustains ~1.6 PF on random data here (the chip clocks down under a dense bf16 MFMA stream),
 // and what is left above it is prologue / epilogue exposure; the simplest structure is kept.
 template <int NS, int TX, int TY, int TZ, bool VEC>
-__global__ __launch_bounds__(256, TX * TY * TZ == 128 ? 4 : (NS == 3 || TX * TY * TZ == 512) ? 2 : 3) void conv3d_igemm_bf16_kernel(const float *__restrict__ x, const uint16_t *__restrict__ wts,
+__global__ __launch_bounds__(256, (NS == 3 || TX * TY * TZ == 512 || TZ <= 16) ? 2 : 3) void conv3d_igemm_bf16_kernel(const float *__restrict__ x, const uint16_t *__restrict__ wts,
                                                                    const float *__restrict__ bias, float *__restrict__ y,
                                                                    int Ci, int Co, int R, int tiles_x, int tiles_y, int tiles_z,
                                                                    float2 *__restrict__ stats_part,
@@ -296,19 +296,15 @@ __global__ __launch_bounds__(256, TX * TY * TZ == 128 ? 4 : (NS == 3 || TX * TY 
 #pragma unroll
         for (int s = 0; s < NS; ++s) af[mb][s] = wq[((dz * NS + s) * kCoTileB * 8 + a_off[mb]) >> 2];
     };
-    uint4 afn[2][NS];
-    load_a(0, afn);
-#pragma unroll
-    for (int tap = 0; tap < 27; ++tap) {
-      uint4 af[2][NS];
-#pragma unroll
-      for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-        for (int s = 0; s < NS; ++s) af[mb][s] = afn[mb][s];
-      if (tap + 1 < 27) load_a(tap + 1, afn);                   // next tap's weights are in flight during this tap's MFMAs
+    // The weight fragments of the next AD taps are in flight during this tap's MFMAs.  AD = 1 hides them behind the other waves of
+    // the SIMD; small grids (R <= 16) have only one or two waves per SIMD and a tap's MFMAs take 160-320 ns, far less than an L2
+    // hit: there the ring is three taps deep (48 more VGPRs, which the 256-voxel tiles have).
+    constexpr int AD = (TZ <= 16 && NS != 3) ? 3 : 1;
+    constexpr bool PIN = AD > 1, BPRE = PIN;                    // (pinning the R = 32 tiles changes nothing: 3 waves per SIMD hide it)
+    uint4 aq[AD + 1][2][NS], bq[2][NBW][NS];
+    auto load_b = [&](int tap, uint4 (&bf)[NBW][NS]) {
       const int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
       const int toff = (dx * HY + dy) * HZ + dz;
-      uint4 bf[NBW][NS];
 #pragma unroll
       for (int nb = 0; nb < NBW; ++nb) {
         const int vi = hb[nb] + toff;
@@ -316,6 +312,21 @@ __global__ __launch_bounds__(256, TX * TY * TZ == 128 ? 4 : (NS == 3 || TX * TY 
 #pragma unroll
         for (int s = 0; s < NS; ++s) bf[nb][s] = *reinterpret_cast<const uint4 *>(xs + s * HS * 8 + boff);
       }
+    };
+#pragma unroll
+    for (int d = 0; d < AD; ++d) load_a(d, aq[d]);
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) {
+      if (tap + AD < 27) load_a(tap + AD, aq[(tap + AD) % (AD + 1)]);
+      if constexpr (BPRE) {                                     // ... and the input fragments (LDS) one tap ahead
+        if (tap == 0) load_b(0, bq[0]);
+        if (tap + 1 < 27) load_b(tap + 1, bq[(tap + 1) & 1]);
+      } else {
+        load_b(tap, bq[tap & 1]);
+      }
+      if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);     // or the scheduler sinks the loads to just before their use
+      uint4 (&af)[2][NS] = aq[tap % (AD + 1)];
+      uint4 (&bf)[NBW][NS] = bq[tap & 1];
       // consecutive MFMAs go to different accumulators (4 independent tiles between two partial products of one tile)
 #define PVCNN_MFMA4(SA, SB)                                                                                              \
       _Pragma("unroll") for (int nb = 0; nb < NBW; ++nb)                                                                 \
