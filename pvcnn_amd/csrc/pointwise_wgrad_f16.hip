@@ -13,7 +13,7 @@
 //     (deterministic, no atomics) and scales back by 2^-(sx + sgy); grad_bias falls out of the grad_y slabs a thread converts.
 // N % 4 == 0 (16-byte loads); other shapes stay on the fp32-MFMA kernel of pointwise.hip.
 // Measured at (16, 1472 -> 512, 4096): 0.61 ms (fp32 MFMA: 0.87).  Tried and slower: 128 x 256 tiles (64 x 128 per wave: 256 VGPRs and
-// spills, 0.95 ms); two chunks of loads in flight in registers (the compiler waits on vmcnt(0) at every conversion anyway: 1.09 ms).
+// spills, 0.95 ms); two chunks in flight with CONDITIONAL loads (the compiler then waits on vmcnt(0) at every conversion: 1.09 ms).
 #include <algorithm>
 
 #include "common.h"
@@ -47,28 +47,33 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_f16_kernel(const float *__res
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b2][r] = 0.0f;
 
-  // staging: item u of a thread = row r0 + 32 u of the 256-row slab (rows 0..127 grad_y, 128..255 x), point quad q
+  // staging: item u of a thread = row r0 + 32 u of the 256-row slab (rows 0..127 grad_y, 128..255 x), point quad q.  The loads are
+  // branch-free (a row outside the tensor reads row 0 and is zeroed afterwards) so that the compiler can count them: TWO chunks
+  // are in flight in registers -- a chunk's MFMAs take ~0.6 us, less than a miss to HBM.
   const int q = tid & 7, r0 = tid >> 3;
-  float4 v[8];
+  const float *rowp[8];
+  bool rowok[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int row = r0 + 32 * (u & 3);
+    rowok[u] = u < 4 ? (m0 + row < M) : (k0 + row < K);
+    rowp[u] = u < 4 ? gy + (size_t)(rowok[u] ? m0 + row : 0) * N : x + (size_t)(rowok[u] ? k0 + row : 0) * N;
+  }
+  float4 va[8], vb[8];
   float gsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   const int c_begin = (int)((long)total_chunks * p / P), c_end = (int)((long)total_chunks * (p + 1) / P);
-  auto load = [&](int c) {
+  auto load = [&](int c, float4 (&v)[8]) {                      // c may run past c_end: it then re-reads the last chunk (discarded)
+    c = min(c, c_end - 1);
+    const int b = c / cps, n = (c - b * cps) * kGwPc + 4 * q;
+    const size_t og = (size_t)b * M * N + (n < N ? n : 0), ox = (size_t)b * K * N + (n < N ? n : 0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4 *>(rowp[u] + (u < 4 ? og : ox));
+  };
+  auto convert = [&](int c, float4 (&v)[8]) {
     const int b = c / cps, n = (c - b * cps) * kGwPc + 4 * q;
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const int row = r0 + 32 * (u & 3);
-      v[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      if (n < N) {                                              // N % 4 == 0: a quad is inside or outside
-        if (u < 4) { if (m0 + row < M) v[u] = *reinterpret_cast<const float4 *>(gy + ((size_t)b * M + m0 + row) * N + n); }
-        else       { if (k0 + row < K) v[u] = *reinterpret_cast<const float4 *>(x + ((size_t)b * K + k0 + row) * N + n); }
-      }
-    }
-  };
-  if (c_begin < c_end) load(c_begin);
-  for (int c = c_begin; c < c_end; ++c) {
-    __syncthreads();                                            // the previous chunk's fragment reads are done
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
+      if (!(rowok[u] && n < N)) v[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       const int row = r0 + 32 * (u & 3);
       const float sc = u < 4 ? gy_scale : x_scale;
       uint32_t w0[2], w1[2];
@@ -79,8 +84,8 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_f16_kernel(const float *__res
       *reinterpret_cast<uint2 *>(dst + kGwPlane) = make_uint2(w0[1], w1[1]);
       if (u < 4) gsum[u] += (v[u].x + v[u].y) + (v[u].z + v[u].w);
     }
-    __syncthreads();
-    if (c + 1 < c_end) load(c + 1);                             // in flight during this chunk's MFMAs
+  };
+  auto multiply = [&]() {
 #pragma unroll
     for (int ks = 0; ks < kGwPc / 16; ++ks) {
       const int off = (ks * 16 + kh * 8) * 2;
@@ -104,6 +109,26 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_f16_kernel(const float *__res
       for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = mfma16<2>(a[mb][0], bq[nb][0], acc[mb][nb]);      // hi x hi
+    }
+  };
+  if (c_begin < c_end) {
+    load(c_begin, va);
+    load(c_begin + 1, vb);
+  }
+  for (int c = c_begin; c < c_end; c += 2) {
+    __syncthreads();                                            // the previous chunk's fragment reads are done
+    convert(c, va);
+    __syncthreads();
+    load(c + 2, va);                                            // lands two chunks of MFMAs later
+    __builtin_amdgcn_sched_barrier(0);                          // keep the loads ahead of the MFMAs
+    multiply();
+    if (c + 1 < c_end) {
+      __syncthreads();
+      convert(c + 1, vb);
+      __syncthreads();
+      load(c + 3, vb);
+      __builtin_amdgcn_sched_barrier(0);
+      multiply();
     }
   }
 
