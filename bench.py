@@ -185,7 +185,7 @@ def dtype_label(backend):
     """fp32 tensors and fp32 accumulation everywhere; what differs is how the dense-convolution PRODUCTS are formed."""
     if getattr(backend, 'conv_math', 'fp32') == 'f16x2':
         pw = getattr(backend, 'pw_math', 'fp32') == 'f16x2'
-        return ('f32 (fp32 tensors, fp32 accumulate; Conv3d fwd / bwd-data / bwd-weight' + (' and the large SharedMLP fwd / bwd-data' if pw else '')
+        return ('f32 (fp32 tensors, fp32 accumulate; Conv3d fwd / bwd-data / bwd-weight' + (' and the large SharedMLP fwd / bwd-data / bwd-weight' if pw else '')
                 + ' products as power-of-two scaled fp16 hi+lo splits, 3 partial products on fp16 MFMA, max rel err vs fp64 1e-6 <= the '
                 'fp32-MFMA kernels\'; PVCNN_CONV_MATH=fp32 PVCNN_PW_MATH=fp32 select single-rounding fp32 MFMA, =bf16x3 the scale-free '
                 '6-product split)')
@@ -413,7 +413,7 @@ def main():
                         'frac_of_achievable_6300': round(head['achieved_GBs'] / 6300.0, 4),
                         'avg_us': head['avg_us'], 'event_pair_us': head['event_pair_us'],
                         'event_overhead_us': round(event_overhead_us, 2),
-                        'timing': 'HIP events around every launch inside the timed steps, on the launch stream; '
+                        'timing': 'HIP events around each launch of this kernel inside the timed steps, on the launch stream; '
                                   'avg_us = mean event-pair time - the time an empty event pair reads on a busy stream',
                         'algorithmic_MB': head['algorithmic_MB']}
             roofline.update(pmc_traffic('trilinear_devoxelize_fwd', head['shape_BCNR']))

@@ -9,7 +9,7 @@ BENCH="python $R/bench.py"
 rm -rf /tmp/kt; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- $BENCH --no-cpu-baseline > $O/bench_under_rocprof.log 2>&1
 grep "^{\"metric\"" $O/bench_under_rocprof.log | tail -1 > $O/bench_under_rocprof.json
 f=$(find /tmp/kt -name "*kernel_stats.csv" | head -1); head -80 $f > $O/bench_kernel_stats.csv
-t=$(find /tmp/kt -name "*kernel_trace.csv" | head -1); python $R/tools/trace_steady.py $t 100 70 > $O/bench_steady_state.txt
+t=$(find /tmp/kt -name "*kernel_trace.csv" | head -1); python $R/tools/trace_steady.py $t 100 70 20 > $O/bench_steady_state.txt
 # 3. HBM traffic counters, separate passes, ON THE BENCH COMMAND ITSELF (the fused gather as it runs in the step) ...
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c; timeout 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -- $BENCH --steps 10 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
@@ -26,7 +26,9 @@ done
 python $R/tools/make_pmc_traffic.py $O > $O/pmc_traffic.json
 # 4. op-level and convolution tables, the other BASELINE configs
 (cd $R && python tools/opbench.py 2>/dev/null | grep median > $O/opbench.jsonl; python tools/opbench.py --kind surface 2>/dev/null | grep median >> $O/opbench.jsonl
- python tools/convcheck.py --time --no-check --shapes 16x9x64x32,16x64x64x32,16x64x64x16,16x64x128x16,16x128x128x16,32x64x64x12,32x64x64x16,32x64x128x12 2>/dev/null | grep time_ > $O/convbench.jsonl
- PVCNN_CONV_MATH=fp32 timeout 300 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_fp32_mfma.json
+ python tools/convcheck.py --time --no-check --shapes 16x9x64x32,16x64x64x32,16x64x64x16,16x64x128x16,16x128x64x16,16x128x128x16,32x64x64x12,32x64x64x16,32x64x128x12 2>/dev/null | grep "time_\|absmax" > $O/convbench.jsonl
+ python tools/pwbench.py 2>/dev/null | grep "^{" > $O/pwbench.jsonl
+ PVCNN_CONV_MATH=fp32 PVCNN_PW_MATH=fp32 timeout 300 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_fp32_mfma.json
+ PVCNN_CONV_MATH=bf16x3 PVCNN_PW_MATH=fp32 timeout 300 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_bf16x3.json
  for c in cfg3 cfg4 cfg5; do timeout 300 python bench.py --config $c --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_$c.json; done)
 ls -la $O

@@ -1,15 +1,17 @@
 #!/usr/bin/env python3
 """Steady-state per-step kernel breakdown from a rocprofv3 kernel-trace CSV.
 
-usage: trace_steady.py <kernel_trace.csv> <timed_steps> [top]
+usage: trace_steady.py <kernel_trace.csv> <timed_steps> [top] [skip_last]
 Training steps are delimited by the optimizer phase (runs of Adam's multi_tensor_apply kernels);
-the LAST `timed_steps` complete steps are aggregated, i.e. bench.py's timed region."""
+the `timed_steps` complete steps before the last `skip_last` ones are aggregated, i.e. bench.py's timed region (bench.py runs
+min(steps, 20) fully instrumented steps AFTER it: skip_last = 20 for the default 100 steps)."""
 import csv
 import sys
 from collections import defaultdict
 
 path, steps = sys.argv[1], int(sys.argv[2])
 top = int(sys.argv[3]) if len(sys.argv) > 3 else 40
+skip = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 rows = list(csv.DictReader(open(path)))
 name_k = 'Kernel_Name' if 'Kernel_Name' in rows[0] else 'Name'
 s_k = 'Start_Timestamp' if 'Start_Timestamp' in rows[0] else 'Start'
@@ -17,9 +19,9 @@ e_k = 'End_Timestamp' if 'End_Timestamp' in rows[0] else 'End'
 rows.sort(key=lambda r: int(r[s_k]))
 is_opt = ['multi_tensor_apply' in r[name_k] for r in rows]
 ends = [i for i in range(len(rows)) if is_opt[i] and (i + 1 == len(rows) or not is_opt[i + 1])]   # last kernel of each optimizer phase
-if len(ends) < steps + 1:
-    raise SystemExit(f'only {len(ends)} optimizer phases in the trace, need {steps + 1}')
-lo, hi = ends[-steps - 1] + 1, ends[-1] + 1
+if len(ends) < steps + 1 + skip:
+    raise SystemExit(f'only {len(ends)} optimizer phases in the trace, need {steps + 1 + skip}')
+lo, hi = ends[-steps - 1 - skip] + 1, ends[-1 - skip] + 1
 steady = rows[lo:hi]
 agg = defaultdict(lambda: [0, 0])
 for r in steady:
