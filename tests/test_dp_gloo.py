@@ -213,3 +213,39 @@ def test_two_rank_pvcnn_gradients_are_the_mean_of_the_shard_gradients():
         want = (a + b) / 2
         # (the workers run torch-CPU with 2 threads, this process with its default: fp32 summation order differs)
         assert (torch.from_numpy(g0) - want).abs().max().item() <= 1e-4 * want.abs().max().item() + 1e-5 * scale
+
+
+def test_gradients_are_packed_into_the_flat_buckets_and_unused_parameters_read_zero():
+    """zero_grad() drops the gradients (autograd then hands each one over without an accumulate-add); when a bucket is
+    complete its gradients are gathered with one multi-tensor copy and `p.grad` become views of the flat buffer -- also
+    for parameters that took no part in this backward (zeros) and for buckets completed only by finish()."""
+    torch.manual_seed(3)
+    used, unused = nn.Linear(5, 7), nn.Linear(3, 2)
+    model = nn.ModuleList([used, unused])
+    reducer = GradBucketReducer(model, bucket_mb=8.0)
+    assert len(reducer.buckets) == 1
+    flat = reducer.buckets[0].flat
+    x = torch.randn(4, 5)
+    for step in range(2):
+        reducer.zero_grad()
+        assert all(p.grad is None for p in model.parameters())
+        used(x).square().sum().backward()
+        # the bucket is not complete (two of its four gradients never arrive): finish() packs it
+        reducer.finish()
+        lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * 4
+        for p in model.parameters():
+            assert lo <= p.grad.data_ptr() < hi and p.grad.shape == p.shape
+        assert unused.weight.grad.abs().max() == 0 and unused.bias.grad.abs().max() == 0
+        twin = nn.Linear(5, 7)
+        twin.load_state_dict(used.state_dict())
+        twin(x).square().sum().backward()
+        assert torch.equal(used.weight.grad, twin.weight.grad) and torch.equal(used.bias.grad, twin.bias.grad)
+        # bucket order = reverse parameter order; the flat buffer is exactly the concatenation of the views
+        want = torch.cat([p.grad.reshape(-1) for p in reversed(list(model.parameters()))])
+        assert torch.equal(flat, want)
+    # gradients zeroed IN PLACE (optimizer.zero_grad(set_to_none=False)) keep accumulating into the views: still correct
+    for p in model.parameters():
+        p.grad.zero_()
+    used(x).square().sum().backward()
+    reducer.finish()
+    assert torch.equal(used.weight.grad, twin.weight.grad)
