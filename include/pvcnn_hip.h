@@ -47,7 +47,7 @@ extern "C" {
 #define PVCNN_API
 #endif
 
-#define PVCNN_ABI_VERSION 3
+#define PVCNN_ABI_VERSION 4
 #define PVCNN_OK 0
 #define PVCNN_ERR_INVALID_ARGUMENT (-1)
 
@@ -252,6 +252,23 @@ PVCNN_API int pvcnn_conv3d_bwd_weight_f16(const float *x, const float *grad_y, c
                                 int Co, int R, float *grad_w, float *grad_bias, void *workspace, size_t workspace_bytes,
                                 void *stream);
 
+/* ---- voxel_layers' FIRST BatchNorm3d + LeakyReLU folded into the SECOND convolution (modules/pvconv.py:20-27) -----
+ * y = conv3d(leaky_relu(bn(x)), w) + bias without ever writing the activated grid: x is the RAW output of the previous
+ * convolution, (mean, rstd, gamma, beta, slope) the BatchNorm + LeakyReLU between the two (per channel Ci; gamma / beta may be
+ * NULL).  The consumer normalises and activates every in-range element while it stages its input tile (the convolution's zero
+ * padding stays zero: it pads the ACTIVATED tensor), with the very expressions of pvcnn_bnact_fwd -- results are bit-identical
+ * to pvcnn_bnact_fwd followed by pvcnn_conv3d_fwd_split / pvcnn_conv3d_bwd_weight_f16 on its output.  f16x2 arithmetic only;
+ * x_absmax = pvcnn_bnact_absmax_bits (max |.| of the tensor the BatchNorm + activation WOULD have written; one read of x). */
+PVCNN_API int pvcnn_bnact_absmax_bits(const float *x, const float *gamma, const float *beta, const float *mean, const float *rstd,
+                            int B, int C, int S, float slope, void *out, void *stream);
+PVCNN_API int pvcnn_conv3d_fwd_split_bnact(const float *x, const void *wts, const float *bias, int B, int Ci, int Co, int R,
+                                 const void *x_absmax, const float *mean, const float *rstd, const float *gamma,
+                                 const float *beta, float slope, float *y, float *stats_part, void *stream);
+PVCNN_API int pvcnn_conv3d_bwd_weight_f16_bnact(const float *x, const float *grad_y, const void *x_absmax, const void *gy_absmax,
+                                      const float *mean, const float *rstd, const float *gamma, const float *beta, float slope,
+                                      int B, int Ci, int Co, int R, float *grad_w, float *grad_bias, void *workspace,
+                                      size_t workspace_bytes, void *stream);
+
 /* ---- 1x1 convolutions of SharedMLP (point branch, classifier) ------------------------------------
  * replaces the nn.Conv1d / nn.Conv2d (kernel 1) calls of modules/shared_mlp.py:9-25 (cuDNN / cuBLAS in the
  * reference) with fp32-MFMA GEMMs that work on the reference's channel-major layout directly:
@@ -341,6 +358,13 @@ PVCNN_API int pvcnn_bnact_bwd_strided(const float *x, const float *grad_y, long 
                             const float *beta, const float *mean, const float *rstd, int B, int C, int S,
                             float slope, int training, float *grad_x, float *grad_gamma, float *grad_beta,
                             void *workspace, size_t workspace_bytes, void *stream);
+/* pvcnn_bnact_bwd_strided that also leaves pvcnn_absmax_bits(grad_x) in gx_absmax (one uint32 in device memory): the f16x2
+ * products that consume grad_x (backward-data / backward-weight of the convolution in front of the BatchNorm) take their
+ * power-of-two scale from it, and here it costs no extra pass over the tensor and no memset launch. */
+PVCNN_API int pvcnn_bnact_bwd_absmax(const float *x, const float *grad_y, long grad_y_batch_stride, const float *gamma,
+                           const float *beta, const float *mean, const float *rstd, int B, int C, int S, float slope,
+                           int training, float *grad_x, float *grad_gamma, float *grad_beta, void *gx_absmax,
+                           void *workspace, size_t workspace_bytes, void *stream);
 PVCNN_API int pvcnn_trilinear_devox_bwd_strided(const float *grad_y, long grad_y_batch_stride, const int32_t *inds,
                                       const float *wgts, int B, int C, int N, int R, float *grad_x,
                                       void *workspace, size_t workspace_bytes, void *stream);

@@ -120,6 +120,43 @@ __global__ __launch_bounds__(kBnThreads) void bnact_apply_kernel(const float *__
   }
 }
 
+// Block-wide max of the bit patterns of non-negative floats, folded into *out (order-independent: deterministic).  Thousands of
+// workgroups target ONE word: same-address atomics serialise at the memory side, so a workgroup first looks at the current
+// value (a stale read only costs a redundant atomic) and most of them find their maximum already covered.
+__device__ __forceinline__ void block_atomic_max_bits(uint32_t m, uint32_t *__restrict__ out) {
+  __shared__ uint32_t red[kBnThreads / 64];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int w = 1; w < kBnThreads / 64; ++w) m = max(m, red[w]);
+    if (m > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, m);
+  }
+}
+
+// grid = (slices, B, C): bits of max |act(scale * x + shift)| -- pvcnn_absmax_bits of the tensor bnact_apply_kernel WOULD write
+// (same expressions, so the same bits), for consumers that apply the transform while staging (conv3d_bf16.hip, XF)
+__global__ __launch_bounds__(kBnThreads) void bnact_absmax_kernel(const float *__restrict__ x, BnActXf xf, int C, int S,
+                                                                 uint32_t *__restrict__ out) {
+  const int sl = blockIdx.x, b = blockIdx.y, c = blockIdx.z;
+  const float2 p = xf.params(c);
+  const size_t off = ((size_t)b * C + c) * S;
+  const int lo = sl * kBnSlice, hi = min(S, lo + kBnSlice);
+  uint32_t m = 0;
+  if ((S & 3) == 0 && aligned16(x + off)) {
+    for (int i = lo + threadIdx.x * 4; i < hi; i += kBnThreads * 4) {
+      const float4 v = *reinterpret_cast<const float4 *>(x + off + i);
+      m = max(max(m, __float_as_uint(fabsf(xf.apply(v.x, p)))), __float_as_uint(fabsf(xf.apply(v.y, p))));
+      m = max(max(m, __float_as_uint(fabsf(xf.apply(v.z, p)))), __float_as_uint(fabsf(xf.apply(v.w, p))));
+    }
+  } else {
+    for (int i = lo + threadIdx.x; i < hi; i += kBnThreads) m = max(m, __float_as_uint(fabsf(xf.apply(x[off + i], p))));
+  }
+  block_atomic_max_bits(m, out);
+}
+
 // grid = (slices, B, C): partial (sum g', sum g' * xhat),  g' = gy * act'(z),  z = scale*x + shift
 __global__ __launch_bounds__(kBnThreads) void bnact_bwd_reduce_kernel(const float *__restrict__ x, const float *__restrict__ gy,
                                                                      const float *__restrict__ mean,
@@ -165,8 +202,10 @@ __global__ __launch_bounds__(kBnThreads) void bnact_bwd_reduce_kernel(const floa
 
 // grid = C: dbeta = sum g', dgamma = sum g' xhat (fp64 combine)
 __global__ __launch_bounds__(64) void bnact_bwd_finalize_kernel(const float2 *__restrict__ part, int nparts,
-                                                               float *__restrict__ dgamma, float *__restrict__ dbeta) {
+                                                               float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                                               uint32_t *__restrict__ gx_absmax) {
   const int c = blockIdx.x;
+  if (gx_absmax != nullptr && c == 0 && threadIdx.x == 0) *gx_absmax = 0u;   // re-armed for bnact_bwd_apply_kernel (next launch)
   double s = 0.0, q = 0.0;
   for (int i = threadIdx.x; i < nparts; i += 64) { const float2 p = part[(size_t)c * nparts + i]; s += p.x; q += p.y; }
 #pragma unroll
@@ -183,7 +222,8 @@ __global__ __launch_bounds__(kBnThreads) void bnact_bwd_apply_kernel(const float
                                                                     const float *__restrict__ dgamma,
                                                                     const float *__restrict__ dbeta, float slope,
                                                                     float inv_count, int training, int C, int S,
-                                                                    float *__restrict__ gx, long gy_bstride) {
+                                                                    float *__restrict__ gx, long gy_bstride,
+                                                                    uint32_t *__restrict__ gx_absmax) {
   const int sl = blockIdx.x, b = blockIdx.y, c = blockIdx.z;
   const float m = mean[c], r = rstd[c];
   const float gmm = gamma ? gamma[c] : 1.0f;
@@ -193,6 +233,7 @@ __global__ __launch_bounds__(kBnThreads) void bnact_bwd_apply_kernel(const float
   const size_t off = ((size_t)b * C + c) * S;
   const size_t goff = (size_t)b * gy_bstride + (size_t)c * S;
   const int lo = sl * kBnSlice, hi = min(S, lo + kBnSlice);
+  uint32_t amax = 0;                                           // bits of max |gx| over this thread's elements
   if ((S & 3) == 0 && aligned16(x + off) && aligned16(gy + goff) && aligned16(gx + off)) {
     for (int i = lo + threadIdx.x * 4; i < hi; i += kBnThreads * 4) {
       const float4 xv = *reinterpret_cast<const float4 *>(x + off + i);
@@ -204,6 +245,7 @@ __global__ __launch_bounds__(kBnThreads) void bnact_bwd_apply_kernel(const float
         const float z = fmaf(xs_[u], scale, shift);
         const float g = gs_[u] * (z > 0.f ? 1.0f : slope);
         o[u] = scale * (g - db - ((xs_[u] - m) * r) * dg);
+        amax = max(amax, __float_as_uint(fabsf(o[u])));
       }
       using v4f = __attribute__((ext_vector_type(4))) float;
       v4f ov = {o[0], o[1], o[2], o[3]};
@@ -215,9 +257,14 @@ __global__ __launch_bounds__(kBnThreads) void bnact_bwd_apply_kernel(const float
       const float z = fmaf(xv, scale, shift);
       const float g = gy[goff + i] * (z > 0.f ? 1.0f : slope);
       const float xhat = (xv - m) * r;
-      gx[off + i] = scale * (g - db - xhat * dg);
+      const float o = scale * (g - db - xhat * dg);
+      gx[off + i] = o;
+      amax = max(amax, __float_as_uint(fabsf(o)));
     }
   }
+  // the gradient's max |.| rides along: the f16x2 products that consume grad_x (Conv3d / 1x1 backward-data and backward-weight)
+  // derive their power-of-two scale from it, and a separate absmax pass would re-read the whole tensor
+  if (gx_absmax != nullptr) block_atomic_max_bits(amax, gx_absmax);
 }
 
 }  // namespace pvcnn
@@ -281,7 +328,8 @@ extern "C" int pvcnn_bn_stats(const float *x, float *running_mean, float *runnin
 
 static int bnact_bwd_impl(const float *x, const float *grad_y, long gy_bstride, const float *gamma, const float *beta,
                           const float *mean, const float *rstd, int B, int C, int S, float slope, int training, float *grad_x,
-                          float *grad_gamma, float *grad_beta, void *workspace, size_t workspace_bytes, void *stream) {
+                          float *grad_gamma, float *grad_beta, void *workspace, size_t workspace_bytes, void *stream,
+                          void *gx_absmax = nullptr) {
   PVCNN_REQUIRE(B > 0 && C > 0 && S > 0 && x && grad_y && mean && rstd && grad_x && grad_gamma && grad_beta, "bad argument");
   PVCNN_REQUIRE(B <= 65535 && C <= 65535, "batch or channel count > 65535");
   PVCNN_REQUIRE(gy_bstride >= (long)C * S, "grad_y batch stride smaller than one sample");
@@ -293,10 +341,11 @@ static int bnact_bwd_impl(const float *x, const float *grad_y, long gy_bstride, 
   hipLaunchKernelGGL(bnact_bwd_reduce_kernel, grid, dim3(kBnThreads), 0, s, x, grad_y, mean, rstd, gamma, beta, slope, C, S,
                      slices, part, gy_bstride);
   if (int e = check_launch("bnact_bwd_reduce")) return e;
-  hipLaunchKernelGGL(bnact_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, part, B * slices, grad_gamma, grad_beta);
+  uint32_t *am = static_cast<uint32_t *>(gx_absmax);
+  hipLaunchKernelGGL(bnact_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, part, B * slices, grad_gamma, grad_beta, am);
   if (int e = check_launch("bnact_bwd_finalize")) return e;
   hipLaunchKernelGGL(bnact_bwd_apply_kernel, grid, dim3(kBnThreads), 0, s, x, grad_y, mean, rstd, gamma, beta, grad_gamma,
-                     grad_beta, slope, (float)(1.0 / ((double)B * S)), training, C, S, grad_x, gy_bstride);
+                     grad_beta, slope, (float)(1.0 / ((double)B * S)), training, C, S, grad_x, gy_bstride, am);
   return check_launch("bnact_bwd_apply");
 }
 
@@ -315,4 +364,29 @@ extern "C" int pvcnn_bnact_bwd_strided(const float *x, const float *grad_y, long
                                        size_t workspace_bytes, void *stream) {
   return bnact_bwd_impl(x, grad_y, grad_y_batch_stride, gamma, beta, mean, rstd, B, C, S, slope, training, grad_x, grad_gamma,
                         grad_beta, workspace, workspace_bytes, stream);
+}
+
+// pvcnn_bnact_bwd_strided that also leaves pvcnn_absmax_bits(grad_x) in gx_absmax (one uint32): the f16x2 products consuming
+// grad_x need it, and here it costs nothing (no extra pass over the tensor, no memset launch).
+extern "C" int pvcnn_bnact_bwd_absmax(const float *x, const float *grad_y, long grad_y_batch_stride, const float *gamma,
+                                      const float *beta, const float *mean, const float *rstd, int B, int C, int S, float slope,
+                                      int training, float *grad_x, float *grad_gamma, float *grad_beta, void *gx_absmax,
+                                      void *workspace, size_t workspace_bytes, void *stream) {
+  PVCNN_REQUIRE(gx_absmax != nullptr, "null gx_absmax");
+  return bnact_bwd_impl(x, grad_y, grad_y_batch_stride, gamma, beta, mean, rstd, B, C, S, slope, training, grad_x, grad_gamma,
+                        grad_beta, workspace, workspace_bytes, stream, gx_absmax);
+}
+
+// out[0] = pvcnn_absmax_bits of act(bn(x)) without materialising it: x (B,C,S), per-channel mean / rstd (+ gamma / beta or NULL).
+extern "C" int pvcnn_bnact_absmax_bits(const float *x, const float *gamma, const float *beta, const float *mean, const float *rstd,
+                                       int B, int C, int S, float slope, void *out, void *stream) {
+  PVCNN_REQUIRE(B > 0 && C > 0 && S > 0 && x && mean && rstd && out, "bad argument");
+  PVCNN_REQUIRE(B <= 65535 && C <= 65535, "batch or channel count > 65535");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipError_t e = hipMemsetAsync(out, 0, sizeof(uint32_t), s);
+  if (e != hipSuccess) { set_error("bnact_absmax: memset: %s", hipGetErrorString(e)); return (int)e; }
+  const BnActXf xf{mean, rstd, gamma, beta, slope};
+  hipLaunchKernelGGL(bnact_absmax_kernel, dim3(ceil_div(S, kBnSlice), B, C), dim3(kBnThreads), 0, s, x, xf, C, S,
+                     static_cast<uint32_t *>(out));
+  return check_launch("bnact_absmax");
 }

@@ -150,12 +150,17 @@ __global__ __launch_bounds__(256) void conv3d_weight_split_kernel(const float *_
 //   the same MFMA stream with NO loads and NO staging at all                                0.43 ms
 // i.e. the matrix pipe itself sustains ~1.6 PF on random data here (the chip clocks down under a dense bf16 MFMA stream),
 // and what is left above it is prologue / epilogue exposure; the simplest structure is kept.
-template <int NS, int TX, int TY, int TZ, bool VEC>
+// XF: the input is consumed THROUGH BatchNorm + LeakyReLU (xf: the statistics / affine parameters of the BatchNorm in front of
+// this convolution): x holds the previous convolution's raw output and every in-range element becomes act(scale_c * x + shift_c)
+// on its way into LDS -- the activated tensor is never written (PVConv: voxel_layers[1..2] folded into voxel_layers[3]'s
+// staging, modules/pvconv.py:20-27).  The zero padding of the convolution stays zero (it pads the ACTIVATED tensor).
+template <int NS, int TX, int TY, int TZ, bool VEC, bool XF = false>
 __global__ __launch_bounds__(256, (NS == 3 || TX * TY * TZ == 512 || TZ <= 16) ? 2 : 3) void conv3d_igemm_bf16_kernel(const float *__restrict__ x, const uint16_t *__restrict__ wts,
                                                                    const float *__restrict__ bias, float *__restrict__ y,
                                                                    int Ci, int Co, int R, int tiles_x, int tiles_y, int tiles_z,
                                                                    float2 *__restrict__ stats_part,
-                                                                   const uint32_t *__restrict__ x_absmax, const int *__restrict__ wexp) {
+                                                                   const uint32_t *__restrict__ x_absmax, const int *__restrict__ wexp,
+                                                                   BnActXf xf) {
   static_assert(TX * TY * TZ == 128 || TX * TY * TZ == 256 || TX * TY * TZ == 512, "a workgroup tile is 4 waves x NBW x 32 voxels");
   const int x_shift = NS == 2 ? scale_shift(*x_absmax) : 0;
   const float x_scale = exp2_int(x_shift);
@@ -164,6 +169,9 @@ __global__ __launch_bounds__(256, (NS == 3 || TX * TY * TZ == 512 || TZ <= 16) ?
   constexpr int WBLK = 3 * NS * kCoTileB * kKc;                 // bf16 elements of one (chunk, dxy, cotile) weight block
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
   uint32_t *xs = lds_u;                                         // [NS][HS][8] words (16 bf16 per voxel)
+  // XF: (scale, shift) of every input channel (padded to whole chunks), behind the tile and the epilogue's statistics
+  constexpr int XF_OFF = NS * HS * 8 > 4 * kCoTileB * 2 ? NS * HS * 8 : 4 * kCoTileB * 2;
+  [[maybe_unused]] float2 *xf_tab = reinterpret_cast<float2 *>(lds_u + XF_OFF);
 
   int bid = blockIdx.x;
   const int tzi = bid % tiles_z; bid /= tiles_z;
@@ -176,6 +184,9 @@ __global__ __launch_bounds__(256, (NS == 3 || TX * TY * TZ == 512 || TZ <= 16) ?
   const size_t RR = (size_t)R * R, S = RR * R;
   const float *xb = x + (size_t)b * Ci * S;
   const int chunks = ceil_div(Ci, kKc);
+  if constexpr (XF) {                                           // visible to every thread after the first chunk's barrier
+    for (int c = threadIdx.x; c < chunks * kKc; c += 256) xf_tab[c] = c < Ci ? xf.params(c) : make_float2(0.0f, 0.0f);
+  }
 
   int hb[NBW];                                                  // halo index of this lane's output voxel (tap 0,0,0 corner)
 #pragma unroll
@@ -217,13 +228,16 @@ __global__ __launch_bounds__(256, (NS == 3 || TX * TY * TZ == 512 || TZ <= 16) ?
 #pragma unroll 1
       for (int batch = 0; batch < BATCHES; ++batch) {
         float4 va[ITER], vb[ITER];
+        [[maybe_unused]] bool oka[ITER], okb[ITER];                 // XF: the element was loaded (padding stays zero)
 #pragma unroll
         for (int u = 0; u < ITER; ++u) {
           const int e = (batch * ITER + u) * 256 + tid;
           const int q = e % QZ, hy = (e / QZ) % HY, hx = (e / (QZ * HY)) % HX, cp = e / (QZ * HY * HX);
           const int gx = x0 + hx - 1, gy = y0 + hy - 1, c = c0 + 2 * cp;
           va[u] = vb[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-          if (e < ITEMS && (unsigned)gx < (unsigned)R && (unsigned)gy < (unsigned)R && 4 * q < R) {
+          const bool inside = e < ITEMS && (unsigned)gx < (unsigned)R && (unsigned)gy < (unsigned)R && 4 * q < R;
+          if constexpr (XF) { oka[u] = inside && c < Ci; okb[u] = inside && c + 1 < Ci; }
+          if (inside) {
             const size_t off = (size_t)gx * RR + (size_t)gy * R + 4 * q;
             if (c < Ci) va[u] = *reinterpret_cast<const float4 *>(xb + (size_t)c * S + off);
             if (c + 1 < Ci) vb[u] = *reinterpret_cast<const float4 *>(xb + (size_t)(c + 1) * S + off);
@@ -235,7 +249,15 @@ __global__ __launch_bounds__(256, (NS == 3 || TX * TY * TZ == 512 || TZ <= 16) ?
           if (e < ITEMS) {
             const int q = e % QZ, hy = (e / QZ) % HY, hx = (e / (QZ * HY)) % HX, cp = e / (QZ * HY * HX);
             const int v0 = (hx * HY + hy) * HZ + 1 + 4 * q;
-            const float fa[4] = {va[u].x, va[u].y, va[u].z, va[u].w}, fb[4] = {vb[u].x, vb[u].y, vb[u].z, vb[u].w};
+            float fa[4] = {va[u].x, va[u].y, va[u].z, va[u].w}, fb[4] = {vb[u].x, vb[u].y, vb[u].z, vb[u].w};
+            if constexpr (XF) {
+              const float2 pa = xf_tab[c0 + 2 * cp], pb = xf_tab[c0 + 2 * cp + 1];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                if (oka[u]) fa[i] = xf.apply(fa[i], pa);
+                if (okb[u]) fb[i] = xf.apply(fb[i], pb);
+              }
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               const int v = v0 + i;
@@ -254,6 +276,7 @@ __global__ __launch_bounds__(256, (NS == 3 || TX * TY * TZ == 512 || TZ <= 16) ?
 #pragma unroll 1
       for (int half = 0; half < 2; ++half) {
         float va[ITER], vb[ITER];
+        [[maybe_unused]] bool oka[ITER], okb[ITER];
 #pragma unroll
         for (int u = 0; u < ITER; ++u) {
           const int e = (half * ITER + u) * 256 + tid;
@@ -262,7 +285,9 @@ __global__ __launch_bounds__(256, (NS == 3 || TX * TY * TZ == 512 || TZ <= 16) ?
           const int gx = x0 + hx - 1, gy = y0 + hy - 1, gz = z0 + hz - 1;
           const int c = c0 + 2 * cp;
           va[u] = vb[u] = 0.0f;
-          if (e < HS * 8 && (unsigned)gx < (unsigned)R && (unsigned)gy < (unsigned)R && (unsigned)gz < (unsigned)R) {
+          const bool inside = e < HS * 8 && (unsigned)gx < (unsigned)R && (unsigned)gy < (unsigned)R && (unsigned)gz < (unsigned)R;
+          if constexpr (XF) { oka[u] = inside && c < Ci; okb[u] = inside && c + 1 < Ci; }
+          if (inside) {
             const size_t off = (size_t)gx * RR + (size_t)gy * R + gz;
             if (c < Ci) va[u] = xb[(size_t)c * S + off];
             if (c + 1 < Ci) vb[u] = xb[(size_t)(c + 1) * S + off];
@@ -273,6 +298,10 @@ __global__ __launch_bounds__(256, (NS == 3 || TX * TY * TZ == 512 || TZ <= 16) ?
           const int e = (half * ITER + u) * 256 + tid;
           if (e < HS * 8) {
             const int cp = e & 7, v = e >> 3;
+            if constexpr (XF) {
+              if (oka[u]) va[u] = xf.apply(va[u], xf_tab[c0 + 2 * cp]);
+              if (okb[u]) vb[u] = xf.apply(vb[u], xf_tab[c0 + 2 * cp + 1]);
+            }
             uint32_t pw[NS];
             if constexpr (NS == 2) split_pair<NS>(va[u] * x_scale, vb[u] * x_scale, pw);
             else split_pair<NS>(va[u], vb[u], pw);
@@ -422,19 +451,21 @@ static SplitTile split_tiles(int B, int Co, int R, int nsplit) {
   return big ? SplitTile{4, 4, 32, true} : SplitTile{2, 4, 32, true};
 }
 
-template <int NS, int TX, int TY, int TZ, bool VEC>
+template <int NS, int TX, int TY, int TZ, bool VEC, bool XF = false>
 static int launch_igemm_bf16(const float *x, const uint16_t *wts, const float *bias, float *y, int B, int Ci, int Co, int R,
-                             hipStream_t s, float2 *stats_part, const uint32_t *x_absmax = nullptr, const int *wexp = nullptr) {
+                             hipStream_t s, float2 *stats_part, const uint32_t *x_absmax = nullptr, const int *wexp = nullptr,
+                             const BnActXf &xf = BnActXf{}) {
   constexpr int HS = (TX + 2) * (TY + 2) * (TZ + 2);
-  const size_t lds = std::max((size_t)NS * HS * 8 * sizeof(uint32_t), (size_t)4 * kCoTileB * sizeof(float2));
+  const size_t lds = std::max((size_t)NS * HS * 8 * sizeof(uint32_t), (size_t)4 * kCoTileB * sizeof(float2))
+                     + (XF ? (size_t)ceil_div(Ci, kKc) * kKc * sizeof(float2) : 0);
   const int tx = ceil_div(R, TX), ty = ceil_div(R, TY), tz = ceil_div(R, TZ);
-  auto k = conv3d_igemm_bf16_kernel<NS, TX, TY, TZ, VEC>;
+  auto k = conv3d_igemm_bf16_kernel<NS, TX, TY, TZ, VEC, XF>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { set_error("conv3d(bf16): LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
   }
   hipLaunchKernelGGL(k, dim3((unsigned)((long)B * tx * ty * tz), ceil_div(Co, kCoTileB)), dim3(256), lds, s, x, wts, bias, y,
-                     Ci, Co, R, tx, ty, tz, stats_part, x_absmax, wexp);
+                     Ci, Co, R, tx, ty, tz, stats_part, x_absmax, wexp, xf);
   return check_launch("conv3d_igemm_bf16");
 }
 
@@ -493,8 +524,8 @@ extern "C" size_t pvcnn_conv3d_fwd_split_stats_parts(int B, int Co, int R, int n
 
 // y = conv3d(x, w) + bias with the pre-split weights of pvcnn_conv3d_weight_split (forward layout: Ci, Co as given; backward-data:
 // call with x = grad_y, Ci = the forward Co, Co = the forward Ci, bias = NULL and the for_bwd_data = 1 weights).
-extern "C" int pvcnn_conv3d_fwd_split(const float *x, const void *wts, const float *bias, int B, int Ci, int Co, int R, int nsplit,
-                                      const void *x_absmax, float *y, float *stats_part, void *stream) {
+static int conv3d_fwd_split_impl(const float *x, const void *wts, const float *bias, int B, int Ci, int Co, int R, int nsplit,
+                                 const void *x_absmax, float *y, float *stats_part, void *stream, const BnActXf *xfp) {
   PVCNN_REQUIRE(B >= 0 && Ci > 0 && Co > 0 && R > 0, "bad size");
   PVCNN_REQUIRE(nsplit >= 1 && nsplit <= 3, "nsplit must be 1 (bf16), 2 (f16x2) or 3 (bf16x3)");
   PVCNN_REQUIRE(nsplit != 2 || x_absmax, "f16x2 needs the input's pvcnn_absmax_bits");
@@ -509,6 +540,16 @@ extern "C" int pvcnn_conv3d_fwd_split(const float *x, const void *wts, const flo
   PVCNN_REQUIRE(!t.vec || aligned16(x), "x must be 16-byte aligned");
   const uint32_t *am = static_cast<const uint32_t *>(x_absmax);
   const int *wexp = nsplit == 2 ? reinterpret_cast<const int *>(static_cast<const char *>(wts) + weight_image_bytes(Ci, Co, 2)) : nullptr;
+  if (xfp != nullptr) {   // BatchNorm + LeakyReLU folded into the staging: f16x2 only
+    const BnActXf xf = *xfp;
+    PVCNN_REQUIRE((size_t)ceil_div(Ci, kKc) * kKc * sizeof(float2) <= 8 * 1024, "too many input channels for the folded BatchNorm table");
+#define PVCNN_IGEMM_XF(TX, TY, TZ, VEC) launch_igemm_bf16<2, TX, TY, TZ, VEC, true>(x, w16, bias, y, B, Ci, Co, R, s, sp, am, wexp, xf)
+    if (t.tz == 8) return t.vec ? PVCNN_IGEMM_XF(4, 8, 8, true) : PVCNN_IGEMM_XF(4, 8, 8, false);
+    if (!t.vec) return PVCNN_IGEMM_XF(4, 4, 16, false);
+    if (t.tz == 16) return t.tx == 2 ? PVCNN_IGEMM_XF(2, 4, 16, true) : PVCNN_IGEMM_XF(4, 4, 16, true);
+    return t.tx == 4 ? PVCNN_IGEMM_XF(4, 4, 32, true) : PVCNN_IGEMM_XF(2, 4, 32, true);
+#undef PVCNN_IGEMM_XF
+  }
 #define PVCNN_IGEMM(NS, TX, TY, TZ, VEC) launch_igemm_bf16<NS, TX, TY, TZ, VEC>(x, w16, bias, y, B, Ci, Co, R, s, sp, am, wexp)
 #define PVCNN_IGEMM_NS(TX, TY, TZ, VEC) (nsplit == 3 ? PVCNN_IGEMM(3, TX, TY, TZ, VEC) : nsplit == 2 ? PVCNN_IGEMM(2, TX, TY, TZ, VEC) : PVCNN_IGEMM(1, TX, TY, TZ, VEC))
 #define PVCNN_IGEMM_BIG(TX, TY, TZ) (nsplit == 2 ? PVCNN_IGEMM(2, TX, TY, TZ, true) : PVCNN_IGEMM(1, TX, TY, TZ, true))
@@ -519,4 +560,20 @@ extern "C" int pvcnn_conv3d_fwd_split(const float *x, const void *wts, const flo
 #undef PVCNN_IGEMM_BIG
 #undef PVCNN_IGEMM_NS
 #undef PVCNN_IGEMM
+}
+
+extern "C" int pvcnn_conv3d_fwd_split(const float *x, const void *wts, const float *bias, int B, int Ci, int Co, int R, int nsplit,
+                                      const void *x_absmax, float *y, float *stats_part, void *stream) {
+  return conv3d_fwd_split_impl(x, wts, bias, B, Ci, Co, R, nsplit, x_absmax, y, stats_part, stream, nullptr);
+}
+
+// y = conv3d(act(bn(x)), w) + bias in f16x2: x is the RAW output of the previous convolution, (mean, rstd, gamma, beta, slope) the
+// BatchNorm + LeakyReLU between the two (gamma / beta may be NULL), x_absmax = pvcnn_bnact_absmax_bits of x through the same
+// transform.  Bit-identical to pvcnn_bnact_fwd followed by pvcnn_conv3d_fwd_split on its output.
+extern "C" int pvcnn_conv3d_fwd_split_bnact(const float *x, const void *wts, const float *bias, int B, int Ci, int Co, int R,
+                                            const void *x_absmax, const float *mean, const float *rstd, const float *gamma,
+                                            const float *beta, float slope, float *y, float *stats_part, void *stream) {
+  PVCNN_REQUIRE(mean && rstd, "null statistics");
+  const BnActXf xf{mean, rstd, gamma, beta, slope};
+  return conv3d_fwd_split_impl(x, wts, bias, B, Ci, Co, R, 2, x_absmax, y, stats_part, stream, &xf);
 }

@@ -37,11 +37,14 @@ struct WgradLds {
   static constexpr int BYTES = 2 * XPL + 2 * GPL;
 };
 
-template <int R>
+// XF: x is consumed through BatchNorm + LeakyReLU (the convolution's input was never materialised: conv3d_bf16.hip, XF) -- a
+// thread stages the same two input channels for the whole kernel, so their (scale, shift) live in registers.
+template <int R, bool XF = false>
 __global__ __launch_bounds__(512, 2) void conv3d_wgrad_f16_kernel(const float *__restrict__ x, const float *__restrict__ gy,
                                                                   const uint32_t *__restrict__ x_absmax,
                                                                   const uint32_t *__restrict__ gy_absmax, int B, int Ci, int Co, int P,
-                                                                  int citiles, float *__restrict__ part, float *__restrict__ gb_part) {
+                                                                  int citiles, float *__restrict__ part, float *__restrict__ gb_part,
+                                                                  BnActXf xf) {
   using L = WgradLds<R>;
   constexpr int QZ = R / 4, KS = R / 16, ROWB = L::ROWB;
   constexpr int XITEMS = 3 * kWgCi * QZ, GITEMS = kWgCo * QZ;
@@ -77,6 +80,11 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_f16_kernel(const float *_
   const int gq = tid % QZ, gco = tid / QZ;
   const bool has_g = tid < GITEMS;
   float gsum = 0.0f;
+  [[maybe_unused]] float2 xfp0 = make_float2(0.0f, 0.0f), xfp1 = make_float2(0.0f, 0.0f);
+  if constexpr (XF) {
+    if (has_x0 && ci0 + xci0 < Ci) xfp0 = xf.params(ci0 + xci0);
+    if (has_x1 && ci0 + xci1 < Ci) xfp1 = xf.params(ci0 + xci1);
+  }
 
   auto store_row = [&](unsigned char *plane0, int plane_bytes, int row_byte, int q, const float4 &v, float scale) {
     uint32_t w0[2], w1[2];
@@ -98,10 +106,14 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_f16_kernel(const float *_
       float4 vx0 = zero4, vx1 = zero4, vg = zero4;
       if (y2 < R) {
         const int gx0 = xo + xdx0 - 1, gx1 = xo + xdx1 - 1;
-        if (has_x0 && (unsigned)gx0 < (unsigned)R && ci0 + xci0 < Ci)
+        if (has_x0 && (unsigned)gx0 < (unsigned)R && ci0 + xci0 < Ci) {
           vx0 = *reinterpret_cast<const float4 *>(xb + (size_t)(ci0 + xci0) * S + (size_t)gx0 * RR + (size_t)y2 * R + 4 * xq0);
-        if (has_x1 && (unsigned)gx1 < (unsigned)R && ci0 + xci1 < Ci)
+          if constexpr (XF) vx0 = make_float4(xf.apply(vx0.x, xfp0), xf.apply(vx0.y, xfp0), xf.apply(vx0.z, xfp0), xf.apply(vx0.w, xfp0));
+        }
+        if (has_x1 && (unsigned)gx1 < (unsigned)R && ci0 + xci1 < Ci) {
           vx1 = *reinterpret_cast<const float4 *>(xb + (size_t)(ci0 + xci1) * S + (size_t)gx1 * RR + (size_t)y2 * R + 4 * xq1);
+          if constexpr (XF) vx1 = make_float4(xf.apply(vx1.x, xfp1), xf.apply(vx1.y, xfp1), xf.apply(vx1.z, xfp1), xf.apply(vx1.w, xfp1));
+        }
       }
       if (y1 >= 0 && y1 < R && has_g && co0 + gco < Co)
         vg = *reinterpret_cast<const float4 *>(gb_ + (size_t)(co0 + gco) * S + (size_t)xo * RR + (size_t)y1 * R + 4 * gq);
@@ -237,17 +249,17 @@ static WgradPlan wgrad_f16_plan(int B, int Ci, int Co, int R) {
   return w;
 }
 
-template <int R>
+template <int R, bool XF = false>
 static int launch_wgrad_f16(const float *x, const float *gy, const uint32_t *xa, const uint32_t *ga, int B, int Ci, int Co, float *gw,
-                            float *gb, float *ws, hipStream_t s) {
+                            float *gb, float *ws, hipStream_t s, const BnActXf &xf = BnActXf{}) {
   const WgradPlan w = wgrad_f16_plan(B, Ci, Co, R);
   float *part = ws, *gb_part = ws + w.part_floats;
-  auto k = conv3d_wgrad_f16_kernel<R>;
+  auto k = conv3d_wgrad_f16_kernel<R, XF>;
   const int lds = WgradLds<R>::BYTES;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e != hipSuccess) { set_error("conv3d_wgrad_f16: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
   hipLaunchKernelGGL(k, dim3((unsigned)(w.P * w.citiles * w.cotiles)), dim3(512), lds, s, x, gy, xa, ga, B, Ci, Co, w.P, w.citiles, part,
-                     gb ? gb_part : nullptr);
+                     gb ? gb_part : nullptr, xf);
   if (int rc = check_launch("conv3d_wgrad_f16")) return rc;
   const int CoP = w.cotiles * kWgCo, CiP = w.citiles * kWgCi;
   hipLaunchKernelGGL(conv3d_wgrad_f16_reduce_kernel, dim3((unsigned)ceil_div(27 * CoP * CiP, 256)), dim3(256), 0, s, part, gb_part, xa, ga, w.P,
@@ -266,9 +278,9 @@ extern "C" size_t pvcnn_conv3d_bwd_weight_f16_workspace_bytes(int B, int Ci, int
   return (w.part_floats + w.gb_floats) * sizeof(float);
 }
 
-extern "C" int pvcnn_conv3d_bwd_weight_f16(const float *x, const float *grad_y, const void *x_absmax, const void *gy_absmax, int B, int Ci,
-                                           int Co, int R, float *grad_w, float *grad_bias, void *workspace, size_t workspace_bytes,
-                                           void *stream) {
+static int conv3d_bwd_weight_f16_impl(const float *x, const float *grad_y, const void *x_absmax, const void *gy_absmax, int B, int Ci,
+                                      int Co, int R, float *grad_w, float *grad_bias, void *workspace, size_t workspace_bytes,
+                                      void *stream, const BnActXf *xfp) {
   PVCNN_REQUIRE(B > 0 && Ci > 0 && Co > 0 && (R == 16 || R == 32), "bad size (R must be 16 or 32)");
   PVCNN_REQUIRE(x && grad_y && grad_w && x_absmax && gy_absmax, "null pointer");
   PVCNN_REQUIRE(aligned16(x) && aligned16(grad_y), "x and grad_y must be 16-byte aligned");
@@ -277,6 +289,29 @@ extern "C" int pvcnn_conv3d_bwd_weight_f16(const float *x, const float *grad_y, 
   hipStream_t s = static_cast<hipStream_t>(stream);
   const uint32_t *xa = static_cast<const uint32_t *>(x_absmax), *ga = static_cast<const uint32_t *>(gy_absmax);
   float *ws = static_cast<float *>(workspace);
+  if (xfp != nullptr)
+    return R == 32 ? launch_wgrad_f16<32, true>(x, grad_y, xa, ga, B, Ci, Co, grad_w, grad_bias, ws, s, *xfp)
+                   : launch_wgrad_f16<16, true>(x, grad_y, xa, ga, B, Ci, Co, grad_w, grad_bias, ws, s, *xfp);
   return R == 32 ? launch_wgrad_f16<32>(x, grad_y, xa, ga, B, Ci, Co, grad_w, grad_bias, ws, s)
                  : launch_wgrad_f16<16>(x, grad_y, xa, ga, B, Ci, Co, grad_w, grad_bias, ws, s);
+}
+
+extern "C" int pvcnn_conv3d_bwd_weight_f16(const float *x, const float *grad_y, const void *x_absmax, const void *gy_absmax, int B, int Ci,
+                                           int Co, int R, float *grad_w, float *grad_bias, void *workspace, size_t workspace_bytes,
+                                           void *stream) {
+  return conv3d_bwd_weight_f16_impl(x, grad_y, x_absmax, gy_absmax, B, Ci, Co, R, grad_w, grad_bias, workspace, workspace_bytes, stream,
+                                    nullptr);
+}
+
+// grad_w of y = conv3d(act(bn(x)), w): x is the RAW tensor in front of the BatchNorm + LeakyReLU that pvcnn_conv3d_fwd_split_bnact
+// folded into its staging; x_absmax = pvcnn_bnact_absmax_bits of x through the same transform.  Bit-identical to
+// pvcnn_conv3d_bwd_weight_f16 on the materialised activation.
+extern "C" int pvcnn_conv3d_bwd_weight_f16_bnact(const float *x, const float *grad_y, const void *x_absmax, const void *gy_absmax,
+                                                 const float *mean, const float *rstd, const float *gamma, const float *beta, float slope,
+                                                 int B, int Ci, int Co, int R, float *grad_w, float *grad_bias, void *workspace,
+                                                 size_t workspace_bytes, void *stream) {
+  PVCNN_REQUIRE(mean && rstd, "null statistics");
+  const BnActXf xf{mean, rstd, gamma, beta, slope};
+  return conv3d_bwd_weight_f16_impl(x, grad_y, x_absmax, gy_absmax, B, Ci, Co, R, grad_w, grad_bias, workspace, workspace_bytes, stream,
+                                    &xf);
 }

@@ -541,6 +541,74 @@ class HipBackend:
                                                             _p(gb) if with_bias else None, _p(ws), ws.numel(), s), 'conv3d_backward_weight_f16')
         return (gw, gb) if with_bias else gw
 
+    # ---- voxel_layers' first BatchNorm3d + LeakyReLU folded into the second convolution's staging ----
+    # bn = (gamma | None, beta | None, mean, rstd, slope) of the BatchNorm + activation IN FRONT of the convolution; x is the raw
+    # tensor in front of that BatchNorm.  f16x2 arithmetic; results bit-identical to the unfused ops.  PVCNN_FOLD_BN=0 disables.
+    has_conv3d_bnact_fold = os.environ.get('PVCNN_FOLD_BN', '1') != '0'
+
+    @staticmethod
+    def _bn_args(bn, channels):
+        gamma, beta, mean, rstd, slope = bn
+        for t, name in ((gamma, 'gamma'), (beta, 'beta'), (mean, 'mean'), (rstd, 'rstd')):
+            if t is not None:
+                _f32(t, name)
+                _shape(t.numel() == channels, f'{name}: one value per input channel expected')
+        _shape(mean is not None and rstd is not None, 'mean / rstd missing')
+        nul = ctypes.c_void_p(None)
+        return (_p(mean), _p(rstd), _p(gamma) if gamma is not None else nul, _p(beta) if beta is not None else nul, float(slope))
+
+    def bnact_absmax_bits(self, x, bn):
+        """absmax_bits of leaky_relu(bn(x)) without materialising it: x (B,C,...) raw, bn as above."""
+        _f32(x, 'x')
+        b, c = x.shape[0], x.shape[1]
+        s3 = x.numel() // max(b * c, 1)
+        mean, rstd, gamma, beta, slope = self._bn_args(bn, c)
+        out = torch.empty((1,), dtype=torch.int32, device=x.device)
+        with _Launch(x) as s:
+            _lib.check(self.lib.pvcnn_bnact_absmax_bits(_p(x), gamma, beta, mean, rstd, b, c, s3, slope, _p(out), s), 'bnact_absmax_bits')
+        return out
+
+    def conv3d_forward_split_bnact(self, x, weight, bias, bn, want_stats=False, amax=None):
+        """conv3d(leaky_relu(bn(x)), weight) + bias in f16x2 with the BatchNorm + activation applied in the staging."""
+        _f32(x, 'x'); _f32(weight, 'weight')
+        _shape(x.dim() == 5 and weight.dim() == 5 and tuple(weight.shape[2:]) == (3, 3, 3) and weight.shape[1] == x.shape[1]
+               and x.shape[2] == x.shape[3] == x.shape[4], 'conv3d: x (B,Ci,R,R,R), weight (Co,Ci,3,3,3) expected')
+        if bias is not None:
+            _f32(bias, 'bias')
+        b, ci, r = x.shape[0], x.shape[1], x.shape[2]
+        co = weight.shape[0]
+        mean, rstd, gamma, beta, slope = self._bn_args(bn, ci)
+        if amax is None:
+            amax = self.bnact_absmax_bits(x, bn)
+        wts = self._conv_wsplit(weight, False, 2)
+        y = torch.empty((b, co, r, r, r), dtype=torch.float32, device=x.device)
+        part = None
+        if want_stats:
+            part = torch.empty((co, self.lib.pvcnn_conv3d_fwd_split_stats_parts(b, co, r, 2), 2), dtype=torch.float32, device=x.device)
+        with _Launch(x) as s:
+            _lib.check(self.lib.pvcnn_conv3d_fwd_split_bnact(_p(x), _p(wts), _p(bias) if bias is not None else None, b, ci, co, r, _p(amax),
+                                                             mean, rstd, gamma, beta, slope, _p(y), _p(part) if want_stats else None, s),
+                       'conv3d_forward_split_bnact')
+        return (y, part) if want_stats else y
+
+    def conv3d_backward_weight_f16_bnact(self, x, grad_y, x_amax, gy_amax, bn, with_bias=False):
+        """grad_w [, grad_bias] of conv3d(leaky_relu(bn(x)), w): x raw, x_amax = bnact_absmax_bits(x, bn)."""
+        _f32(x, 'x'); _f32(grad_y, 'grad_y')
+        b, ci, r = x.shape[0], x.shape[1], x.shape[2]
+        co = grad_y.shape[1]
+        _shape(self.conv3d_backward_weight_f16_serves(x) and tuple(grad_y.shape) == (b, co, r, r, r), 'conv3d_backward_weight_f16: R must be 16 or 32')
+        mean, rstd, gamma, beta, slope = self._bn_args(bn, ci)
+        x_amax = x_amax if x_amax is not None else self.bnact_absmax_bits(x, bn)
+        gy_amax = gy_amax if gy_amax is not None else self.absmax_bits(grad_y)
+        gw = torch.empty((co, ci, 3, 3, 3), dtype=torch.float32, device=x.device)
+        gb = torch.empty((co,), dtype=torch.float32, device=x.device) if with_bias else None
+        ws = self._scratch(self.lib.pvcnn_conv3d_bwd_weight_f16_workspace_bytes(b, ci, co, r), x.device)
+        with _Launch(x) as s:
+            _lib.check(self.lib.pvcnn_conv3d_bwd_weight_f16_bnact(_p(x), _p(grad_y), _p(x_amax), _p(gy_amax), mean, rstd, gamma, beta, slope,
+                                                                  b, ci, co, r, _p(gw), _p(gb) if with_bias else None, _p(ws), ws.numel(), s),
+                       'conv3d_backward_weight_f16_bnact')
+        return (gw, gb) if with_bias else gw
+
     # ---- SharedMLP 1x1 convolutions as channel-major MFMA GEMMs (csrc/pointwise.hip) --------------------
     has_pwconv = True
 
@@ -744,7 +812,10 @@ class HipBackend:
                 'trilinear_devoxelize_bnact_forward')
         return [outs, inds, wgts]
 
-    def bnact_backward(self, x, grad_y, gamma, beta, mean, rstd, slope, training):
+    # bnact_backward(..., want_amax=True) -> (gx, ggamma, gbeta, absmax_bits(gx)): the maximum rides on the apply pass
+    has_bnact_bwd_absmax = os.environ.get('PVCNN_BWD_AMAX', '1') != '0'
+
+    def bnact_backward(self, x, grad_y, gamma, beta, mean, rstd, slope, training, want_amax=False):
         _f32(x, 'x')
         gy_bstride = _f32_rows(grad_y, 'grad_y')
         b, c, s3 = x.shape
@@ -754,6 +825,14 @@ class HipBackend:
         gb = torch.empty((c,), dtype=torch.float32, device=dev)
         ws = self._scratch(self.lib.pvcnn_bnact_workspace_bytes(b, c, s3), dev)
         nul = ctypes.c_void_p(None)
+        if want_amax:
+            amax = torch.empty((1,), dtype=torch.int32, device=dev)
+            with _Launch(x) as s:
+                _lib.check(self.lib.pvcnn_bnact_bwd_absmax(_p(x), _p(grad_y), gy_bstride, _p(gamma) if gamma is not None else nul,
+                                                           _p(beta) if beta is not None else nul, _p(mean), _p(rstd), b, c, s3, float(slope),
+                                                           int(bool(training)), _p(gx), _p(gg), _p(gb), _p(amax), _p(ws), ws.numel(), s),
+                           'bnact_backward')
+            return gx, gg, gb, amax
         with _Launch(x) as s:
             _lib.check(self.lib.pvcnn_bnact_bwd_strided(_p(x), _p(grad_y), gy_bstride, _p(gamma) if gamma is not None else nul,
                                                 _p(beta) if beta is not None else nul, _p(mean), _p(rstd), b, c, s3, float(slope),

@@ -10,6 +10,7 @@ import torch
 import torch.nn as nn
 from torch.autograd import Function
 
+from . import _cache
 from ._autograd import native, amp_fwd, amp_bwd
 from .devoxelization import CornerTaps
 
@@ -27,7 +28,19 @@ def _rows(t, shape):
             pass
     return t.contiguous().view(shape[0], shape[1], -1)
 
-__all__ = ['batch_norm_act', 'batch_norm_act_devoxelize', 'fusable_tail', 'run_layers']
+
+def _bnact_backward(x3, g3, w, b, mean, rstd, slope, training, shape):
+    """native bnact_backward -> (grad_x viewed as `shape`, grad_gamma, grad_beta); the apply pass also leaves max |grad_x| on the
+    returned tensor (_cache.tag_absmax) for the f16x2 backward products of the convolution in front of this BatchNorm."""
+    be = native()
+    if x3.is_cuda and getattr(be, 'has_bnact_bwd_absmax', False):
+        gx, gw, gb, amax = be.bnact_backward(x3, g3, w, b, mean, rstd, slope, training, want_amax=True)
+        return _cache.tag_absmax(gx.view(shape), amax), gw, gb
+    gx, gw, gb = be.bnact_backward(x3, g3, w, b, mean, rstd, slope, training)
+    return gx.view(shape), gw, gb
+
+
+__all__ = ['batch_norm_act', 'batch_norm_act_conv3d', 'batch_norm_act_devoxelize', 'fusable_tail', 'run_layers']
 
 
 class BatchNormAct(Function):
@@ -51,8 +64,8 @@ class BatchNormAct(Function):
     def backward(ctx, grad_y):
         x3, w, b, mean, rstd = ctx.saved_tensors
         g3 = _rows(grad_y, ctx.shape)
-        gx, gw, gb = native().bnact_backward(x3, g3, w, b, mean, rstd, ctx.slope, ctx.training)
-        return (gx.view(ctx.shape), gw if w is not None else None, gb if b is not None else None,
+        gx, gw, gb = _bnact_backward(x3, g3, w, b, mean, rstd, ctx.slope, ctx.training, ctx.shape)
+        return (gx, gw if w is not None else None, gb if b is not None else None,
                 None, None, None, None, None, None, None, None)
 
 
@@ -123,8 +136,8 @@ class BatchNormActDevoxelize(Function):
     def backward(ctx, grad_out):
         x3, w, b, mean, rstd, _, _ = ctx.saved_tensors
         g_act = ctx.taps.backward(_rows(grad_out, grad_out.shape))
-        gx, gw, gb = native().bnact_backward(x3, g_act.view(x3.shape), w, b, mean, rstd, ctx.slope, ctx.use_batch_stats)
-        return (gx.view(ctx.shape), None, gw if w is not None else None, gb if b is not None else None,
+        gx, gw, gb = _bnact_backward(x3, g_act.view(x3.shape), w, b, mean, rstd, ctx.slope, ctx.use_batch_stats, ctx.shape)
+        return (gx, None, gw if w is not None else None, gb if b is not None else None,
                 None, None, None, None, None, None, None, None, None, None, grad_out if ctx.has_addend else None)
 
 
@@ -134,6 +147,16 @@ def batch_norm_act_devoxelize(grid, coords, bn, slope, resolution, is_training, 
     part, shift = _split(stats_part)
     return BatchNormActDevoxelize.apply(grid, coords, bn.weight, bn.bias, rm, rv, use_batch_stats, momentum, bn.eps, slope,
                                         resolution, is_training, part, shift, addend)
+
+
+def batch_norm_act_conv3d(x, bn, slope, conv_weight, conv_bias, stats_part=None, want_stats=False):
+    """conv3d(act(bn(x)), conv_weight) + conv_bias with the BatchNorm + activation folded into the convolution's staging
+    (functional.conv3d.BnActVoxelConv3d); -> y or (y, stats partials of y)."""
+    from .conv3d import bnact_voxel_conv3d
+    use_batch_stats, momentum, rm, rv = _bn_mode(bn)
+    part, shift = _split(stats_part)
+    return bnact_voxel_conv3d(x, bn.weight, bn.bias, rm, rv, use_batch_stats, momentum, bn.eps, slope, part, shift,
+                              conv_weight, conv_bias, want_stats)
 
 
 def fusable_tail(layers, x):
@@ -207,6 +230,20 @@ def run_layers(layers, x, stop=None, tail_stats=False):
             else:
                 x = res
             i += 1
+        elif (fuse and isinstance(m, nn.modules.batchnorm._BatchNorm) and i + 2 < len(mods) and _slope(mods[i + 1]) is not None
+                and hasattr(mods[i + 2], 'forward_bnact_folded') and x.numel() > 0 and mods[i + 2].can_fold_bnact(x)):
+            # (BatchNorm3d, LeakyReLU, Conv3d): the convolution normalises and activates while it stages its input --
+            # the activated grid is neither written nor read back (modules/pvconv.py:21-23 folded into :23's successor)
+            conv = mods[i + 2]
+            after = all_mods[i + 3] if i + 3 < len(all_mods) else None
+            want2 = _wants_batch_stats(after)
+            res = conv.forward_bnact_folded(x, m, _slope(mods[i + 1]), carried, want2)
+            if want2:
+                x, part = res
+                part = (part, conv.bias)
+            else:
+                x = res
+            i += 3
         elif (fuse and isinstance(m, nn.modules.batchnorm._BatchNorm) and i + 1 < len(mods) and x.dim() >= 3
                 and x.dtype == torch.float32 and _slope(mods[i + 1]) is not None and x.numel() > 0):
             x = batch_norm_act(x, m, _slope(mods[i + 1]), stats_part=carried)

@@ -5,6 +5,7 @@ backward-data, backward-weight + bias gradient) run on the fp32-MFMA kernels of 
 on the channel-major (B, C, N) tensors."""
 from torch.autograd import Function
 
+from . import _cache
 from ._autograd import native, amp_fwd, amp_bwd
 
 __all__ = ['pointwise_conv']
@@ -45,7 +46,8 @@ class PointwiseConv(Function):
         be = native()
         f16 = ctx.split == 2
         wgrad_f16 = f16 and ctx.needs_input_grad[1] and be.pwconv_backward_weight_f16_serves(x3)
-        g_amax = be.absmax_bits(g3) if f16 and (ctx.needs_input_grad[0] or wgrad_f16) else None      # shared by both products
+        # shared by both products; the BatchNorm backward that produced grad_y usually left it on the tensor (_cache.tag_absmax)
+        g_amax = _cache.absmax_of(grad_y, lambda: be.absmax_bits(g3)) if f16 and (ctx.needs_input_grad[0] or wgrad_f16) else None
         gx = None
         if ctx.needs_input_grad[0]:
             gx = (be.pwconv_backward_data_split(g3, w2, ctx.split, **({'amax': g_amax} if f16 else {})) if ctx.split

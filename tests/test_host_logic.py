@@ -103,3 +103,148 @@ def test_coordinate_memo_survives_a_weakref_callback_inside_its_own_critical_sec
     th.start()
     th.join(30)
     assert done.is_set(), 'memo() deadlocked against its own weak-reference callback'
+
+
+# ---- the folded (BatchNorm3d, LeakyReLU, Conv3d) autograd node, wired to a torch stand-in of the native entry points ----------
+class _FoldStandIn:
+    """The native calls BnActVoxelConv3d makes, evaluated with torch on the CPU: what is under test is the node's WIRING
+    (argument order, saved tensors, which gradient goes where), not the kernels (tests/test_gpu_fold.py)."""
+    has_bnact_bwd_absmax = True
+
+    def __init__(self):
+        self.calls = []
+
+    @staticmethod
+    def _act(x, bn):
+        import torch
+        g, b, mean, rstd, slope = bn
+        c = x.shape[1]
+        shape = (1, c) + (1,) * (x.dim() - 2)
+        scale = (g if g is not None else torch.ones(c)) * rstd
+        shift = (b if b is not None else torch.zeros(c)) - mean * scale
+        z = x * scale.view(shape) + shift.view(shape)
+        return torch.where(z > 0, z, z * slope)
+
+    @staticmethod
+    def _bits(t):
+        import torch
+        return t.abs().max().reshape(1).view(torch.int32)
+
+    def bn_stats(self, x3, rm, rv, momentum, eps):
+        import torch
+        self.calls.append('bn_stats')
+        mean = x3.mean(dim=(0, 2))
+        var = x3.var(dim=(0, 2), unbiased=False)
+        if rm is not None:
+            n = x3.shape[0] * x3.shape[2]
+            rm.mul_(1 - momentum).add_(momentum * mean)
+            rv.mul_(1 - momentum).add_(momentum * var * n / (n - 1))
+        return mean, torch.rsqrt(var + eps)
+
+    def absmax_bits(self, x):
+        self.calls.append('absmax_bits')
+        return self._bits(x)
+
+    def bnact_absmax_bits(self, x, bn):
+        self.calls.append('bnact_absmax_bits')
+        return self._bits(self._act(x, bn))
+
+    def conv3d_forward_split_bnact(self, x, weight, bias, bn, want_stats=False, amax=None):
+        import torch
+        assert amax is not None and torch.equal(amax, self._bits(self._act(x, bn)))
+        y = torch.nn.functional.conv3d(self._act(x, bn), weight, bias, padding=1)
+        if want_stats:
+            return y, torch.zeros(weight.shape[0], 1, 2)
+        return y
+
+    def conv3d_backward_data_split(self, grad_y, weight, nsplit, amax=None):
+        import torch
+        assert nsplit == 2 and torch.equal(amax, self._bits(grad_y))
+        b, _, r = grad_y.shape[:3]
+        return torch.nn.grad.conv3d_input((b, weight.shape[1], r, r, r), weight, grad_y, padding=1)
+
+    def conv3d_backward_weight_f16_bnact(self, x, grad_y, x_amax, gy_amax, bn, with_bias=False):
+        import torch
+        assert torch.equal(x_amax, self._bits(self._act(x, bn))) and torch.equal(gy_amax, self._bits(grad_y))
+        co, ci = grad_y.shape[1], x.shape[1]
+        gw = torch.nn.grad.conv3d_weight(self._act(x, bn), (co, ci, 3, 3, 3), grad_y, padding=1)
+        return (gw, grad_y.sum(dim=(0, 2, 3, 4))) if with_bias else gw
+
+    def bnact_backward(self, x3, g3, w, b, mean, rstd, slope, training, want_amax=False):
+        import torch
+        assert training                                       # batch statistics are differentiated through
+        with torch.enable_grad():                             # (called from inside a backward pass)
+            xr = x3.detach().clone().requires_grad_()
+            wr = w.detach().clone().requires_grad_()
+            br = b.detach().clone().requires_grad_()
+            m = xr.mean(dim=(0, 2), keepdim=True)
+            v = xr.var(dim=(0, 2), unbiased=False, keepdim=True)
+            eps = (1.0 / rstd.view(1, -1, 1) ** 2 - v.detach())  # the eps the statistics were finalised with
+            z = (xr - m) * torch.rsqrt(v + eps) * wr.view(1, -1, 1) + br.view(1, -1, 1)
+            torch.where(z > 0, z, z * slope).backward(g3)
+        out = (xr.grad, wr.grad, br.grad)
+        return out + (self._bits(xr.grad),) if want_amax else out
+
+
+def test_folded_batchnorm_conv3d_node_routes_every_gradient(monkeypatch):
+    """BnActVoxelConv3d == Conv3d(LeakyReLU(BatchNorm3d(x))) for the output, the input gradient, all four parameter gradients
+    and the running statistics; the input gradient leaves the node tagged with its max |.| and the convolution in front of it
+    picks that up instead of measuring the tensor again."""
+    import torch
+    import torch.nn as nn
+    from pvcnn_amd.modules.functional import _cache, backend as seam
+    from pvcnn_amd.modules.functional.bnact import batch_norm_act_conv3d
+    torch.manual_seed(11)
+    fake = _FoldStandIn()
+    monkeypatch.setattr(seam, '_backend', fake)
+    bn, act, conv = nn.BatchNorm3d(6, eps=1e-4), nn.LeakyReLU(0.1), nn.Conv3d(6, 5, 3, padding=1)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.5, 0.5)
+    bn2 = nn.BatchNorm3d(6, eps=1e-4)
+    bn2.load_state_dict(bn.state_dict())
+    x = torch.randn(3, 6, 4, 4, 4)
+    x1 = x.clone().requires_grad_()
+    y1 = conv(act(bn(x1)))
+    w = torch.randn_like(y1)
+    (y1 * w).sum().backward()
+    want = [x1.grad, bn.weight.grad, bn.bias.grad, conv.weight.grad, conv.bias.grad]
+    for p in (bn.weight, bn.bias, conv.weight, conv.bias):
+        p.grad = None
+    x2 = x.clone().requires_grad_()
+    seen = {}
+
+    class Probe(torch.autograd.Function):                    # stands where the first convolution's backward would
+        @staticmethod
+        def forward(ctx, t):
+            return t.view_as(t)
+
+        @staticmethod
+        def backward(ctx, g):
+            seen['amax'] = _cache.absmax_of(g, lambda: None)
+            seen['bits'] = _FoldStandIn._bits(g)
+            return g
+
+    y2, part = batch_norm_act_conv3d(Probe.apply(x2), bn2, 0.1, conv.weight, conv.bias, stats_part=None, want_stats=True)
+    assert part.shape[0] == 5 and not part.requires_grad
+    assert torch.allclose(y2, y1, atol=1e-5)
+    (y2 * w).sum().backward()
+    got = [x2.grad, bn2.weight.grad, bn2.bias.grad, conv.weight.grad, conv.bias.grad]
+    for a, b in zip(got, want):
+        assert a is not None and torch.allclose(a, b, rtol=1e-4, atol=1e-5), (a - b).abs().max()
+    assert torch.allclose(bn.running_mean, bn2.running_mean, atol=1e-6) and torch.allclose(bn.running_var, bn2.running_var, atol=1e-6)
+    assert int(bn2.num_batches_tracked) == 1
+    # the tag travelled with the tensor object from one autograd node to the next
+    assert seen['amax'] is not None and torch.equal(seen['amax'], seen['bits'])
+    assert fake.calls.count('bnact_absmax_bits') == 1 and fake.calls.count('absmax_bits') == 1   # only y's incoming gradient was measured
+
+
+def test_absmax_tag_dies_with_an_in_place_update():
+    import torch
+    from pvcnn_amd.modules.functional import _cache
+    t = torch.randn(8)
+    tag = torch.tensor([7], dtype=torch.int32)
+    _cache.tag_absmax(t, tag)
+    assert _cache.absmax_of(t, lambda: None) is tag
+    assert _cache.absmax_of(t.view(8), lambda: None) is None          # another tensor object: not tagged
+    t.mul_(2.0)                                                       # modified in place: the tag no longer describes it
+    assert _cache.absmax_of(t, lambda: None) is None
