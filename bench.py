@@ -103,6 +103,11 @@ class KernelClock:
         'conv3d_igemm_split': lambda a, out: ('conv3d_igemm_bf16 ' + {3: 'bf16x3', 2: 'f16x2', 1: 'bf16'}[int(a[4])],
                                               2.0 * a[0].shape[0] * a[0].shape[2] ** 3 * 27 * a[0].shape[1] * int(a[3]),
                                               (a[0].shape[0], a[0].shape[1], int(a[3]), a[0].shape[2])),
+        # the same launch with the BatchNorm3d + LeakyReLU in front of the convolution applied in its staging:
+        # conv3d_igemm_split_bnact(x, wts, bias, co, bn, want_stats, amax)
+        'conv3d_igemm_split_bnact': lambda a, out: ('conv3d_igemm_bf16 f16x2',
+                                                    2.0 * a[0].shape[0] * a[0].shape[2] ** 3 * 27 * a[0].shape[1] * int(a[3]),
+                                                    (a[0].shape[0], a[0].shape[1], int(a[3]), a[0].shape[2])),
     }
 
     def __init__(self, backend):

@@ -543,8 +543,11 @@ class HipBackend:
 
     # ---- voxel_layers' first BatchNorm3d + LeakyReLU folded into the second convolution's staging ----
     # bn = (gamma | None, beta | None, mean, rstd, slope) of the BatchNorm + activation IN FRONT of the convolution; x is the raw
-    # tensor in front of that BatchNorm.  f16x2 arithmetic; results bit-identical to the unfused ops.  PVCNN_FOLD_BN=0 disables.
-    has_conv3d_bnact_fold = os.environ.get('PVCNN_FOLD_BN', '1') != '0'
+    # tensor in front of that BatchNorm.  f16x2 arithmetic; results bit-identical to the unfused ops.
+    # OPT-IN (PVCNN_FOLD_BN=1): measured on MI355X (profiles/r02_fold_ab.md) the fold saves the 0.08 ms/step of the BatchNorm pass
+    # and costs 0.3 ms/step in the two consumers (the extra VALU work lands in staging loops that the f16x2 MFMA stream does not
+    # hide: forward 179 -> 274 us at 64->64, R = 32; backward-weight 225 -> 344 us), so the default keeps the separate pass.
+    has_conv3d_bnact_fold = os.environ.get('PVCNN_FOLD_BN', '0') == '1'
 
     @staticmethod
     def _bn_args(bn, channels):
@@ -575,12 +578,14 @@ class HipBackend:
                and x.shape[2] == x.shape[3] == x.shape[4], 'conv3d: x (B,Ci,R,R,R), weight (Co,Ci,3,3,3) expected')
         if bias is not None:
             _f32(bias, 'bias')
-        b, ci, r = x.shape[0], x.shape[1], x.shape[2]
-        co = weight.shape[0]
-        mean, rstd, gamma, beta, slope = self._bn_args(bn, ci)
         if amax is None:
             amax = self.bnact_absmax_bits(x, bn)
-        wts = self._conv_wsplit(weight, False, 2)
+        return self.conv3d_igemm_split_bnact(x, self._conv_wsplit(weight, False, 2), bias, weight.shape[0], bn, want_stats, amax)
+
+    def conv3d_igemm_split_bnact(self, x, wts, bias, co, bn, want_stats, amax):
+        """The implicit-GEMM launch alone (pre-split f16x2 weight image, amax = bnact_absmax_bits(x, bn))."""
+        b, ci, r = x.shape[0], x.shape[1], x.shape[2]
+        mean, rstd, gamma, beta, slope = self._bn_args(bn, ci)
         y = torch.empty((b, co, r, r, r), dtype=torch.float32, device=x.device)
         part = None
         if want_stats:
@@ -812,8 +817,11 @@ class HipBackend:
                 'trilinear_devoxelize_bnact_forward')
         return [outs, inds, wgts]
 
-    # bnact_backward(..., want_amax=True) -> (gx, ggamma, gbeta, absmax_bits(gx)): the maximum rides on the apply pass
-    has_bnact_bwd_absmax = os.environ.get('PVCNN_BWD_AMAX', '1') != '0'
+    # bnact_backward(..., want_amax=True) -> (gx, ggamma, gbeta, absmax_bits(gx)): the maximum rides on the apply pass.
+    # OPT-IN (PVCNN_BWD_AMAX=1): it removes 15 of the step's 22 absmax passes (0.41 -> 0.15 ms/step) but the apply kernel slows
+    # from 35 to 44 us per launch (the block reduction's barrier waits for the streaming stores) -- no net gain yet
+    # (profiles/r02_fold_ab.md).
+    has_bnact_bwd_absmax = os.environ.get('PVCNN_BWD_AMAX', '0') == '1'
 
     def bnact_backward(self, x, grad_y, gamma, beta, mean, rstd, slope, training, want_amax=False):
         _f32(x, 'x')

@@ -101,13 +101,18 @@ def test_pvconv_with_the_fold_is_bit_identical_to_without(hip, r, cin, cout, wit
     from pvcnn_amd.modules.functional._autograd import native
     torch.manual_seed(23)
     be = native()
-    assert be.has_conv3d_bnact_fold and be.conv_math == 'f16x2'
+    assert be.conv_math == 'f16x2'
+    default = type(be).has_conv3d_bnact_fold                 # the fold is opt-in (PVCNN_FOLD_BN=1): switched on here
     folded = PVConv(cin, cout, 3, r, with_se=with_se).to(DEV).train()
     plain = copy.deepcopy(folded)
     feats = torch.randn(2, cin, 1500, device=DEV)
     coords = torch.rand(2, 3, 1500, device=DEV) * 2 - 1
     fa, fb = feats.clone().requires_grad_(), feats.clone().requires_grad_()
-    ya, _ = folded((fa, coords))
+    type(be).has_conv3d_bnact_fold = True
+    try:
+        ya, _ = folded((fa, coords))
+    finally:
+        type(be).has_conv3d_bnact_fold = default
     # the folded node is in the graph: walk it
     used, seen, stack = [], set(), [ya.grad_fn]
     while stack:
@@ -124,7 +129,7 @@ def test_pvconv_with_the_fold_is_bit_identical_to_without(hip, r, cin, cout, wit
         yb, _ = plain((fb, coords))
         yb.square().sum().backward()
     finally:
-        type(be).has_conv3d_bnact_fold = True
+        type(be).has_conv3d_bnact_fold = default
     assert torch.equal(ya, yb)
     assert torch.equal(fa.grad, fb.grad)
     for (na, pa), (_, pb) in zip(folded.named_parameters(), plain.named_parameters()):
@@ -133,12 +138,13 @@ def test_pvconv_with_the_fold_is_bit_identical_to_without(hip, r, cin, cout, wit
         assert torch.equal(ba, bb), na
     folded.eval(); plain.eval()
     with torch.no_grad():
-        ya, _ = folded((feats, coords))
         try:
+            type(be).has_conv3d_bnact_fold = True
+            ya, _ = folded((feats, coords))
             type(be).has_conv3d_bnact_fold = False
             yb, _ = plain((feats, coords))
         finally:
-            type(be).has_conv3d_bnact_fold = True
+            type(be).has_conv3d_bnact_fold = default
     assert torch.equal(ya, yb)
 
 
@@ -158,15 +164,16 @@ def test_gradient_maxima_are_handed_over_not_measured_again(hip):
         calls = []
         orig = type(be).absmax_bits
         type(be).absmax_bits = lambda self, t: (calls.append(tuple(t.shape)), orig(self, t))[1]
-        prev = type(be).has_bnact_bwd_absmax
-        type(be).has_bnact_bwd_absmax = emit
+        prev, prev_fold = type(be).has_bnact_bwd_absmax, type(be).has_conv3d_bnact_fold
+        type(be).has_bnact_bwd_absmax = emit                   # both are opt-in (PVCNN_BWD_AMAX=1, PVCNN_FOLD_BN=1): switched on here
+        type(be).has_conv3d_bnact_fold = True
         try:
             f = feats.clone().requires_grad_()
             y, _ = mod((f, coords))
             y.square().sum().backward()
         finally:
             type(be).absmax_bits = orig
-            type(be).has_bnact_bwd_absmax = prev
+            type(be).has_bnact_bwd_absmax, type(be).has_conv3d_bnact_fold = prev, prev_fold
         return y, f.grad, calls
 
     ya, ga, calls_a = run(layer, True)
