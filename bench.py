@@ -28,6 +28,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# multi-process GPU work on this pool: the host driver only supports dmabuf IPC (RCCL / cross-process tensors fail otherwise)
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
 import torch
 import torch.distributed as dist

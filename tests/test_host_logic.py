@@ -248,3 +248,28 @@ def test_absmax_tag_dies_with_an_in_place_update():
     assert _cache.absmax_of(t.view(8), lambda: None) is None          # another tensor object: not tagged
     t.mul_(2.0)                                                       # modified in place: the tag no longer describes it
     assert _cache.absmax_of(t, lambda: None) is None
+
+
+def test_trace_steady_delimits_steps_by_the_optimizer_not_by_the_gradient_packing(tmp_path):
+    """tools/trace_steady.py: the fused-Adam launches end a step; the multi_tensor_apply COPY kernels of the gradient packing
+    (pvcnn_amd/dp.py) must not -- counting them as optimizer phases halved every per-step figure once."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    adam = ('void at::native::(anonymous namespace)::multi_tensor_apply_kernel<at::native::(anonymous namespace)::'
+            'FusedOptimizerTensorListMetadata<4>, at::native::(anonymous namespace)::FusedAdamMathFunctor<float, 4>, float*>(...)')
+    pack = ('void at::native::(anonymous namespace)::multi_tensor_apply_kernel<at::native::(anonymous namespace)::'
+            'TensorListMetadata<2>, at::native::(anonymous namespace)::CopyFunctor<float, float, 2, 1, 1>>(...)')
+    rows, t = ['Kernel_Name,Start_Timestamp,End_Timestamp'], 0
+    for step in range(6):
+        for name, dur in (('pvcnn::conv', 300), (pack, 10), ('pvcnn::bn', 50), (pack, 10), (adam, 70), (adam, 70)):
+            rows.append(f'"{name}",{t},{t + dur * 1000}')
+            t += dur * 1000 + 1000
+    trace = tmp_path / 'kernel_trace.csv'
+    trace.write_text('\n'.join(rows) + '\n')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'trace_steady.py'), str(trace), '4', '10', '1'],
+                         capture_output=True, text=True, check=True).stdout
+    first = out.splitlines()[0]
+    assert 'last 4 steps: 24 kernel launches (6/step)' in first, first
+    assert 'kernel time 0.510 ms/step' in first, first
