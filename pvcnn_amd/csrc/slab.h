@@ -24,6 +24,7 @@
 // The index/weight source ("provider") is a template parameter; see the structs below.
 #pragma once
 #include <algorithm>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -280,6 +281,14 @@ struct XfBnAct {
     v = fmaf(v, scale, shift);
     return v > 0.f ? v : v * slope;
   }
+  // params() in two halves, for kernels that fetch a row's raw parameters one slab ahead and combine them when the row arrives
+  __device__ __forceinline__ void fetch(int c, float (&raw)[4]) const {
+    raw[0] = gamma ? gamma[c] : 1.0f; raw[1] = rstd[c]; raw[2] = beta ? beta[c] : 0.0f; raw[3] = mean[c];
+  }
+  __device__ __forceinline__ void combine(const float (&raw)[4], float &scale, float &shift) const {
+    scale = raw[0] * raw[1];
+    shift = raw[2] - raw[3] * scale;
+  }
 };
 
 // one row of a slab through a transform (row = channel c of the cloud)
@@ -415,6 +424,109 @@ __global__ __launch_bounds__(THREADS) void gather_lds_kernel(P p, XF xf, const f
   }
 }
 
+// EXPERIMENTAL (PVCNN_GATHER_PIPE=1, not the default until measured): the single-row-slab case (R = 32: one 128 KiB grid fills
+// the CU's LDS, ONE 1024-thread workgroup per CU, so nothing overlaps the HBM -> LDS stream with the gather phase -- per slab
+// ~5 us of streaming and ~3 us of tap expansion + LDS gather run back to back, which is why the kernel sits at 0.52 of the HBM
+// peak).  Here the NEXT slab's 8 x 16-byte loads per thread are issued right after the barrier that publishes the current slab
+// and stay in flight (32 VGPRs) while the current slab is gathered; to make room the four points of a thread are expanded one at
+// a time.  Same expressions, same order: bit-identical to gather_lds_kernel<P, 4, 1024, true, XF, true>.
+template <class P, class XF>
+__global__ __launch_bounds__(1024) void gather_lds_pipe_kernel(P p, XF xf, const float *__restrict__ src, float *__restrict__ dst,
+                                                               int C, int L, int J, int SEQ, int pshift,
+                                                               const float *__restrict__ addend = nullptr) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int NC = P::NC, THREADS = 1024, kB = 8;
+  const int b = blockIdx.y;
+  const int jf = threadIdx.x * 4;
+  const bool has = jf < J;
+  typename P::Packed pk[4];
+  if (has) {
+    p.pack4(b, jf, pk);
+    if (blockIdx.x == 0) {                                  // side outputs (devoxelize: inds / wgts) once per cloud
+      Taps<NC> t[4];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) p.unpack(pk[v], t[v]);
+      p.post4(b, jf, t);
+    }
+  }
+  const int nq = L >> 2;                                    // <= THREADS * kB quads (checked by the launcher)
+  float4 v[kB];
+  // loads through a buffer descriptor: ONE per-lane offset register (tid * 16) for all eight loads, the rest of the address
+  // (row base, u * 16 KiB) is scalar; the hardware bounds check returns zeros past the row (no clamp)
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const int voff = (int)threadIdx.x * 16;
+  auto issue = [&](int c) {
+    // (the row base is wave-uniform; readfirstlane says so to the compiler, which otherwise wraps every load in a waterfall loop)
+    const uintptr_t rowp = reinterpret_cast<uintptr_t>(src + ((size_t)b * C + c) * L);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)rowp), hi = __builtin_amdgcn_readfirstlane((uint32_t)(rowp >> 32));
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<void *>(((uintptr_t)hi << 32) | lo), /*stride*/ 0, /*bytes*/ L * 4, 0x00020000);
+#pragma unroll
+    for (int u = 0; u < kB; ++u) {
+      const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, u * THREADS * 16, 0);
+      v[u] = make_float4(__uint_as_float(raw.x), __uint_as_float(raw.y), __uint_as_float(raw.z), __uint_as_float(raw.w));
+    }
+  };
+  // the row transform's raw parameters are fetched one slab ahead, BEFORE the row's own loads (so that waiting for them
+  // never waits for the row), and combined into (scale, shift) when the row is committed
+  float scale = 1.0f, shift = 0.0f;
+  [[maybe_unused]] float raw[4] = {1.0f, 1.0f, 0.0f, 0.0f};
+  auto commit = [&]() {
+    if constexpr (!XF::kIdentity) xf.combine(raw, scale, shift);
+    auto f = [&](float x) {
+      if constexpr (XF::kIdentity) return x; else return xf.apply(x, scale, shift);
+    };
+#pragma unroll
+    for (int u = 0; u < kB; ++u) {
+      const int q = (int)threadIdx.x + u * THREADS;
+      if (q < nq) {
+        const int i = q * 4;
+        float *d = lds + i + (i >> pshift);
+        d[0] = f(v[u].x); d[1] = f(v[u].y); d[2] = f(v[u].z); d[3] = f(v[u].w);
+      }
+    }
+  };
+  const int first = blockIdx.x * SEQ;
+  if (first < C) {
+    if constexpr (!XF::kIdentity) xf.fetch(first, raw);
+    issue(first);
+  }
+  for (int sq = 0; sq < SEQ; ++sq) {
+    const int c = first + sq;
+    if (c >= C) break;
+    if (sq > 0) lds_barrier();                              // every wave is done reading the previous slab
+    commit();                                               // waits for this slab's loads only
+    lds_barrier();                                          // slab visible (LDS-only: the previous outputs keep draining)
+    if (sq + 1 < SEQ && c + 1 < C) {
+      if constexpr (!XF::kIdentity) xf.fetch(c + 1, raw);
+      issue(c + 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);                      // keep the loads HERE: the scheduler sinks them to their first use
+    if (has) {
+      float r[4];
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        // the taps are re-expanded per slab ON PURPOSE (4 registers per point instead of 16 held across the loop): hide the
+        // loop invariance from the optimiser, or it hoists the expansion out of the slab loop and spills it
+        if constexpr (sizeof(typename P::Packed) == 16) {
+          uint4 &raw = reinterpret_cast<uint4 &>(pk[h]);
+          asm volatile("" : "+v"(raw.x), "+v"(raw.y), "+v"(raw.z), "+v"(raw.w));
+        }
+        Taps<NC> t;
+        p.unpack(pk[h], t);
+        r[h] = combine<NC, P::kMaySkip, true>(t, lds, pshift);
+      }
+      // uniform row base + the thread's 32-bit byte offset (jf * 4): no 64-bit per-lane addresses live across the loop
+      const size_t rowoff = ((size_t)b * C + c) * J;
+      if (addend) {
+        const float4 a = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(addend + rowoff) + (uint32_t)jf * 4u);
+        r[0] = r[0] + a.x; r[1] = r[1] + a.y; r[2] = r[2] + a.z; r[3] = r[3] + a.w;
+      }
+      *reinterpret_cast<float4 *>(reinterpret_cast<char *>(dst + rowoff) + (uint32_t)jf * 4u) = make_float4(r[0], r[1], r[2], r[3]);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Direct (no-LDS) fallbacks for rows larger than LDS.  grid = (ceil(J/256), ceil(C/CT), B).
 // scatter_direct needs dst zeroed first (the launcher enqueues a hipMemsetAsync).
@@ -518,6 +630,17 @@ int launch_gather(const P &p, const float *src, float *dst, int B, int C, int L,
     }
   }
   const dim3 grid(ceil_div(ceil_div(C, pl.G), pl.seq), B);
+  if constexpr (P::kGridRows) {
+    // EXPERIMENTAL software-pipelined single-row-slab variant (see gather_lds_pipe_kernel); opt-in, read once per process
+    static const bool pipe = [] { const char *e = getenv("PVCNN_GATHER_PIPE"); return e && e[0] == '1'; }();
+    if (pipe && pl.threads == 1024 && pl.G == 1 && pshift > 0 && vec_ok && J <= 1024 * 4 && (L & 3) == 0 && (L >> 2) <= 1024 * 8 &&
+        aligned16(src) && (((size_t)L * sizeof(float)) & 15) == 0) {
+      auto k = gather_lds_pipe_kernel<P, XF>;
+      if (int e = enable_big_lds(k, pl.bytes)) { set_error("%s: LDS attribute: %d", what, e); return e; }
+      hipLaunchKernelGGL(k, grid, dim3(1024), pl.bytes, s, p, xf, src, dst, C, L, J, pl.seq, pshift, addend);
+      return check_launch(what);
+    }
+  }
 #define PVCNN_LAUNCH_GATHER_P(VEC, T, PADV)                                                      \
   do {                                                                                           \
     auto k = (J <= T * VEC) ? gather_lds_kernel<P, VEC, T, true, XF, PADV> : gather_lds_kernel<P, VEC, T, false, XF, PADV>; \
