@@ -414,7 +414,7 @@ def main():
         mfma = max(convs, key=lambda k: (k['GFLOP'], k['calls'])) if convs else None
         roofline = None
         if head:
-            roofline = {'bound': 'hbm', 'kernel': 'trilinear_devoxelize_fwd (gather_lds_kernel<TrilinearFromCoords>; BatchNorm+LeakyReLU fused into its LDS staging inside PVConv)',
+            roofline = {'bound': 'hbm', 'kernel': 'trilinear_devoxelize_fwd (gather_lds_pipe_kernel<TrilinearFromCoords> at R = 32, else gather_lds_kernel; BatchNorm+LeakyReLU fused into its LDS staging and the point branch added in its store inside PVConv)',
                         'shape_BCNR': head['shape_BCNR'], 'achieved': head['achieved_GBs'], 'peak': HBM_PEAK_GBS,
                         'unit': 'GB/s', 'frac': round(head['achieved_GBs'] / HBM_PEAK_GBS, 4),
                         'frac_of_achievable_6300': round(head['achieved_GBs'] / 6300.0, 4),

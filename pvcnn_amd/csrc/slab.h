@@ -424,12 +424,13 @@ __global__ __launch_bounds__(THREADS) void gather_lds_kernel(P p, XF xf, const f
   }
 }
 
-// EXPERIMENTAL (PVCNN_GATHER_PIPE=1, not the default until measured): the single-row-slab case (R = 32: one 128 KiB grid fills
-// the CU's LDS, ONE 1024-thread workgroup per CU, so nothing overlaps the HBM -> LDS stream with the gather phase -- per slab
-// ~5 us of streaming and ~3 us of tap expansion + LDS gather run back to back, which is why the kernel sits at 0.52 of the HBM
-// peak).  Here the NEXT slab's 8 x 16-byte loads per thread are issued right after the barrier that publishes the current slab
-// and stay in flight (32 VGPRs) while the current slab is gathered; to make room the four points of a thread are expanded one at
-// a time.  Same expressions, same order: bit-identical to gather_lds_kernel<P, 4, 1024, true, XF, true>.
+// The single-row-slab case, software-pipelined (R = 32: one 128 KiB grid fills the CU's LDS, ONE 1024-thread workgroup per CU, so
+// in gather_lds_kernel nothing overlaps the HBM -> LDS stream with the gather phase -- per slab ~5 us of streaming and ~3 us of
+// tap expansion + LDS gather run back to back: 41.6 us, 0.51 of the HBM peak at (16,64,4096,32)).  Here the NEXT slab's 8 x 16-byte
+// loads per thread are issued right after the barrier that publishes the current slab and stay in flight (32 VGPRs) while the
+// current slab is gathered; to make room the four points of a thread are expanded one at a time.  Same expressions, same order:
+// bit-identical to gather_lds_kernel<P, 4, 1024, true, XF, true> (tools/pipecheck*.py: 7 ragged shapes x training / eval x plain /
+// BatchNorm / addend) and 36.3 us on the same box (profiles/ab/r02_pipecheck_*).  PVCNN_GATHER_PIPE=0 selects the classic kernel.
 template <class P, class XF>
 __global__ __launch_bounds__(1024) void gather_lds_pipe_kernel(P p, XF xf, const float *__restrict__ src, float *__restrict__ dst,
                                                                int C, int L, int J, int SEQ, int pshift,
@@ -631,8 +632,8 @@ int launch_gather(const P &p, const float *src, float *dst, int B, int C, int L,
   }
   const dim3 grid(ceil_div(ceil_div(C, pl.G), pl.seq), B);
   if constexpr (P::kGridRows) {
-    // EXPERIMENTAL software-pipelined single-row-slab variant (see gather_lds_pipe_kernel); opt-in, read once per process
-    static const bool pipe = [] { const char *e = getenv("PVCNN_GATHER_PIPE"); return e && e[0] == '1'; }();
+    // software-pipelined single-row-slab variant (see gather_lds_pipe_kernel); PVCNN_GATHER_PIPE=0 opts out (read once per process)
+    static const bool pipe = [] { const char *e = getenv("PVCNN_GATHER_PIPE"); return !(e && e[0] == '0'); }();
     if (pipe && pl.threads == 1024 && pl.G == 1 && pshift > 0 && vec_ok && J <= 1024 * 4 && (L & 3) == 0 && (L >> 2) <= 1024 * 8 &&
         aligned16(src) && (((size_t)L * sizeof(float)) & 15) == 0) {
       auto k = gather_lds_pipe_kernel<P, XF>;

@@ -1,9 +1,10 @@
-"""EXPERIMENTAL kernel variants that are built but not yet measured on the chip.  They are opt-in by environment variable and
-so are these tests: `PVCNN_EXPERIMENTAL=1 python -m pytest tests/test_gpu_experimental.py -m gpu`.  Each variant must be
-BIT-IDENTICAL to the default path before it is timed (tools/opbench.py under the same environment variable).
+"""Kernel variants selected by environment variable, compared across PROCESSES (the switch is read once per process).  Opt-in:
+`PVCNN_EXPERIMENTAL=1 python -m pytest tests/test_gpu_experimental.py -m gpu` (the in-process equivalents that ran on the GPU
+are tools/pipecheck.py / pipecheck2.py: profiles/ab/r02_pipecheck_*).
 
-  PVCNN_GATHER_PIPE=1   software-pipelined single-row-slab gather (csrc/slab.h, gather_lds_pipe_kernel): trilinear_devoxelize
-                        forward at R = 32 (the bench's roofline kernel), with and without the fused BatchNorm + LeakyReLU + addend.
+  PVCNN_GATHER_PIPE=0 | 1   classic | software-pipelined (default) single-row-slab gather (csrc/slab.h, gather_lds_pipe_kernel):
+                            trilinear_devoxelize forward at R = 32 (the bench's roofline kernel), with and without the fused
+                            BatchNorm + LeakyReLU + addend.  Must be BIT-IDENTICAL.
 """
 import os
 import subprocess
