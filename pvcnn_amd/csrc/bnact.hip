@@ -9,6 +9,7 @@
 // Tensors are (B, C, S) channel-major (S = R^3 voxels or N points); statistics per channel over B*S.
 // Sums are accumulated in fp32 per workgroup slice (<= 8192 elements) and combined in fp64.
 #include <algorithm>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -136,6 +137,24 @@ __device__ __forceinline__ void block_atomic_max_bits(uint32_t m, uint32_t *__re
   }
 }
 
+// EXPERIMENTAL second form (PVCNN_AMAX_REDUCE=2; built, not yet measured): measured on the chip, the form above makes
+// bnact_bwd_apply_kernel 27 % slower (34.6 -> 44.1 us) -- __syncthreads() waits for the kernel's outstanding streaming STORES, and
+// the filter load is a dependent global round trip at the very end of a ~10 us workgroup.  Here the barrier orders LDS only
+// (lds_barrier), the filter value `seen` was loaded when the kernel STARTED (thread 0; stale by design), and the atomic has no
+// return value (fire and forget).  Same result: the maximum is order-independent.
+__device__ __forceinline__ void block_atomic_max_bits_v2(uint32_t m, uint32_t seen, uint32_t *__restrict__ out) {
+  __shared__ uint32_t red2[kBnThreads / 64];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+  if ((threadIdx.x & 63) == 0) red2[threadIdx.x >> 6] = m;
+  lds_barrier();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int w = 1; w < kBnThreads / 64; ++w) m = max(m, red2[w]);
+    if (m > seen) atomicMax(out, m);
+  }
+}
+
 // grid = (slices, B, C): bits of max |act(scale * x + shift)| -- pvcnn_absmax_bits of the tensor bnact_apply_kernel WOULD write
 // (same expressions, so the same bits), for consumers that apply the transform while staging (conv3d_bf16.hip, XF)
 __global__ __launch_bounds__(kBnThreads) void bnact_absmax_kernel(const float *__restrict__ x, BnActXf xf, int C, int S,
@@ -223,8 +242,10 @@ __global__ __launch_bounds__(kBnThreads) void bnact_bwd_apply_kernel(const float
                                                                     const float *__restrict__ dbeta, float slope,
                                                                     float inv_count, int training, int C, int S,
                                                                     float *__restrict__ gx, long gy_bstride,
-                                                                    uint32_t *__restrict__ gx_absmax) {
+                                                                    uint32_t *__restrict__ gx_absmax, int amax_form) {
   const int sl = blockIdx.x, b = blockIdx.y, c = blockIdx.z;
+  uint32_t seen = 0;                                           // form 2: the maximum other workgroups have posted so far
+  if (gx_absmax != nullptr && amax_form == 2 && threadIdx.x == 0) seen = __hip_atomic_load(gx_absmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const float m = mean[c], r = rstd[c];
   const float gmm = gamma ? gamma[c] : 1.0f;
   const float scale = gmm * r;
@@ -264,7 +285,10 @@ __global__ __launch_bounds__(kBnThreads) void bnact_bwd_apply_kernel(const float
   }
   // the gradient's max |.| rides along: the f16x2 products that consume grad_x (Conv3d / 1x1 backward-data and backward-weight)
   // derive their power-of-two scale from it, and a separate absmax pass would re-read the whole tensor
-  if (gx_absmax != nullptr) block_atomic_max_bits(amax, gx_absmax);
+  if (gx_absmax != nullptr) {
+    if (amax_form == 2) block_atomic_max_bits_v2(amax, seen, gx_absmax);
+    else block_atomic_max_bits(amax, gx_absmax);
+  }
 }
 
 }  // namespace pvcnn
@@ -342,10 +366,12 @@ static int bnact_bwd_impl(const float *x, const float *grad_y, long gy_bstride, 
                      slices, part, gy_bstride);
   if (int e = check_launch("bnact_bwd_reduce")) return e;
   uint32_t *am = static_cast<uint32_t *>(gx_absmax);
+  // which form of the in-kernel maximum (see block_atomic_max_bits_v2); read once per process
+  static const int amax_form = [] { const char *e = getenv("PVCNN_AMAX_REDUCE"); return (e && e[0] == '2') ? 2 : 1; }();
   hipLaunchKernelGGL(bnact_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, part, B * slices, grad_gamma, grad_beta, am);
   if (int e = check_launch("bnact_bwd_finalize")) return e;
   hipLaunchKernelGGL(bnact_bwd_apply_kernel, grid, dim3(kBnThreads), 0, s, x, grad_y, mean, rstd, gamma, beta, grad_gamma,
-                     grad_beta, slope, (float)(1.0 / ((double)B * S)), training, C, S, grad_x, gy_bstride, am);
+                     grad_beta, slope, (float)(1.0 / ((double)B * S)), training, C, S, grad_x, gy_bstride, am, amax_form);
   return check_launch("bnact_bwd_apply");
 }
 

@@ -5,6 +5,9 @@ are tools/pipecheck.py / pipecheck2.py: profiles/ab/r02_pipecheck_*).
   PVCNN_GATHER_PIPE=0 | 1   classic | software-pipelined (default) single-row-slab gather (csrc/slab.h, gather_lds_pipe_kernel):
                             trilinear_devoxelize forward at R = 32 (the bench's roofline kernel), with and without the fused
                             BatchNorm + LeakyReLU + addend.  Must be BIT-IDENTICAL.
+  PVCNN_AMAX_REDUCE=2       second form of the gradient maximum that rides on the BatchNorm backward's apply pass (csrc/bnact.hip,
+                            block_atomic_max_bits_v2: LDS-only barrier, filter value read at kernel start, fire-and-forget
+                            atomic).  Must give the same bits as pvcnn_absmax_bits of the gradient; time it with tools/foldbench.py.
 """
 import os
 import subprocess
@@ -60,3 +63,33 @@ def test_pipelined_gather_is_bit_identical(tmp_path):
     for case, (a, b_) in enumerate(zip(outs['default'], outs['pipe'])):
         for k, (x, y) in enumerate(zip(a, b_)):
             assert torch.equal(x, y), (case, k)
+
+
+_CHILD_AMAX = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from pvcnn_amd.modules.functional.backend import HipBackend
+be = HipBackend()
+torch.manual_seed(3)
+ok = True
+for b, c, s in [(16, 64, 32 ** 3), (2, 64, 4096), (3, 24, 1000), (2, 7, 1001), (16, 128, 16 ** 3)]:
+    x = torch.randn(b, c, s, device='cuda')
+    g = torch.randn(b, c, s, device='cuda') * 1e-3
+    gamma, beta = torch.rand(c, device='cuda') + 0.5, torch.randn(c, device='cuda')
+    mean, rstd = torch.randn(c, device='cuda') * 0.3, torch.rand(c, device='cuda') + 0.5
+    for training in (True, False):
+        for scale in (1.0, 0.5):
+            gx, gg, gb, amax = be.bnact_backward(x, g * scale, gamma, beta, mean, rstd, 0.1, training, want_amax=True)
+            plain = be.bnact_backward(x, g * scale, gamma, beta, mean, rstd, 0.1, training)
+            ok = ok and torch.equal(gx, plain[0]) and torch.equal(amax, be.absmax_bits(gx))
+print('AMAX_OK' if ok else 'AMAX_MISMATCH')
+"""
+
+
+def test_second_form_of_the_gradient_maximum(tmp_path):
+    script = tmp_path / 'child_amax.py'
+    script.write_text(_CHILD_AMAX)
+    for form in ('1', '2'):
+        out = subprocess.run([sys.executable, str(script), ROOT], check=True, env=dict(os.environ, PVCNN_AMAX_REDUCE=form), timeout=300,
+                             capture_output=True, text=True).stdout
+        assert 'AMAX_OK' in out, (form, out)
