@@ -8,6 +8,8 @@
 //             of each point from its 12-byte coordinate (cheaper than re-reading 64 bytes of
 //             saved inds/wgts), and serves the 8*C random reads per point from LDS.  The
 //             workgroups of channel-slab 0 also emit inds/wgts (B,8,N) in training mode.
+//             At R = 32 (one grid = the whole LDS of a CU) the software-pipelined
+//             gather_lds_pipe_kernel keeps the next grid's loads in flight during the gather.
 //   backward: the deterministic CSR scatter of csr.h with 8 entries per point (entry id =
 //             point*8 + corner, the reference's loop order): one counting sort per cloud, then
 //             lane-owned sums over grad_y rows staged in LDS; every grid element written once;

@@ -15,7 +15,8 @@
 //            are a per-cloud counting sort + lane-owned segmented sums instead.
 // HBM traffic is therefore the compulsory minimum (slab once + per-element streams once).
 // An R=32 grid row is 128 KiB: it fits the 160 KiB LDS of a gfx950 CU as a single-row slab.
-// Refinements (all below): a workgroup walks several slabs with its elements' taps packed in registers;
+// Refinements (all below): a workgroup walks several slabs with its elements' taps packed in registers (and, when a slab is
+// a whole LDS, prefetches the next one into registers while it gathers from the current one: gather_lds_pipe_kernel);
 // voxel-grid rows are staged with a padded z-row stride so planar clouds do not serialise on one LDS bank;
 // a per-row transform (BatchNorm + LeakyReLU) can be applied while a slab is staged.
 // Rows that do not fit LDS (R > 34, N > 40960) take the *_direct kernels (global gathers /
