@@ -214,9 +214,12 @@ def pmc_traffic(kernel, shape):
         return {'traffic': None}
     for row in table.get('kernels', []):
         if row.get('op') == kernel and list(row.get('shape_BCNR', [])) == list(shape):
-            return {'traffic': int((2 * row['FETCH_SIZE_KiB'] + row['WRITE_SIZE_KiB']) * 1024),
-                    'traffic_source': f"profiles/pmc_traffic.json: {row.get('kernel_name', '?')}, FETCH_SIZE {row['FETCH_SIZE_KiB']} KiB "
-                                      f"(x2, gfx950 correction) + WRITE_SIZE {row['WRITE_SIZE_KiB']} KiB; {table.get('command', '')}"}
+            out = {'traffic': int((2 * row['FETCH_SIZE_KiB'] + row['WRITE_SIZE_KiB']) * 1024),
+                   'traffic_source': f"profiles/pmc_traffic.json: {row.get('kernel_name', '?')}, FETCH_SIZE {row['FETCH_SIZE_KiB']} KiB "
+                                     f"(x2, gfx950 correction) + WRITE_SIZE {row['WRITE_SIZE_KiB']} KiB; {table.get('command', '')}"}
+            if row.get('note'):
+                out['traffic_note'] = row['note']
+            return out
     return {'traffic': None}
 
 

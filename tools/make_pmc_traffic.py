@@ -25,14 +25,18 @@ def pick(table, *needles):
 rows = []
 fb, wb = load('pmc_FETCH_SIZE_bench.json'), load('pmc_WRITE_SIZE_bench.json')
 # the fused devoxelize gather of the R=32 stage inside the training step: 1024-thread, BatchNorm+LeakyReLU transform
-kf, vf = pick(fb, 'gather_lds_kernel', 'TrilinearFromCoords', '1024', 'XfBnAct')
-kw, vw = pick(wb, 'gather_lds_kernel', 'TrilinearFromCoords', '1024', 'XfBnAct')
+# (the software-pipelined kernel since the end of round 2; the classic one in older traces or with PVCNN_GATHER_PIPE=0)
+kf, vf = pick(fb, 'gather_lds_pipe_kernel', 'TrilinearFromCoords', 'XfBnAct')
+kw, vw = pick(wb, 'gather_lds_pipe_kernel', 'TrilinearFromCoords', 'XfBnAct')
+if not (vf and vw):
+    kf, vf = pick(fb, 'gather_lds_kernel', 'TrilinearFromCoords', '1024', 'XfBnAct')
+    kw, vw = pick(wb, 'gather_lds_kernel', 'TrilinearFromCoords', '1024', 'XfBnAct')
 if vf and vw:
     rows.append({'op': 'trilinear_devoxelize_fwd', 'shape_BCNR': [16, 64, 4096, 32], 'kernel_name': kf[:120], 'where': 'inside bench.py steps',
                  'FETCH_SIZE_KiB': round(vf['FETCH_SIZE'], 1), 'WRITE_SIZE_KiB': round(vw['WRITE_SIZE'], 1), 'dispatches': vf['dispatches']})
 for shp in ('16x64x4096x16', '16x128x4096x16', '16x64x4096x32'):
     fo, wo = load(f'pmc_FETCH_SIZE_opbench_{shp}.json'), load(f'pmc_WRITE_SIZE_opbench_{shp}.json')
-    for op, needles in (('trilinear_devoxelize_bwd', ('segsum_tile_kernel',)), ('trilinear_devoxelize_fwd (op-level, unfused)', ('gather_lds_kernel', 'TrilinearFromCoords'))):
+    for op, needles in (('trilinear_devoxelize_bwd', ('segsum_tile_kernel',)), ('trilinear_devoxelize_fwd (op-level, unfused)', ('gather_lds_', 'TrilinearFromCoords'))):
         kf, vf = pick(fo, *needles)
         kw, vw = pick(wo, *needles)
         if vf and vw:
