@@ -1,6 +1,7 @@
 #!/bin/bash
-# Round-2 evidence set, one gpurun call:  tools/collect_evidence.sh   (outputs -> gpurun_out/r02/, copy what is judged to profiles/)
-R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/r02; mkdir -p $O
+# Evidence set, one gpurun call (~6 GPU-minutes):  [ROUND=r03] tools/collect_evidence.sh   (outputs -> gpurun_out/$ROUND/, copy what is judged to
+# profiles/ as ${ROUND}_*; tools/collect_evidence_short.sh is the 90-second subset: bench + rocprof stats + steady state)
+R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/${ROUND:-r03}; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $R/bench.py"
 # 1. the bench line (default flags: 1 GPU, 100 steps, 30 warm-up; includes cpu_baseline at the full batch)
@@ -31,4 +32,11 @@ python $R/tools/make_pmc_traffic.py $O > $O/pmc_traffic.json
  PVCNN_CONV_MATH=fp32 PVCNN_PW_MATH=fp32 timeout 300 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_fp32_mfma.json
  PVCNN_CONV_MATH=bf16x3 PVCNN_PW_MATH=fp32 timeout 300 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_bf16x3.json
  for c in cfg3 cfg4 cfg5; do timeout 300 python bench.py --config $c --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_$c.json; done)
+# 5. opt-in / environment-selected kernel variants: bit-identity across processes, kernel-level A/B
+(cd $R && PVCNN_EXPERIMENTAL=1 timeout 300 python -m pytest tests/test_gpu_experimental.py -q -m gpu -p no:cacheprovider > $O/experimental_tests.log 2>&1
+ timeout 120 python tools/foldbench.py 2>/dev/null | grep "^{" > $O/foldbench.jsonl
+ PVCNN_AMAX_REDUCE=2 timeout 120 python tools/foldbench.py 2>/dev/null | grep "^{" > $O/foldbench_amax_form2.jsonl
+ PVCNN_GATHER_PIPE=0 timeout 60 python tools/pipecheck.py 2>/dev/null | grep "^{" > $O/pipecheck.jsonl
+ timeout 60 python tools/pipecheck.py 2>/dev/null | grep "^{" >> $O/pipecheck.jsonl
+ PVCNN_BWD_AMAX=1 PVCNN_AMAX_REDUCE=2 timeout 200 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_amax_form2.json)
 ls -la $O
