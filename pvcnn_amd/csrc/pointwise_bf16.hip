@@ -26,6 +26,7 @@
 // XCD-aware tile order (L2 hit rate 75 %: x is fetched from HBM once), issue priority for the multiplying wave.  Selected with
 // `backend.pw_math = 'bf16x3'`.
 #include <algorithm>
+#include <stdlib.h>
 
 #include "common.h"
 #include "split16.h"
@@ -103,8 +104,12 @@ __global__ __launch_bounds__(256) void pw_weight_split_f16_kernel(const float *_
   }
 }
 
+// MB = 8 (EXPERIMENTAL, PVCNN_PW_MB8=1; built, not yet measured): a workgroup owns 256 points x 256 output channels, one workgroup per
+// CU (256 accumulator registers per lane live in the AGPR half of the file).  Every staged and converted input element then feeds
+// twice as many MFMAs: at 1472 -> 512 the kernel spends ~2/3 of its 513 us in the staging phases (185 us of MFMA at the sustained
+// rate), and with M = 512 the x tile is staged by 2 workgroups instead of 4.
 template <int NS, int MB>
-__global__ __launch_bounds__(256, 2) void pw_gemm_bf16_kernel(const float *__restrict__ x, const uint16_t *__restrict__ wts,
+__global__ __launch_bounds__(256, MB > 4 ? 1 : 2) void pw_gemm_bf16_kernel(const float *__restrict__ x, const uint16_t *__restrict__ wts,
                                                               const float *__restrict__ bias, float *__restrict__ y, int K, int M,
                                                               int N, int tiles_n, int tiles_total, float2 *__restrict__ stats_part,
                                                               const uint32_t *__restrict__ x_absmax, const int *__restrict__ wexp) {
@@ -290,7 +295,12 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_bf16_kernel(const float *__res
   }
 }
 
-static int pb_mb(int M) { return M > 64 ? 4 : 2; }
+static int pb_mb(int M) {
+  // EXPERIMENTAL 256-channel tile for the wide layers (read once per process; the weight image layout follows the tile)
+  static const bool mb8 = [] { const char *e = getenv("PVCNN_PW_MB8"); return e && e[0] == '1'; }();
+  if (mb8 && M >= 256 && M % 256 == 0) return 8;
+  return M > 64 ? 4 : 2;
+}
 
 }  // namespace pvcnn
 
@@ -356,8 +366,9 @@ extern "C" int pvcnn_pwconv_fwd_split(const float *x, const void *wts, const flo
   const uint32_t *am = static_cast<const uint32_t *>(x_absmax);
   const int *wexp = nsplit == 2 ? reinterpret_cast<const int *>(static_cast<const char *>(wts) + pb_image_bytes(K, M, 2)) : nullptr;
 #define PVCNN_PB_LAUNCH(NSV, MBV) hipLaunchKernelGGL((pw_gemm_bf16_kernel<NSV, MBV>), grid, dim3(256), 0, s, x, w16, bias, y, K, M, N, tiles_n, (int)tiles_total, sp, am, wexp)
+  PVCNN_REQUIRE(MB != 8 || nsplit == 2, "the 256-channel tile (PVCNN_PW_MB8) is built for f16x2 only");
   if (nsplit == 3)      { if (MB == 4) PVCNN_PB_LAUNCH(3, 4); else PVCNN_PB_LAUNCH(3, 2); }
-  else if (nsplit == 2) { if (MB == 4) PVCNN_PB_LAUNCH(2, 4); else PVCNN_PB_LAUNCH(2, 2); }
+  else if (nsplit == 2) { if (MB == 8) PVCNN_PB_LAUNCH(2, 8); else if (MB == 4) PVCNN_PB_LAUNCH(2, 4); else PVCNN_PB_LAUNCH(2, 2); }
   else                  { if (MB == 4) PVCNN_PB_LAUNCH(1, 4); else PVCNN_PB_LAUNCH(1, 2); }
 #undef PVCNN_PB_LAUNCH
   return check_launch("pwconv_fwd_split");

@@ -8,6 +8,9 @@ are tools/pipecheck.py / pipecheck2.py: profiles/ab/r02_pipecheck_*).
   PVCNN_AMAX_REDUCE=2       second form of the gradient maximum that rides on the BatchNorm backward's apply pass (csrc/bnact.hip,
                             block_atomic_max_bits_v2: LDS-only barrier, filter value read at kernel start, fire-and-forget
                             atomic).  Must give the same bits as pvcnn_absmax_bits of the gradient; time it with tools/foldbench.py.
+  PVCNN_PW_MB8=1            256-channel workgroup tile of the f16x2 1x1 GEMM for M % 256 == 0 (csrc/pointwise_bf16.hip, MB = 8: one
+                            workgroup per CU, accumulators in AGPRs).  Same products in the same order: BIT-IDENTICAL to the 128-channel
+                            tile, statistics partials included; time it with `PVCNN_PW_MB8=1 python tools/pwbench.py`.
 """
 import os
 import subprocess
@@ -93,3 +96,37 @@ def test_second_form_of_the_gradient_maximum(tmp_path):
         out = subprocess.run([sys.executable, str(script), ROOT], check=True, env=dict(os.environ, PVCNN_AMAX_REDUCE=form), timeout=300,
                              capture_output=True, text=True).stdout
         assert 'AMAX_OK' in out, (form, out)
+
+
+_CHILD_PW = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from pvcnn_amd.modules.functional.backend import HipBackend
+be = HipBackend()
+torch.manual_seed(4)
+out = []
+for b, k, m, n in [(16, 1472, 512, 4096), (2, 512, 256, 4096), (3, 128, 1024, 1000), (1, 40, 256, 260), (2, 64, 768, 512)]:
+    x = torch.randn(b, k, n, device='cuda')
+    w = torch.randn(m, k, device='cuda') * 0.05
+    bias = torch.randn(m, device='cuda')
+    y, part = be.pwconv_forward_split(x, w, bias, 2, want_stats=True)
+    gx = be.pwconv_backward_data_split(torch.randn(b, m, n, device='cuda', generator=torch.Generator('cuda').manual_seed(9)) * 1e-3, w, 2)
+    ref = torch.einsum('mk,bkn->bmn', w.double(), x.double()) + bias.double().view(1, -1, 1)
+    err = ((y.double() - ref).abs().max() / ref.abs().max()).item()
+    out.append((y.cpu(), part.cpu(), gx.cpu(), err))
+torch.save(out, sys.argv[2])
+"""
+
+
+def test_256_channel_tile_of_the_pointwise_gemm(tmp_path):
+    script = tmp_path / 'child_pw.py'
+    script.write_text(_CHILD_PW)
+    res = {}
+    for flag in ('0', '1'):
+        subprocess.run([sys.executable, str(script), ROOT, str(tmp_path / f'pw{flag}.pt')], check=True, env=dict(os.environ, PVCNN_PW_MB8=flag),
+                       timeout=300)
+        res[flag] = torch.load(tmp_path / f'pw{flag}.pt')
+    for case, (a, b_) in enumerate(zip(res['0'], res['1'])):
+        assert b_[3] < 1e-5, (case, b_[3])
+        for k in range(3):
+            assert torch.equal(a[k], b_[k]), (case, k)
