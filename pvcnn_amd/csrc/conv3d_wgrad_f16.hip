@@ -20,6 +20,7 @@
 //     2^-(sx + sgy) and transposes to (Co, Ci, 27).  grad_bias falls out of the grad_y rows a thread stages.
 // R must be a multiple of 16 (R = 16 and 32 are instantiated); anything else stays on the fp32-MFMA kernel of conv3d.hip.
 #include <algorithm>
+#include <stdlib.h>
 
 #include "common.h"
 #include "split16.h"
@@ -236,6 +237,48 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_f16_reduce_kernel(const floa
   }
 }
 
+// EXPERIMENTAL second form of the split-K reduction (PVCNN_WGRAD_REDUCE=2; built, not yet measured).  The kernel above gives ONE
+// thread all P partials of an element: at 64 -> 64 channels that is 110 592 threads each walking 128 strided values -- 41.5 us per
+// launch, 0.33 ms per PVCNN step, for 57 MB that stream in ~12 us.  Here four threads share an element (each sums a contiguous
+// quarter of the partitions with four independent accumulators), a wave still reads 256 contiguous bytes per step, and the four
+// partial sums are combined through LDS in a fixed order: deterministic, but NOT the same rounding as the first form.
+__global__ __launch_bounds__(256) void conv3d_wgrad_f16_reduce_v2_kernel(const float *__restrict__ part, const float *__restrict__ gb_part,
+                                                                         const uint32_t *__restrict__ x_absmax,
+                                                                         const uint32_t *__restrict__ gy_absmax, int P, int CoP, int CiP,
+                                                                         int Co, int Ci, float *__restrict__ gw, float *__restrict__ gb) {
+  constexpr int PS = 4, EL = 256 / PS;                         // partition slices per element, elements per workgroup
+  __shared__ float red[PS][EL];
+  const int el = threadIdx.x % EL, ps = threadIdx.x / EL;
+  const size_t block = (size_t)27 * CoP * CiP;
+  const size_t e = (size_t)blockIdx.x * EL + el;
+  const int per = ceil_div(P, PS), q0 = ps * per, q1 = min(P, q0 + per);
+  float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+  if (e < block) {
+    int q = q0;
+    for (; q + 3 < q1; q += 4) {
+      s0 += part[(size_t)q * block + e];
+      s1 += part[(size_t)(q + 1) * block + e];
+      s2 += part[(size_t)(q + 2) * block + e];
+      s3 += part[(size_t)(q + 3) * block + e];
+    }
+    for (; q < q1; ++q) s0 += part[(size_t)q * block + e];
+  }
+  red[ps][el] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (ps == 0 && e < block) {
+    const int ci = (int)(e % CiP), co = (int)((e / CiP) % CoP), tap = (int)(e / ((size_t)CiP * CoP));
+    if (co < Co && ci < Ci) {
+      const float s = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
+      gw[((size_t)co * Ci + ci) * 27 + tap] = s * exp2_int(-scale_shift(*x_absmax)) * exp2_int(-scale_shift(*gy_absmax));
+    }
+  }
+  if (gb != nullptr && ps == 0 && e < (size_t)Co) {            // grad_bias: P values per channel, fixed order (as in the first form)
+    float s = 0.0f;
+    for (int q = 0; q < P; ++q) s += gb_part[(size_t)q * CoP + e];
+    gb[e] = s;
+  }
+}
+
 struct WgradPlan { int cotiles, citiles, P; size_t part_floats, gb_floats; };
 
 static WgradPlan wgrad_f16_plan(int B, int Ci, int Co, int R) {
@@ -262,6 +305,12 @@ static int launch_wgrad_f16(const float *x, const float *gy, const uint32_t *xa,
                      gb ? gb_part : nullptr, xf);
   if (int rc = check_launch("conv3d_wgrad_f16")) return rc;
   const int CoP = w.cotiles * kWgCo, CiP = w.citiles * kWgCi;
+  static const bool reduce_v2 = [] { const char *e = getenv("PVCNN_WGRAD_REDUCE"); return e && e[0] == '2'; }();   // read once per process
+  if (reduce_v2 && Co <= 27 * CoP * CiP / 64 * 64) {
+    hipLaunchKernelGGL(conv3d_wgrad_f16_reduce_v2_kernel, dim3((unsigned)ceil_div(27 * CoP * CiP, 64)), dim3(256), 0, s, part, gb_part, xa,
+                       ga, w.P, CoP, CiP, Co, Ci, gw, gb);
+    return check_launch("conv3d_wgrad_f16_reduce_v2");
+  }
   hipLaunchKernelGGL(conv3d_wgrad_f16_reduce_kernel, dim3((unsigned)ceil_div(27 * CoP * CiP, 256)), dim3(256), 0, s, part, gb_part, xa, ga, w.P,
                      CoP, CiP, Co, Ci, gw, gb);
   return check_launch("conv3d_wgrad_f16_reduce");

@@ -11,6 +11,9 @@ are tools/pipecheck.py / pipecheck2.py: profiles/ab/r02_pipecheck_*).
   PVCNN_PW_MB8=1            256-channel workgroup tile of the f16x2 1x1 GEMM for M % 256 == 0 (csrc/pointwise_bf16.hip, MB = 8: one
                             workgroup per CU, accumulators in AGPRs).  Same products in the same order: BIT-IDENTICAL to the 128-channel
                             tile, statistics partials included; time it with `PVCNN_PW_MB8=1 python tools/pwbench.py`.
+  PVCNN_WGRAD_REDUCE=2      four threads per element in the split-K reduction of the Conv3d backward-weight (csrc/conv3d_wgrad_f16.hip,
+                            conv3d_wgrad_f16_reduce_v2_kernel).  Deterministic, within 1e-5 of fp64, NOT bit-identical to the first
+                            form (another summation tree); time: `PVCNN_WGRAD_REDUCE=2 python tools/convcheck.py --time --no-check`.
 """
 import os
 import subprocess
@@ -130,3 +133,39 @@ def test_256_channel_tile_of_the_pointwise_gemm(tmp_path):
         assert b_[3] < 1e-5, (case, b_[3])
         for k in range(3):
             assert torch.equal(a[k], b_[k]), (case, k)
+
+
+_CHILD_WG = r"""
+import sys, torch
+import torch.nn.functional as F
+sys.path.insert(0, sys.argv[1])
+from pvcnn_amd.modules.functional.backend import HipBackend
+be = HipBackend()
+g = torch.Generator().manual_seed(7)
+out = []
+for b, ci, co, r in [(2, 9, 64, 32), (16, 64, 64, 16), (3, 40, 70, 16), (1, 33, 130, 32), (1, 1, 1, 16), (20, 64, 128, 16)]:
+    x = torch.randn(b, ci, r, r, r, generator=g).cuda()
+    gy = (torch.randn(b, co, r, r, r, generator=g) * 1e-3).cuda()
+    wd = torch.zeros(co, ci, 3, 3, 3, device='cuda', dtype=torch.float64, requires_grad=True)
+    F.conv3d(x.double(), wd, padding=1).backward(gy.double())
+    gw, gb = be.conv3d_backward_weight_f16(x, gy, with_bias=True)
+    gw2, gb2 = be.conv3d_backward_weight_f16(x, gy, with_bias=True)
+    err = ((gw.double() - wd.grad).abs().max() / wd.grad.abs().max()).item()
+    out.append((gw.cpu(), gb.cpu(), err, bool(torch.equal(gw, gw2) and torch.equal(gb, gb2))))
+torch.save(out, sys.argv[2])
+"""
+
+
+def test_second_form_of_the_backward_weight_reduction(tmp_path):
+    script = tmp_path / 'child_wg.py'
+    script.write_text(_CHILD_WG)
+    res = {}
+    for form in ('1', '2'):
+        subprocess.run([sys.executable, str(script), ROOT, str(tmp_path / f'wg{form}.pt')], check=True,
+                       env=dict(os.environ, PVCNN_WGRAD_REDUCE=form), timeout=300)
+        res[form] = torch.load(tmp_path / f'wg{form}.pt')
+    for case, (a, b_) in enumerate(zip(res['1'], res['2'])):
+        assert b_[2] < 1e-5 and b_[3], (case, b_[2], b_[3])              # within the fp64 bar, run-to-run identical
+        assert torch.equal(a[1], b_[1]), case                             # grad_bias: same order in both forms
+        scale = a[0].abs().max().item()
+        assert (a[0] - b_[0]).abs().max().item() <= 2e-6 * scale, case     # another summation tree, same sum
