@@ -273,3 +273,27 @@ def test_trace_steady_delimits_steps_by_the_optimizer_not_by_the_gradient_packin
     first = out.splitlines()[0]
     assert 'last 4 steps: 24 kernel launches (6/step)' in first, first
     assert 'kernel time 0.510 ms/step' in first, first
+
+
+def test_bench_byte_formulas_reproduce_the_survey_totals():
+    """bench.py's algorithmic bytes (what roofline.achieved is computed from) are SURVEY 8(d)'s formulas: devoxelize forward of the
+    R = 32 stage 156.0 MB, backward 155.2 MB, and the eight voxelize + devoxelize calls of a cfg2 step forward + backward 844 MB."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location('bench_for_test', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    b, n, s32, s16 = 16, 4096, 32 ** 3, 16 ** 3
+    assert bench.bytes_devox_fwd(b, 64, n, s32) == 155_975_680
+    assert bench.bytes_devox_bwd(b, 64, n, s32) == 155_189_248
+    assert bench.bytes_devox_fwd(b, 64, n, s32, training=False) == 155_975_680 - 64 * b * n
+    total = bench.bytes_vox_fwd(b, 9, n, s32) + bench.bytes_vox_bwd(b, 9, n, s32)
+    total += sum(bench.bytes_vox_fwd(b, c, n, s16) + bench.bytes_vox_bwd(b, c, n, s16) for c in (64, 64, 64))
+    total += bench.bytes_devox_fwd(b, 64, n, s32) + bench.bytes_devox_bwd(b, 64, n, s32)
+    total += sum(bench.bytes_devox_fwd(b, c, n, s16) + bench.bytes_devox_bwd(b, c, n, s16) for c in (64, 64, 128))
+    assert round(total / 1e6) == 844
+    # the traffic table: the committed PMC passes, doubled FETCH_SIZE (gfx950), per launch
+    t = bench.pmc_traffic('trilinear_devoxelize_fwd', [16, 64, 4096, 32])
+    assert t['traffic'] is not None and 1.0 <= t['traffic'] / (bench.bytes_devox_fwd(b, 64, n, s32) + 4 * b * 64 * n) <= 1.1
+    assert bench.pmc_traffic('no_such_op', [1, 2, 3, 4]) == {'traffic': None}
