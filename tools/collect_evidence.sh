@@ -41,5 +41,6 @@ python $R/tools/make_pmc_traffic.py $O > $O/pmc_traffic.json
  PVCNN_WGRAD_REDUCE=2 timeout 120 python tools/convcheck.py --time --no-check --shapes 16x64x64x32,16x64x64x16,16x128x128x16 2>/dev/null | grep "time_wgrad_f16" > $O/convbench_wgrad_reduce2.jsonl
  PVCNN_PW_MB8=1 timeout 120 python tools/pwbench.py 2>/dev/null | grep "^{" > $O/pwbench_mb8.jsonl
  PVCNN_PW_MB8=1 timeout 200 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_pw_mb8.json
- PVCNN_BWD_AMAX=1 PVCNN_AMAX_REDUCE=2 timeout 200 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_amax_form2.json)
+ PVCNN_BWD_AMAX=1 PVCNN_AMAX_REDUCE=2 timeout 200 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_amax_form2.json
+ timeout 120 python tools/step_profile.py > $O/step_profile.txt 2>/dev/null)
 ls -la $O
