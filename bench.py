@@ -260,6 +260,34 @@ def cpu_baseline(args, sample_batch):
                       f'(oracle C backend + torch-CPU conv/BN, {cores} threads; 1 warm-up step excluded)'}
 
 
+def graph_replay(args, dev):
+    """The same step (zero_grad, forward, loss, backward, fused Adam) captured once in a hipGraph and replayed: one launch per step.
+    Reported next to the eager figure, never instead of it (a replayed graph cannot carry per-kernel events)."""
+    from pvcnn_amd import workload
+    from pvcnn_amd.dp import GradBucketReducer
+    from pvcnn_amd.graph import GraphedTrainStep
+    try:
+        torch.manual_seed(workload.SEED)
+        model = workload.PVCNN(13, 6, width_multiplier=args.width).to(dev).train()
+        x, y = workload.make_s3dis_batch(args.batch, args.points, device=dev, seed=workload.SEED)
+        reducer = GradBucketReducer(model, bucket_mb=args.bucket_mb)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5, fused=True, capturable=True)
+        step = GraphedTrainStep(model, lambda: tf.cross_entropy(model(x), y), opt, reducer, warmup=3)
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        return {'value': round(args.batch * args.steps / el, 2), 'unit': 'point-clouds/s', 'ms_per_step': round(el / args.steps * 1e3, 3),
+                'steps': args.steps, 'final_loss': round(float(loss.detach()), 4),
+                'note': 'whole step replayed from one hipGraph (pvcnn_amd/graph.py); same kernels as the eager step, no per-kernel events'}
+    except Exception as exc:                                     # an extra: it must never cost the bench line
+        return {'error': f'{type(exc).__name__}: {exc}'[:300]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -274,6 +302,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-batch', type=int, default=0, help='clouds per CPU-baseline step (0 = the same batch as the GPU run)')
     ap.add_argument('--bucket-mb', type=float, default=8.0)
+    ap.add_argument('--graph', action='store_true',
+                    help='ALSO report the same step captured in a hipGraph (pvcnn_amd/graph.py) as an extra "graph_replay" object; the headline '
+                         'value stays the eager step, whose roofline kernels carry HIP events inside the timed region (single GPU, cfg2 only)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -450,6 +481,8 @@ def main():
                         'effective = algorithmic 2*B*R^3*27*Ci*Co / launch time'},
             'kernels': kernels,
         }
+        if args.graph and world == 1 and args.config == 'cfg2':
+            line['graph_replay'] = graph_replay(args, dev)
         if world == 1 and not args.no_cpu_baseline and args.config == 'cfg2':
             line['cpu_baseline'] = cpu_baseline(args, args.cpu_sample_batch or args.batch)
         print(json.dumps(line), flush=True)
