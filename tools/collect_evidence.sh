@@ -42,5 +42,6 @@ python $R/tools/make_pmc_traffic.py $O > $O/pmc_traffic.json
  PVCNN_PW_MB8=1 timeout 120 python tools/pwbench.py 2>/dev/null | grep "^{" > $O/pwbench_mb8.jsonl
  PVCNN_PW_MB8=1 timeout 200 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_pw_mb8.json
  PVCNN_BWD_AMAX=1 PVCNN_AMAX_REDUCE=2 timeout 200 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_amax_form2.json
- timeout 120 python tools/step_profile.py > $O/step_profile.txt 2>/dev/null)
+ timeout 120 python tools/step_profile.py > $O/step_profile.txt 2>/dev/null
+ timeout 200 python bench.py --graph --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_with_graph_replay.json)
 ls -la $O
