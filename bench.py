@@ -7,13 +7,21 @@ metric : point-clouds/sec, forward+backward(+Adam step), PVCNN (1xC) S3DIS, N=40
 A "step" = zero_grad -> forward -> cross-entropy -> backward (+ gradient all-reduce) -> Adam.step
 on one synthetic batch already resident in HBM.
 
+How the step is issued.  A PVCNN step is ~320 kernel launches of 4-250 us; one Python thread issues them slower (~25 us each)
+than the GPU retires them, so an eagerly issued step measures the host, not the GPU.  The timed region therefore REPLAYS the
+step from a hipGraph captured once (pvcnn_amd/graph.py: the same kernels on the same stream in the same order; 1 GPU: the
+whole step incl. the fused Adam update; N GPUs: forward + backward captured, the bucketed RCCL all-reduce and Adam issued
+after each replay).  `value` / `ms_per_step` are that region; `eager_value` is the same step issued launch by launch from
+Python (timed separately, after the timed region).  `--eager` times the eager step instead.
+
 Extra objects on the JSON line:
   roofline     : the hot path's headline kernel (trilinear_devoxelize fwd at the R=32 stage,
-                 16x64x4096 points from a 16x64x32^3 grid), timed LIVE inside the timed region with
-                 HIP events on the launch stream; achieved = algorithmic bytes / (mean event-pair time -
+                 16x64x4096 points from a 16x64x32^3 grid), timed LIVE in this process with HIP events on the
+                 launch stream around every launch of it in instrumented eager steps AFTER the timed region (a replayed
+                 graph cannot carry per-kernel events); achieved = SURVEY 8(d) algorithmic bytes / (mean event-pair time -
                  the calibrated time of an empty event pair on a busy stream).
   roofline_mfma: the step's largest MFMA-bound launch (Conv3d forward, 64->64 at 32^3), same live timing,
-                 against the 157.3 TF fp32-MFMA peak.
+                 against the dense fp16 MFMA peak (f16x2 executes 3 fp16 products per fp32 product).
   kernels      : the same for every watched kernel family that ran in the step.
   cpu_baseline : the same network on the host cores with the CPU oracle as native backend
                  (kind "port": the reference has no CPU implementation), bounded sample.
@@ -260,34 +268,6 @@ def cpu_baseline(args, sample_batch):
                       f'(oracle C backend + torch-CPU conv/BN, {cores} threads; 1 warm-up step excluded)'}
 
 
-def graph_replay(args, dev):
-    """The same step (zero_grad, forward, loss, backward, fused Adam) captured once in a hipGraph and replayed: one launch per step.
-    Reported next to the eager figure, never instead of it (a replayed graph cannot carry per-kernel events)."""
-    from pvcnn_amd import workload
-    from pvcnn_amd.dp import GradBucketReducer
-    from pvcnn_amd.graph import GraphedTrainStep
-    try:
-        torch.manual_seed(workload.SEED)
-        model = workload.PVCNN(13, 6, width_multiplier=args.width).to(dev).train()
-        x, y = workload.make_s3dis_batch(args.batch, args.points, device=dev, seed=workload.SEED)
-        reducer = GradBucketReducer(model, bucket_mb=args.bucket_mb)
-        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5, fused=True, capturable=True)
-        step = GraphedTrainStep(model, lambda: tf.cross_entropy(model(x), y), opt, reducer, warmup=3)
-        for _ in range(args.warmup):
-            step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            loss = step()
-        torch.cuda.synchronize()
-        el = time.perf_counter() - t0
-        return {'value': round(args.batch * args.steps / el, 2), 'unit': 'point-clouds/s', 'ms_per_step': round(el / args.steps * 1e3, 3),
-                'steps': args.steps, 'final_loss': round(float(loss.detach()), 4),
-                'note': 'whole step replayed from one hipGraph (pvcnn_amd/graph.py); same kernels as the eager step, no per-kernel events'}
-    except Exception as exc:                                     # an extra: it must never cost the bench line
-        return {'error': f'{type(exc).__name__}: {exc}'[:300]}
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -302,9 +282,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-batch', type=int, default=0, help='clouds per CPU-baseline step (0 = the same batch as the GPU run)')
     ap.add_argument('--bucket-mb', type=float, default=8.0)
-    ap.add_argument('--graph', action='store_true',
-                    help='ALSO report the same step captured in a hipGraph (pvcnn_amd/graph.py) as an extra "graph_replay" object; the headline '
-                         'value stays the eager step, whose roofline kernels carry HIP events inside the timed region (single GPU, cfg2 only)')
+    ap.add_argument('--eager', action='store_true',
+                    help='time the eagerly issued step (one Python thread issues every launch: host-bound) instead of the hipGraph replay')
+    ap.add_argument('--graph', action='store_true', help='(default since round 3; accepted for older command lines)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -374,12 +354,38 @@ def main():
         metric = 'frustums/sec fwd+bwd, Frustum-PVCNN KITTI N=1024'
     model = model.to(dev).train()
     reducer = GradBucketReducer(model, bucket_mb=args.bucket_mb)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5, fused=True)   # one multi-tensor kernel per step
+    # one multi-tensor kernel per step; capturable: the step counter lives on the device (needed inside a hipGraph, harmless outside)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5, fused=True, capturable=True)
 
     clock = KernelClock(seam._backend)
     clock.install()
 
-    def step():
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def all_ranks(ok):
+        """True iff `ok` on every rank (the ranks must take the same branch: a captured and an eager rank would deadlock)."""
+        if world == 1:
+            return ok
+        t = torch.tensor([1 if ok else 0], device=dev, dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
+    # ---- the step, captured once (pvcnn_amd/graph.py) ----
+    from pvcnn_amd.graph import GraphedTrainStep
+    graphed, graph_error = None, None
+    if not args.eager:
+        try:
+            graphed = GraphedTrainStep(model, lambda: loss_of(model(x)), opt, reducer, autocast=autocast, warmup=3)
+        except Exception as exc:                                 # reported on the line; the eager step is timed instead
+            graph_error = f'{type(exc).__name__}: {exc}'[:400]
+        if not all_ranks(graphed is not None):
+            graphed = None
+            graph_error = graph_error or 'capture failed on another rank'
+
+    def eager_step():
         reducer.zero_grad()
         with autocast():
             loss = loss_of(model(x))
@@ -388,56 +394,50 @@ def main():
         opt.step()
         return loss
 
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
+    step = graphed if graphed is not None else eager_step
     for _ in range(args.warmup):
         step()
     fence()
-    # One fully instrumented step names the two roofline kernels of this workload: the largest devoxelize forward (HBM-bound)
-    # and the largest implicit-GEMM launch (MFMA-bound).  Inside the timed region ONLY those carry a HIP event pair (an event
-    # pair costs ~5 us of stream time: around every watched launch -- ~45 per step -- the instrumentation itself was 4 % of the
-    # step); the table of all watched kernels comes from an instrumented pass AFTER the timed region.
-    clock.enabled = True
-    step()
-    fence()
-    seen = clock.summary(0.0)
-    clock.records.clear()
-    dv = [k for k in seen if k['kernel'] == 'trilinear_devoxelize_fwd']
-    cv = [k for k in seen if k['kernel'].startswith('conv3d_igemm')]
-    heads = set()
-    if dv:
-        k = max(dv, key=lambda k: k['shape_BCNR'][3] ** 3 * k['shape_BCNR'][1])
-        heads.add((k['kernel'], tuple(k['shape_BCNR'])))
-    if cv:
-        k = max(cv, key=lambda k: (k['GFLOP'], k['calls']))
-        heads.add((k['kernel'], tuple(k['shape_BCiCoR'])))
-    clock.only = heads
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     fence()
     elapsed = time.perf_counter() - t0
+    per_rank_ms = [elapsed / args.steps * 1e3]
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        gathered = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)
+        per_rank_ms = [round(float(g.item()) / args.steps * 1e3, 3) for g in gathered]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     final_loss = float(loss.detach())
+
+    # ---- the same step issued launch by launch (host-bound on one Python thread): eager_value ----
+    eager_steps = min(args.steps, 20)
+    eager_elapsed = None
+    if graphed is not None:
+        for _ in range(3):
+            eager_step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(eager_steps):
+            eager_step()
+        fence()
+        eager_elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([eager_elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            eager_elapsed = t.item()
+
+    # ---- per-kernel HIP events: instrumented eager steps (every watched launch carries an event pair on the launch stream) ----
     event_overhead_us = KernelClock.event_pair_overhead_us()
-    head_kernels = clock.summary(event_overhead_us)          # the roofline kernels, timed inside the timed region
-    clock.records.clear()
-    clock.only = None
-    for _ in range(min(args.steps, 20)):                     # every watched kernel, outside the timed region
-        step()
+    clock.enabled = True
+    for _ in range(eager_steps):
+        eager_step()
     fence()
     clock.enabled = False
     kernels = clock.summary(event_overhead_us)
-    for hk in head_kernels:                                  # the in-region measurement replaces the later one
-        hk['timed'] = 'inside the timed region'
-        kernels = [hk if (k['kernel'] == hk['kernel'] and k.get('shape_BCNR') == hk.get('shape_BCNR')
-                          and k.get('shape_BCiCoR') == hk.get('shape_BCiCoR')) else k for k in kernels]
     clock.uninstall()
 
     if rank == 0:
@@ -448,16 +448,29 @@ def main():
         mfma = max(convs, key=lambda k: (k['GFLOP'], k['calls'])) if convs else None
         roofline = None
         if head:
-            roofline = {'bound': 'hbm', 'kernel': 'trilinear_devoxelize_fwd (gather_lds_pipe_kernel<TrilinearFromCoords> at R = 32, else gather_lds_kernel; BatchNorm+LeakyReLU fused into its LDS staging and the point branch added in its store inside PVConv)',
-                        'shape_BCNR': head['shape_BCNR'], 'achieved': head['achieved_GBs'], 'peak': HBM_PEAK_GBS,
-                        'unit': 'GB/s', 'frac': round(head['achieved_GBs'] / HBM_PEAK_GBS, 4),
-                        'frac_of_achievable_6300': round(head['achieved_GBs'] / 6300.0, 4),
-                        'avg_us': head['avg_us'], 'event_pair_us': head['event_pair_us'],
+            b_, c_, n_, r_ = head['shape_BCNR']
+            fused = args.config != 'cfg5'                       # under autocast the BatchNorm tail is not folded into the gather
+            pipe = r_ == 32 and os.environ.get('PVCNN_GATHER_PIPE', '1') != '0'
+            survey_bytes = bytes_devox_fwd(b_, c_, n_, r_ ** 3, True)
+            roofline = {'bound': 'hbm',
+                        'kernel': ('pvcnn::gather_lds_pipe_kernel<TrilinearFromCoords, XfBnAct>' if pipe else 'pvcnn::gather_lds_kernel<TrilinearFromCoords>')
+                                  + ' = trilinear_devoxelize fwd' + (' with PVConv\'s last BatchNorm+LeakyReLU applied in its LDS staging and the point branch added in its store' if fused else ''),
+                        'shape_BCNR': head['shape_BCNR'],
+                        'achieved': round(survey_bytes / (head['avg_us'] * 1e-6) / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                        'frac': round(survey_bytes / (head['avg_us'] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                        'algorithmic_MB': round(survey_bytes / 1e6, 3),
+                        'algorithmic_bytes_formula': 'SURVEY 8(d): 4B(3N + C*min(S,8N) + C*N) + 64BN',
+                        # the launch also reads the fused addend (4BCN more compulsory bytes): stated separately, not in `frac`
+                        'with_fused_addend': {'algorithmic_MB': head['algorithmic_MB'], 'achieved': head['achieved_GBs'],
+                                              'frac': round(head['achieved_GBs'] / HBM_PEAK_GBS, 4)},
+                        'frac_of_achievable_6300': round(survey_bytes / (head['avg_us'] * 1e-6) / 1e9 / 6300.0, 4),
+                        'avg_us': head['avg_us'], 'event_pair_us': head['event_pair_us'], 'calls': head['calls'],
                         'event_overhead_us': round(event_overhead_us, 2),
-                        'timing': 'HIP events around each launch of this kernel inside the timed steps, on the launch stream; '
-                                  'avg_us = mean event-pair time - the time an empty event pair reads on a busy stream',
-                        'algorithmic_MB': head['algorithmic_MB']}
+                        'timing': f'HIP events on the launch stream around each launch of this kernel in {eager_steps} eager steps after the timed region; '
+                                  'avg_us = mean event-pair time - the time an empty event pair reads on a busy stream; the rocprofv3 '
+                                  'average of the same kernel inside the replayed graph is in profiles/ (README there)'}
             roofline.update(pmc_traffic('trilinear_devoxelize_fwd', head['shape_BCNR']))
+        timed = 'hipGraph replay' if graphed is not None else 'eager'
         line = {
             'metric': metric,
             'value': round(global_batch * args.steps / elapsed, 2),
@@ -469,11 +482,18 @@ def main():
             'data': 'synthetic',
             'config': {'workload': label, 'baseline_config': args.config,
                        'global_batch': global_batch, 'points': args.points, 'parallelism': f'dp{world}',
-                       'gradient_bytes': reducer.gradient_bytes, 'final_loss': round(final_loss, 4)},
+                       'gradient_bytes': reducer.gradient_bytes, 'final_loss': round(final_loss, 4),
+                       'step_issue': (timed + (' (1 GPU: zero_grad, forward, loss, backward, fused Adam in one graph launch)' if world == 1 else
+                                               ' of forward + backward; bucketed RCCL all-reduce + fused Adam issued after each replay')
+                                      if graphed is not None else 'eager: one Python thread issues every launch'),
+                       'rccl_ranks': world if world > 1 else 0, 'per_rank_ms_per_step': per_rank_ms},
+            'timed_region': timed,
+            'eager_value': None if eager_elapsed is None else round(global_batch * eager_steps / eager_elapsed, 2),
+            'eager_ms_per_step': None if eager_elapsed is None else round(eager_elapsed / eager_steps * 1e3, 3),
             'roofline': roofline,
-            # the step's largest MFMA-bound launch (Conv3d forward of the R=32 stage), same live event timing
+            # the step's largest MFMA-bound launch (Conv3d forward of the R=32 stage), same event timing
             'roofline_mfma': None if mfma is None else {
-                'bound': 'mfma', 'kernel': mfma['kernel'] + ' (Conv3d 3x3x3 forward / backward-data of the R=32 stage)',
+                'bound': 'mfma', 'kernel': mfma['kernel'] + ' (Conv3d 3x3x3 forward / backward-data of the largest stage)',
                 'shape_BCiCoR': mfma['shape_BCiCoR'], 'achieved': mfma['executed_mfma_TFLOPs'], 'peak': mfma['peak_TFLOPs'],
                 'unit': 'TFLOP/s', 'frac': mfma['frac_of_peak'], 'avg_us': mfma['avg_us'], 'algorithmic_GFLOP': mfma['GFLOP'],
                 'effective_fp32_TFLOPs': mfma['effective_TFLOPs'], 'x_fp32_mfma_peak_157TF': mfma['x_fp32_mfma_peak'],
@@ -481,8 +501,8 @@ def main():
                         'effective = algorithmic 2*B*R^3*27*Ci*Co / launch time'},
             'kernels': kernels,
         }
-        if args.graph and world == 1 and args.config == 'cfg2':
-            line['graph_replay'] = graph_replay(args, dev)
+        if graph_error:
+            line['graph_error'] = graph_error
         if world == 1 and not args.no_cpu_baseline and args.config == 'cfg2':
             line['cpu_baseline'] = cpu_baseline(args, args.cpu_sample_batch or args.batch)
         print(json.dumps(line), flush=True)

@@ -9,6 +9,7 @@ libamdhip64.so.7, and the dynamic loader resolves this library's DT_NEEDED entry
 soname to that copy, so kernels, streams and device pointers share ONE HIP runtime.
 """
 import ctypes
+import functools
 import os
 
 import torch  # noqa: F401  (must be imported before the dlopen, see above)
@@ -113,6 +114,11 @@ def load():
     got = lib.pvcnn_version()
     if got != ABI_VERSION:
         raise PvcnnHipError(f'libpvcnn_hip.so ABI version {got}, binding expects {ABI_VERSION}: rebuild')
+    # the `*_bytes` / `*_parts` queries are pure functions of a few ints and are asked before every launch: memoise them
+    # (one dict lookup instead of a foreign call on the eager step's critical path)
+    for name, (res, _args) in SIGNATURES.items():
+        if res is _sz:
+            setattr(lib, name, functools.lru_cache(maxsize=4096)(getattr(lib, name)))
     _lib = lib
     return lib
 

@@ -156,6 +156,10 @@ class GradBucketReducer:
                 b.work.wait()
                 if self.world > 1:
                     b.flat.div_(self.world)
+        self.rearm()
+
+    def rearm(self):
+        """Forget the per-step bucket state (gradients pending, in-flight work, packed flag): the state after finish()."""
         for b in self.buckets:
             b.pending, b.work, b.packed = len(b.params), None, False
 

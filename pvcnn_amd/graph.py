@@ -26,13 +26,22 @@ class GraphedTrainStep:
 
     loss_fn() -> scalar loss tensor, reading the model's inputs / targets from static device tensors.
     optimizer: built with capturable=True when it is to be captured (single GPU).
+    capture=False (the default without a GPU): the same sequencing -- forward + backward with the reducer's collectives held back,
+    then finish() in fixed bucket order and the optimizer -- issued eagerly; this is what the world-size-2 gloo test drives.
     """
 
-    def __init__(self, model, loss_fn, optimizer, reducer, autocast=contextlib.nullcontext, warmup=3):
+    def __init__(self, model, loss_fn, optimizer, reducer, autocast=contextlib.nullcontext, warmup=3, capture=None):
         self.model, self.loss_fn, self.optimizer, self.reducer, self.autocast = model, loss_fn, optimizer, reducer, autocast
         self.collective = bool(reducer.collective)
+        self.capture = torch.cuda.is_available() if capture is None else bool(capture)
+        self.graph = self.loss = None
         if self.collective:
             reducer.launch_from_hooks = False            # collectives are issued by finish(), outside the graph
+        elif self.capture and not all(g.get('capturable', False) for g in optimizer.param_groups):
+            # a non-capturable optimizer keeps its step counter on the host: the captured update would replay step 1 forever
+            raise ValueError('GraphedTrainStep captures optimizer.step(): build the optimizer with capturable=True')
+        if not self.capture:
+            return
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                    # warm up on the capture stream's side: lazy inits, allocator pools
@@ -47,6 +56,10 @@ class GraphedTrainStep:
             if not self.collective:
                 self.reducer.finish()
                 self.optimizer.step()
+        if self.collective:
+            # the capture ran the reducer's hooks (pending -> 0, packed) but not finish(): re-arm the buckets so that an eager
+            # backward after construction does not trip the "already all-reduced" guard
+            self.reducer.rearm()
         _cache.clear()                                   # nothing outside may alias tensors of the graph's private pool
 
     def _forward_backward(self):
@@ -63,6 +76,8 @@ class GraphedTrainStep:
         return loss
 
     def __call__(self):
+        if self.graph is None:
+            return self.eager_step()
         self.graph.replay()
         if self.collective:
             self.reducer.finish()

@@ -249,3 +249,70 @@ def test_gradients_are_packed_into_the_flat_buckets_and_unused_parameters_read_z
     used(x).square().sum().backward()
     reducer.finish()
     assert torch.equal(used.weight.grad, twin.weight.grad)
+
+
+def _graphed_worker(rank, world, port, q):
+    """GraphedTrainStep's multi-rank branch on CPU (capture=False: same sequencing as the GPU path -- the reducer's hooks only
+    pack, finish() issues every collective in fixed bucket order after forward + backward, then the optimizer)."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from pvcnn_amd.graph import GraphedTrainStep
+        torch.manual_seed(100 + rank)
+        model = _net()
+        reducer = GradBucketReducer(model, bucket_mb=0.0005)       # several buckets
+        opt = torch.optim.SGD(model.parameters(), lr=0.1)
+        g = torch.Generator().manual_seed(7)
+        x = torch.randn(8, 6, 32, generator=g)
+        y = torch.randint(0, 5, (8, 32), generator=g)
+        sl = shard_batch(8, world, rank)
+        step = GraphedTrainStep(model, lambda: nn.functional.cross_entropy(model(x[sl]), y[sl]), opt, reducer, capture=False)
+        assert step.collective and reducer.launch_from_hooks is False
+        start = [p.detach().numpy().copy() for p in model.parameters()]
+        losses = [float(step()) for _ in range(3)]
+        # an eager backward after the graphed steps must still be accepted by the reducer (buckets re-armed)
+        extra = float(step.eager_step())
+        q.put((rank, start, [p.detach().numpy().copy() for p in model.parameters()], losses + [extra], len(reducer.buckets)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_graphed_step_multi_rank_branch_matches_big_batch_sgd():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_graphed_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, start0, end0, _, nb0), (_, start1, end1, _, nb1) = results
+    assert nb0 == nb1 and nb0 > 1
+    for a, b in zip(end0, end1):
+        assert (a == b).all()                         # the ranks stay in lock-step
+    # single-process reference: 4 SGD steps on the whole batch
+    model = _net()
+    with torch.no_grad():
+        for p, src in zip(model.parameters(), start0):
+            p.copy_(torch.from_numpy(src))
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(8, 6, 32, generator=g)
+    y = torch.randint(0, 5, (8, 32), generator=g)
+    for _ in range(4):
+        opt.zero_grad()
+        nn.functional.cross_entropy(model(x), y).backward()
+        opt.step()
+    for p, got in zip(model.parameters(), end0):
+        assert torch.allclose(torch.from_numpy(got), p.detach(), atol=1e-5, rtol=1e-4)
+
+
+def test_graphed_step_wants_a_capturable_optimizer_when_it_captures_the_update():
+    from pvcnn_amd.graph import GraphedTrainStep
+    model = _net()
+    reducer = GradBucketReducer(model)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    with pytest.raises(ValueError, match='capturable'):
+        GraphedTrainStep(model, lambda: model(torch.randn(2, 6, 8)).sum(), opt, reducer, capture=True)
