@@ -104,7 +104,7 @@ class KernelClock:
 
     # MFMA-bound family: the Conv3d implicit-GEMM launches (forward and backward-data are the same kernel); the "bytes" slot
     # carries the ALGORITHMIC FLOPs 2*B*R^3*27*Ci*Co.  conv3d_igemm_split(x, wts, bias, co, nsplit): the launch alone (the
-    # weight image and, for f16x2, the input's absmax -- one 134 MB read, 26 us at R = 32 -- are prepared outside the timed call); nsplit = 3 / 2 executes 6 bf16 / 3 fp16 MFMA
+    # weight image and, for f16x2, the input's amax buffer are prepared outside the timed call); nsplit = 3 / 2 executes 6 bf16 / 3 fp16 MFMA
     # products per algorithmic one.
     WATCH_FLOPS = {
         'conv3d_forward': lambda a, out: ('conv3d_igemm fp32-MFMA (incl. weight transform)',
@@ -113,11 +113,6 @@ class KernelClock:
         'conv3d_igemm_split': lambda a, out: ('conv3d_igemm_bf16 ' + {3: 'bf16x3', 2: 'f16x2', 1: 'bf16'}[int(a[4])],
                                               2.0 * a[0].shape[0] * a[0].shape[2] ** 3 * 27 * a[0].shape[1] * int(a[3]),
                                               (a[0].shape[0], a[0].shape[1], int(a[3]), a[0].shape[2])),
-        # the same launch with the BatchNorm3d + LeakyReLU in front of the convolution applied in its staging:
-        # conv3d_igemm_split_bnact(x, wts, bias, co, bn, want_stats, amax)
-        'conv3d_igemm_split_bnact': lambda a, out: ('conv3d_igemm_bf16 f16x2',
-                                                    2.0 * a[0].shape[0] * a[0].shape[2] ** 3 * 27 * a[0].shape[1] * int(a[3]),
-                                                    (a[0].shape[0], a[0].shape[1], int(a[3]), a[0].shape[2])),
     }
 
     def __init__(self, backend):
@@ -380,7 +375,9 @@ def main():
         try:
             graphed = GraphedTrainStep(model, lambda: loss_of(model(x)), opt, reducer, autocast=autocast, warmup=3)
         except Exception as exc:                                 # reported on the line; the eager step is timed instead
-            graph_error = f'{type(exc).__name__}: {exc}'[:400]
+            import traceback
+            frames = [f'{os.path.basename(f.filename)}:{f.lineno} {f.name}' for f in traceback.extract_tb(exc.__traceback__)]
+            graph_error = f'{type(exc).__name__}: {str(exc)[:160]} @ ' + ' < '.join(reversed(frames[-8:]))
         if not all_ranks(graphed is not None):
             graphed = None
             graph_error = graph_error or 'capture failed on another rank'

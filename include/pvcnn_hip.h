@@ -47,7 +47,7 @@ extern "C" {
 #define PVCNN_API
 #endif
 
-#define PVCNN_ABI_VERSION 4
+#define PVCNN_ABI_VERSION 5
 #define PVCNN_OK 0
 #define PVCNN_ERR_INVALID_ARGUMENT (-1)
 
@@ -228,10 +228,23 @@ PVCNN_API int pvcnn_conv3d_bwd_weight(const float *x, const float *grad_y, int B
  * nsplit = 3: "bf16x3" -- both fp32 operands split exactly into three bf16 pieces, the six significant partial products
  *             accumulated in fp32: fp32-class accuracy (<= 1e-5 vs fp64, like pvcnn_conv3d_fwd) at up to 16/6 = 2.7x
  *             the fp32-MFMA rate.
- * nsplit = 2: "f16x2" -- both fp32 operands scaled by a power of two (per tensor for x, per output channel for w) and split
- *             into fp16 hi + lo (11 + 11 bits); hi*hi + hi*lo + lo*hi accumulated in fp32 and scaled back exactly: fp32-class
- *             accuracy (<= 1e-5 vs fp64) at 3 MFMAs per k-step.  Needs x_absmax = pvcnn_absmax_bits of the input (one
- *             uint32 in device memory: the bit pattern of max |x|).
+ * nsplit = 2: "f16x2" -- both fp32 operands scaled by a power of two (x: per workgroup tile, see "amax buffers" below; w: per
+ *             output channel) and split into fp16 hi + lo (11 + 11 bits); hi*hi + hi*lo + lo*hi accumulated in fp32 and scaled
+ *             back exactly: fp32-class accuracy (<= 1e-5 vs fp64) at 3 MFMAs per k-step.  Needs x_absmax = an amax buffer of the
+ *             input.
+ * amax buffers (f16x2 operand scales): 1 + T uint32 in device memory, T = B * ceil(L / seg) for x viewed as (B, C, L):
+ *             [0]     = bit pattern of max |x| over the whole tensor -- the scale of the backward-weight kernels (they reduce
+ *                       over positions, where small entries are negligible next to large ones in fp32 as well);
+ *             [1 + t] = bit pattern of max |x| over ALL CHANNELS of position segment t = b * ceil(L / seg) + l / seg.
+ *             The forward / backward-data kernels scale the tile of x a workgroup stages by the largest segment that tile
+ *             (with its halo) touches: Conv3d seg = R (one z row of the grid, T = B*R*R), 1x1 GEMM seg = 256 points (its
+ *             point tile).  RANGE CONTRACT: an output element is fp32-class (operands keep 22 bits) whenever the inputs it
+ *             depends on are within 2^-17 of the largest magnitude of ITS OWN tile; smaller inputs keep fewer bits (absolute
+ *             error <= 2^-38 of the tile maximum per product).  An outlier or a heavy-tailed gradient therefore costs
+ *             precision only inside the tiles it occupies -- tests/test_gpu_range.py.  amax_seg = 0 selects the old single
+ *             scale ([0] only; any 1-word buffer from pvcnn_absmax_bits will do).
+ *             pvcnn_absmax_tiles computes a buffer in one read of x; pvcnn_bnact_fwd / pvcnn_bnact_bwd_strided emit the buffer
+ *             of the tensor they write (no extra pass).
  * weight_split: w (Co,Ci,3,3,3) fp32 -> the kernels' pre-split, pre-swizzled LDS image (opaque, *_split_bytes bytes,
  *             16-byte aligned); for_bwd_data = 1 builds the flipped / channel-transposed image with which
  *             grad_x = conv3d_fwd_split(grad_y, wts, NULL, B, Ci = Co_fwd, Co = Ci_fwd, ...).
@@ -241,8 +254,10 @@ PVCNN_API size_t pvcnn_conv3d_weight_split_bytes(int Co, int Ci, int for_bwd_dat
 PVCNN_API int pvcnn_conv3d_weight_split(const float *w, int Co, int Ci, int for_bwd_data, int nsplit, void *wts, void *stream);
 PVCNN_API size_t pvcnn_conv3d_fwd_split_stats_parts(int B, int Co, int R, int nsplit);
 PVCNN_API int pvcnn_absmax_bits(const float *x, size_t n, void *out, void *stream);
+PVCNN_API size_t pvcnn_absmax_tiles_count(int B, long L, int seg);      /* 1 + T words */
+PVCNN_API int pvcnn_absmax_tiles(const float *x, int B, int C, long L, int seg, void *out, void *stream);
 PVCNN_API int pvcnn_conv3d_fwd_split(const float *x, const void *wts, const float *bias, int B, int Ci, int Co, int R, int nsplit,
-                           const void *x_absmax, float *y, float *stats_part, void *stream);
+                           const void *x_absmax, int amax_seg /* 0 | R */, float *y, float *stats_part, void *stream);
 
 /* Backward-weight in the same f16x2 arithmetic (csrc/conv3d_wgrad_f16.hip), R = 16 or 32 (workspace_bytes returns 0 for
  * any other R: use pvcnn_conv3d_bwd_weight).  x_absmax / gy_absmax: pvcnn_absmax_bits of x and grad_y.  Deterministic
@@ -251,23 +266,6 @@ PVCNN_API size_t pvcnn_conv3d_bwd_weight_f16_workspace_bytes(int B, int Ci, int 
 PVCNN_API int pvcnn_conv3d_bwd_weight_f16(const float *x, const float *grad_y, const void *x_absmax, const void *gy_absmax, int B, int Ci,
                                 int Co, int R, float *grad_w, float *grad_bias, void *workspace, size_t workspace_bytes,
                                 void *stream);
-
-/* ---- voxel_layers' FIRST BatchNorm3d + LeakyReLU folded into the SECOND convolution (modules/pvconv.py:20-27) -----
- * y = conv3d(leaky_relu(bn(x)), w) + bias without ever writing the activated grid: x is the RAW output of the previous
- * convolution, (mean, rstd, gamma, beta, slope) the BatchNorm + LeakyReLU between the two (per channel Ci; gamma / beta may be
- * NULL).  The consumer normalises and activates every in-range element while it stages its input tile (the convolution's zero
- * padding stays zero: it pads the ACTIVATED tensor), with the very expressions of pvcnn_bnact_fwd -- results are bit-identical
- * to pvcnn_bnact_fwd followed by pvcnn_conv3d_fwd_split / pvcnn_conv3d_bwd_weight_f16 on its output.  f16x2 arithmetic only;
- * x_absmax = pvcnn_bnact_absmax_bits (max |.| of the tensor the BatchNorm + activation WOULD have written; one read of x). */
-PVCNN_API int pvcnn_bnact_absmax_bits(const float *x, const float *gamma, const float *beta, const float *mean, const float *rstd,
-                            int B, int C, int S, float slope, void *out, void *stream);
-PVCNN_API int pvcnn_conv3d_fwd_split_bnact(const float *x, const void *wts, const float *bias, int B, int Ci, int Co, int R,
-                                 const void *x_absmax, const float *mean, const float *rstd, const float *gamma,
-                                 const float *beta, float slope, float *y, float *stats_part, void *stream);
-PVCNN_API int pvcnn_conv3d_bwd_weight_f16_bnact(const float *x, const float *grad_y, const void *x_absmax, const void *gy_absmax,
-                                      const float *mean, const float *rstd, const float *gamma, const float *beta, float slope,
-                                      int B, int Ci, int Co, int R, float *grad_w, float *grad_bias, void *workspace,
-                                      size_t workspace_bytes, void *stream);
 
 /* ---- 1x1 convolutions of SharedMLP (point branch, classifier) ------------------------------------
  * replaces the nn.Conv1d / nn.Conv2d (kernel 1) calls of modules/shared_mlp.py:9-25 (cuDNN / cuBLAS in the
@@ -296,7 +294,7 @@ PVCNN_API size_t pvcnn_pwconv_weight_split_bytes(int Co, int Ci, int for_bwd_dat
 PVCNN_API int pvcnn_pwconv_weight_split(const float *w, int Co, int Ci, int for_bwd_data, int nsplit, void *wts, void *stream);
 PVCNN_API size_t pvcnn_pwconv_fwd_split_stats_parts(int B, int N);
 PVCNN_API int pvcnn_pwconv_fwd_split(const float *x, const void *wts, const float *bias, int B, int K, int M, int N, int nsplit,
-                           const void *x_absmax, float *y, float *stats_part, void *stream);
+                           const void *x_absmax, int amax_seg /* 0 | 256 */, float *y, float *stats_part, void *stream);
 /* Backward-weight of the 1x1 convolution in f16x2 (csrc/pointwise_wgrad_f16.hip), N % 4 == 0 (workspace_bytes returns 0 otherwise:
  * use pvcnn_pwconv_bwd_weight).  x (B,K,N), grad_y (B,M,N) -> grad_w (M,K) [, grad_bias (M)]; *_absmax: pvcnn_absmax_bits of the two
  * tensors.  Deterministic split-K, <= 1e-5 vs fp64. */
@@ -313,12 +311,15 @@ PVCNN_API int pvcnn_pwconv_bwd_weight_f16(const float *x, const float *grad_y, c
  * fwd, training == 0: the caller supplies mean = running_mean and rstd = 1/sqrt(running_var+eps).
  * bwd: grad_x, grad_gamma, grad_beta (batch statistics differentiated through when training != 0).
  * gamma / beta may be NULL (affine = False).  `workspace`: >= pvcnn_bnact_workspace_bytes(B,C,S).
+ * y_amax / gx_amax (NULL, or pvcnn_absmax_tiles_count(B, S, amax_seg) words): the amax buffer of the tensor the call writes (y
+ *      resp. grad_x) with segments of amax_seg positions, emitted by the apply pass itself -- the f16x2 convolution that consumes
+ *      that tensor needs no pass of its own over it.  Requires amax_seg <= 256 and C <= 4096.
  */
 PVCNN_API size_t pvcnn_bnact_workspace_bytes(int B, int C, int S);
 PVCNN_API int pvcnn_bnact_fwd(const float *x, const float *gamma, const float *beta, float *running_mean,
                               float *running_var, int B, int C, int S, float eps, float momentum, float slope,
-                              int training, float *mean, float *rstd, float *y, void *workspace,
-                              size_t workspace_bytes, void *stream);
+                              int training, float *mean, float *rstd, float *y, void *y_amax, int amax_seg,
+                              void *workspace, size_t workspace_bytes, void *stream);
 /* Batch statistics only (training): mean / rstd per channel + running-stat update; the first half of bnact_fwd.
  * Used with pvcnn_trilinear_devox_bnact_fwd, which applies BatchNorm + LeakyReLU while it stages the voxel
  * grid into LDS -- out = trilinear_devoxelize(leaky_relu(bn(feat))) without writing the activated grid
@@ -357,14 +358,7 @@ PVCNN_API int pvcnn_bnact_bwd(const float *x, const float *grad_y, const float *
 PVCNN_API int pvcnn_bnact_bwd_strided(const float *x, const float *grad_y, long grad_y_batch_stride, const float *gamma,
                             const float *beta, const float *mean, const float *rstd, int B, int C, int S,
                             float slope, int training, float *grad_x, float *grad_gamma, float *grad_beta,
-                            void *workspace, size_t workspace_bytes, void *stream);
-/* pvcnn_bnact_bwd_strided that also leaves pvcnn_absmax_bits(grad_x) in gx_absmax (one uint32 in device memory): the f16x2
- * products that consume grad_x (backward-data / backward-weight of the convolution in front of the BatchNorm) take their
- * power-of-two scale from it, and here it costs no extra pass over the tensor and no memset launch. */
-PVCNN_API int pvcnn_bnact_bwd_absmax(const float *x, const float *grad_y, long grad_y_batch_stride, const float *gamma,
-                           const float *beta, const float *mean, const float *rstd, int B, int C, int S, float slope,
-                           int training, float *grad_x, float *grad_gamma, float *grad_beta, void *gx_absmax,
-                           void *workspace, size_t workspace_bytes, void *stream);
+                            void *gx_amax, int amax_seg, void *workspace, size_t workspace_bytes, void *stream);
 PVCNN_API int pvcnn_trilinear_devox_bwd_strided(const float *grad_y, long grad_y_batch_stride, const int32_t *inds,
                                       const float *wgts, int B, int C, int N, int R, float *grad_x,
                                       void *workspace, size_t workspace_bytes, void *stream);

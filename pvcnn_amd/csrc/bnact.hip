@@ -9,7 +9,6 @@
 // Tensors are (B, C, S) channel-major (S = R^3 voxels or N points); statistics per channel over B*S.
 // Sums are accumulated in fp32 per workgroup slice (<= 8192 elements) and combined in fp64.
 #include <algorithm>
-#include <stdlib.h>
 
 #include "common.h"
 
@@ -121,61 +120,6 @@ __global__ __launch_bounds__(kBnThreads) void bnact_apply_kernel(const float *__
   }
 }
 
-// Block-wide max of the bit patterns of non-negative floats, folded into *out (order-independent: deterministic).  Thousands of
-// workgroups target ONE word: same-address atomics serialise at the memory side, so a workgroup first looks at the current
-// value (a stale read only costs a redundant atomic) and most of them find their maximum already covered.
-__device__ __forceinline__ void block_atomic_max_bits(uint32_t m, uint32_t *__restrict__ out) {
-  __shared__ uint32_t red[kBnThreads / 64];
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int w = 1; w < kBnThreads / 64; ++w) m = max(m, red[w]);
-    if (m > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, m);
-  }
-}
-
-// EXPERIMENTAL second form (PVCNN_AMAX_REDUCE=2; built, not yet measured): measured on the chip, the form above makes
-// bnact_bwd_apply_kernel 27 % slower (34.6 -> 44.1 us) -- __syncthreads() waits for the kernel's outstanding streaming STORES, and
-// the filter load is a dependent global round trip at the very end of a ~10 us workgroup.  Here the barrier orders LDS only
-// (lds_barrier), the filter value `seen` was loaded when the kernel STARTED (thread 0; stale by design), and the atomic has no
-// return value (fire and forget).  Same result: the maximum is order-independent.
-__device__ __forceinline__ void block_atomic_max_bits_v2(uint32_t m, uint32_t seen, uint32_t *__restrict__ out) {
-  __shared__ uint32_t red2[kBnThreads / 64];
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
-  if ((threadIdx.x & 63) == 0) red2[threadIdx.x >> 6] = m;
-  lds_barrier();
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int w = 1; w < kBnThreads / 64; ++w) m = max(m, red2[w]);
-    if (m > seen) atomicMax(out, m);
-  }
-}
-
-// grid = (slices, B, C): bits of max |act(scale * x + shift)| -- pvcnn_absmax_bits of the tensor bnact_apply_kernel WOULD write
-// (same expressions, so the same bits), for consumers that apply the transform while staging (conv3d_bf16.hip, XF)
-__global__ __launch_bounds__(kBnThreads) void bnact_absmax_kernel(const float *__restrict__ x, BnActXf xf, int C, int S,
-                                                                 uint32_t *__restrict__ out) {
-  const int sl = blockIdx.x, b = blockIdx.y, c = blockIdx.z;
-  const float2 p = xf.params(c);
-  const size_t off = ((size_t)b * C + c) * S;
-  const int lo = sl * kBnSlice, hi = min(S, lo + kBnSlice);
-  uint32_t m = 0;
-  if ((S & 3) == 0 && aligned16(x + off)) {
-    for (int i = lo + threadIdx.x * 4; i < hi; i += kBnThreads * 4) {
-      const float4 v = *reinterpret_cast<const float4 *>(x + off + i);
-      m = max(max(m, __float_as_uint(fabsf(xf.apply(v.x, p)))), __float_as_uint(fabsf(xf.apply(v.y, p))));
-      m = max(max(m, __float_as_uint(fabsf(xf.apply(v.z, p)))), __float_as_uint(fabsf(xf.apply(v.w, p))));
-    }
-  } else {
-    for (int i = lo + threadIdx.x; i < hi; i += kBnThreads) m = max(m, __float_as_uint(fabsf(xf.apply(x[off + i], p))));
-  }
-  block_atomic_max_bits(m, out);
-}
-
 // grid = (slices, B, C): partial (sum g', sum g' * xhat),  g' = gy * act'(z),  z = scale*x + shift
 __global__ __launch_bounds__(kBnThreads) void bnact_bwd_reduce_kernel(const float *__restrict__ x, const float *__restrict__ gy,
                                                                      const float *__restrict__ mean,
@@ -221,10 +165,8 @@ __global__ __launch_bounds__(kBnThreads) void bnact_bwd_reduce_kernel(const floa
 
 // grid = C: dbeta = sum g', dgamma = sum g' xhat (fp64 combine)
 __global__ __launch_bounds__(64) void bnact_bwd_finalize_kernel(const float2 *__restrict__ part, int nparts,
-                                                               float *__restrict__ dgamma, float *__restrict__ dbeta,
-                                                               uint32_t *__restrict__ gx_absmax) {
+                                                               float *__restrict__ dgamma, float *__restrict__ dbeta) {
   const int c = blockIdx.x;
-  if (gx_absmax != nullptr && c == 0 && threadIdx.x == 0) *gx_absmax = 0u;   // re-armed for bnact_bwd_apply_kernel (next launch)
   double s = 0.0, q = 0.0;
   for (int i = threadIdx.x; i < nparts; i += 64) { const float2 p = part[(size_t)c * nparts + i]; s += p.x; q += p.y; }
 #pragma unroll
@@ -241,11 +183,8 @@ __global__ __launch_bounds__(kBnThreads) void bnact_bwd_apply_kernel(const float
                                                                     const float *__restrict__ dgamma,
                                                                     const float *__restrict__ dbeta, float slope,
                                                                     float inv_count, int training, int C, int S,
-                                                                    float *__restrict__ gx, long gy_bstride,
-                                                                    uint32_t *__restrict__ gx_absmax, int amax_form) {
+                                                                    float *__restrict__ gx, long gy_bstride) {
   const int sl = blockIdx.x, b = blockIdx.y, c = blockIdx.z;
-  uint32_t seen = 0;                                           // form 2: the maximum other workgroups have posted so far
-  if (gx_absmax != nullptr && amax_form == 2 && threadIdx.x == 0) seen = __hip_atomic_load(gx_absmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const float m = mean[c], r = rstd[c];
   const float gmm = gamma ? gamma[c] : 1.0f;
   const float scale = gmm * r;
@@ -254,7 +193,6 @@ __global__ __launch_bounds__(kBnThreads) void bnact_bwd_apply_kernel(const float
   const size_t off = ((size_t)b * C + c) * S;
   const size_t goff = (size_t)b * gy_bstride + (size_t)c * S;
   const int lo = sl * kBnSlice, hi = min(S, lo + kBnSlice);
-  uint32_t amax = 0;                                           // bits of max |gx| over this thread's elements
   if ((S & 3) == 0 && aligned16(x + off) && aligned16(gy + goff) && aligned16(gx + off)) {
     for (int i = lo + threadIdx.x * 4; i < hi; i += kBnThreads * 4) {
       const float4 xv = *reinterpret_cast<const float4 *>(x + off + i);
@@ -266,7 +204,6 @@ __global__ __launch_bounds__(kBnThreads) void bnact_bwd_apply_kernel(const float
         const float z = fmaf(xs_[u], scale, shift);
         const float g = gs_[u] * (z > 0.f ? 1.0f : slope);
         o[u] = scale * (g - db - ((xs_[u] - m) * r) * dg);
-        amax = max(amax, __float_as_uint(fabsf(o[u])));
       }
       using v4f = __attribute__((ext_vector_type(4))) float;
       v4f ov = {o[0], o[1], o[2], o[3]};
@@ -278,17 +215,100 @@ __global__ __launch_bounds__(kBnThreads) void bnact_bwd_apply_kernel(const float
       const float z = fmaf(xv, scale, shift);
       const float g = gy[goff + i] * (z > 0.f ? 1.0f : slope);
       const float xhat = (xv - m) * r;
-      const float o = scale * (g - db - xhat * dg);
-      gx[off + i] = o;
-      amax = max(amax, __float_as_uint(fabsf(o)));
+      gx[off + i] = scale * (g - db - xhat * dg);
     }
   }
-  // the gradient's max |.| rides along: the f16x2 products that consume grad_x (Conv3d / 1x1 backward-data and backward-weight)
-  // derive their power-of-two scale from it, and a separate absmax pass would re-read the whole tensor
-  if (gx_absmax != nullptr) {
-    if (amax_form == 2) block_atomic_max_bits_v2(amax, seen, gx_absmax);
-    else block_atomic_max_bits(amax, gx_absmax);
+}
+
+// ---- the two apply passes in POSITION-BLOCK-MAJOR form: a workgroup owns <= 256 consecutive positions of one sample and walks ALL
+// channels (its four waves take every fourth channel, four rows in flight each), so the maximum over the channels of every position
+// segment -- the "amax buffer" of the tensor being written (include/pvcnn_hip.h: the f16x2 scale table of the convolution that
+// consumes it) -- falls out of the pass: per-lane maxima of four positions, combined across waves and positions with ds_max_u32,
+// every table entry written by exactly one workgroup.  The arithmetic is the expressions of bnact_apply_kernel /
+// bnact_bwd_apply_kernel above, element for element (same bits).
+template <bool BWD>
+__global__ __launch_bounds__(256) void bnact_apply_pb_kernel(const float *__restrict__ x, const float *__restrict__ gy, long gy_bstride,
+                                                             const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                             const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                             const float *__restrict__ dgamma, const float *__restrict__ dbeta,
+                                                             float slope, float inv_count, int training, int C, int S, int seg,
+                                                             int nseg, int vec, float *__restrict__ out, uint32_t *__restrict__ amax) {
+  __shared__ uint32_t seg_max[256];
+  const int spb = seg >= 256 ? 1 : 256 / seg;                  // whole segments per workgroup (seg <= 256 enforced by the host)
+  const int b = blockIdx.y, s0 = blockIdx.x * spb;
+  const int p0 = s0 * seg, span = min(spb * seg, S - p0);
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, pos = 4 * lane;
+  if (tid < spb) seg_max[tid] = 0u;
+  __syncthreads();
+  const float *xb = x + (size_t)b * C * S + p0;
+  const float *gb = BWD ? gy + (size_t)b * gy_bstride + p0 : nullptr;
+  float *ob = out + (size_t)b * C * S + p0;
+  uint32_t mx[4] = {0u, 0u, 0u, 0u};
+  struct Par { float scale, shift, m, r, db, dg; };
+  auto par_of = [&](int c) {
+    Par p;
+    p.m = mean[c]; p.r = rstd[c];
+    p.scale = (gamma ? gamma[c] : 1.0f) * p.r;
+    p.shift = (beta ? beta[c] : 0.0f) - p.m * p.scale;
+    p.db = (BWD && training) ? dbeta[c] * inv_count : 0.0f;
+    p.dg = (BWD && training) ? dgamma[c] * inv_count : 0.0f;
+    return p;
+  };
+  auto one = [&](float xv, float gv, const Par &p) {
+    if constexpr (BWD) {
+      const float z = fmaf(xv, p.scale, p.shift);
+      const float g = gv * (z > 0.f ? 1.0f : slope);
+      return p.scale * (g - p.db - ((xv - p.m) * p.r) * p.dg);
+    } else {
+      const float v = fmaf(xv, p.scale, p.shift);
+      return v > 0.f ? v : v * slope;
+    }
+  };
+  if (pos < span) {
+    if (vec) {
+      using v4f = __attribute__((ext_vector_type(4))) float;
+      for (int c0 = wave; c0 < C; c0 += 16) {                  // channels c0, c0 + 4, c0 + 8, c0 + 12: four rows in flight
+        float4 xv[4], gv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int c = c0 + 4 * u;
+          xv[u] = gv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (c < C) {
+            xv[u] = *reinterpret_cast<const float4 *>(xb + (size_t)c * S + pos);
+            if constexpr (BWD) gv[u] = *reinterpret_cast<const float4 *>(gb + (size_t)c * S + pos);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int c = c0 + 4 * u;
+          if (c < C) {
+            const Par p = par_of(c);
+            const float o0 = one(xv[u].x, gv[u].x, p), o1 = one(xv[u].y, gv[u].y, p), o2 = one(xv[u].z, gv[u].z, p), o3 = one(xv[u].w, gv[u].w, p);
+            mx[0] = max(mx[0], __float_as_uint(fabsf(o0))); mx[1] = max(mx[1], __float_as_uint(fabsf(o1)));
+            mx[2] = max(mx[2], __float_as_uint(fabsf(o2))); mx[3] = max(mx[3], __float_as_uint(fabsf(o3)));
+            v4f ov = {o0, o1, o2, o3};
+            __builtin_nontemporal_store(ov, reinterpret_cast<v4f *>(ob + (size_t)c * S + pos));   // streaming: read next by another kernel
+          }
+        }
+      }
+    } else {
+      for (int c = wave; c < C; c += 4) {
+        const Par p = par_of(c);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (pos + i < span) {
+            const float o = one(xb[(size_t)c * S + pos + i], BWD ? gb[(size_t)c * S + pos + i] : 0.0f, p);
+            ob[(size_t)c * S + pos + i] = o;
+            mx[i] = max(mx[i], __float_as_uint(fabsf(o)));
+          }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (pos + i < span) atomicMax(&seg_max[(pos + i) / seg], mx[i]);
   }
+  lds_barrier();                                                // LDS only: the streaming stores above need not have drained
+  if (tid < spb && s0 + tid < nseg) amax[1 + (size_t)b * nseg + s0 + tid] = seg_max[tid];
 }
 
 }  // namespace pvcnn
@@ -302,9 +322,11 @@ extern "C" size_t pvcnn_bnact_workspace_bytes(int B, int C, int S) {
 
 extern "C" int pvcnn_bnact_fwd(const float *x, const float *gamma, const float *beta, float *running_mean,
                                float *running_var, int B, int C, int S, float eps, float momentum, float slope, int training,
-                               float *mean, float *rstd, float *y, void *workspace, size_t workspace_bytes, void *stream) {
+                               float *mean, float *rstd, float *y, void *y_amax, int amax_seg, void *workspace, size_t workspace_bytes,
+                               void *stream) {
   PVCNN_REQUIRE(B > 0 && C > 0 && S > 0 && x && y && mean && rstd, "bad argument");
   PVCNN_REQUIRE(B <= 65535 && C <= 65535, "batch or channel count > 65535");
+  PVCNN_REQUIRE(!y_amax || (amax_seg > 0 && amax_seg <= 256), "amax_seg must be in 1..256");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int slices = ceil_div(S, kBnSlice);
   const dim3 grid(slices, B, C);
@@ -319,6 +341,15 @@ extern "C" int pvcnn_bnact_fwd(const float *x, const float *gamma, const float *
     if (int e = check_launch("bn_finalize")) return e;
   }
   // eval: the caller passes mean = running_mean and rstd = 1/sqrt(running_var + eps)
+  if (y_amax != nullptr) {                                      // position-block-major pass that also emits y's amax buffer
+    const int nseg = ceil_div(S, amax_seg), spb = amax_seg >= 256 ? 1 : 256 / amax_seg;
+    const int vec = (S % 4 == 0) && (amax_seg % 4 == 0) && aligned16(x) && aligned16(y);
+    uint32_t *am = static_cast<uint32_t *>(y_amax);
+    hipLaunchKernelGGL(bnact_apply_pb_kernel<false>, dim3(ceil_div(nseg, spb), B), dim3(256), 0, s, x, nullptr, 0L, mean, rstd, gamma, beta,
+                       nullptr, nullptr, slope, 0.0f, 0, C, S, amax_seg, nseg, vec, y, am);
+    if (int e = check_launch("bnact_apply_pb")) return e;
+    return launch_amax_reduce(am, (long)B * nseg, s);
+  }
   hipLaunchKernelGGL(bnact_apply_kernel, grid, dim3(kBnThreads), 0, s, x, mean, rstd, gamma, beta, slope, C, S, y);
   return check_launch("bnact_apply");
 }
@@ -353,11 +384,12 @@ extern "C" int pvcnn_bn_stats(const float *x, float *running_mean, float *runnin
 static int bnact_bwd_impl(const float *x, const float *grad_y, long gy_bstride, const float *gamma, const float *beta,
                           const float *mean, const float *rstd, int B, int C, int S, float slope, int training, float *grad_x,
                           float *grad_gamma, float *grad_beta, void *workspace, size_t workspace_bytes, void *stream,
-                          void *gx_absmax = nullptr) {
+                          void *gx_amax = nullptr, int amax_seg = 0) {
   PVCNN_REQUIRE(B > 0 && C > 0 && S > 0 && x && grad_y && mean && rstd && grad_x && grad_gamma && grad_beta, "bad argument");
   PVCNN_REQUIRE(B <= 65535 && C <= 65535, "batch or channel count > 65535");
   PVCNN_REQUIRE(gy_bstride >= (long)C * S, "grad_y batch stride smaller than one sample");
   PVCNN_REQUIRE(workspace && workspace_bytes >= pvcnn_bnact_workspace_bytes(B, C, S), "workspace too small");
+  PVCNN_REQUIRE(!gx_amax || (amax_seg > 0 && amax_seg <= 256), "amax_seg must be in 1..256");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int slices = ceil_div(S, kBnSlice);
   const dim3 grid(slices, B, C);
@@ -365,13 +397,20 @@ static int bnact_bwd_impl(const float *x, const float *grad_y, long gy_bstride, 
   hipLaunchKernelGGL(bnact_bwd_reduce_kernel, grid, dim3(kBnThreads), 0, s, x, grad_y, mean, rstd, gamma, beta, slope, C, S,
                      slices, part, gy_bstride);
   if (int e = check_launch("bnact_bwd_reduce")) return e;
-  uint32_t *am = static_cast<uint32_t *>(gx_absmax);
-  // which form of the in-kernel maximum (see block_atomic_max_bits_v2); read once per process
-  static const int amax_form = [] { const char *e = getenv("PVCNN_AMAX_REDUCE"); return (e && e[0] == '2') ? 2 : 1; }();
-  hipLaunchKernelGGL(bnact_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, part, B * slices, grad_gamma, grad_beta, am);
+  hipLaunchKernelGGL(bnact_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, part, B * slices, grad_gamma, grad_beta);
   if (int e = check_launch("bnact_bwd_finalize")) return e;
+  const float inv_count = (float)(1.0 / ((double)B * S));
+  if (gx_amax != nullptr) {                                     // position-block-major pass that also emits grad_x's amax buffer
+    const int nseg = ceil_div(S, amax_seg), spb = amax_seg >= 256 ? 1 : 256 / amax_seg;
+    const int vec = (S % 4 == 0) && (amax_seg % 4 == 0) && (gy_bstride % 4 == 0) && aligned16(x) && aligned16(grad_y) && aligned16(grad_x);
+    uint32_t *am = static_cast<uint32_t *>(gx_amax);
+    hipLaunchKernelGGL(bnact_apply_pb_kernel<true>, dim3(ceil_div(nseg, spb), B), dim3(256), 0, s, x, grad_y, gy_bstride, mean, rstd, gamma,
+                       beta, grad_gamma, grad_beta, slope, inv_count, training, C, S, amax_seg, nseg, vec, grad_x, am);
+    if (int e = check_launch("bnact_bwd_apply_pb")) return e;
+    return launch_amax_reduce(am, (long)B * nseg, s);
+  }
   hipLaunchKernelGGL(bnact_bwd_apply_kernel, grid, dim3(kBnThreads), 0, s, x, grad_y, mean, rstd, gamma, beta, grad_gamma,
-                     grad_beta, slope, (float)(1.0 / ((double)B * S)), training, C, S, grad_x, gy_bstride, am, amax_form);
+                     grad_beta, slope, inv_count, training, C, S, grad_x, gy_bstride);
   return check_launch("bnact_bwd_apply");
 }
 
@@ -386,33 +425,8 @@ extern "C" int pvcnn_bnact_bwd(const float *x, const float *grad_y, const float 
 // channels of one sample contiguous, samples grad_y_batch_stride elements apart -- no .contiguous() copy needed.
 extern "C" int pvcnn_bnact_bwd_strided(const float *x, const float *grad_y, long grad_y_batch_stride, const float *gamma,
                                        const float *beta, const float *mean, const float *rstd, int B, int C, int S, float slope,
-                                       int training, float *grad_x, float *grad_gamma, float *grad_beta, void *workspace,
-                                       size_t workspace_bytes, void *stream) {
+                                       int training, float *grad_x, float *grad_gamma, float *grad_beta, void *gx_amax, int amax_seg,
+                                       void *workspace, size_t workspace_bytes, void *stream) {
   return bnact_bwd_impl(x, grad_y, grad_y_batch_stride, gamma, beta, mean, rstd, B, C, S, slope, training, grad_x, grad_gamma,
-                        grad_beta, workspace, workspace_bytes, stream);
-}
-
-// pvcnn_bnact_bwd_strided that also leaves pvcnn_absmax_bits(grad_x) in gx_absmax (one uint32): the f16x2 products consuming
-// grad_x need it, and here it costs nothing (no extra pass over the tensor, no memset launch).
-extern "C" int pvcnn_bnact_bwd_absmax(const float *x, const float *grad_y, long grad_y_batch_stride, const float *gamma,
-                                      const float *beta, const float *mean, const float *rstd, int B, int C, int S, float slope,
-                                      int training, float *grad_x, float *grad_gamma, float *grad_beta, void *gx_absmax,
-                                      void *workspace, size_t workspace_bytes, void *stream) {
-  PVCNN_REQUIRE(gx_absmax != nullptr, "null gx_absmax");
-  return bnact_bwd_impl(x, grad_y, grad_y_batch_stride, gamma, beta, mean, rstd, B, C, S, slope, training, grad_x, grad_gamma,
-                        grad_beta, workspace, workspace_bytes, stream, gx_absmax);
-}
-
-// out[0] = pvcnn_absmax_bits of act(bn(x)) without materialising it: x (B,C,S), per-channel mean / rstd (+ gamma / beta or NULL).
-extern "C" int pvcnn_bnact_absmax_bits(const float *x, const float *gamma, const float *beta, const float *mean, const float *rstd,
-                                       int B, int C, int S, float slope, void *out, void *stream) {
-  PVCNN_REQUIRE(B > 0 && C > 0 && S > 0 && x && mean && rstd && out, "bad argument");
-  PVCNN_REQUIRE(B <= 65535 && C <= 65535, "batch or channel count > 65535");
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  hipError_t e = hipMemsetAsync(out, 0, sizeof(uint32_t), s);
-  if (e != hipSuccess) { set_error("bnact_absmax: memset: %s", hipGetErrorString(e)); return (int)e; }
-  const BnActXf xf{mean, rstd, gamma, beta, slope};
-  hipLaunchKernelGGL(bnact_absmax_kernel, dim3(ceil_div(S, kBnSlice), B, C), dim3(kBnThreads), 0, s, x, xf, C, S,
-                     static_cast<uint32_t *>(out));
-  return check_launch("bnact_absmax");
+                        grad_beta, workspace, workspace_bytes, stream, gx_amax, amax_seg);
 }

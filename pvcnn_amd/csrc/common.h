@@ -22,23 +22,8 @@ __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; 
 inline int grid_pad_shift(int R) { int s = 0; while ((1 << s) < R) ++s; return ((1 << s) == R && R >= 4) ? s : 0; }
 __host__ __device__ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-// BatchNorm (per-channel scale / shift from mean, rstd, gamma, beta) + LeakyReLU applied by a CONSUMER while it stages its
-// input -- the very expressions of bnact_apply_kernel (bnact.hip), so consuming y through it is bit-identical to consuming the
-// tensor that kernel would have written (slab.h's XfBnAct does the same for the devoxelize gather).  mean == nullptr: identity.
-struct BnActXf {
-  const float *mean, *rstd, *gamma, *beta;   // per channel; gamma / beta may be null
-  float slope;
-#ifdef __HIPCC__
-  __device__ __forceinline__ float2 params(int c) const {
-    const float scale = (gamma ? gamma[c] : 1.0f) * rstd[c];
-    return make_float2(scale, (beta ? beta[c] : 0.0f) - mean[c] * scale);
-  }
-  __device__ __forceinline__ float apply(float v, const float2 &p) const {
-    v = fmaf(v, p.x, p.y);
-    return v > 0.f ? v : v * slope;
-  }
-#endif
-};
+// out[0] = max over out[1 .. T] of an amax buffer whose table has just been written on stream s (conv3d_bf16.hip)
+int launch_amax_reduce(uint32_t *out, long T, hipStream_t s);
 
 #ifdef __HIPCC__
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding GLOBAL store of the

@@ -82,6 +82,84 @@ __global__ __launch_bounds__(512) void absmax_kernel(const float *__restrict__ x
   }
 }
 
+// ---- "amax buffers": [0] = bits of max |x| over the tensor, [1 + t] = bits of max |x| over ALL CHANNELS of position segment t of
+// x viewed as (B, C, L): segments of `seg` consecutive positions, t = b * nseg + l / seg (include/pvcnn_hip.h).
+// A workgroup owns SPB whole segments (<= 256 positions) of one sample; its four waves split the channels, a lane keeps the
+// maxima of four consecutive positions; the waves and the positions of a segment meet in LDS (ds_max_u32).  Every table entry
+// is written by exactly one workgroup (no global atomics, no memset); the global maximum is a second, tiny kernel.
+constexpr int kAmaxBlock = 256;    // positions per workgroup (at most)
+
+__host__ __device__ inline int amax_segs_per_block(int seg) { return seg >= kAmaxBlock ? 1 : kAmaxBlock / seg; }
+
+__device__ __forceinline__ uint32_t abs_bits(float v) { return __float_as_uint(fabsf(v)); }
+
+__global__ __launch_bounds__(256) void absmax_tiles_kernel(const float *__restrict__ x, int C, long L, int seg, int nseg, int vec,
+                                                           uint32_t *__restrict__ out) {
+  __shared__ uint32_t seg_max[kAmaxBlock];
+  const int spb = amax_segs_per_block(seg);
+  const int b = blockIdx.y, s0 = blockIdx.x * spb;             // first segment of this workgroup
+  const long p0 = (long)s0 * seg;
+  const int span = (int)min((long)spb * seg, L - p0);          // positions of this workgroup (<= 256 when seg <= 256)
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  if (tid < spb) seg_max[tid] = 0u;
+  __syncthreads();
+  const float *xb = x + (size_t)b * C * L + p0;
+  // seg > 256 (never used by the kernels of this library, kept general): the workgroup walks its one segment in 256-position steps
+  for (int base = 0; base < span; base += kAmaxBlock) {
+    const int pos = base + 4 * lane;
+    uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+    if (pos < span) {
+      if (vec) {                                               // L % 4 == 0, seg % 4 == 0, x 16-byte aligned: whole quads in range
+        int c = wave;
+        for (; c + 12 < C; c += 16) {                          // four independent 16-byte loads in flight per lane
+          const float4 a = *reinterpret_cast<const float4 *>(xb + (size_t)c * L + pos);
+          const float4 d = *reinterpret_cast<const float4 *>(xb + (size_t)(c + 4) * L + pos);
+          const float4 e = *reinterpret_cast<const float4 *>(xb + (size_t)(c + 8) * L + pos);
+          const float4 f = *reinterpret_cast<const float4 *>(xb + (size_t)(c + 12) * L + pos);
+          m0 = max(max(m0, abs_bits(a.x)), max(abs_bits(d.x), max(abs_bits(e.x), abs_bits(f.x))));
+          m1 = max(max(m1, abs_bits(a.y)), max(abs_bits(d.y), max(abs_bits(e.y), abs_bits(f.y))));
+          m2 = max(max(m2, abs_bits(a.z)), max(abs_bits(d.z), max(abs_bits(e.z), abs_bits(f.z))));
+          m3 = max(max(m3, abs_bits(a.w)), max(abs_bits(d.w), max(abs_bits(e.w), abs_bits(f.w))));
+        }
+        for (; c < C; c += 4) {
+          const float4 a = *reinterpret_cast<const float4 *>(xb + (size_t)c * L + pos);
+          m0 = max(m0, abs_bits(a.x)); m1 = max(m1, abs_bits(a.y)); m2 = max(m2, abs_bits(a.z)); m3 = max(m3, abs_bits(a.w));
+        }
+      } else {
+        for (int c = wave; c < C; c += 4) {
+          const float *row = xb + (size_t)c * L + pos;
+          m0 = max(m0, abs_bits(row[0]));
+          if (pos + 1 < span) m1 = max(m1, abs_bits(row[1]));
+          if (pos + 2 < span) m2 = max(m2, abs_bits(row[2]));
+          if (pos + 3 < span) m3 = max(m3, abs_bits(row[3]));
+        }
+      }
+      atomicMax(&seg_max[pos / seg], m0);
+      if (pos + 1 < span) atomicMax(&seg_max[(pos + 1) / seg], m1);
+      if (pos + 2 < span) atomicMax(&seg_max[(pos + 2) / seg], m2);
+      if (pos + 3 < span) atomicMax(&seg_max[(pos + 3) / seg], m3);
+    }
+  }
+  __syncthreads();
+  if (tid < spb && s0 + tid < nseg) out[1 + (size_t)b * nseg + s0 + tid] = seg_max[tid];
+}
+
+// out[0] = max over the table out[1 .. T] (one workgroup; T is a few thousand words)
+__global__ __launch_bounds__(1024) void absmax_tiles_reduce_kernel(uint32_t *__restrict__ out, long T) {
+  __shared__ uint32_t red[16];
+  uint32_t m = 0;
+  for (long i = threadIdx.x; i < T; i += 1024) m = max(m, out[1 + i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int w = 1; w < 16; ++w) m = max(m, red[w]);
+    out[0] = m;
+  }
+}
+
 // f16x2 weights: one workgroup per (padded) output channel finds the row maximum, then writes the row's hi / lo planes in the
 // image layout below and the row's shift to wexp[co].
 __global__ __launch_bounds__(256) void conv3d_weight_split_f16_kernel(const float *__restrict__ w, int Co, int Ci, int for_bwd_data,
@@ -150,28 +228,22 @@ __global__ __launch_bounds__(256) void conv3d_weight_split_kernel(const float *_
 //   the same MFMA stream with NO loads and NO staging at all                                0.43 ms
 // i.e. the matrix pipe itself sustains ~1.6 PF on random data here (the chip clocks down under a dense bf16 MFMA stream),
 // and what is left above it is prologue / epilogue exposure; the simplest structure is kept.
-// XF: the input is consumed THROUGH BatchNorm + LeakyReLU (xf: the statistics / affine parameters of the BatchNorm in front of
-// this convolution): x holds the previous convolution's raw output and every in-range element becomes act(scale_c * x + shift_c)
-// on its way into LDS -- the activated tensor is never written (PVConv: voxel_layers[1..2] folded into voxel_layers[3]'s
-// staging, modules/pvconv.py:20-27).  The zero padding of the convolution stays zero (it pads the ACTIVATED tensor).
-template <int NS, int TX, int TY, int TZ, bool VEC, bool XF = false>
+// f16x2 operand scale: amax_seg = 0 -> one scale for the whole tensor (x_absmax[0]); amax_seg = R -> x_absmax is an "amax buffer"
+// (include/pvcnn_hip.h) with one maximum per z row (b, gx, gy) behind the global one, and the workgroup scales ITS halo tile by the
+// largest row it stages: an outlier somewhere in the grid costs precision only in the tiles that contain it.
+template <int NS, int TX, int TY, int TZ, bool VEC>
 __global__ __launch_bounds__(256, (NS == 3 || TX * TY * TZ == 512 || TZ <= 16) ? 2 : 3) void conv3d_igemm_bf16_kernel(const float *__restrict__ x, const uint16_t *__restrict__ wts,
                                                                    const float *__restrict__ bias, float *__restrict__ y,
                                                                    int Ci, int Co, int R, int tiles_x, int tiles_y, int tiles_z,
                                                                    float2 *__restrict__ stats_part,
                                                                    const uint32_t *__restrict__ x_absmax, const int *__restrict__ wexp,
-                                                                   BnActXf xf) {
+                                                                   int amax_seg) {
   static_assert(TX * TY * TZ == 128 || TX * TY * TZ == 256 || TX * TY * TZ == 512, "a workgroup tile is 4 waves x NBW x 32 voxels");
-  const int x_shift = NS == 2 ? scale_shift(*x_absmax) : 0;
-  const float x_scale = exp2_int(x_shift);
   constexpr int HX = TX + 2, HY = TY + 2, HZ = TZ + 2, HS = HX * HY * HZ;
   constexpr int NBW = TX * TY * TZ / 128;                       // 32-voxel MFMA column blocks per wave
   constexpr int WBLK = 3 * NS * kCoTileB * kKc;                 // bf16 elements of one (chunk, dxy, cotile) weight block
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
   uint32_t *xs = lds_u;                                         // [NS][HS][8] words (16 bf16 per voxel)
-  // XF: (scale, shift) of every input channel (padded to whole chunks), behind the tile and the epilogue's statistics
-  constexpr int XF_OFF = NS * HS * 8 > 4 * kCoTileB * 2 ? NS * HS * 8 : 4 * kCoTileB * 2;
-  [[maybe_unused]] float2 *xf_tab = reinterpret_cast<float2 *>(lds_u + XF_OFF);
 
   int bid = blockIdx.x;
   const int tzi = bid % tiles_z; bid /= tiles_z;
@@ -184,9 +256,26 @@ __global__ __launch_bounds__(256, (NS == 3 || TX * TY * TZ == 512 || TZ <= 16) ?
   const size_t RR = (size_t)R * R, S = RR * R;
   const float *xb = x + (size_t)b * Ci * S;
   const int chunks = ceil_div(Ci, kKc);
-  if constexpr (XF) {                                           // visible to every thread after the first chunk's barrier
-    for (int c = threadIdx.x; c < chunks * kKc; c += 256) xf_tab[c] = c < Ci ? xf.params(c) : make_float2(0.0f, 0.0f);
+  int x_shift = 0;
+  if constexpr (NS == 2) {
+    uint32_t tm = 0;
+    if (amax_seg > 0) {                                         // max over the z rows (b, gx, gy) of this workgroup's halo
+      __shared__ uint32_t tile_max[4];
+      for (int e = tid; e < HX * HY; e += 256) {
+        const int gx = x0 + e / HY - 1, gy = y0 + e % HY - 1;
+        if ((unsigned)gx < (unsigned)R && (unsigned)gy < (unsigned)R) tm = max(tm, x_absmax[1 + ((size_t)b * R + gx) * R + gy]);
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) tm = max(tm, (uint32_t)__shfl_xor((int)tm, o));
+      if (lane == 0) tile_max[wave] = tm;
+      __syncthreads();
+      tm = max(max(tile_max[0], tile_max[1]), max(tile_max[2], tile_max[3]));
+    } else {
+      tm = *x_absmax;
+    }
+    x_shift = scale_shift(tm);
   }
+  const float x_scale = exp2_int(x_shift);
 
   int hb[NBW];                                                  // halo index of this lane's output voxel (tap 0,0,0 corner)
 #pragma unroll
@@ -228,7 +317,6 @@ __global__ __launch_bounds__(256, (NS == 3 || TX * TY * TZ == 512 || TZ <= 16) ?
 #pragma unroll 1
       for (int batch = 0; batch < BATCHES; ++batch) {
         float4 va[ITER], vb[ITER];
-        [[maybe_unused]] bool oka[ITER], okb[ITER];                 // XF: the element was loaded (padding stays zero)
 #pragma unroll
         for (int u = 0; u < ITER; ++u) {
           const int e = (batch * ITER + u) * 256 + tid;
@@ -236,7 +324,6 @@ __global__ __launch_bounds__(256, (NS == 3 || TX * TY * TZ == 512 || TZ <= 16) ?
           const int gx = x0 + hx - 1, gy = y0 + hy - 1, c = c0 + 2 * cp;
           va[u] = vb[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
           const bool inside = e < ITEMS && (unsigned)gx < (unsigned)R && (unsigned)gy < (unsigned)R && 4 * q < R;
-          if constexpr (XF) { oka[u] = inside && c < Ci; okb[u] = inside && c + 1 < Ci; }
           if (inside) {
             const size_t off = (size_t)gx * RR + (size_t)gy * R + 4 * q;
             if (c < Ci) va[u] = *reinterpret_cast<const float4 *>(xb + (size_t)c * S + off);
@@ -249,15 +336,7 @@ __global__ __launch_bounds__(256, (NS == 3 || TX * TY * TZ == 512 || TZ <= 16) ?
           if (e < ITEMS) {
             const int q = e % QZ, hy = (e / QZ) % HY, hx = (e / (QZ * HY)) % HX, cp = e / (QZ * HY * HX);
             const int v0 = (hx * HY + hy) * HZ + 1 + 4 * q;
-            float fa[4] = {va[u].x, va[u].y, va[u].z, va[u].w}, fb[4] = {vb[u].x, vb[u].y, vb[u].z, vb[u].w};
-            if constexpr (XF) {
-              const float2 pa = xf_tab[c0 + 2 * cp], pb = xf_tab[c0 + 2 * cp + 1];
-#pragma unroll
-              for (int i = 0; i < 4; ++i) {
-                if (oka[u]) fa[i] = xf.apply(fa[i], pa);
-                if (okb[u]) fb[i] = xf.apply(fb[i], pb);
-              }
-            }
+            const float fa[4] = {va[u].x, va[u].y, va[u].z, va[u].w}, fb[4] = {vb[u].x, vb[u].y, vb[u].z, vb[u].w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               const int v = v0 + i;
@@ -276,7 +355,6 @@ __global__ __launch_bounds__(256, (NS == 3 || TX * TY * TZ == 512 || TZ <= 16) ?
 #pragma unroll 1
       for (int half = 0; half < 2; ++half) {
         float va[ITER], vb[ITER];
-        [[maybe_unused]] bool oka[ITER], okb[ITER];
 #pragma unroll
         for (int u = 0; u < ITER; ++u) {
           const int e = (half * ITER + u) * 256 + tid;
@@ -286,7 +364,6 @@ __global__ __launch_bounds__(256, (NS == 3 || TX * TY * TZ == 512 || TZ <= 16) ?
           const int c = c0 + 2 * cp;
           va[u] = vb[u] = 0.0f;
           const bool inside = e < HS * 8 && (unsigned)gx < (unsigned)R && (unsigned)gy < (unsigned)R && (unsigned)gz < (unsigned)R;
-          if constexpr (XF) { oka[u] = inside && c < Ci; okb[u] = inside && c + 1 < Ci; }
           if (inside) {
             const size_t off = (size_t)gx * RR + (size_t)gy * R + gz;
             if (c < Ci) va[u] = xb[(size_t)c * S + off];
@@ -298,10 +375,6 @@ __global__ __launch_bounds__(256, (NS == 3 || TX * TY * TZ == 512 || TZ <= 16) ?
           const int e = (half * ITER + u) * 256 + tid;
           if (e < HS * 8) {
             const int cp = e & 7, v = e >> 3;
-            if constexpr (XF) {
-              if (oka[u]) va[u] = xf.apply(va[u], xf_tab[c0 + 2 * cp]);
-              if (okb[u]) vb[u] = xf.apply(vb[u], xf_tab[c0 + 2 * cp + 1]);
-            }
             uint32_t pw[NS];
             if constexpr (NS == 2) split_pair<NS>(va[u] * x_scale, vb[u] * x_scale, pw);
             else split_pair<NS>(va[u], vb[u], pw);
@@ -451,21 +524,20 @@ static SplitTile split_tiles(int B, int Co, int R, int nsplit) {
   return big ? SplitTile{4, 4, 32, true} : SplitTile{2, 4, 32, true};
 }
 
-template <int NS, int TX, int TY, int TZ, bool VEC, bool XF = false>
+template <int NS, int TX, int TY, int TZ, bool VEC>
 static int launch_igemm_bf16(const float *x, const uint16_t *wts, const float *bias, float *y, int B, int Ci, int Co, int R,
                              hipStream_t s, float2 *stats_part, const uint32_t *x_absmax = nullptr, const int *wexp = nullptr,
-                             const BnActXf &xf = BnActXf{}) {
+                             int amax_seg = 0) {
   constexpr int HS = (TX + 2) * (TY + 2) * (TZ + 2);
-  const size_t lds = std::max((size_t)NS * HS * 8 * sizeof(uint32_t), (size_t)4 * kCoTileB * sizeof(float2))
-                     + (XF ? (size_t)ceil_div(Ci, kKc) * kKc * sizeof(float2) : 0);
+  const size_t lds = std::max((size_t)NS * HS * 8 * sizeof(uint32_t), (size_t)4 * kCoTileB * sizeof(float2));
   const int tx = ceil_div(R, TX), ty = ceil_div(R, TY), tz = ceil_div(R, TZ);
-  auto k = conv3d_igemm_bf16_kernel<NS, TX, TY, TZ, VEC, XF>;
+  auto k = conv3d_igemm_bf16_kernel<NS, TX, TY, TZ, VEC>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { set_error("conv3d(bf16): LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
   }
   hipLaunchKernelGGL(k, dim3((unsigned)((long)B * tx * ty * tz), ceil_div(Co, kCoTileB)), dim3(256), lds, s, x, wts, bias, y,
-                     Ci, Co, R, tx, ty, tz, stats_part, x_absmax, wexp, xf);
+                     Ci, Co, R, tx, ty, tz, stats_part, x_absmax, wexp, amax_seg);
   return check_launch("conv3d_igemm_bf16");
 }
 
@@ -497,6 +569,37 @@ extern "C" int pvcnn_absmax_bits(const float *x, size_t n, void *out, void *stre
   return check_launch("absmax");
 }
 
+int pvcnn::launch_amax_reduce(uint32_t *out, long T, hipStream_t s) {
+  hipLaunchKernelGGL(absmax_tiles_reduce_kernel, dim3(1), dim3(1024), 0, s, out, T);
+  return check_launch("absmax_tiles_reduce");
+}
+
+extern "C" size_t pvcnn_absmax_tiles_count(int B, long L, int seg) {
+  if (B <= 0 || L <= 0 || seg <= 0) return 1;
+  return 1 + (size_t)B * (size_t)((L + seg - 1) / seg);
+}
+
+// x (B, C, L) -> amax buffer `out` (pvcnn_absmax_tiles_count(B, L, seg) uint32): [0] global, [1 + b * nseg + l / seg] per segment
+extern "C" int pvcnn_absmax_tiles(const float *x, int B, int C, long L, int seg, void *out, void *stream) {
+  PVCNN_REQUIRE(out && B >= 0 && C >= 0 && L >= 0 && seg > 0, "bad argument");
+  PVCNN_REQUIRE(B <= 65535, "batch > 65535");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  uint32_t *o = static_cast<uint32_t *>(out);
+  if (B == 0 || C == 0 || L == 0) {
+    hipError_t e = hipMemsetAsync(out, 0, pvcnn_absmax_tiles_count(B, L, seg) * sizeof(uint32_t), s);
+    if (e != hipSuccess) { set_error("absmax_tiles: memset: %s", hipGetErrorString(e)); return (int)e; }
+    return 0;
+  }
+  PVCNN_REQUIRE(x, "null pointer");
+  const long nseg = (L + seg - 1) / seg;
+  PVCNN_REQUIRE(nseg <= 0x7fffffffL && (long)B * nseg <= 0x7fffffffL, "too many segments");
+  const int spb = amax_segs_per_block(seg);
+  const int vec = (L % 4 == 0) && (seg % 4 == 0) && aligned16(x);
+  hipLaunchKernelGGL(absmax_tiles_kernel, dim3((unsigned)((nseg + spb - 1) / spb), B), dim3(256), 0, s, x, C, L, seg, (int)nseg, vec, o);
+  if (int rc = check_launch("absmax_tiles")) return rc;
+  return launch_amax_reduce(o, (long)B * nseg, s);
+}
+
 extern "C" int pvcnn_conv3d_weight_split(const float *w, int Co, int Ci, int for_bwd_data, int nsplit, void *wts, void *stream) {
   PVCNN_REQUIRE(w && wts && Co > 0 && Ci > 0, "bad argument");
   PVCNN_REQUIRE(nsplit >= 1 && nsplit <= 3, "nsplit must be 1 (bf16), 2 (f16x2) or 3 (bf16x3)");
@@ -525,10 +628,11 @@ extern "C" size_t pvcnn_conv3d_fwd_split_stats_parts(int B, int Co, int R, int n
 // y = conv3d(x, w) + bias with the pre-split weights of pvcnn_conv3d_weight_split (forward layout: Ci, Co as given; backward-data:
 // call with x = grad_y, Ci = the forward Co, Co = the forward Ci, bias = NULL and the for_bwd_data = 1 weights).
 static int conv3d_fwd_split_impl(const float *x, const void *wts, const float *bias, int B, int Ci, int Co, int R, int nsplit,
-                                 const void *x_absmax, float *y, float *stats_part, void *stream, const BnActXf *xfp) {
+                                 const void *x_absmax, int amax_seg, float *y, float *stats_part, void *stream) {
   PVCNN_REQUIRE(B >= 0 && Ci > 0 && Co > 0 && R > 0, "bad size");
   PVCNN_REQUIRE(nsplit >= 1 && nsplit <= 3, "nsplit must be 1 (bf16), 2 (f16x2) or 3 (bf16x3)");
-  PVCNN_REQUIRE(nsplit != 2 || x_absmax, "f16x2 needs the input's pvcnn_absmax_bits");
+  PVCNN_REQUIRE(nsplit != 2 || x_absmax, "f16x2 needs the input's pvcnn_absmax_bits / pvcnn_absmax_tiles");
+  PVCNN_REQUIRE(amax_seg == 0 || amax_seg == R, "amax_seg must be 0 (scalar scale) or R (one maximum per z row)");
   if (B == 0) return 0;
   PVCNN_REQUIRE(x && wts && y && aligned16(wts), "null or misaligned pointer");
   PVCNN_REQUIRE(!stats_part || (reinterpret_cast<uintptr_t>(stats_part) & 7) == 0, "stats_part must be 8-byte aligned");
@@ -540,17 +644,7 @@ static int conv3d_fwd_split_impl(const float *x, const void *wts, const float *b
   PVCNN_REQUIRE(!t.vec || aligned16(x), "x must be 16-byte aligned");
   const uint32_t *am = static_cast<const uint32_t *>(x_absmax);
   const int *wexp = nsplit == 2 ? reinterpret_cast<const int *>(static_cast<const char *>(wts) + weight_image_bytes(Ci, Co, 2)) : nullptr;
-  if (xfp != nullptr) {   // BatchNorm + LeakyReLU folded into the staging: f16x2 only
-    const BnActXf xf = *xfp;
-    PVCNN_REQUIRE((size_t)ceil_div(Ci, kKc) * kKc * sizeof(float2) <= 8 * 1024, "too many input channels for the folded BatchNorm table");
-#define PVCNN_IGEMM_XF(TX, TY, TZ, VEC) launch_igemm_bf16<2, TX, TY, TZ, VEC, true>(x, w16, bias, y, B, Ci, Co, R, s, sp, am, wexp, xf)
-    if (t.tz == 8) return t.vec ? PVCNN_IGEMM_XF(4, 8, 8, true) : PVCNN_IGEMM_XF(4, 8, 8, false);
-    if (!t.vec) return PVCNN_IGEMM_XF(4, 4, 16, false);
-    if (t.tz == 16) return t.tx == 2 ? PVCNN_IGEMM_XF(2, 4, 16, true) : PVCNN_IGEMM_XF(4, 4, 16, true);
-    return t.tx == 4 ? PVCNN_IGEMM_XF(4, 4, 32, true) : PVCNN_IGEMM_XF(2, 4, 32, true);
-#undef PVCNN_IGEMM_XF
-  }
-#define PVCNN_IGEMM(NS, TX, TY, TZ, VEC) launch_igemm_bf16<NS, TX, TY, TZ, VEC>(x, w16, bias, y, B, Ci, Co, R, s, sp, am, wexp)
+#define PVCNN_IGEMM(NS, TX, TY, TZ, VEC) launch_igemm_bf16<NS, TX, TY, TZ, VEC>(x, w16, bias, y, B, Ci, Co, R, s, sp, am, wexp, amax_seg)
 #define PVCNN_IGEMM_NS(TX, TY, TZ, VEC) (nsplit == 3 ? PVCNN_IGEMM(3, TX, TY, TZ, VEC) : nsplit == 2 ? PVCNN_IGEMM(2, TX, TY, TZ, VEC) : PVCNN_IGEMM(1, TX, TY, TZ, VEC))
 #define PVCNN_IGEMM_BIG(TX, TY, TZ) (nsplit == 2 ? PVCNN_IGEMM(2, TX, TY, TZ, true) : PVCNN_IGEMM(1, TX, TY, TZ, true))
   if (t.tz == 8) return t.vec ? PVCNN_IGEMM_NS(4, 8, 8, true) : PVCNN_IGEMM_NS(4, 8, 8, false);
@@ -563,17 +657,6 @@ static int conv3d_fwd_split_impl(const float *x, const void *wts, const float *b
 }
 
 extern "C" int pvcnn_conv3d_fwd_split(const float *x, const void *wts, const float *bias, int B, int Ci, int Co, int R, int nsplit,
-                                      const void *x_absmax, float *y, float *stats_part, void *stream) {
-  return conv3d_fwd_split_impl(x, wts, bias, B, Ci, Co, R, nsplit, x_absmax, y, stats_part, stream, nullptr);
-}
-
-// y = conv3d(act(bn(x)), w) + bias in f16x2: x is the RAW output of the previous convolution, (mean, rstd, gamma, beta, slope) the
-// BatchNorm + LeakyReLU between the two (gamma / beta may be NULL), x_absmax = pvcnn_bnact_absmax_bits of x through the same
-// transform.  Bit-identical to pvcnn_bnact_fwd followed by pvcnn_conv3d_fwd_split on its output.
-extern "C" int pvcnn_conv3d_fwd_split_bnact(const float *x, const void *wts, const float *bias, int B, int Ci, int Co, int R,
-                                            const void *x_absmax, const float *mean, const float *rstd, const float *gamma,
-                                            const float *beta, float slope, float *y, float *stats_part, void *stream) {
-  PVCNN_REQUIRE(mean && rstd, "null statistics");
-  const BnActXf xf{mean, rstd, gamma, beta, slope};
-  return conv3d_fwd_split_impl(x, wts, bias, B, Ci, Co, R, 2, x_absmax, y, stats_part, stream, &xf);
+                                      const void *x_absmax, int amax_seg, float *y, float *stats_part, void *stream) {
+  return conv3d_fwd_split_impl(x, wts, bias, B, Ci, Co, R, nsplit, x_absmax, amax_seg, y, stats_part, stream);
 }

@@ -20,7 +20,6 @@
 //     2^-(sx + sgy) and transposes to (Co, Ci, 27).  grad_bias falls out of the grad_y rows a thread stages.
 // R must be a multiple of 16 (R = 16 and 32 are instantiated); anything else stays on the fp32-MFMA kernel of conv3d.hip.
 #include <algorithm>
-#include <stdlib.h>
 
 #include "common.h"
 #include "split16.h"
@@ -38,14 +37,11 @@ struct WgradLds {
   static constexpr int BYTES = 2 * XPL + 2 * GPL;
 };
 
-// XF: x is consumed through BatchNorm + LeakyReLU (the convolution's input was never materialised: conv3d_bf16.hip, XF) -- a
-// thread stages the same two input channels for the whole kernel, so their (scale, shift) live in registers.
-template <int R, bool XF = false>
+template <int R>
 __global__ __launch_bounds__(512, 2) void conv3d_wgrad_f16_kernel(const float *__restrict__ x, const float *__restrict__ gy,
                                                                   const uint32_t *__restrict__ x_absmax,
                                                                   const uint32_t *__restrict__ gy_absmax, int B, int Ci, int Co, int P,
-                                                                  int citiles, float *__restrict__ part, float *__restrict__ gb_part,
-                                                                  BnActXf xf) {
+                                                                  int citiles, float *__restrict__ part, float *__restrict__ gb_part) {
   using L = WgradLds<R>;
   constexpr int QZ = R / 4, KS = R / 16, ROWB = L::ROWB;
   constexpr int XITEMS = 3 * kWgCi * QZ, GITEMS = kWgCo * QZ;
@@ -81,11 +77,6 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_f16_kernel(const float *_
   const int gq = tid % QZ, gco = tid / QZ;
   const bool has_g = tid < GITEMS;
   float gsum = 0.0f;
-  [[maybe_unused]] float2 xfp0 = make_float2(0.0f, 0.0f), xfp1 = make_float2(0.0f, 0.0f);
-  if constexpr (XF) {
-    if (has_x0 && ci0 + xci0 < Ci) xfp0 = xf.params(ci0 + xci0);
-    if (has_x1 && ci0 + xci1 < Ci) xfp1 = xf.params(ci0 + xci1);
-  }
 
   auto store_row = [&](unsigned char *plane0, int plane_bytes, int row_byte, int q, const float4 &v, float scale) {
     uint32_t w0[2], w1[2];
@@ -107,14 +98,10 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_f16_kernel(const float *_
       float4 vx0 = zero4, vx1 = zero4, vg = zero4;
       if (y2 < R) {
         const int gx0 = xo + xdx0 - 1, gx1 = xo + xdx1 - 1;
-        if (has_x0 && (unsigned)gx0 < (unsigned)R && ci0 + xci0 < Ci) {
+        if (has_x0 && (unsigned)gx0 < (unsigned)R && ci0 + xci0 < Ci)
           vx0 = *reinterpret_cast<const float4 *>(xb + (size_t)(ci0 + xci0) * S + (size_t)gx0 * RR + (size_t)y2 * R + 4 * xq0);
-          if constexpr (XF) vx0 = make_float4(xf.apply(vx0.x, xfp0), xf.apply(vx0.y, xfp0), xf.apply(vx0.z, xfp0), xf.apply(vx0.w, xfp0));
-        }
-        if (has_x1 && (unsigned)gx1 < (unsigned)R && ci0 + xci1 < Ci) {
+        if (has_x1 && (unsigned)gx1 < (unsigned)R && ci0 + xci1 < Ci)
           vx1 = *reinterpret_cast<const float4 *>(xb + (size_t)(ci0 + xci1) * S + (size_t)gx1 * RR + (size_t)y2 * R + 4 * xq1);
-          if constexpr (XF) vx1 = make_float4(xf.apply(vx1.x, xfp1), xf.apply(vx1.y, xfp1), xf.apply(vx1.z, xfp1), xf.apply(vx1.w, xfp1));
-        }
       }
       if (y1 >= 0 && y1 < R && has_g && co0 + gco < Co)
         vg = *reinterpret_cast<const float4 *>(gb_ + (size_t)(co0 + gco) * S + (size_t)xo * RR + (size_t)y1 * R + 4 * gq);
@@ -208,74 +195,57 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_f16_kernel(const float *_
 }
 
 // gw[co][ci][tap] = 2^-(sx + sgy) * sum_p part[p][tap][co][ci];  gb[co] = sum_p gb_part[p][co]
-__global__ __launch_bounds__(256) void conv3d_wgrad_f16_reduce_kernel(const float *__restrict__ part, const float *__restrict__ gb_part,
-                                                                      const uint32_t *__restrict__ x_absmax,
-                                                                      const uint32_t *__restrict__ gy_absmax, int P, int CoP, int CiP,
-                                                                      int Co, int Ci, float *__restrict__ gw, float *__restrict__ gb) {
-  const size_t block = (size_t)27 * CoP * CiP;
-  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (e < block) {
-    const int ci = (int)(e % CiP), co = (int)((e / CiP) % CoP), tap = (int)(e / ((size_t)CiP * CoP));
-    if (co < Co && ci < Ci) {
-      float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-      int q = 0;
-      for (; q + 3 < P; q += 4) {
-        s0 += part[(size_t)q * block + e];
-        s1 += part[(size_t)(q + 1) * block + e];
-        s2 += part[(size_t)(q + 2) * block + e];
-        s3 += part[(size_t)(q + 3) * block + e];
-      }
-      for (; q < P; ++q) s0 += part[(size_t)q * block + e];
-      const float s = (s0 + s1) + (s2 + s3);
-      gw[((size_t)co * Ci + ci) * 27 + tap] = s * exp2_int(-scale_shift(*x_absmax)) * exp2_int(-scale_shift(*gy_absmax));
-    }
-  }
-  if (gb != nullptr && e < (size_t)Co) {
-    float s = 0.0f;
-    for (int q = 0; q < P; ++q) s += gb_part[(size_t)q * CoP + e];
-    gb[e] = s;
-  }
-}
+// One workgroup per (co, 32-channel ci block): it owns the 27 x 32 = 864 CONTIGUOUS floats gw[co][ci0 .. ci0+31][0 .. 26].
+// 864 of its 1024 threads = 216 float4 columns (tap, ci quad) x 4 partition slices; a thread sums its slice's partitions in a
+// fixed order with eight 16-byte loads in flight (the first form gave one thread ALL partitions of one element behind four 4-byte
+// loads: 1.8 MB in flight on the whole chip, 41.5 us for 57 MB), the four slices meet in LDS in a fixed order, and the block is
+// written back transposed as one coalesced run.  Deterministic; no atomics.  Wave 14 sums the grad_bias partials of `co`.
+constexpr int kRedSlices = 4, kRedCols = 27 * (kWgCi / 4);     // 216 float4 columns
 
-// EXPERIMENTAL second form of the split-K reduction (PVCNN_WGRAD_REDUCE=2; built, not yet measured).  The kernel above gives ONE
-// thread all P partials of an element: at 64 -> 64 channels that is 110 592 threads each walking 128 strided values -- 41.5 us per
-// launch, 0.33 ms per PVCNN step, for 57 MB that stream in ~12 us.  Here four threads share an element (each sums a contiguous
-// quarter of the partitions with four independent accumulators), a wave still reads 256 contiguous bytes per step, and the four
-// partial sums are combined through LDS in a fixed order: deterministic, but NOT the same rounding as the first form.
-__global__ __launch_bounds__(256) void conv3d_wgrad_f16_reduce_v2_kernel(const float *__restrict__ part, const float *__restrict__ gb_part,
-                                                                         const uint32_t *__restrict__ x_absmax,
-                                                                         const uint32_t *__restrict__ gy_absmax, int P, int CoP, int CiP,
-                                                                         int Co, int Ci, float *__restrict__ gw, float *__restrict__ gb) {
-  constexpr int PS = 4, EL = 256 / PS;                         // partition slices per element, elements per workgroup
-  __shared__ float red[PS][EL];
-  const int el = threadIdx.x % EL, ps = threadIdx.x / EL;
+__global__ __launch_bounds__(1024) void conv3d_wgrad_f16_reduce_kernel(const float *__restrict__ part, const float *__restrict__ gb_part,
+                                                                       const uint32_t *__restrict__ x_absmax,
+                                                                       const uint32_t *__restrict__ gy_absmax, int P, int CoP, int CiP,
+                                                                       int Co, int Ci, float *__restrict__ gw, float *__restrict__ gb) {
+  __shared__ __attribute__((aligned(16))) float red[kRedSlices][27 * kWgCi];
+  const int citiles = CiP / kWgCi;
+  const int co = blockIdx.x / citiles, ci0 = (blockIdx.x - co * citiles) * kWgCi;
+  const int tid = threadIdx.x;
   const size_t block = (size_t)27 * CoP * CiP;
-  const size_t e = (size_t)blockIdx.x * EL + el;
-  const int per = ceil_div(P, PS), q0 = ps * per, q1 = min(P, q0 + per);
-  float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-  if (e < block) {
-    int q = q0;
-    for (; q + 3 < q1; q += 4) {
-      s0 += part[(size_t)q * block + e];
-      s1 += part[(size_t)(q + 1) * block + e];
-      s2 += part[(size_t)(q + 2) * block + e];
-      s3 += part[(size_t)(q + 3) * block + e];
+  if (tid < kRedSlices * kRedCols) {
+    const int col = tid % kRedCols, sl = tid / kRedCols;
+    const int tap = col / (kWgCi / 4), q = col - tap * (kWgCi / 4);
+    const float *src = part + ((size_t)tap * CoP + co) * CiP + ci0 + 4 * q;
+    const int per = ceil_div(P, kRedSlices), p0 = sl * per, p1 = min(P, p0 + per);
+    float4 acc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto add = [](float4 &a, const float4 &v) { a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; };
+    int p = p0;
+    for (; p + 7 < p1; p += 8) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4 *>(src + (size_t)(p + u) * block);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) add(acc[u & 3], v[u]);
     }
-    for (; q < q1; ++q) s0 += part[(size_t)q * block + e];
-  }
-  red[ps][el] = (s0 + s1) + (s2 + s3);
-  __syncthreads();
-  if (ps == 0 && e < block) {
-    const int ci = (int)(e % CiP), co = (int)((e / CiP) % CoP), tap = (int)(e / ((size_t)CiP * CoP));
-    if (co < Co && ci < Ci) {
-      const float s = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
-      gw[((size_t)co * Ci + ci) * 27 + tap] = s * exp2_int(-scale_shift(*x_absmax)) * exp2_int(-scale_shift(*gy_absmax));
-    }
-  }
-  if (gb != nullptr && ps == 0 && e < (size_t)Co) {            // grad_bias: P values per channel, fixed order (as in the first form)
+    for (; p < p1; ++p) add(acc[0], *reinterpret_cast<const float4 *>(src + (size_t)p * block));
+    add(acc[0], acc[1]); add(acc[2], acc[3]); add(acc[0], acc[2]);
+    *reinterpret_cast<float4 *>(&red[sl][tap * kWgCi + 4 * q]) = acc[0];
+  } else if (gb != nullptr && ci0 == 0 && co < Co && tid >= 896 && tid < 960) {
+    const int lane = tid - 896;
     float s = 0.0f;
-    for (int q = 0; q < P; ++q) s += gb_part[(size_t)q * CoP + e];
-    gb[e] = s;
+    for (int q = lane; q < P; q += 64) s += gb_part[(size_t)q * CoP + co];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);    // fixed butterfly: deterministic
+    if (lane == 0) gb[co] = s;
+  }
+  __syncthreads();
+  if (tid < 27 * kWgCi) {
+    const int ci_l = tid / 27, tap = tid - ci_l * 27;
+    const int e = tap * kWgCi + ci_l;
+    const float s = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    if (co < Co && ci0 + ci_l < Ci)
+      gw[((size_t)co * Ci + ci0 + ci_l) * 27 + tap] = s * exp2_int(-scale_shift(*x_absmax)) * exp2_int(-scale_shift(*gy_absmax));
   }
 }
 
@@ -292,27 +262,21 @@ static WgradPlan wgrad_f16_plan(int B, int Ci, int Co, int R) {
   return w;
 }
 
-template <int R, bool XF = false>
+template <int R>
 static int launch_wgrad_f16(const float *x, const float *gy, const uint32_t *xa, const uint32_t *ga, int B, int Ci, int Co, float *gw,
-                            float *gb, float *ws, hipStream_t s, const BnActXf &xf = BnActXf{}) {
+                            float *gb, float *ws, hipStream_t s) {
   const WgradPlan w = wgrad_f16_plan(B, Ci, Co, R);
   float *part = ws, *gb_part = ws + w.part_floats;
-  auto k = conv3d_wgrad_f16_kernel<R, XF>;
+  auto k = conv3d_wgrad_f16_kernel<R>;
   const int lds = WgradLds<R>::BYTES;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e != hipSuccess) { set_error("conv3d_wgrad_f16: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
   hipLaunchKernelGGL(k, dim3((unsigned)(w.P * w.citiles * w.cotiles)), dim3(512), lds, s, x, gy, xa, ga, B, Ci, Co, w.P, w.citiles, part,
-                     gb ? gb_part : nullptr, xf);
+                     gb ? gb_part : nullptr);
   if (int rc = check_launch("conv3d_wgrad_f16")) return rc;
   const int CoP = w.cotiles * kWgCo, CiP = w.citiles * kWgCi;
-  static const bool reduce_v2 = [] { const char *e = getenv("PVCNN_WGRAD_REDUCE"); return e && e[0] == '2'; }();   // read once per process
-  if (reduce_v2 && Co <= 27 * CoP * CiP / 64 * 64) {
-    hipLaunchKernelGGL(conv3d_wgrad_f16_reduce_v2_kernel, dim3((unsigned)ceil_div(27 * CoP * CiP, 64)), dim3(256), 0, s, part, gb_part, xa,
-                       ga, w.P, CoP, CiP, Co, Ci, gw, gb);
-    return check_launch("conv3d_wgrad_f16_reduce_v2");
-  }
-  hipLaunchKernelGGL(conv3d_wgrad_f16_reduce_kernel, dim3((unsigned)ceil_div(27 * CoP * CiP, 256)), dim3(256), 0, s, part, gb_part, xa, ga, w.P,
-                     CoP, CiP, Co, Ci, gw, gb);
+  hipLaunchKernelGGL(conv3d_wgrad_f16_reduce_kernel, dim3((unsigned)(CoP * w.citiles)), dim3(1024), 0, s, part, gb_part, xa, ga, w.P, CoP, CiP,
+                     Co, Ci, gw, gb);
   return check_launch("conv3d_wgrad_f16_reduce");
 }
 
@@ -327,9 +291,9 @@ extern "C" size_t pvcnn_conv3d_bwd_weight_f16_workspace_bytes(int B, int Ci, int
   return (w.part_floats + w.gb_floats) * sizeof(float);
 }
 
-static int conv3d_bwd_weight_f16_impl(const float *x, const float *grad_y, const void *x_absmax, const void *gy_absmax, int B, int Ci,
-                                      int Co, int R, float *grad_w, float *grad_bias, void *workspace, size_t workspace_bytes,
-                                      void *stream, const BnActXf *xfp) {
+extern "C" int pvcnn_conv3d_bwd_weight_f16(const float *x, const float *grad_y, const void *x_absmax, const void *gy_absmax, int B, int Ci,
+                                           int Co, int R, float *grad_w, float *grad_bias, void *workspace, size_t workspace_bytes,
+                                           void *stream) {
   PVCNN_REQUIRE(B > 0 && Ci > 0 && Co > 0 && (R == 16 || R == 32), "bad size (R must be 16 or 32)");
   PVCNN_REQUIRE(x && grad_y && grad_w && x_absmax && gy_absmax, "null pointer");
   PVCNN_REQUIRE(aligned16(x) && aligned16(grad_y), "x and grad_y must be 16-byte aligned");
@@ -338,29 +302,6 @@ static int conv3d_bwd_weight_f16_impl(const float *x, const float *grad_y, const
   hipStream_t s = static_cast<hipStream_t>(stream);
   const uint32_t *xa = static_cast<const uint32_t *>(x_absmax), *ga = static_cast<const uint32_t *>(gy_absmax);
   float *ws = static_cast<float *>(workspace);
-  if (xfp != nullptr)
-    return R == 32 ? launch_wgrad_f16<32, true>(x, grad_y, xa, ga, B, Ci, Co, grad_w, grad_bias, ws, s, *xfp)
-                   : launch_wgrad_f16<16, true>(x, grad_y, xa, ga, B, Ci, Co, grad_w, grad_bias, ws, s, *xfp);
   return R == 32 ? launch_wgrad_f16<32>(x, grad_y, xa, ga, B, Ci, Co, grad_w, grad_bias, ws, s)
                  : launch_wgrad_f16<16>(x, grad_y, xa, ga, B, Ci, Co, grad_w, grad_bias, ws, s);
-}
-
-extern "C" int pvcnn_conv3d_bwd_weight_f16(const float *x, const float *grad_y, const void *x_absmax, const void *gy_absmax, int B, int Ci,
-                                           int Co, int R, float *grad_w, float *grad_bias, void *workspace, size_t workspace_bytes,
-                                           void *stream) {
-  return conv3d_bwd_weight_f16_impl(x, grad_y, x_absmax, gy_absmax, B, Ci, Co, R, grad_w, grad_bias, workspace, workspace_bytes, stream,
-                                    nullptr);
-}
-
-// grad_w of y = conv3d(act(bn(x)), w): x is the RAW tensor in front of the BatchNorm + LeakyReLU that pvcnn_conv3d_fwd_split_bnact
-// folded into its staging; x_absmax = pvcnn_bnact_absmax_bits of x through the same transform.  Bit-identical to
-// pvcnn_conv3d_bwd_weight_f16 on the materialised activation.
-extern "C" int pvcnn_conv3d_bwd_weight_f16_bnact(const float *x, const float *grad_y, const void *x_absmax, const void *gy_absmax,
-                                                 const float *mean, const float *rstd, const float *gamma, const float *beta, float slope,
-                                                 int B, int Ci, int Co, int R, float *grad_w, float *grad_bias, void *workspace,
-                                                 size_t workspace_bytes, void *stream) {
-  PVCNN_REQUIRE(mean && rstd, "null statistics");
-  const BnActXf xf{mean, rstd, gamma, beta, slope};
-  return conv3d_bwd_weight_f16_impl(x, grad_y, x_absmax, gy_absmax, B, Ci, Co, R, grad_w, grad_bias, workspace, workspace_bytes, stream,
-                                    &xf);
 }

@@ -104,18 +104,17 @@ __global__ __launch_bounds__(256) void pw_weight_split_f16_kernel(const float *_
   }
 }
 
-// MB = 8 (EXPERIMENTAL, PVCNN_PW_MB8=1; built, not yet measured): a workgroup owns 256 points x 256 output channels, one workgroup per
-// CU (256 accumulator registers per lane live in the AGPR half of the file).  Every staged and converted input element then feeds
-// twice as many MFMAs: at 1472 -> 512 the kernel spends ~2/3 of its 513 us in the staging phases (185 us of MFMA at the sustained
-// rate), and with M = 512 the x tile is staged by 2 workgroups instead of 4.
+// f16x2 operand scale: amax_seg = 0 -> one scale for the whole tensor (x_absmax[0]); amax_seg = 256 -> x_absmax is an "amax buffer"
+// (include/pvcnn_hip.h) with one maximum per 256-point tile behind the global one: every workgroup scales by ITS tile's maximum.
+// (A 256-channel tile, MB = 8 with the accumulators in AGPRs, was built and measured in round 3: 0.196 vs 0.154 ms at 128 -> 1024,
+// 1730 vs 1760 clouds/s in the step -- removed.)
 template <int NS, int MB>
-__global__ __launch_bounds__(256, MB > 4 ? 1 : 2) void pw_gemm_bf16_kernel(const float *__restrict__ x, const uint16_t *__restrict__ wts,
+__global__ __launch_bounds__(256, 2) void pw_gemm_bf16_kernel(const float *__restrict__ x, const uint16_t *__restrict__ wts,
                                                               const float *__restrict__ bias, float *__restrict__ y, int K, int M,
                                                               int N, int tiles_n, int tiles_total, float2 *__restrict__ stats_part,
-                                                              const uint32_t *__restrict__ x_absmax, const int *__restrict__ wexp) {
+                                                              const uint32_t *__restrict__ x_absmax, const int *__restrict__ wexp,
+                                                              int amax_seg) {
   constexpr int TM = 32 * MB, NBW = 2;
-  const int x_shift = NS == 2 ? scale_shift(*x_absmax) : 0;
-  const float x_scale = exp2_int(x_shift);
   constexpr int WBLK = NS * TM * kPbK;                          // bf16 elements of one (chunk, mtile) weight block
   __shared__ __attribute__((aligned(16))) uint32_t xs[NS * 8 * kPbN];       // [NS][8 channel pairs][256 points] words
 
@@ -126,6 +125,8 @@ __global__ __launch_bounds__(256, MB > 4 ? 1 : 2) void pw_gemm_bf16_kernel(const
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int tile = (slot / mtiles) * 8 + xcd, mt = slot - (slot / mtiles) * mtiles;
   if (tile >= tiles_total) return;
+  const int x_shift = NS == 2 ? scale_shift(amax_seg > 0 ? x_absmax[1 + tile] : *x_absmax) : 0;    // tile = b * tiles_n + point tile
+  const float x_scale = exp2_int(x_shift);
   const int b = tile / tiles_n, n0 = (tile - b * tiles_n) * kPbN, m0 = mt * TM;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, kh = lane >> 5;
   const float *xb = x + (size_t)b * K * N;
@@ -295,12 +296,7 @@ __global__ __launch_bounds__(256, MB > 4 ? 1 : 2) void pw_gemm_bf16_kernel(const
   }
 }
 
-static int pb_mb(int M) {
-  // EXPERIMENTAL 256-channel tile for the wide layers (read once per process; the weight image layout follows the tile)
-  static const bool mb8 = [] { const char *e = getenv("PVCNN_PW_MB8"); return e && e[0] == '1'; }();
-  if (mb8 && M >= 256 && M % 256 == 0) return 8;
-  return M > 64 ? 4 : 2;
-}
+static int pb_mb(int M) { return M > 64 ? 4 : 2; }
 
 }  // namespace pvcnn
 
@@ -347,10 +343,11 @@ extern "C" size_t pvcnn_pwconv_fwd_split_stats_parts(int B, int N) {
 // y (B,M,N) = W x + bias with the pre-split weights (forward: K = Ci, M = Co; backward-data: x = grad_y, K = Co, M = Ci, bias NULL,
 // for_bwd_data = 1 image).  stats_part: NULL or (M, *_split_stats_parts) float pairs of (sum, sum of squares) of (y - bias).
 extern "C" int pvcnn_pwconv_fwd_split(const float *x, const void *wts, const float *bias, int B, int K, int M, int N, int nsplit,
-                                      const void *x_absmax, float *y, float *stats_part, void *stream) {
+                                      const void *x_absmax, int amax_seg, float *y, float *stats_part, void *stream) {
   PVCNN_REQUIRE(B >= 0 && K > 0 && M > 0 && N >= 0, "bad size");
+  PVCNN_REQUIRE(amax_seg == 0 || amax_seg == kPbN, "amax_seg must be 0 (scalar scale) or 256 (one maximum per point tile)");
   PVCNN_REQUIRE(nsplit >= 1 && nsplit <= 3, "nsplit must be 1 (bf16), 2 (f16x2) or 3 (bf16x3)");
-  PVCNN_REQUIRE(nsplit != 2 || x_absmax, "f16x2 needs the input's pvcnn_absmax_bits");
+  PVCNN_REQUIRE(nsplit != 2 || x_absmax, "f16x2 needs the input's pvcnn_absmax_bits / pvcnn_absmax_tiles");
   if (B == 0 || N == 0) return 0;
   PVCNN_REQUIRE(x && wts && y && aligned16(wts), "null or misaligned pointer");
   PVCNN_REQUIRE(!stats_part || (reinterpret_cast<uintptr_t>(stats_part) & 7) == 0, "stats_part must be 8-byte aligned");
@@ -365,10 +362,9 @@ extern "C" int pvcnn_pwconv_fwd_split(const float *x, const void *wts, const flo
   float2 *sp = reinterpret_cast<float2 *>(stats_part);
   const uint32_t *am = static_cast<const uint32_t *>(x_absmax);
   const int *wexp = nsplit == 2 ? reinterpret_cast<const int *>(static_cast<const char *>(wts) + pb_image_bytes(K, M, 2)) : nullptr;
-#define PVCNN_PB_LAUNCH(NSV, MBV) hipLaunchKernelGGL((pw_gemm_bf16_kernel<NSV, MBV>), grid, dim3(256), 0, s, x, w16, bias, y, K, M, N, tiles_n, (int)tiles_total, sp, am, wexp)
-  PVCNN_REQUIRE(MB != 8 || nsplit == 2, "the 256-channel tile (PVCNN_PW_MB8) is built for f16x2 only");
+#define PVCNN_PB_LAUNCH(NSV, MBV) hipLaunchKernelGGL((pw_gemm_bf16_kernel<NSV, MBV>), grid, dim3(256), 0, s, x, w16, bias, y, K, M, N, tiles_n, (int)tiles_total, sp, am, wexp, amax_seg)
   if (nsplit == 3)      { if (MB == 4) PVCNN_PB_LAUNCH(3, 4); else PVCNN_PB_LAUNCH(3, 2); }
-  else if (nsplit == 2) { if (MB == 8) PVCNN_PB_LAUNCH(2, 8); else if (MB == 4) PVCNN_PB_LAUNCH(2, 4); else PVCNN_PB_LAUNCH(2, 2); }
+  else if (nsplit == 2) { if (MB == 4) PVCNN_PB_LAUNCH(2, 4); else PVCNN_PB_LAUNCH(2, 2); }
   else                  { if (MB == 4) PVCNN_PB_LAUNCH(1, 4); else PVCNN_PB_LAUNCH(1, 2); }
 #undef PVCNN_PB_LAUNCH
   return check_launch("pwconv_fwd_split");

@@ -13,7 +13,7 @@ by a later tensor can never hit a stale entry.
 import threading
 import weakref
 
-__all__ = ['memo', 'clear', 'enabled', 'tag_absmax', 'absmax_of']
+__all__ = ['memo', 'clear', 'enabled', 'tag_amax', 'amax_of']
 
 # re-entrant: a weak-reference callback (_drop) can fire from the garbage collector at any allocation, including inside
 # memo()'s own critical section on the same thread -- a plain Lock deadlocks there (seen in the GPU test-suite)
@@ -56,23 +56,25 @@ def clear():
         _entries.clear()
 
 
-# ---- max |x| of a tensor, handed from the kernel that wrote it to the kernels that consume it --------------------------------
-# The f16x2 products take their power-of-two operand scale from the bit pattern of max |x| (csrc/split16.h).  A producer that
-# already touches every element (the BatchNorm backward's apply pass) emits it for free; the consumer -- the next autograd
-# node, which receives the very same tensor object -- finds it here instead of re-reading the tensor.  Keyed like every memo
-# entry by (object identity, in-place version): a tensor that was modified, accumulated into or replaced simply misses.
-def tag_absmax(tensor, amax):
+# ---- the f16x2 scale table ("amax buffer", include/pvcnn_hip.h) of a tensor, handed from the kernel that wrote the tensor to the
+# kernels that consume it ----------------------------------------------------------------------------------------------------------
+# The f16x2 products take their power-of-two operand scales from the bit patterns of max |x| per position segment (csrc/split16.h).
+# A producer that touches every element anyway (the BatchNorm apply passes, forward and backward) emits the buffer for free; the
+# consumer -- the next module / the next autograd node, which receives the very same tensor object -- finds it here instead of
+# re-reading the tensor.  Keyed like every memo entry by (object identity, in-place version) plus the segment length: a tensor that
+# was modified, accumulated into or replaced simply misses, and so does a consumer that wants another segmentation.
+def tag_amax(tensor, seg, amax):
     if enabled and amax is not None:
-        memo(tensor, 'absmax_bits', lambda: amax)
+        memo(tensor, ('amax', int(seg)), lambda: amax)
     return tensor
 
 
-def absmax_of(tensor, compute):
-    """The tagged maximum of `tensor` if its producer left one, else compute() (not stored: nothing else would ask again)."""
+def amax_of(tensor, seg):
+    """The amax buffer its producer left on `tensor` for segments of `seg` positions, or None."""
     if enabled:
-        tid = id(tensor)
+        tid, key = id(tensor), ('amax', int(seg))
         with _lock:
             ent = _entries.get(tid)
-            if ent is not None and ent[0]() is tensor and ent[1] == tensor._version and 'absmax_bits' in ent[2]:
-                return ent[2]['absmax_bits']
-    return compute()
+            if ent is not None and ent[0]() is tensor and ent[1] == tensor._version and key in ent[2]:
+                return ent[2][key]
+    return None

@@ -473,12 +473,44 @@ class HipBackend:
     CONV_NSPLIT = {'f16x2': 2, 'bf16x3': 3, 'fp32': 0}
 
     def absmax_bits(self, x):
-        """One uint32 on the device: the bit pattern of max |x| (the f16x2 kernels derive their power-of-two input scale from it)."""
+        """One uint32 on the device: the bit pattern of max |x| (a 1-word amax buffer: the scalar scale of the f16x2 kernels)."""
         _f32(x, 'x')
         out = torch.empty((1,), dtype=torch.int32, device=x.device)
         with _Launch(x) as s:
             _lib.check(self.lib.pvcnn_absmax_bits(_p(x), x.numel(), _p(out), s), 'absmax_bits')
         return out
+
+    # "amax buffers" (include/pvcnn_hip.h): [0] = bits of max |x| over the tensor, [1 + t] = bits of the maximum over all channels of
+    # position segment t.  The f16x2 forward / backward-data kernels scale each workgroup's tile of x by the maxima of the segments it
+    # touches (an outlier costs precision only inside its own tile); the backward-weight kernels use [0].
+    PW_AMAX_SEG = 256          # the 1x1 GEMM's point tile
+
+    def absmax_tiles(self, x, seg):
+        """x (B, C, L) -> int32 (1 + B * ceil(L / seg),): the amax buffer of x with segments of `seg` positions (one read of x)."""
+        _f32(x, 'x')
+        _shape(x.dim() == 3, 'absmax_tiles: x (B,C,L) expected')
+        b, c, n = x.shape
+        seg = int(seg)
+        out = torch.empty((self.lib.pvcnn_absmax_tiles_count(b, n, seg),), dtype=torch.int32, device=x.device)
+        with _Launch(x) as s:
+            _lib.check(self.lib.pvcnn_absmax_tiles(_p(x), b, c, n, seg, _p(out), s), 'absmax_tiles')
+        return out
+
+    def conv_amax(self, x):
+        """amax buffer of a voxel grid x (B,C,R,R,R) in the layout the Conv3d kernels take: one maximum per z row."""
+        return self.absmax_tiles(x.view(x.shape[0], x.shape[1], -1), x.shape[2])
+
+    def pw_amax(self, x):
+        """amax buffer of point features x (B,C,N) in the layout the 1x1 GEMM takes: one maximum per 256-point tile."""
+        return self.absmax_tiles(x, self.PW_AMAX_SEG)
+
+    @staticmethod
+    def _amax_seg(amax, tiles, seg):
+        """0 when `amax` is a 1-word buffer (scalar scale), `seg` when it carries the `tiles`-entry table; anything else is an error."""
+        if amax.numel() == 1:
+            return 0
+        _shape(amax.numel() == 1 + tiles, f'amax buffer has {amax.numel()} words, expected 1 or {1 + tiles}')
+        return seg
 
     def _conv_wsplit(self, weight, for_bwd_data, nsplit):
         co, ci = weight.shape[0], weight.shape[1]
@@ -495,21 +527,22 @@ class HipBackend:
         if bias is not None:
             _f32(bias, 'bias')
         return self.conv3d_igemm_split(x, self._conv_wsplit(weight, False, nsplit), bias, weight.shape[0], nsplit, want_stats,
-                                       amax if amax is not None else (self.absmax_bits(x) if int(nsplit) == 2 else None))
+                                       amax if amax is not None else (self.conv_amax(x) if int(nsplit) == 2 else None))
 
     def conv3d_igemm_split(self, x, wts, bias, co, nsplit, want_stats=False, amax=None):
-        """The implicit-GEMM launch alone (pre-split weight image `wts`; f16x2: `amax` = absmax_bits(x)): x (B,Ci,R,R,R) ->
-        y (B,co,R,R,R) [, stats partials]."""
+        """The implicit-GEMM launch alone (pre-split weight image `wts`; f16x2: `amax` = conv_amax(x), or a 1-word absmax_bits(x)
+        for the single-scale mode): x (B,Ci,R,R,R) -> y (B,co,R,R,R) [, stats partials]."""
         b, ci, r = x.shape[0], x.shape[1], x.shape[2]
         y = torch.empty((b, co, r, r, r), dtype=torch.float32, device=x.device)
         part = None
         if want_stats:
             part = torch.empty((co, self.lib.pvcnn_conv3d_fwd_split_stats_parts(b, co, r, int(nsplit)), 2), dtype=torch.float32, device=x.device)
         if int(nsplit) == 2 and amax is None:
-            amax = self.absmax_bits(x)
+            amax = self.conv_amax(x)
+        seg = self._amax_seg(amax, b * r * r, r) if int(nsplit) == 2 else 0
         with _Launch(x) as s:
             _lib.check(self.lib.pvcnn_conv3d_fwd_split(_p(x), _p(wts), _p(bias) if bias is not None else None, b, ci, co, r, int(nsplit),
-                                                       _p(amax) if amax is not None else None,
+                                                       _p(amax) if amax is not None else None, seg,
                                                        _p(y), _p(part) if want_stats else None, s), 'conv3d_forward_split')
         return (y, part) if want_stats else y
 
@@ -519,14 +552,15 @@ class HipBackend:
         ci = weight.shape[1]
         # a convolution with Ci and Co exchanged on the flipped weights
         return self.conv3d_igemm_split(grad_y, self._conv_wsplit(weight, True, nsplit), None, ci, nsplit, False,
-                                       amax if amax is not None else (self.absmax_bits(grad_y) if int(nsplit) == 2 else None))
+                                       amax if amax is not None else (self.conv_amax(grad_y) if int(nsplit) == 2 else None))
 
     # ---- backward-weight in f16x2 (csrc/conv3d_wgrad_f16.hip): R = 16 and 32; other grids stay on the fp32-MFMA kernel ----
     def conv3d_backward_weight_f16_serves(self, x):
         return x.dim() == 5 and x.shape[2] in (16, 32)
 
     def conv3d_backward_weight_f16(self, x, grad_y, x_amax=None, gy_amax=None, with_bias=False):
-        """grad_w (Co,Ci,3,3,3) [, grad_bias]: x (B,Ci,R,R,R), grad_y (B,Co,R,R,R); *_amax = absmax_bits of the two tensors."""
+        """grad_w (Co,Ci,3,3,3) [, grad_bias]: x (B,Ci,R,R,R), grad_y (B,Co,R,R,R); *_amax = amax buffers of the two tensors (word [0],
+        the global maximum, is what this kernel scales by)."""
         _f32(x, 'x'); _f32(grad_y, 'grad_y')
         b, ci, r = x.shape[0], x.shape[1], x.shape[2]
         co = grad_y.shape[1]
@@ -539,79 +573,6 @@ class HipBackend:
         with _Launch(x) as s:
             _lib.check(self.lib.pvcnn_conv3d_bwd_weight_f16(_p(x), _p(grad_y), _p(x_amax), _p(gy_amax), b, ci, co, r, _p(gw),
                                                             _p(gb) if with_bias else None, _p(ws), ws.numel(), s), 'conv3d_backward_weight_f16')
-        return (gw, gb) if with_bias else gw
-
-    # ---- voxel_layers' first BatchNorm3d + LeakyReLU folded into the second convolution's staging ----
-    # bn = (gamma | None, beta | None, mean, rstd, slope) of the BatchNorm + activation IN FRONT of the convolution; x is the raw
-    # tensor in front of that BatchNorm.  f16x2 arithmetic; results bit-identical to the unfused ops.
-    # OPT-IN (PVCNN_FOLD_BN=1): measured on MI355X (profiles/r02_fold_ab.md) the fold saves the 0.08 ms/step of the BatchNorm pass
-    # and costs 0.3 ms/step in the two consumers (the extra VALU work lands in staging loops that the f16x2 MFMA stream does not
-    # hide: forward 179 -> 274 us at 64->64, R = 32; backward-weight 225 -> 344 us), so the default keeps the separate pass.
-    has_conv3d_bnact_fold = os.environ.get('PVCNN_FOLD_BN', '0') == '1'
-
-    @staticmethod
-    def _bn_args(bn, channels):
-        gamma, beta, mean, rstd, slope = bn
-        for t, name in ((gamma, 'gamma'), (beta, 'beta'), (mean, 'mean'), (rstd, 'rstd')):
-            if t is not None:
-                _f32(t, name)
-                _shape(t.numel() == channels, f'{name}: one value per input channel expected')
-        _shape(mean is not None and rstd is not None, 'mean / rstd missing')
-        nul = ctypes.c_void_p(None)
-        return (_p(mean), _p(rstd), _p(gamma) if gamma is not None else nul, _p(beta) if beta is not None else nul, float(slope))
-
-    def bnact_absmax_bits(self, x, bn):
-        """absmax_bits of leaky_relu(bn(x)) without materialising it: x (B,C,...) raw, bn as above."""
-        _f32(x, 'x')
-        b, c = x.shape[0], x.shape[1]
-        s3 = x.numel() // max(b * c, 1)
-        mean, rstd, gamma, beta, slope = self._bn_args(bn, c)
-        out = torch.empty((1,), dtype=torch.int32, device=x.device)
-        with _Launch(x) as s:
-            _lib.check(self.lib.pvcnn_bnact_absmax_bits(_p(x), gamma, beta, mean, rstd, b, c, s3, slope, _p(out), s), 'bnact_absmax_bits')
-        return out
-
-    def conv3d_forward_split_bnact(self, x, weight, bias, bn, want_stats=False, amax=None):
-        """conv3d(leaky_relu(bn(x)), weight) + bias in f16x2 with the BatchNorm + activation applied in the staging."""
-        _f32(x, 'x'); _f32(weight, 'weight')
-        _shape(x.dim() == 5 and weight.dim() == 5 and tuple(weight.shape[2:]) == (3, 3, 3) and weight.shape[1] == x.shape[1]
-               and x.shape[2] == x.shape[3] == x.shape[4], 'conv3d: x (B,Ci,R,R,R), weight (Co,Ci,3,3,3) expected')
-        if bias is not None:
-            _f32(bias, 'bias')
-        if amax is None:
-            amax = self.bnact_absmax_bits(x, bn)
-        return self.conv3d_igemm_split_bnact(x, self._conv_wsplit(weight, False, 2), bias, weight.shape[0], bn, want_stats, amax)
-
-    def conv3d_igemm_split_bnact(self, x, wts, bias, co, bn, want_stats, amax):
-        """The implicit-GEMM launch alone (pre-split f16x2 weight image, amax = bnact_absmax_bits(x, bn))."""
-        b, ci, r = x.shape[0], x.shape[1], x.shape[2]
-        mean, rstd, gamma, beta, slope = self._bn_args(bn, ci)
-        y = torch.empty((b, co, r, r, r), dtype=torch.float32, device=x.device)
-        part = None
-        if want_stats:
-            part = torch.empty((co, self.lib.pvcnn_conv3d_fwd_split_stats_parts(b, co, r, 2), 2), dtype=torch.float32, device=x.device)
-        with _Launch(x) as s:
-            _lib.check(self.lib.pvcnn_conv3d_fwd_split_bnact(_p(x), _p(wts), _p(bias) if bias is not None else None, b, ci, co, r, _p(amax),
-                                                             mean, rstd, gamma, beta, slope, _p(y), _p(part) if want_stats else None, s),
-                       'conv3d_forward_split_bnact')
-        return (y, part) if want_stats else y
-
-    def conv3d_backward_weight_f16_bnact(self, x, grad_y, x_amax, gy_amax, bn, with_bias=False):
-        """grad_w [, grad_bias] of conv3d(leaky_relu(bn(x)), w): x raw, x_amax = bnact_absmax_bits(x, bn)."""
-        _f32(x, 'x'); _f32(grad_y, 'grad_y')
-        b, ci, r = x.shape[0], x.shape[1], x.shape[2]
-        co = grad_y.shape[1]
-        _shape(self.conv3d_backward_weight_f16_serves(x) and tuple(grad_y.shape) == (b, co, r, r, r), 'conv3d_backward_weight_f16: R must be 16 or 32')
-        mean, rstd, gamma, beta, slope = self._bn_args(bn, ci)
-        x_amax = x_amax if x_amax is not None else self.bnact_absmax_bits(x, bn)
-        gy_amax = gy_amax if gy_amax is not None else self.absmax_bits(grad_y)
-        gw = torch.empty((co, ci, 3, 3, 3), dtype=torch.float32, device=x.device)
-        gb = torch.empty((co,), dtype=torch.float32, device=x.device) if with_bias else None
-        ws = self._scratch(self.lib.pvcnn_conv3d_bwd_weight_f16_workspace_bytes(b, ci, co, r), x.device)
-        with _Launch(x) as s:
-            _lib.check(self.lib.pvcnn_conv3d_bwd_weight_f16_bnact(_p(x), _p(grad_y), _p(x_amax), _p(gy_amax), mean, rstd, gamma, beta, slope,
-                                                                  b, ci, co, r, _p(gw), _p(gb) if with_bias else None, _p(ws), ws.numel(), s),
-                       'conv3d_backward_weight_f16_bnact')
         return (gw, gb) if with_bias else gw
 
     # ---- SharedMLP 1x1 convolutions as channel-major MFMA GEMMs (csrc/pointwise.hip) --------------------
@@ -666,17 +627,19 @@ class HipBackend:
         return wts
 
     def pwconv_gemm_split(self, x, wts, bias, m, nsplit, want_stats=False, amax=None):
-        """The GEMM launch alone: x (B,K,N), pre-split weight image (f16x2: amax = absmax_bits(x)) -> y (B,m,N) [, stats partials]."""
+        """The GEMM launch alone: x (B,K,N), pre-split weight image (f16x2: amax = pw_amax(x), or a 1-word absmax_bits(x) for the
+        single-scale mode) -> y (B,m,N) [, stats partials]."""
         b, k, n = x.shape
         y = torch.empty((b, m, n), dtype=torch.float32, device=x.device)
         part = None
         if want_stats:
             part = torch.empty((m, self.lib.pvcnn_pwconv_fwd_split_stats_parts(b, n), 2), dtype=torch.float32, device=x.device)
         if int(nsplit) == 2 and amax is None:
-            amax = self.absmax_bits(x)
+            amax = self.pw_amax(x)
+        seg = self._amax_seg(amax, b * ((n + self.PW_AMAX_SEG - 1) // self.PW_AMAX_SEG), self.PW_AMAX_SEG) if int(nsplit) == 2 else 0
         with _Launch(x) as s:
             _lib.check(self.lib.pvcnn_pwconv_fwd_split(_p(x), _p(wts), _p(bias) if bias is not None else None, b, k, m, n, int(nsplit),
-                                                       _p(amax) if amax is not None else None,
+                                                       _p(amax) if amax is not None else None, seg,
                                                        _p(y), _p(part) if want_stats else None, s), 'pwconv_forward_split')
         return (y, part) if want_stats else y
 
@@ -726,10 +689,13 @@ class HipBackend:
     # ---- BatchNorm + ReLU/LeakyReLU in two passes each way (csrc/bnact.hip) ---------------------------
     has_bnact = True
 
-    def bnact_forward(self, x, gamma, beta, running_mean, running_var, training, momentum, eps, slope, stats=None):
+    BNACT_AMAX_MAX_SEG = 256   # the apply passes emit amax buffers for segments up to this long
+
+    def bnact_forward(self, x, gamma, beta, running_mean, running_var, training, momentum, eps, slope, stats=None, amax_seg=0):
         """x (B,C,S) -> (y, mean, rstd).  Training: batch statistics (running stats updated in place);
         eval: running statistics.  stats = (mean, rstd) already known (from a convolution epilogue +
-        bn_finalize): only the normalise + activate pass runs."""
+        bn_finalize): only the normalise + activate pass runs.
+        amax_seg > 0: -> (y, mean, rstd, y_amax), y's amax buffer with segments of amax_seg positions emitted by the apply pass."""
         _f32(x, 'x')
         b, c, s3 = x.shape
         dev = x.device
@@ -745,13 +711,16 @@ class HipBackend:
             rstd = torch.rsqrt(running_var + eps)
         ws = self._scratch(self.lib.pvcnn_bnact_workspace_bytes(b, c, s3), dev)
         nul = ctypes.c_void_p(None)
+        amax_seg = int(amax_seg)
+        y_amax = (torch.empty((self.lib.pvcnn_absmax_tiles_count(b, s3, amax_seg),), dtype=torch.int32, device=dev) if amax_seg > 0 else None)
         with _Launch(x) as s:
             _lib.check(self.lib.pvcnn_bnact_fwd(_p(x), _p(gamma) if gamma is not None else nul, _p(beta) if beta is not None else nul,
                                                 _p(running_mean) if (training and running_mean is not None) else nul,
                                                 _p(running_var) if (training and running_var is not None) else nul,
                                                 b, c, s3, float(eps), float(momentum), float(slope), int(bool(training)),
-                                                _p(mean), _p(rstd), _p(y), _p(ws), ws.numel(), s), 'bnact_forward')
-        return y, mean, rstd
+                                                _p(mean), _p(rstd), _p(y), _p(y_amax) if amax_seg > 0 else nul, amax_seg,
+                                                _p(ws), ws.numel(), s), 'bnact_forward')
+        return (y, mean, rstd, y_amax) if amax_seg > 0 else (y, mean, rstd)
 
     has_devox_bnact = True
 
@@ -817,13 +786,8 @@ class HipBackend:
                 'trilinear_devoxelize_bnact_forward')
         return [outs, inds, wgts]
 
-    # bnact_backward(..., want_amax=True) -> (gx, ggamma, gbeta, absmax_bits(gx)): the maximum rides on the apply pass.
-    # OPT-IN (PVCNN_BWD_AMAX=1): it removes 15 of the step's 22 absmax passes (0.41 -> 0.15 ms/step) but the apply kernel slows
-    # from 35 to 44 us per launch (the block reduction's barrier waits for the streaming stores) -- no net gain yet
-    # (profiles/r02_fold_ab.md).
-    has_bnact_bwd_absmax = os.environ.get('PVCNN_BWD_AMAX', '0') == '1'
-
-    def bnact_backward(self, x, grad_y, gamma, beta, mean, rstd, slope, training, want_amax=False):
+    def bnact_backward(self, x, grad_y, gamma, beta, mean, rstd, slope, training, amax_seg=0):
+        """-> (grad_x, grad_gamma, grad_beta [, grad_x's amax buffer with segments of amax_seg positions, emitted by the apply pass])."""
         _f32(x, 'x')
         gy_bstride = _f32_rows(grad_y, 'grad_y')
         b, c, s3 = x.shape
@@ -833,19 +797,14 @@ class HipBackend:
         gb = torch.empty((c,), dtype=torch.float32, device=dev)
         ws = self._scratch(self.lib.pvcnn_bnact_workspace_bytes(b, c, s3), dev)
         nul = ctypes.c_void_p(None)
-        if want_amax:
-            amax = torch.empty((1,), dtype=torch.int32, device=dev)
-            with _Launch(x) as s:
-                _lib.check(self.lib.pvcnn_bnact_bwd_absmax(_p(x), _p(grad_y), gy_bstride, _p(gamma) if gamma is not None else nul,
-                                                           _p(beta) if beta is not None else nul, _p(mean), _p(rstd), b, c, s3, float(slope),
-                                                           int(bool(training)), _p(gx), _p(gg), _p(gb), _p(amax), _p(ws), ws.numel(), s),
-                           'bnact_backward')
-            return gx, gg, gb, amax
+        amax_seg = int(amax_seg)
+        gx_amax = (torch.empty((self.lib.pvcnn_absmax_tiles_count(b, s3, amax_seg),), dtype=torch.int32, device=dev) if amax_seg > 0 else None)
         with _Launch(x) as s:
             _lib.check(self.lib.pvcnn_bnact_bwd_strided(_p(x), _p(grad_y), gy_bstride, _p(gamma) if gamma is not None else nul,
-                                                _p(beta) if beta is not None else nul, _p(mean), _p(rstd), b, c, s3, float(slope),
-                                                int(bool(training)), _p(gx), _p(gg), _p(gb), _p(ws), ws.numel(), s), 'bnact_backward')
-        return gx, gg, gb
+                                                        _p(beta) if beta is not None else nul, _p(mean), _p(rstd), b, c, s3, float(slope),
+                                                        int(bool(training)), _p(gx), _p(gg), _p(gb),
+                                                        _p(gx_amax) if amax_seg > 0 else nul, amax_seg, _p(ws), ws.numel(), s), 'bnact_backward')
+        return (gx, gg, gb, gx_amax) if amax_seg > 0 else (gx, gg, gb)
 
 
 _backend = HipBackend()

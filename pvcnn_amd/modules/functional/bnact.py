@@ -29,24 +29,45 @@ def _rows(t, shape):
     return t.contiguous().view(shape[0], shape[1], -1)
 
 
-def _bnact_backward(x3, g3, w, b, mean, rstd, slope, training, shape):
-    """native bnact_backward -> (grad_x viewed as `shape`, grad_gamma, grad_beta); the apply pass also leaves max |grad_x| on the
-    returned tensor (_cache.tag_absmax) for the f16x2 backward products of the convolution in front of this BatchNorm."""
+def _amax_seg_for(shape, is_cuda):
+    """Segment length of the amax buffer (include/pvcnn_hip.h) the convolution NEXT TO a BatchNorm over a tensor of `shape` wants of
+    that tensor, or 0: a cubic voxel grid (B,C,R,R,R) feeds / is fed by a 3x3x3 convolution in f16x2 arithmetic -> one z row (R);
+    point features (B,C,N) / (B,C,M,U) a 1x1 GEMM -> its 256-point tile.  0 when that arithmetic is off (no table is needed)."""
     be = native()
-    if x3.is_cuda and getattr(be, 'has_bnact_bwd_absmax', False):
-        gx, gw, gb, amax = be.bnact_backward(x3, g3, w, b, mean, rstd, slope, training, want_amax=True)
-        return _cache.tag_absmax(gx.view(shape), amax), gw, gb
+    if not is_cuda or torch.is_autocast_enabled():
+        return 0
+    cap = getattr(be, 'BNACT_AMAX_MAX_SEG', 0)
+    if len(shape) == 5 and shape[2] == shape[3] == shape[4]:
+        ok = getattr(be, 'has_conv3d_split', False) and getattr(be, 'conv_math', '') == 'f16x2'
+        return int(shape[2]) if ok and shape[2] <= cap else 0
+    if len(shape) in (3, 4):
+        ok = getattr(be, 'has_pwconv_split', False) and getattr(be, 'pw_math', '') == 'f16x2'
+        seg = getattr(be, 'PW_AMAX_SEG', 0)
+        return seg if ok and 0 < seg <= cap else 0
+    return 0
+
+
+def _bnact_backward(x3, g3, w, b, mean, rstd, slope, training, shape):
+    """native bnact_backward -> (grad_x viewed as `shape`, grad_gamma, grad_beta); the apply pass also leaves grad_x's amax buffer
+    on the returned tensor (_cache.tag_amax) for the f16x2 backward products of the convolution in front of this BatchNorm."""
+    be = native()
+    seg = _amax_seg_for(shape, x3.is_cuda)
+    if seg:
+        gx, gw, gb, amax = be.bnact_backward(x3, g3, w, b, mean, rstd, slope, training, amax_seg=seg)
+        return _cache.tag_amax(gx.view(shape), seg, amax), gw, gb
     gx, gw, gb = be.bnact_backward(x3, g3, w, b, mean, rstd, slope, training)
     return gx.view(shape), gw, gb
 
 
-__all__ = ['batch_norm_act', 'batch_norm_act_conv3d', 'batch_norm_act_devoxelize', 'fusable_tail', 'run_layers']
+__all__ = ['batch_norm_act', 'batch_norm_act_devoxelize', 'fusable_tail', 'run_layers']
 
 
 class BatchNormAct(Function):
     @staticmethod
     @amp_fwd
-    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, slope, stats_part=None, stats_shift=None):
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, slope, stats_part=None, stats_shift=None,
+                amax_seg=0):
+        """-> y, or (y, y's amax buffer) when amax_seg > 0 (second output: not differentiable)."""
         shape = x.shape
         x3 = x.contiguous().view(shape[0], shape[1], -1)
         w = weight.contiguous() if weight is not None else None
@@ -54,19 +75,28 @@ class BatchNormAct(Function):
         stats = None
         if training and stats_part is not None:   # partial sums from the producing convolution's epilogue
             stats = native().bn_finalize(stats_part, x3.shape[0] * x3.shape[2], running_mean, running_var, momentum, eps, stats_shift)
+        ctx.slope, ctx.training, ctx.shape = slope, training, shape
+        if amax_seg:
+            y, mean, rstd, amax = native().bnact_forward(x3, w, b, running_mean, running_var, training, momentum, eps, slope, stats=stats,
+                                                         amax_seg=amax_seg)
+            ctx.save_for_backward(x3, w, b, mean, rstd)
+            ctx.mark_non_differentiable(amax)
+            ctx.set_materialize_grads(False)
+            return y.view(shape), amax
         y, mean, rstd = native().bnact_forward(x3, w, b, running_mean, running_var, training, momentum, eps, slope, stats=stats)
         ctx.save_for_backward(x3, w, b, mean, rstd)
-        ctx.slope, ctx.training, ctx.shape = slope, training, shape
         return y.view(shape)
 
     @staticmethod
     @amp_bwd
-    def backward(ctx, grad_y):
+    def backward(ctx, grad_y, grad_amax=None):
+        if grad_y is None:
+            return (None,) * 12
         x3, w, b, mean, rstd = ctx.saved_tensors
         g3 = _rows(grad_y, ctx.shape)
         gx, gw, gb = _bnact_backward(x3, g3, w, b, mean, rstd, ctx.slope, ctx.training, ctx.shape)
         return (gx, gw if w is not None else None, gb if b is not None else None,
-                None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None)
 
 
 def _bn_mode(bn):
@@ -96,6 +126,11 @@ def batch_norm_act(x, bn, slope, stats_part=None):
     stats_part: (per-workgroup partial sums of x - shift written by the convolution that produced x, shift = its bias)."""
     use_batch_stats, momentum, rm, rv = _bn_mode(bn)
     part, shift = _split(stats_part)
+    # the apply pass emits the f16x2 scale table of what it writes for the convolution that (usually) consumes it
+    seg = _amax_seg_for(x.shape, x.is_cuda) if x.dtype == torch.float32 else 0
+    if seg:
+        y, amax = BatchNormAct.apply(x, bn.weight, bn.bias, rm, rv, use_batch_stats, momentum, bn.eps, slope, part, shift, seg)
+        return _cache.tag_amax(y, seg, amax)
     return BatchNormAct.apply(x, bn.weight, bn.bias, rm, rv, use_batch_stats, momentum, bn.eps, slope, part, shift)
 
 
@@ -149,20 +184,12 @@ def batch_norm_act_devoxelize(grid, coords, bn, slope, resolution, is_training, 
                                         resolution, is_training, part, shift, addend)
 
 
-def batch_norm_act_conv3d(x, bn, slope, conv_weight, conv_bias, stats_part=None, want_stats=False):
-    """conv3d(act(bn(x)), conv_weight) + conv_bias with the BatchNorm + activation folded into the convolution's staging
-    (functional.conv3d.BnActVoxelConv3d); -> y or (y, stats partials of y)."""
-    from .conv3d import bnact_voxel_conv3d
-    use_batch_stats, momentum, rm, rv = _bn_mode(bn)
-    part, shift = _split(stats_part)
-    return bnact_voxel_conv3d(x, bn.weight, bn.bias, rm, rv, use_batch_stats, momentum, bn.eps, slope, part, shift,
-                              conv_weight, conv_bias, want_stats)
-
-
 def fusable_tail(layers, x):
     """If the nn.Sequential ends in (BatchNorm, ReLU|LeakyReLU) and the GPU path can fuse that pair into the
     devoxelize gather for tensor x (the Sequential's INPUT: same device / dtype), return (bn, slope)."""
     mods = list(layers)
+    if _has_hooks(layers) or any(_has_hooks(m) for m in mods):   # hooks only fire through __call__: run module by module then
+        return None
     if (len(mods) >= 2 and x.is_cuda and x.dtype == torch.float32 and getattr(native(), 'has_devox_bnact', False)
             and isinstance(mods[-2], nn.modules.batchnorm._BatchNorm) and _slope(mods[-1]) is not None
             and not torch.is_autocast_enabled()):
@@ -230,20 +257,6 @@ def run_layers(layers, x, stop=None, tail_stats=False):
             else:
                 x = res
             i += 1
-        elif (fuse and isinstance(m, nn.modules.batchnorm._BatchNorm) and i + 2 < len(mods) and _slope(mods[i + 1]) is not None
-                and hasattr(mods[i + 2], 'forward_bnact_folded') and x.numel() > 0 and mods[i + 2].can_fold_bnact(x)):
-            # (BatchNorm3d, LeakyReLU, Conv3d): the convolution normalises and activates while it stages its input --
-            # the activated grid is neither written nor read back (modules/pvconv.py:21-23 folded into :23's successor)
-            conv = mods[i + 2]
-            after = all_mods[i + 3] if i + 3 < len(all_mods) else None
-            want2 = _wants_batch_stats(after)
-            res = conv.forward_bnact_folded(x, m, _slope(mods[i + 1]), carried, want2)
-            if want2:
-                x, part = res
-                part = (part, conv.bias)
-            else:
-                x = res
-            i += 3
         elif (fuse and isinstance(m, nn.modules.batchnorm._BatchNorm) and i + 1 < len(mods) and x.dim() >= 3
                 and x.dtype == torch.float32 and _slope(mods[i + 1]) is not None and x.numel() > 0):
             x = batch_norm_act(x, m, _slope(mods[i + 1]), stats_part=carried)

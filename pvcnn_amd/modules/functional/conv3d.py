@@ -1,15 +1,17 @@
 """voxel_conv3d: the 3x3x3, stride-1, padding-1 convolution of PVConv.voxel_layers.
 
-The reference calls nn.Conv3d (cuDNN) here (modules/pvconv.py:20-27).  On gfx950 the three GEMMs
-(forward, backward-data, backward-weight) run on the fp32-MFMA implicit-GEMM kernels of
-csrc/conv3d.hip; gradients w.r.t. the bias are a plain reduction."""
+The reference calls nn.Conv3d (cuDNN) here (modules/pvconv.py:20-27).  On gfx950 the three GEMMs (forward, backward-data,
+backward-weight) run on hand-written implicit-GEMM kernels: by default in "f16x2" arithmetic on the fp16 matrix cores (fp32
+tensors, operands split into scaled fp16 hi + lo, fp32 accumulation: csrc/conv3d_bf16.hip, conv3d_wgrad_f16.hip), plain bf16
+operands under torch.autocast, exact fp32 MFMA (csrc/conv3d.hip) with PVCNN_CONV_MATH=fp32 and for the grids the f16x2
+backward-weight kernel does not serve.  The bias gradient rides on the backward-weight kernel."""
 import torch
 from torch.autograd import Function
 
 from . import _cache
 from ._autograd import native, amp_fwd, amp_bwd
 
-__all__ = ['voxel_conv3d', 'conv_nsplit', 'bnact_voxel_conv3d']
+__all__ = ['voxel_conv3d', 'conv_nsplit']
 
 
 def conv_nsplit():
@@ -29,15 +31,20 @@ class VoxelConv3d(Function):
     @staticmethod
     @amp_fwd
     def forward(ctx, x, weight, bias, want_stats=False, nsplit=0):
-        x = x.contiguous()
+        given, x = x, x.contiguous()
         weight = weight.contiguous()
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         ctx.nsplit = int(nsplit)
         b = bias.contiguous() if bias is not None else None
         be = native()
-        # f16x2: the input's max |x| (its power-of-two scale) is measured once and reused by backward-weight
-        ctx.x_amax = be.absmax_bits(x) if ctx.nsplit == 2 else None
+        # f16x2: the input's amax buffer (its power-of-two scales, one per z row) -- left on the tensor by the BatchNorm pass that
+        # wrote it (_cache.tag_amax), else measured here in one read -- is reused by backward-weight
+        ctx.x_amax = None
+        if ctx.nsplit == 2:
+            ctx.x_amax = _cache.amax_of(given, x.shape[2])
+            if ctx.x_amax is None:
+                ctx.x_amax = be.conv_amax(x)
         kw = {'amax': ctx.x_amax} if ctx.nsplit == 2 else {}
         if want_stats:   # second output: BatchNorm partial sums from the epilogue (not differentiable)
             y, part = (be.conv3d_forward_split(x, weight, b, ctx.nsplit, want_stats=True, **kw) if ctx.nsplit
@@ -57,8 +64,12 @@ class VoxelConv3d(Function):
         be = native()
         f16 = ctx.nsplit == 2
         wgrad_f16 = f16 and ctx.needs_input_grad[1] and be.conv3d_backward_weight_f16_serves(x)
-        # shared by both products; the BatchNorm backward that produced grad_y usually left it on the tensor (_cache.tag_absmax)
-        g_amax = _cache.absmax_of(received, lambda: be.absmax_bits(grad_y)) if f16 and (ctx.needs_input_grad[0] or wgrad_f16) else None
+        # shared by both products; the BatchNorm backward that produced grad_y left it on the tensor (_cache.tag_amax)
+        g_amax = None
+        if f16 and (ctx.needs_input_grad[0] or wgrad_f16):
+            g_amax = _cache.amax_of(received, grad_y.shape[2])
+            if g_amax is None:
+                g_amax = be.conv_amax(grad_y)
         gx = None
         if ctx.needs_input_grad[0]:
             gx = (be.conv3d_backward_data_split(grad_y, weight, ctx.nsplit, **({'amax': g_amax} if f16 else {})) if ctx.nsplit
@@ -76,73 +87,3 @@ class VoxelConv3d(Function):
 
 
 voxel_conv3d = VoxelConv3d.apply
-
-
-class BnActVoxelConv3d(Function):
-    """conv3d(leaky_relu(batch_norm(x)), weight) + bias -- voxel_layers[1..3] of PVConv (modules/pvconv.py:20-27) as ONE node: the
-    BatchNorm3d + LeakyReLU between the two convolutions is applied by the second convolution while it stages its input (forward
-    and backward-weight), so the activated grid is never written or read back.  x is the first convolution's raw
-    output; its batch statistics come from that convolution's epilogue (stats_part).  f16x2 arithmetic; bit-identical to the
-    unfused BatchNormAct -> VoxelConv3d pair."""
-
-    @staticmethod
-    @amp_fwd
-    def forward(ctx, x, bn_weight, bn_bias, running_mean, running_var, use_batch_stats, momentum, eps, slope, stats_part, stats_shift,
-                weight, bias, want_stats=False):
-        be = native()
-        x = x.contiguous()
-        x3 = x.view(x.shape[0], x.shape[1], -1)
-        weight = weight.contiguous()
-        g = bn_weight.contiguous() if bn_weight is not None else None
-        b = bn_bias.contiguous() if bn_bias is not None else None
-        if use_batch_stats and stats_part is not None:
-            mean, rstd = be.bn_finalize(stats_part, x3.shape[0] * x3.shape[2], running_mean, running_var, momentum, eps, stats_shift)
-        elif use_batch_stats:
-            mean, rstd = be.bn_stats(x3, running_mean, running_var, momentum, eps)
-        else:
-            mean, rstd = running_mean.clone(), torch.rsqrt(running_var + eps)     # saved for backward: must not alias the live buffers
-        bn = (g, b, mean, rstd, float(slope))
-        amax = be.bnact_absmax_bits(x, bn)                       # max |act(bn(x))|: one read of x (the activation is never written)
-        cb = bias.contiguous() if bias is not None else None
-        ctx.save_for_backward(x, g, b, mean, rstd, weight, amax)
-        ctx.slope, ctx.use_batch_stats, ctx.has_bias = float(slope), bool(use_batch_stats), bias is not None
-        if want_stats:
-            y, part = be.conv3d_forward_split_bnact(x, weight, cb, bn, want_stats=True, amax=amax)
-            ctx.mark_non_differentiable(part)
-            ctx.set_materialize_grads(False)
-            return y, part
-        return be.conv3d_forward_split_bnact(x, weight, cb, bn, amax=amax)
-
-    @staticmethod
-    @amp_bwd
-    def backward(ctx, grad_y, grad_part=None):
-        none = (None,) * 14
-        if grad_y is None:
-            return none
-        x, g, b, mean, rstd, weight, x_amax = ctx.saved_tensors
-        be = native()
-        received, grad_y = grad_y, grad_y.contiguous()
-        g_amax = _cache.absmax_of(received, lambda: be.absmax_bits(grad_y))
-        bn = (g, b, mean, rstd, ctx.slope)
-        gx = gg = gb = gw = gcb = None
-        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            g_act = be.conv3d_backward_data_split(grad_y, weight, 2, amax=g_amax)          # gradient w.r.t. the activated grid
-            x3 = x.view(x.shape[0], x.shape[1], -1)
-            ga3 = g_act.view(x3.shape)
-            if getattr(be, 'has_bnact_bwd_absmax', False):
-                gx3, gg, gb, amax = be.bnact_backward(x3, ga3, g, b, mean, rstd, ctx.slope, ctx.use_batch_stats, want_amax=True)
-                gx = _cache.tag_absmax(gx3.view(x.shape), amax)
-            else:
-                gx3, gg, gb = be.bnact_backward(x3, ga3, g, b, mean, rstd, ctx.slope, ctx.use_batch_stats)
-                gx = gx3.view(x.shape)
-        want_bias = ctx.has_bias and ctx.needs_input_grad[12]
-        if ctx.needs_input_grad[11]:
-            res = be.conv3d_backward_weight_f16_bnact(x, grad_y, x_amax, g_amax, bn, with_bias=want_bias)
-            gw, gcb = res if want_bias else (res, None)
-        elif want_bias:
-            gcb = grad_y.sum(dim=(0, 2, 3, 4))
-        return (gx, gg if g is not None else None, gb if b is not None else None, None, None, None, None, None, None, None, None,
-                gw, gcb, None)
-
-
-bnact_voxel_conv3d = BnActVoxelConv3d.apply

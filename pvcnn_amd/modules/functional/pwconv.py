@@ -1,8 +1,9 @@
 """pointwise_conv: the kernel-size-1 Conv1d / Conv2d of SharedMLP (reference: modules/shared_mlp.py:9-25).
 
-The reference calls nn.Conv1d / nn.Conv2d (cuDNN / cuBLAS).  On gfx950 the three GEMMs (forward,
-backward-data, backward-weight + bias gradient) run on the fp32-MFMA kernels of csrc/pointwise.hip, directly
-on the channel-major (B, C, N) tensors."""
+The reference calls nn.Conv1d / nn.Conv2d (cuDNN / cuBLAS).  On gfx950 the three GEMMs (forward, backward-data,
+backward-weight + bias gradient) run directly on the channel-major (B, C, N) tensors: the large ones (>= 4.3 G multiply-adds)
+in "f16x2" arithmetic on the fp16 matrix cores (csrc/pointwise_bf16.hip, pointwise_wgrad_f16.hip: fp32 tensors, operands split
+into scaled fp16 hi + lo, fp32 accumulation), the small, launch-bound ones on the fp32-MFMA kernels of csrc/pointwise.hip."""
 from torch.autograd import Function
 
 from . import _cache
@@ -26,7 +27,11 @@ class PointwiseConv(Function):
         ctx.split = getattr(be, 'PW_NSPLIT', {}).get(getattr(be, 'pw_math', 'fp32'), 0) if getattr(be, 'has_pwconv_split', False) else 0
         if ctx.split and w2.shape[0] * w2.shape[1] * x3.shape[0] * x3.shape[2] < getattr(be, 'pw_split_min_macs', 0):
             ctx.split = 0      # small GEMMs are launch-bound: the weight split and the absmax pass would cost more than they save
-        ctx.x_amax = be.absmax_bits(x3) if ctx.split == 2 else None
+        ctx.x_amax = None
+        if ctx.split == 2:     # the input's amax buffer (one scale per 256-point tile): left on it by its producer, else one read
+            ctx.x_amax = _cache.amax_of(x, be.PW_AMAX_SEG)
+            if ctx.x_amax is None:
+                ctx.x_amax = be.pw_amax(x3)
         akw = {'amax': ctx.x_amax} if ctx.split == 2 else {}
         run = (lambda **kw: be.pwconv_forward_split(x3, w2, b, ctx.split, **akw, **kw)) if ctx.split else (lambda **kw: be.pwconv_forward(x3, w2, b, **kw))
         if want_stats:   # second output: BatchNorm partial sums from the epilogue (not differentiable)
@@ -46,8 +51,12 @@ class PointwiseConv(Function):
         be = native()
         f16 = ctx.split == 2
         wgrad_f16 = f16 and ctx.needs_input_grad[1] and be.pwconv_backward_weight_f16_serves(x3)
-        # shared by both products; the BatchNorm backward that produced grad_y usually left it on the tensor (_cache.tag_absmax)
-        g_amax = _cache.absmax_of(grad_y, lambda: be.absmax_bits(g3)) if f16 and (ctx.needs_input_grad[0] or wgrad_f16) else None
+        # shared by both products; the BatchNorm backward that produced grad_y left it on the tensor (_cache.tag_amax)
+        g_amax = None
+        if f16 and (ctx.needs_input_grad[0] or wgrad_f16):
+            g_amax = _cache.amax_of(grad_y, be.PW_AMAX_SEG)
+            if g_amax is None:
+                g_amax = be.pw_amax(g3)
         gx = None
         if ctx.needs_input_grad[0]:
             gx = (be.pwconv_backward_data_split(g3, w2, ctx.split, **({'amax': g_amax} if f16 else {})) if ctx.split

@@ -13,7 +13,7 @@ import torch.nn as nn
 
 from . import functional as F
 from .functional._autograd import native
-from .functional.bnact import batch_norm_act_conv3d, batch_norm_act_devoxelize, fusable_tail, run_layers
+from .functional.bnact import batch_norm_act_devoxelize, fusable_tail, run_layers
 from .functional.conv3d import conv_nsplit, voxel_conv3d
 from .se import SE3d
 from .shared_mlp import SharedMLP
@@ -23,8 +23,8 @@ __all__ = ['PVConv']
 
 
 class _VoxelConv3d(nn.Conv3d):
-    """nn.Conv3d (same parameters, same state_dict keys) whose 3x3x3 / stride 1 / padding 1 case on
-    the GPU runs the fp32-MFMA implicit-GEMM kernels instead of the vendor library."""
+    """nn.Conv3d (same parameters, same state_dict keys) whose 3x3x3 / stride 1 / padding 1 case on the GPU runs this package's
+    implicit-GEMM kernels (functional/conv3d.py: f16x2 on the fp16 matrix cores by default) instead of the vendor library."""
 
     def forward(self, x):
         fast = (x.is_cuda and getattr(native(), 'has_conv3d', False) and self.kernel_size == (3, 3, 3)
@@ -46,22 +46,6 @@ class _VoxelConv3d(nn.Conv3d):
         if not fast:
             return self.forward(x)
         return voxel_conv3d(x, self.weight, self.bias, True, conv_nsplit())
-
-
-    def can_fold_bnact(self, x):
-        """True when (BatchNorm3d, LeakyReLU) in front of this convolution can be applied inside its staging for input x: the
-        3x3x3 fast path in f16x2 arithmetic on a grid the f16x2 backward-weight kernel serves, outside autocast."""
-        be = native()
-        return (x.is_cuda and getattr(be, 'has_conv3d_bnact_fold', False) and getattr(be, 'has_conv3d', False)
-                and self.kernel_size == (3, 3, 3) and self.stride == (1, 1, 1) and self.padding == (1, 1, 1)
-                and self.dilation == (1, 1, 1) and self.groups == 1 and self.padding_mode == 'zeros' and x.dim() == 5
-                and x.shape[2] == x.shape[3] == x.shape[4] and x.dtype == torch.float32 and self.weight.dtype == torch.float32
-                and x.shape[1] == self.in_channels and not torch.is_autocast_enabled() and conv_nsplit() == 2
-                and be.conv3d_backward_weight_f16_serves(x))
-
-    def forward_bnact_folded(self, x, bn, slope, stats_part, want_stats):
-        """self(leaky_relu(bn(x))) [, BatchNorm partial sums of the result]: see functional.bnact.batch_norm_act_conv3d."""
-        return batch_norm_act_conv3d(x, bn, slope, self.weight, self.bias, stats_part=stats_part, want_stats=want_stats)
 
 
 class PVConv(nn.Module):

@@ -270,3 +270,113 @@ def test_frustum_segmentation_train_gradients_match_the_oracle_stack(hip, oracle
         return {'features': feats, 'one_hot_vectors': in0['one_hot_vectors'].to(dev, dtype)}, feats, y0.to(dev)
 
     _check_network('Frustum-PVCNN segmentation net (R=16,16,12,12)', build, make, tf.cross_entropy, oracle, 2e-2)
+
+
+@contextlib.contextmanager
+def count_native_calls(names):
+    """Count calls of the product backend's methods `names` (instance-level wrappers on the live HipBackend object)."""
+    from pvcnn_amd.modules.functional import backend as seam
+    be, counts = seam._backend, {n: 0 for n in names}
+    for n in names:
+        orig = getattr(be, n)
+
+        def wrapped(*a, _o=orig, _n=n, **kw):
+            counts[_n] += 1
+            return _o(*a, **kw)
+        setattr(be, n, wrapped)
+    try:
+        yield counts
+    finally:
+        for n in names:
+            delattr(be, n)
+
+
+def test_full_width_cfg2_step_runs_the_default_arithmetic_and_matches_the_oracle_stack(hip, oracle):
+    """BASELINE configs[1] AS BENCHED: PVCNN 1xC, B = 16, N = 4096 (dropout 0), one train step.  At this size -- and only at this
+    size -- the SharedMLP GEMMs cross `pw_split_min_macs` and take the f16x2 kernels (forward, backward-data, backward-weight) through
+    autograd, with the absmax hand-over (`x_amax` saved in ctx, the gradient's tagged maximum); the call counter proves those
+    routes ran.  Same criteria as the reduced-width networks: loss to 1e-5 against the fp32 oracle stack and the fp64 truth; every
+    gradient within max(4 x the oracle stack's own distance from the truth, 1/sqrt(B*N)) of the truth."""
+    from pvcnn_amd import workload
+    x0, y0 = workload.make_s3dis_batch(16, 4096)
+
+    def make(dev, dtype):
+        x = x0.clone().to(dev, dtype).requires_grad_()
+        return x, x, y0.to(dev)
+
+    watched = ['pwconv_gemm_split', 'pwconv_backward_weight_f16', 'pwconv_forward', 'conv3d_igemm_split', 'conv3d_backward_weight_f16',
+               'trilinear_devoxelize_bnact_forward', 'avg_voxelize_apply', 'trilinear_devoxelize_backward_apply']
+    with count_native_calls(watched) as calls:
+        res = _run_three(lambda: workload.PVCNN(13, 6, width_multiplier=1), make, tf.cross_entropy, oracle, pin_winners=True)
+    print(f'[train parity] full-width cfg2 native calls: {calls}')
+    # forward 128->1024, 1472->512 (+ 512->256 if above the threshold) and their backward-data launches; three f16x2 weight gradients
+    assert calls['pwconv_gemm_split'] >= 4 and calls['pwconv_backward_weight_f16'] >= 2, calls
+    assert calls['conv3d_igemm_split'] >= 15 and calls['conv3d_backward_weight_f16'] == 8, calls
+    assert calls['trilinear_devoxelize_bnact_forward'] == 4 and calls['avg_voxelize_apply'] == 4 and calls['trilinear_devoxelize_backward_apply'] == 4, calls
+    rows = _report('PVCNN 1xC B=16 N=4096 (cfg2 as benched) [max-pool winners pinned]', *res)
+    (lg, _), (lc, _), (lt, _) = res
+    assert abs(lg - lt) <= TOL_LOSS * max(abs(lt), 1.0) and abs(lg - lc) <= TOL_LOSS * max(abs(lc), 1.0), (lg, lc, lt)
+    worst_cpu = max(c for _, _, _, c in rows)
+    bound = max(NET_FACTOR * worst_cpu, 1.0 / (16 * 4096) ** 0.5)
+    bad = [(k, b) for k, _, b, _ in rows if b > bound]
+    assert not bad, f'beyond {bound:.1e} of the fp64 truth: {bad[:6]}'
+    med = sorted(b for _, _, b, _ in rows)[len(rows) // 2]
+    print(f'[train parity] full-width cfg2: median over tensors of hip-vs-truth {med:.2e}; bound used {bound:.1e}')
+
+
+# bf16 operands keep 8 bits: 2^-9 = 2e-3 relative per rounded operand; through 8 bf16 convolutions + BatchNorms the measured
+# distances are recorded by the test (printed) and asserted against these stated bounds
+BF16_LOSS_TOL = 2e-2
+BF16_GRAD_TOL = 0.15          # per tensor, relative to the tensor's largest entry (worst tensor)
+BF16_GRAD_MEDIAN = 4e-2       # median over the tensors
+
+
+def test_frustum_segmentation_train_step_under_bf16_autocast(hip, oracle):
+    """BASELINE configs[4]'s mode: the Frustum-PVCNN segmentation net (every PVConv of that model: R = 16, 16, 12, 12) under
+    torch.autocast(bfloat16) -- Conv3d on bf16 MFMA operands with fp32 accumulation -- one train step against the fp32 oracle
+    stack and the fp64 truth.  The reference has no reduced-precision path: the tolerance is the stated bf16 one."""
+    from pvcnn_amd import workload
+    from truth_backend import TruthBackend
+    in0, y0 = workload.make_frustum_batch(8, 1024)
+
+    def build():
+        return workload.FrustumPVCNNE(3, 12, 8, 128, workload.frustum_size_templates(), 1, 0.5).inst_seg_net
+
+    torch.manual_seed(11)
+    cpu_net = _no_dropout(build()).train()
+    state = {k: v.clone() for k, v in cpu_net.state_dict().items()}
+    gpu_net = _no_dropout(build())
+    gpu_net.load_state_dict(state)
+    gpu_net = gpu_net.to(DEV).train()
+    f64_net = _no_dropout(build())
+    f64_net.load_state_dict(state)
+    f64_net = f64_net.double().train()
+
+    def make(dev, dtype):
+        feats = in0['features'].clone().to(dev, dtype).requires_grad_()
+        return {'features': feats, 'one_hot_vectors': in0['one_hot_vectors'].to(dev, dtype)}, feats, y0.to(dev)
+
+    with cpu_stack(TruthBackend(oracle)):
+        inp, leaf, tgt = make('cpu', torch.float64)
+        loss_t = tf.cross_entropy(f64_net(inp), tgt)
+        loss_t.backward()
+    res_t = (loss_t.item(), _grads(f64_net, leaf))
+    with count_native_calls(['conv3d_igemm_split']) as calls:
+        inp, leaf, tgt = make(DEV, torch.float32)
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            loss_g = tf.cross_entropy(gpu_net(inp).float(), tgt)
+        loss_g.backward()
+        torch.cuda.synchronize()
+    res_g = (loss_g.item(), _grads(gpu_net, leaf))
+    assert calls['conv3d_igemm_split'] >= 15, calls            # the bf16 implicit GEMM ran (forward + backward-data of 8 convolutions)
+    with cpu_stack(oracle):
+        inp, leaf, tgt = make('cpu', torch.float32)
+        loss_c = tf.cross_entropy(cpu_net(inp), tgt)
+        loss_c.backward()
+    res_c = (loss_c.item(), _grads(cpu_net, leaf))
+    rows = _report('Frustum-PVCNN segmentation net under autocast(bf16)', res_g, res_c, res_t)
+    assert abs(res_g[0] - res_t[0]) <= BF16_LOSS_TOL * max(abs(res_t[0]), 1.0), (res_g[0], res_t[0])
+    errs = sorted(b for _, _, b, _ in rows)
+    print(f'[train parity] bf16 autocast: loss rel err {abs(res_g[0] - res_t[0]) / max(abs(res_t[0]), 1.0):.2e}; '
+          f'per-tensor hip-vs-truth median {errs[len(errs) // 2]:.2e} worst {errs[-1]:.2e}')
+    assert errs[-1] <= BF16_GRAD_TOL and errs[len(errs) // 2] <= BF16_GRAD_MEDIAN, (errs[len(errs) // 2], errs[-1])

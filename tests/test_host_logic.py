@@ -105,149 +105,154 @@ def test_coordinate_memo_survives_a_weakref_callback_inside_its_own_critical_sec
     assert done.is_set(), 'memo() deadlocked against its own weak-reference callback'
 
 
-# ---- the folded (BatchNorm3d, LeakyReLU, Conv3d) autograd node, wired to a torch stand-in of the native entry points ----------
-class _FoldStandIn:
-    """The native calls BnActVoxelConv3d makes, evaluated with torch on the CPU: what is under test is the node's WIRING
-    (argument order, saved tensors, which gradient goes where), not the kernels (tests/test_gpu_fold.py)."""
-    has_bnact_bwd_absmax = True
+# ---- the f16x2 scale tables ("amax buffers") travel from the BatchNorm pass that writes a tensor to the convolution that reads it ----
+class _AmaxStandIn:
+    """The native calls of BatchNormAct / VoxelConv3d evaluated with torch on the CPU: what is under test is the WIRING -- the
+    BatchNorm apply passes (forward and backward) emit the amax buffer of what they write, the tag rides on the tensor object,
+    and the neighbouring convolution picks it up instead of measuring the tensor again."""
+    has_conv3d_split = True
+    conv_math = 'f16x2'
+    CONV_NSPLIT = {'f16x2': 2}
+    BNACT_AMAX_MAX_SEG = 256
+    PW_AMAX_SEG = 256
 
     def __init__(self):
-        self.calls = []
+        self.calls, self.emitted = [], []
 
     @staticmethod
-    def _act(x, bn):
+    def _table(x3, seg):
         import torch
-        g, b, mean, rstd, slope = bn
-        c = x.shape[1]
-        shape = (1, c) + (1,) * (x.dim() - 2)
-        scale = (g if g is not None else torch.ones(c)) * rstd
-        shift = (b if b is not None else torch.zeros(c)) - mean * scale
-        z = x * scale.view(shape) + shift.view(shape)
-        return torch.where(z > 0, z, z * slope)
+        b, c, n = x3.shape
+        nseg = (n + seg - 1) // seg
+        pad = torch.zeros(b, c, nseg * seg)
+        pad[:, :, :n] = x3.abs()
+        rows = pad.view(b, c, nseg, seg).amax(dim=(1, 3)).reshape(-1)
+        return torch.cat([rows.max().reshape(1), rows]).view(torch.int32)
 
-    @staticmethod
-    def _bits(t):
-        import torch
-        return t.abs().max().reshape(1).view(torch.int32)
+    def conv_amax(self, x):
+        self.calls.append('conv_amax')
+        return self._table(x.reshape(x.shape[0], x.shape[1], -1), x.shape[2])
 
-    def bn_stats(self, x3, rm, rv, momentum, eps):
+    def bnact_forward(self, x3, w, b, rm, rv, training, momentum, eps, slope, stats=None, amax_seg=0):
         import torch
-        self.calls.append('bn_stats')
         mean = x3.mean(dim=(0, 2))
         var = x3.var(dim=(0, 2), unbiased=False)
-        if rm is not None:
-            n = x3.shape[0] * x3.shape[2]
-            rm.mul_(1 - momentum).add_(momentum * mean)
-            rv.mul_(1 - momentum).add_(momentum * var * n / (n - 1))
-        return mean, torch.rsqrt(var + eps)
+        rstd = torch.rsqrt(var + eps)
+        z = (x3 - mean.view(1, -1, 1)) * (rstd * w).view(1, -1, 1) + b.view(1, -1, 1)
+        y = torch.where(z > 0, z, z * slope)
+        if amax_seg:
+            self.emitted.append(self._table(y, amax_seg))
+            return y, mean, rstd, self.emitted[-1]
+        return y, mean, rstd
 
-    def absmax_bits(self, x):
-        self.calls.append('absmax_bits')
-        return self._bits(x)
-
-    def bnact_absmax_bits(self, x, bn):
-        self.calls.append('bnact_absmax_bits')
-        return self._bits(self._act(x, bn))
-
-    def conv3d_forward_split_bnact(self, x, weight, bias, bn, want_stats=False, amax=None):
+    def bnact_backward(self, x3, g3, w, b, mean, rstd, slope, training, amax_seg=0):
         import torch
-        assert amax is not None and torch.equal(amax, self._bits(self._act(x, bn)))
-        y = torch.nn.functional.conv3d(self._act(x, bn), weight, bias, padding=1)
-        if want_stats:
-            return y, torch.zeros(weight.shape[0], 1, 2)
-        return y
-
-    def conv3d_backward_data_split(self, grad_y, weight, nsplit, amax=None):
-        import torch
-        assert nsplit == 2 and torch.equal(amax, self._bits(grad_y))
-        b, _, r = grad_y.shape[:3]
-        return torch.nn.grad.conv3d_input((b, weight.shape[1], r, r, r), weight, grad_y, padding=1)
-
-    def conv3d_backward_weight_f16_bnact(self, x, grad_y, x_amax, gy_amax, bn, with_bias=False):
-        import torch
-        assert torch.equal(x_amax, self._bits(self._act(x, bn))) and torch.equal(gy_amax, self._bits(grad_y))
-        co, ci = grad_y.shape[1], x.shape[1]
-        gw = torch.nn.grad.conv3d_weight(self._act(x, bn), (co, ci, 3, 3, 3), grad_y, padding=1)
-        return (gw, grad_y.sum(dim=(0, 2, 3, 4))) if with_bias else gw
-
-    def bnact_backward(self, x3, g3, w, b, mean, rstd, slope, training, want_amax=False):
-        import torch
-        assert training                                       # batch statistics are differentiated through
-        with torch.enable_grad():                             # (called from inside a backward pass)
+        with torch.enable_grad():
             xr = x3.detach().clone().requires_grad_()
-            wr = w.detach().clone().requires_grad_()
-            br = b.detach().clone().requires_grad_()
+            wr, br = w.detach().clone().requires_grad_(), b.detach().clone().requires_grad_()
             m = xr.mean(dim=(0, 2), keepdim=True)
             v = xr.var(dim=(0, 2), unbiased=False, keepdim=True)
-            eps = (1.0 / rstd.view(1, -1, 1) ** 2 - v.detach())  # the eps the statistics were finalised with
+            eps = (1.0 / rstd.view(1, -1, 1) ** 2 - v.detach())
             z = (xr - m) * torch.rsqrt(v + eps) * wr.view(1, -1, 1) + br.view(1, -1, 1)
             torch.where(z > 0, z, z * slope).backward(g3)
         out = (xr.grad, wr.grad, br.grad)
-        return out + (self._bits(xr.grad),) if want_amax else out
+        if amax_seg:
+            self.emitted.append(self._table(xr.grad, amax_seg))
+            return out + (self.emitted[-1],)
+        return out
+
+    def conv3d_forward_split(self, x, weight, bias, nsplit, want_stats=False, amax=None):
+        import torch
+        assert nsplit == 2 and amax is not None and torch.equal(amax, self._table(x.reshape(x.shape[0], x.shape[1], -1), x.shape[2]))
+        self.calls.append(('fwd', amax))
+        return torch.nn.functional.conv3d(x, weight, bias, padding=1)
+
+    def conv3d_backward_data_split(self, grad_y, weight, nsplit, amax=None):
+        import torch
+        assert torch.equal(amax, self._table(grad_y.reshape(grad_y.shape[0], grad_y.shape[1], -1), grad_y.shape[2]))
+        self.calls.append(('bwd_data', amax))
+        b, _, r = grad_y.shape[:3]
+        return torch.nn.grad.conv3d_input((b, weight.shape[1], r, r, r), weight, grad_y, padding=1)
+
+    def conv3d_backward_weight_f16_serves(self, x):
+        return True
+
+    def conv3d_backward_weight_f16(self, x, grad_y, x_amax, gy_amax, with_bias=False):
+        import torch
+        self.calls.append(('wgrad', x_amax, gy_amax))
+        gw = torch.nn.grad.conv3d_weight(x, (grad_y.shape[1], x.shape[1], 3, 3, 3), grad_y, padding=1)
+        return (gw, grad_y.sum(dim=(0, 2, 3, 4))) if with_bias else gw
 
 
-def test_folded_batchnorm_conv3d_node_routes_every_gradient(monkeypatch):
-    """BnActVoxelConv3d == Conv3d(LeakyReLU(BatchNorm3d(x))) for the output, the input gradient, all four parameter gradients
-    and the running statistics; the input gradient leaves the node tagged with its max |.| and the convolution in front of it
-    picks that up instead of measuring the tensor again."""
+def test_amax_buffers_travel_from_the_batchnorm_passes_to_the_convolutions(monkeypatch):
+    """Conv3d -> BatchNorm3d + LeakyReLU -> Conv3d -> BatchNorm3d + LeakyReLU (PVConv.voxel_layers, modules/pvconv.py:20-27) on the
+    autograd nodes of the GPU path with a torch stand-in for the kernels: same output and gradients as the plain modules; the
+    second convolution's forward and both convolutions' backward products take the table their BatchNorm neighbour emitted (the
+    very same tensor object), and only the first convolution's input is measured by a pass of its own."""
     import torch
     import torch.nn as nn
-    from pvcnn_amd.modules.functional import _cache, backend as seam
-    from pvcnn_amd.modules.functional.bnact import batch_norm_act_conv3d
-    torch.manual_seed(11)
-    fake = _FoldStandIn()
+    from pvcnn_amd.modules.functional import backend as seam, bnact as bnact_mod
+    from pvcnn_amd.modules.functional.bnact import BatchNormAct
+    from pvcnn_amd.modules.functional import _cache
+    from pvcnn_amd.modules.functional.conv3d import voxel_conv3d
+    torch.manual_seed(5)
+    fake = _AmaxStandIn()
     monkeypatch.setattr(seam, '_backend', fake)
-    bn, act, conv = nn.BatchNorm3d(6, eps=1e-4), nn.LeakyReLU(0.1), nn.Conv3d(6, 5, 3, padding=1)
+    monkeypatch.setattr(bnact_mod, '_amax_seg_for', lambda shape, is_cuda: int(shape[2]) if len(shape) == 5 else 0)
+    r = 4
+    convs = [nn.Conv3d(3, 6, 3, padding=1), nn.Conv3d(6, 5, 3, padding=1)]
+    bns = [nn.BatchNorm3d(6, eps=1e-4), nn.BatchNorm3d(5, eps=1e-4)]
     with torch.no_grad():
-        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.5, 0.5)
-    bn2 = nn.BatchNorm3d(6, eps=1e-4)
-    bn2.load_state_dict(bn.state_dict())
-    x = torch.randn(3, 6, 4, 4, 4)
+        for bn in bns:
+            bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.5, 0.5)
+    x = torch.randn(2, 3, r, r, r)
     x1 = x.clone().requires_grad_()
-    y1 = conv(act(bn(x1)))
-    w = torch.randn_like(y1)
-    (y1 * w).sum().backward()
-    want = [x1.grad, bn.weight.grad, bn.bias.grad, conv.weight.grad, conv.bias.grad]
-    for p in (bn.weight, bn.bias, conv.weight, conv.bias):
-        p.grad = None
+    ref = x1
+    for conv, bn in zip(convs, bns):
+        ref = nn.functional.leaky_relu(bn(conv(ref)), 0.1)
+    wgt = torch.randn_like(ref)
+    (ref * wgt).sum().backward()
+    want = [x1.grad] + [p.grad.clone() for m in convs + bns for p in m.parameters()]
+    for m in convs + bns:
+        for p in m.parameters():
+            p.grad = None
+
+    def bn_act(t, bn):          # batch_norm_act() without its is_cuda gate
+        seg = t.shape[2]
+        y, amax = BatchNormAct.apply(t, bn.weight, bn.bias, None, None, True, 0.1, bn.eps, 0.1, None, None, seg)
+        return _cache.tag_amax(y, seg, amax)
     x2 = x.clone().requires_grad_()
-    seen = {}
-
-    class Probe(torch.autograd.Function):                    # stands where the first convolution's backward would
-        @staticmethod
-        def forward(ctx, t):
-            return t.view_as(t)
-
-        @staticmethod
-        def backward(ctx, g):
-            seen['amax'] = _cache.absmax_of(g, lambda: None)
-            seen['bits'] = _FoldStandIn._bits(g)
-            return g
-
-    y2, part = batch_norm_act_conv3d(Probe.apply(x2), bn2, 0.1, conv.weight, conv.bias, stats_part=None, want_stats=True)
-    assert part.shape[0] == 5 and not part.requires_grad
-    assert torch.allclose(y2, y1, atol=1e-5)
-    (y2 * w).sum().backward()
-    got = [x2.grad, bn2.weight.grad, bn2.bias.grad, conv.weight.grad, conv.bias.grad]
-    for a, b in zip(got, want):
-        assert a is not None and torch.allclose(a, b, rtol=1e-4, atol=1e-5), (a - b).abs().max()
-    assert torch.allclose(bn.running_mean, bn2.running_mean, atol=1e-6) and torch.allclose(bn.running_var, bn2.running_var, atol=1e-6)
-    assert int(bn2.num_batches_tracked) == 1
-    # the tag travelled with the tensor object from one autograd node to the next
-    assert seen['amax'] is not None and torch.equal(seen['amax'], seen['bits'])
-    assert fake.calls.count('bnact_absmax_bits') == 1 and fake.calls.count('absmax_bits') == 1   # only y's incoming gradient was measured
+    h = x2
+    for conv, bn in zip(convs, bns):
+        h = bn_act(voxel_conv3d(h, conv.weight, conv.bias, False, 2), bn)
+    assert torch.allclose(h, ref, atol=1e-5)
+    (h * wgt).sum().backward()
+    got = [x2.grad] + [p.grad for m in convs + bns for p in m.parameters()]
+    for a, b in zip(got, want):     # (a bias in front of a train-mode BatchNorm has a zero true gradient: pure round-off, ~1e-5)
+        assert a is not None and torch.allclose(a, b, rtol=1e-4, atol=1e-4), (a - b).abs().max()
+    assert fake.calls.count('conv_amax') == 1                             # only the network input was measured by a separate pass
+    emitted = {id(t) for t in fake.emitted}
+    assert len(fake.emitted) == 4                                         # two forward applies, two backward applies
+    fwd = [c for c in fake.calls if isinstance(c, tuple) and c[0] == 'fwd']
+    assert id(fwd[0][1]) not in emitted and id(fwd[1][1]) in emitted      # conv 2 consumed BatchNorm 1's table
+    for c in fake.calls:
+        if isinstance(c, tuple) and c[0] == 'bwd_data':
+            assert id(c[1]) in emitted                                    # gradients arrive tagged by the BatchNorm backward
+        if isinstance(c, tuple) and c[0] == 'wgrad':
+            assert id(c[2]) in emitted
 
 
-def test_absmax_tag_dies_with_an_in_place_update():
+def test_amax_tag_dies_with_an_in_place_update_and_is_keyed_by_segment_length():
     import torch
     from pvcnn_amd.modules.functional import _cache
     t = torch.randn(8)
-    tag = torch.tensor([7], dtype=torch.int32)
-    _cache.tag_absmax(t, tag)
-    assert _cache.absmax_of(t, lambda: None) is tag
-    assert _cache.absmax_of(t.view(8), lambda: None) is None          # another tensor object: not tagged
-    t.mul_(2.0)                                                       # modified in place: the tag no longer describes it
-    assert _cache.absmax_of(t, lambda: None) is None
+    tag = torch.tensor([7, 7], dtype=torch.int32)
+    _cache.tag_amax(t, 16, tag)
+    assert _cache.amax_of(t, 16) is tag
+    assert _cache.amax_of(t, 32) is None                               # another segmentation: not this table
+    assert _cache.amax_of(t.view(8), 16) is None                       # another tensor object: not tagged
+    t.mul_(2.0)                                                        # modified in place: the tag no longer describes it
+    assert _cache.amax_of(t, 16) is None
 
 
 def test_trace_steady_delimits_steps_by_the_optimizer_not_by_the_gradient_packing(tmp_path):

@@ -53,8 +53,10 @@ def split_wts(w, for_bwd, ns):
 
 
 def absmax(x):
-    out = torch.empty(1, dtype=torch.int32, device=dev)
-    _lib.check(lib.pvcnn_absmax_bits(P(x), x.numel(), P(out), S()), 'absmax')
+    """The amax buffer of a voxel grid (include/pvcnn_hip.h): [0] global, then one maximum per z row."""
+    b, c, r = x.shape[0], x.shape[1], x.shape[2]
+    out = torch.empty(lib.pvcnn_absmax_tiles_count(b, r ** 3, r), dtype=torch.int32, device=dev)
+    _lib.check(lib.pvcnn_absmax_tiles(P(x), b, c, r ** 3, r, P(out), S()), 'absmax_tiles')
     return out
 
 
@@ -62,7 +64,7 @@ def fwd_split(x, w, bias, ns):
     b, ci, r = x.shape[0], x.shape[1], x.shape[2]
     co = w.shape[0]
     y = torch.empty(b, co, r, r, r, device=dev)
-    _lib.check(lib.pvcnn_conv3d_fwd_split(P(x), P(split_wts(w, 0, ns)), P(bias), b, ci, co, r, ns, P(absmax(x)) if ns == 2 else None, P(y), None, S()), 'fwd_split')
+    _lib.check(lib.pvcnn_conv3d_fwd_split(P(x), P(split_wts(w, 0, ns)), P(bias), b, ci, co, r, ns, P(absmax(x)) if ns == 2 else None, r if ns == 2 else 0, P(y), None, S()), 'fwd_split')
     return y
 
 
@@ -70,7 +72,7 @@ def bwd_data_split(gy, w, ns):
     b, co, r = gy.shape[0], gy.shape[1], gy.shape[2]
     ci = w.shape[1]
     gx = torch.empty(b, ci, r, r, r, device=dev)
-    _lib.check(lib.pvcnn_conv3d_fwd_split(P(gy), P(split_wts(w, 1, ns)), None, b, co, ci, r, ns, P(absmax(gy)) if ns == 2 else None, P(gx), None, S()), 'bwd_data_split')
+    _lib.check(lib.pvcnn_conv3d_fwd_split(P(gy), P(split_wts(w, 1, ns)), None, b, co, ci, r, ns, P(absmax(gy)) if ns == 2 else None, r if ns == 2 else 0, P(gx), None, S()), 'bwd_data_split')
     return gx
 
 
@@ -182,8 +184,8 @@ def main():
             wsb = torch.empty(nb, dtype=torch.uint8, device=dev)
             msw = graph_time(lambda: lib.pvcnn_conv3d_bwd_weight(P(x), P(gy), b, ci, co, r, P(gw), None, P(wsb), nb, S()))
             am = absmax(x)
-            msa = graph_time(lambda: lib.pvcnn_absmax_bits(P(x), x.numel(), P(am), S()))
-            print(json.dumps({'absmax_BCR': [b, ci, r], 'ms': round(msa, 4), 'GBps': round(x.numel() * 4 / msa / 1e6, 0)}), flush=True)
+            msa = graph_time(lambda: lib.pvcnn_absmax_tiles(P(x), b, ci, r ** 3, r, P(am), S()))
+            print(json.dumps({'absmax_tiles_BCR': [b, ci, r], 'ms': round(msa, 4), 'GBps': round(x.numel() * 4 / msa / 1e6, 0)}), flush=True)
             if r in (16, 32):
                 nb16 = lib.pvcnn_conv3d_bwd_weight_f16_workspace_bytes(b, ci, co, r)
                 ws16 = torch.empty(nb16, dtype=torch.uint8, device=dev)
@@ -193,7 +195,7 @@ def main():
                                   'fp32_mfma_kernel_ms': round(msw, 4), 'ws_MB': round(nb16 / 1e6, 1)}), flush=True)
             for ns, dbg in [(2, 0), (3, 0), (1, 0)]:
                 wts = split_wts(w, 0, ns)
-                mss = graph_time(lambda: lib.pvcnn_conv3d_fwd_split(P(x), P(wts), P(bias), b, ci, co, r, ns, P(am), P(y), None, S()))
+                mss = graph_time(lambda: lib.pvcnn_conv3d_fwd_split(P(x), P(wts), P(bias), b, ci, co, r, ns, P(am), r if ns == 2 else 0, P(y), None, S()))
                 print(json.dumps({'time_split_BCiCoR': [b, ci, co, r], 'nsplit': ns, 'fwd_ms': round(mss, 4),
                                   'effective_TFLOPs': round(fl / mss / 1e9, 1), 'bf16_mfma_TFLOPs': round({3: 6, 2: 3, 1: 1}[ns] * fl / mss / 1e9, 1),
                                   'frac_2500TF': round({3: 6, 2: 3, 1: 1}[ns] * fl / mss / 1e9 / 2500, 3)}), flush=True)

@@ -33,7 +33,7 @@ for (b, ci, co, n) in shapes:
     bias = torch.randn(co, device=dev)
     gy = torch.randn(b, co, n, device=dev)
     fl = 2.0 * b * n * ci * co
-    ax, ag = be.absmax_bits(x), be.absmax_bits(gy)
+    ax, ag = be.pw_amax(x), be.pw_amax(gy)
     wf, wb = be._pw_wsplit(w, False, 2), be._pw_wsplit(w, True, 2)
     f2 = t(lambda: be.pwconv_gemm_split(x, wf, bias, co, 2, False, ax))        # the GEMM launch alone
     d2 = t(lambda: be.pwconv_gemm_split(gy, wb, None, ci, 2, False, ag))
