@@ -259,17 +259,16 @@ __global__ __launch_bounds__(256, (NS == 3 || TX * TY * TZ == 512 || TZ <= 16) ?
   int x_shift = 0;
   if constexpr (NS == 2) {
     uint32_t tm = 0;
-    if (amax_seg > 0) {                                         // max over the z rows (b, gx, gy) of this workgroup's halo
-      __shared__ uint32_t tile_max[4];
-      for (int e = tid; e < HX * HY; e += 256) {
-        const int gx = x0 + e / HY - 1, gy = y0 + e % HY - 1;
-        if ((unsigned)gx < (unsigned)R && (unsigned)gy < (unsigned)R) tm = max(tm, x_absmax[1 + ((size_t)b * R + gx) * R + gy]);
-      }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) tm = max(tm, (uint32_t)__shfl_xor((int)tm, o));
-      if (lane == 0) tile_max[wave] = tm;
-      __syncthreads();
-      tm = max(max(tile_max[0], tile_max[1]), max(tile_max[2], tile_max[3]));
+    if (amax_seg > 0) {
+      // max over the z rows (b, gx, gy) of this workgroup's halo tile.  All addresses are uniform (block index + kernel arguments):
+      // scalar loads and s_max_u32 only -- the scale stays in a scalar register like the single-scale mode's one load.  (A
+      // lane-parallel version with a wave reduction pushed the 256-register tiles into hundreds of spilled registers.)
+      constexpr int LX = HX, LY = HY;
+      const int lenx = min(LX, R), leny = min(LY, R);
+      const int sx = min(max(x0 - 1, 0), R - lenx), sy = min(max(y0 - 1, 0), R - leny);   // clamped runs: a superset of the halo
+      const uint32_t *tab = x_absmax + 1 + ((size_t)b * R + sx) * R + sy;
+      for (int ix = 0; ix < lenx; ++ix)
+        for (int iy = 0; iy < leny; ++iy) tm = max(tm, tab[(size_t)ix * R + iy]);
     } else {
       tm = *x_absmax;
     }

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void pw_weight_split_f16_kernel(const float *_
 // (include/pvcnn_hip.h) with one maximum per 256-point tile behind the global one: every workgroup scales by ITS tile's maximum.
 // (A 256-channel tile, MB = 8 with the accumulators in AGPRs, was built and measured in round 3: 0.196 vs 0.154 ms at 128 -> 1024,
 // 1730 vs 1760 clouds/s in the step -- removed.)
-template <int NS, int MB>
+template <int NS, int MB, int PF = 1>
 __global__ __launch_bounds__(256, 2) void pw_gemm_bf16_kernel(const float *__restrict__ x, const uint16_t *__restrict__ wts,
                                                               const float *__restrict__ bias, float *__restrict__ y, int K, int M,
                                                               int N, int tiles_n, int tiles_total, float2 *__restrict__ stats_part,
@@ -158,9 +158,12 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_bf16_kernel(const float *__res
   // Pipeline: the next chunk's rows are requested right after the barrier that publishes this chunk's tile (they land during
   // its MFMAs); the next chunk's weight fragments as soon as this chunk's MFMAs have been issued.
   constexpr int ITEMS = (kPbK / 2) * (kPbN / 4) / 256;          // 2 items per thread and chunk
-  float4 va[ITEMS], vb[ITEMS];
+  // PF = how many chunks ahead the rows are requested (a register ring of PF stages; the chunk loop is unrolled PF times so
+  // that the ring indices are compile-time).  With PF = 1 every workgroup on the chip alternates "burst of loads" / "multiply":
+  // the loads of chunk i + 1 have only chunk i's MFMAs (~0.3 us) to land in.
+  float4 va_[PF][ITEMS], vb_[PF][ITEMS];
   const bool vec = (N % 4 == 0) && aligned16(xb) && (n0 + kPbN <= N);
-  auto load_x = [&](int chunk) {
+  auto load_x = [&](int chunk, float4 (&va)[ITEMS], float4 (&vb)[ITEMS]) {
     const int c0 = chunk * kPbK;
 #pragma unroll
     for (int u = 0; u < ITEMS; ++u) {
@@ -192,9 +195,17 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_bf16_kernel(const float *__res
 #pragma unroll
       for (int s = 0; s < NS; ++s) af[mb][s] = wq[s * (TM * kPbK / 8) + a_off[mb]];
   };
-  load_x(0);
+#pragma unroll
+  for (int d = 0; d < PF; ++d) load_x(d, va_[d], vb_[d]);       // (a chunk beyond K loads zeros: c >= K)
   load_a(0);
-  for (int chunk = 0; chunk < chunks; ++chunk) {
+  // the chunk count is padded to a multiple of PF: a padding chunk stages zeros and multiplies them with the previous chunk's
+  // (finite) weight fragments -- nothing is added, and the unrolled body stays straight-line code
+  for (int chunk0 = 0; chunk0 < chunks; chunk0 += PF) {
+#pragma unroll
+  for (int d = 0; d < PF; ++d) {
+    const int chunk = chunk0 + d;
+    float4 (&va)[ITEMS] = va_[d];
+    float4 (&vb)[ITEMS] = vb_[d];
     __syncthreads();                                            // previous chunk's fragment reads are done
 #pragma unroll
     for (int u = 0; u < ITEMS; ++u) {
@@ -215,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_bf16_kernel(const float *__res
         *reinterpret_cast<uint4 *>(xs + (s * 8 + kp) * kPbN + 4 * q) = make_uint4(w[s][0], w[s][1], w[s][2], w[s][3]);
     }
     __syncthreads();
-    if (chunk + 1 < chunks) load_x(chunk + 1);                  // in flight during this chunk's MFMAs
+    load_x(chunk + PF, va, vb);                                 // in flight during the next PF chunks' MFMAs
     uint4 bf[NBW][NS];
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb)
@@ -242,6 +253,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_bf16_kernel(const float *__res
 #undef PVCNN_PB_MFMA
     __builtin_amdgcn_sched_barrier(0);
     if (chunk + 1 < chunks) load_a(chunk + 1);                  // overwrites af once this chunk's MFMAs have been issued
+  }
   }
 
   // ---- epilogue: D[i = m][j = point]; lanes = consecutive points (128-byte rows) ----
@@ -363,9 +375,12 @@ extern "C" int pvcnn_pwconv_fwd_split(const float *x, const void *wts, const flo
   const uint32_t *am = static_cast<const uint32_t *>(x_absmax);
   const int *wexp = nsplit == 2 ? reinterpret_cast<const int *>(static_cast<const char *>(wts) + pb_image_bytes(K, M, 2)) : nullptr;
 #define PVCNN_PB_LAUNCH(NSV, MBV) hipLaunchKernelGGL((pw_gemm_bf16_kernel<NSV, MBV>), grid, dim3(256), 0, s, x, w16, bias, y, K, M, N, tiles_n, (int)tiles_total, sp, am, wexp, amax_seg)
+#define PVCNN_PB_LAUNCH_PF(NSV, MBV, PFV) hipLaunchKernelGGL((pw_gemm_bf16_kernel<NSV, MBV, PFV>), grid, dim3(256), 0, s, x, w16, bias, y, K, M, N, tiles_n, (int)tiles_total, sp, am, wexp, amax_seg)
+  static const int pf = [] { const char *e = getenv("PVCNN_PW_PF"); return e ? atoi(e) : 1; }();   // EXPERIMENT (round 3): prefetch depth A/B
   if (nsplit == 3)      { if (MB == 4) PVCNN_PB_LAUNCH(3, 4); else PVCNN_PB_LAUNCH(3, 2); }
-  else if (nsplit == 2) { if (MB == 4) PVCNN_PB_LAUNCH(2, 4); else PVCNN_PB_LAUNCH(2, 2); }
+  else if (nsplit == 2) { if (MB == 4) { if (pf == 3) PVCNN_PB_LAUNCH_PF(2, 4, 3); else if (pf == 2) PVCNN_PB_LAUNCH_PF(2, 4, 2); else PVCNN_PB_LAUNCH(2, 4); } else PVCNN_PB_LAUNCH(2, 2); }
   else                  { if (MB == 4) PVCNN_PB_LAUNCH(1, 4); else PVCNN_PB_LAUNCH(1, 2); }
 #undef PVCNN_PB_LAUNCH
+#undef PVCNN_PB_LAUNCH_PF
   return check_launch("pwconv_fwd_split");
 }

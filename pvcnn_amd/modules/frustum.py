@@ -17,13 +17,23 @@ _SY = (1, 1, 1, 1, -1, -1, -1, -1)
 _SZ = (1, -1, -1, 1, 1, -1, -1, 1)
 
 
+_SIGNS = {}      # (device, dtype) -> the three sign rows as device tensors
+
+
+def _corner_signs(like):
+    """The constant sign patterns on `like`'s device: uploaded once per (device, dtype) -- a host-to-device copy inside every
+    forward would also be illegal while the step is being captured into a hipGraph (pvcnn_amd/graph.py)."""
+    key = (like.device, like.dtype)
+    if key not in _SIGNS:
+        _SIGNS[key] = tuple(torch.tensor(v, device=like.device, dtype=like.dtype) for v in (_SX, _SY, _SZ))
+    return _SIGNS[key]
+
+
 def get_box_corners_3d(centers, headings, sizes, with_flip=False):
     """centers (N,3), headings (N,), sizes (N,3)=(l,w,h) -> corners (N,3,8) rotated about y;
     with_flip also returns the box turned by pi."""
     half = sizes / 2
-    sx = half.new_tensor(_SX)
-    sy = half.new_tensor(_SY)
-    sz = half.new_tensor(_SZ)
+    sx, sy, sz = _corner_signs(half)
     local = torch.stack([half[:, 0:1] * sx, half[:, 2:3] * sy, half[:, 1:2] * sz], dim=1)   # (N,3,8)
     c, s = torch.cos(headings), torch.sin(headings)
     o, z = torch.ones_like(headings), torch.zeros_like(headings)

@@ -356,12 +356,16 @@ def test_frustum_segmentation_train_step_under_bf16_autocast(hip, oracle):
         feats = in0['features'].clone().to(dev, dtype).requires_grad_()
         return {'features': feats, 'one_hot_vectors': in0['one_hot_vectors'].to(dev, dtype)}, feats, y0.to(dev)
 
-    with cpu_stack(TruthBackend(oracle)):
+    # the global max-pool's winners are pinned to the fp64 run's (PinMaxWinners): at bf16 accuracy (2^-9) the top-2 gap of a
+    # channel over 1024 points is crossed in most channels, and a flipped winner re-routes that channel's whole gradient --
+    # a property of 8-bit operands, not of the kernels under test (unpinned, the layer in front of the pool differs by 0.4)
+    record = PinMaxWinners()
+    with cpu_stack(TruthBackend(oracle)), record:
         inp, leaf, tgt = make('cpu', torch.float64)
         loss_t = tf.cross_entropy(f64_net(inp), tgt)
         loss_t.backward()
     res_t = (loss_t.item(), _grads(f64_net, leaf))
-    with count_native_calls(['conv3d_igemm_split']) as calls:
+    with count_native_calls(['conv3d_igemm_split']) as calls, PinMaxWinners(record.winners):
         inp, leaf, tgt = make(DEV, torch.float32)
         with torch.autocast('cuda', dtype=torch.bfloat16):
             loss_g = tf.cross_entropy(gpu_net(inp).float(), tgt)
@@ -369,7 +373,7 @@ def test_frustum_segmentation_train_step_under_bf16_autocast(hip, oracle):
         torch.cuda.synchronize()
     res_g = (loss_g.item(), _grads(gpu_net, leaf))
     assert calls['conv3d_igemm_split'] >= 15, calls            # the bf16 implicit GEMM ran (forward + backward-data of 8 convolutions)
-    with cpu_stack(oracle):
+    with cpu_stack(oracle), PinMaxWinners(record.winners):
         inp, leaf, tgt = make('cpu', torch.float32)
         loss_c = tf.cross_entropy(cpu_net(inp), tgt)
         loss_c.backward()
