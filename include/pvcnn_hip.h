@@ -259,7 +259,7 @@ PVCNN_API int pvcnn_absmax_tiles(const float *x, int B, int C, long L, int seg, 
 PVCNN_API int pvcnn_conv3d_fwd_split(const float *x, const void *wts, const float *bias, int B, int Ci, int Co, int R, int nsplit,
                            const void *x_absmax, int amax_seg /* 0 | R */, float *y, float *stats_part, void *stream);
 
-/* Backward-weight in the same f16x2 arithmetic (csrc/conv3d_wgrad_f16.hip), R = 16 or 32 (workspace_bytes returns 0 for
+/* Backward-weight in the same f16x2 arithmetic (csrc/conv3d_wgrad_f16.hip), R = 8, 12, 16 or 32 (workspace_bytes returns 0 for
  * any other R: use pvcnn_conv3d_bwd_weight).  x_absmax / gy_absmax: pvcnn_absmax_bits of x and grad_y.  Deterministic
  * (split-K partials summed in a fixed order), <= 1e-5 vs fp64 like pvcnn_conv3d_bwd_weight. */
 PVCNN_API size_t pvcnn_conv3d_bwd_weight_f16_workspace_bytes(int B, int Ci, int Co, int R);
@@ -313,12 +313,15 @@ PVCNN_API int pvcnn_pwconv_bwd_weight_f16(const float *x, const float *grad_y, c
  * gamma / beta may be NULL (affine = False).  `workspace`: >= pvcnn_bnact_workspace_bytes(B,C,S).
  * y_amax / gx_amax (NULL, or pvcnn_absmax_tiles_count(B, S, amax_seg) words): the amax buffer of the tensor the call writes (y
  *      resp. grad_x) with segments of amax_seg positions, emitted by the apply pass itself -- the f16x2 convolution that consumes
- *      that tensor needs no pass of its own over it.  Requires amax_seg <= 256 and C <= 4096.
+ *      that tensor needs no pass of its own over it.  Requires amax_seg <= 256.  Word [0] (the global maximum) is accumulated with
+ *      one atomic per workgroup when it was zeroed beforehand: by the call's own finalize kernel (training != 0, and always in
+ *      bwd), or -- amax_zeroed != 0 -- by the pvcnn_bn_finalize call that produced mean / rstd (its zero_word argument); with
+ *      training == 0 and amax_zeroed == 0 a one-workgroup reduction of the table is launched behind the pass instead.
  */
 PVCNN_API size_t pvcnn_bnact_workspace_bytes(int B, int C, int S);
 PVCNN_API int pvcnn_bnact_fwd(const float *x, const float *gamma, const float *beta, float *running_mean,
                               float *running_var, int B, int C, int S, float eps, float momentum, float slope,
-                              int training, float *mean, float *rstd, float *y, void *y_amax, int amax_seg,
+                              int training, float *mean, float *rstd, float *y, void *y_amax, int amax_seg, int amax_zeroed,
                               void *workspace, size_t workspace_bytes, void *stream);
 /* Batch statistics only (training): mean / rstd per channel + running-stat update; the first half of bnact_fwd.
  * Used with pvcnn_trilinear_devox_bnact_fwd, which applies BatchNorm + LeakyReLU while it stages the voxel
@@ -340,7 +343,8 @@ PVCNN_API int pvcnn_pwconv_fwd_stats(const float *x, const float *wt, int wt_row
 /* The epilogue partials are sums of (y - bias) and (y - bias)^2: pass the convolution's bias as `shift` (NULL = no bias) and
  * bn_finalize adds it back to the mean -- a variance from E[a^2] - E[a]^2 stays accurate when the bias dwarfs the spread. */
 PVCNN_API int pvcnn_bn_finalize(const float *part, int C, long nparts, double count, float eps, float momentum, const float *shift,
-                      float *running_mean, float *running_var, float *mean, float *rstd, void *stream);
+                      float *running_mean, float *running_var, float *mean, float *rstd, void *zero_word /* NULL | one uint32 set to 0 */,
+                      void *stream);
 PVCNN_API int pvcnn_bn_stats(const float *x, float *running_mean, float *running_var, int B, int C, int S,
                    float eps, float momentum, float *mean, float *rstd, void *workspace,
                    size_t workspace_bytes, void *stream);

@@ -68,8 +68,9 @@ __global__ __launch_bounds__(kBnThreads) void bn_stats_kernel(const float *__res
 __global__ __launch_bounds__(64) void bn_finalize_kernel(const float2 *__restrict__ part, int nparts, double count, float eps,
                                                         float momentum, const float *__restrict__ shift, float *__restrict__ mean,
                                                         float *__restrict__ rstd, float *__restrict__ running_mean,
-                                                        float *__restrict__ running_var) {
+                                                        float *__restrict__ running_var, uint32_t *__restrict__ zero_word) {
   const int c = blockIdx.x;
+  if (zero_word != nullptr && c == 0 && threadIdx.x == 0) *zero_word = 0u;   // arms word [0] of the amax buffer the apply pass will fill
   double s = 0.0, q = 0.0;
   for (int i = threadIdx.x; i < nparts; i += 64) { const float2 p = part[(size_t)c * nparts + i]; s += p.x; q += p.y; }
 #pragma unroll
@@ -165,8 +166,10 @@ __global__ __launch_bounds__(kBnThreads) void bnact_bwd_reduce_kernel(const floa
 
 // grid = C: dbeta = sum g', dgamma = sum g' xhat (fp64 combine)
 __global__ __launch_bounds__(64) void bnact_bwd_finalize_kernel(const float2 *__restrict__ part, int nparts,
-                                                               float *__restrict__ dgamma, float *__restrict__ dbeta) {
+                                                               float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                                               uint32_t *__restrict__ zero_word) {
   const int c = blockIdx.x;
+  if (zero_word != nullptr && c == 0 && threadIdx.x == 0) *zero_word = 0u;   // arms word [0] of grad_x's amax buffer (apply pass)
   double s = 0.0, q = 0.0;
   for (int i = threadIdx.x; i < nparts; i += 64) { const float2 p = part[(size_t)c * nparts + i]; s += p.x; q += p.y; }
 #pragma unroll
@@ -232,7 +235,8 @@ __global__ __launch_bounds__(256) void bnact_apply_pb_kernel(const float *__rest
                                                              const float *__restrict__ gamma, const float *__restrict__ beta,
                                                              const float *__restrict__ dgamma, const float *__restrict__ dbeta,
                                                              float slope, float inv_count, int training, int C, int S, int seg,
-                                                             int nseg, int vec, float *__restrict__ out, uint32_t *__restrict__ amax) {
+                                                             int nseg, int vec, float *__restrict__ out, uint32_t *__restrict__ amax,
+                                                             int global_by_atomic) {
   __shared__ uint32_t seg_max[256];
   const int spb = seg >= 256 ? 1 : 256 / seg;                  // whole segments per workgroup (seg <= 256 enforced by the host)
   const int b = blockIdx.y, s0 = blockIdx.x * spb;
@@ -309,6 +313,13 @@ __global__ __launch_bounds__(256) void bnact_apply_pb_kernel(const float *__rest
   }
   lds_barrier();                                                // LDS only: the streaming stores above need not have drained
   if (tid < spb && s0 + tid < nseg) amax[1 + (size_t)b * nseg + s0 + tid] = seg_max[tid];
+  // word [0], the tensor's maximum: zeroed by the finalize kernel that ran before this pass -> one fire-and-forget atomic per
+  // workgroup (order-independent: deterministic); otherwise the host launches the table reduction behind this kernel
+  if (global_by_atomic && tid == 0) {
+    uint32_t m = 0;
+    for (int i = 0; i < spb; ++i) m = max(m, seg_max[i]);
+    if (m != 0) atomicMax(amax, m);
+  }
 }
 
 }  // namespace pvcnn
@@ -322,8 +333,8 @@ extern "C" size_t pvcnn_bnact_workspace_bytes(int B, int C, int S) {
 
 extern "C" int pvcnn_bnact_fwd(const float *x, const float *gamma, const float *beta, float *running_mean,
                                float *running_var, int B, int C, int S, float eps, float momentum, float slope, int training,
-                               float *mean, float *rstd, float *y, void *y_amax, int amax_seg, void *workspace, size_t workspace_bytes,
-                               void *stream) {
+                               float *mean, float *rstd, float *y, void *y_amax, int amax_seg, int amax_zeroed, void *workspace,
+                               size_t workspace_bytes, void *stream) {
   PVCNN_REQUIRE(B > 0 && C > 0 && S > 0 && x && y && mean && rstd, "bad argument");
   PVCNN_REQUIRE(B <= 65535 && C <= 65535, "batch or channel count > 65535");
   PVCNN_REQUIRE(!y_amax || (amax_seg > 0 && amax_seg <= 256), "amax_seg must be in 1..256");
@@ -337,8 +348,9 @@ extern "C" int pvcnn_bnact_fwd(const float *x, const float *gamma, const float *
     hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(kBnThreads), 0, s, x, C, S, slices, part, shift);
     if (int e = check_launch("bn_stats")) return e;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, s, part, B * slices, (double)B * S, eps, momentum, shift, mean, rstd,
-                       running_mean, running_var);
+                       running_mean, running_var, static_cast<uint32_t *>(y_amax));
     if (int e = check_launch("bn_finalize")) return e;
+    amax_zeroed = 1;
   }
   // eval: the caller passes mean = running_mean and rstd = 1/sqrt(running_var + eps)
   if (y_amax != nullptr) {                                      // position-block-major pass that also emits y's amax buffer
@@ -346,9 +358,9 @@ extern "C" int pvcnn_bnact_fwd(const float *x, const float *gamma, const float *
     const int vec = (S % 4 == 0) && (amax_seg % 4 == 0) && aligned16(x) && aligned16(y);
     uint32_t *am = static_cast<uint32_t *>(y_amax);
     hipLaunchKernelGGL(bnact_apply_pb_kernel<false>, dim3(ceil_div(nseg, spb), B), dim3(256), 0, s, x, nullptr, 0L, mean, rstd, gamma, beta,
-                       nullptr, nullptr, slope, 0.0f, 0, C, S, amax_seg, nseg, vec, y, am);
+                       nullptr, nullptr, slope, 0.0f, 0, C, S, amax_seg, nseg, vec, y, am, amax_zeroed ? 1 : 0);
     if (int e = check_launch("bnact_apply_pb")) return e;
-    return launch_amax_reduce(am, (long)B * nseg, s);
+    return amax_zeroed ? 0 : launch_amax_reduce(am, (long)B * nseg, s);
   }
   hipLaunchKernelGGL(bnact_apply_kernel, grid, dim3(kBnThreads), 0, s, x, mean, rstd, gamma, beta, slope, C, S, y);
   return check_launch("bnact_apply");
@@ -357,11 +369,11 @@ extern "C" int pvcnn_bnact_fwd(const float *x, const float *gamma, const float *
 // mean / rstd (+ running statistics) from per-workgroup partials produced by a convolution epilogue
 // (pvcnn_conv3d_fwd_stats, pvcnn_pwconv_fwd_stats): part is (C, nparts) float2 {sum, sum of squares}.
 extern "C" int pvcnn_bn_finalize(const float *part, int C, long nparts, double count, float eps, float momentum, const float *shift,
-                                 float *running_mean, float *running_var, float *mean, float *rstd, void *stream) {
+                                 float *running_mean, float *running_var, float *mean, float *rstd, void *zero_word, void *stream) {
   PVCNN_REQUIRE(C > 0 && nparts > 0 && nparts <= 0x7fffffffL && count > 0 && part && mean && rstd, "bad argument");
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, static_cast<hipStream_t>(stream),
                      reinterpret_cast<const float2 *>(part), (int)nparts, count, eps, momentum, shift, mean, rstd, running_mean,
-                     running_var);
+                     running_var, static_cast<uint32_t *>(zero_word));
   return check_launch("bn_finalize");
 }
 
@@ -377,7 +389,7 @@ extern "C" int pvcnn_bn_stats(const float *x, float *running_mean, float *runnin
   hipLaunchKernelGGL(bn_stats_kernel, dim3(slices, B, C), dim3(kBnThreads), 0, s, x, C, S, slices, part, shift);
   if (int e = check_launch("bn_stats")) return e;
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, s, part, B * slices, (double)B * S, eps, momentum, shift, mean, rstd,
-                     running_mean, running_var);
+                     running_mean, running_var, static_cast<uint32_t *>(nullptr));
   return check_launch("bn_finalize");
 }
 
@@ -397,7 +409,8 @@ static int bnact_bwd_impl(const float *x, const float *grad_y, long gy_bstride, 
   hipLaunchKernelGGL(bnact_bwd_reduce_kernel, grid, dim3(kBnThreads), 0, s, x, grad_y, mean, rstd, gamma, beta, slope, C, S,
                      slices, part, gy_bstride);
   if (int e = check_launch("bnact_bwd_reduce")) return e;
-  hipLaunchKernelGGL(bnact_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, part, B * slices, grad_gamma, grad_beta);
+  hipLaunchKernelGGL(bnact_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, part, B * slices, grad_gamma, grad_beta,
+                     static_cast<uint32_t *>(gx_amax));
   if (int e = check_launch("bnact_bwd_finalize")) return e;
   const float inv_count = (float)(1.0 / ((double)B * S));
   if (gx_amax != nullptr) {                                     // position-block-major pass that also emits grad_x's amax buffer
@@ -405,9 +418,8 @@ static int bnact_bwd_impl(const float *x, const float *grad_y, long gy_bstride, 
     const int vec = (S % 4 == 0) && (amax_seg % 4 == 0) && (gy_bstride % 4 == 0) && aligned16(x) && aligned16(grad_y) && aligned16(grad_x);
     uint32_t *am = static_cast<uint32_t *>(gx_amax);
     hipLaunchKernelGGL(bnact_apply_pb_kernel<true>, dim3(ceil_div(nseg, spb), B), dim3(256), 0, s, x, grad_y, gy_bstride, mean, rstd, gamma,
-                       beta, grad_gamma, grad_beta, slope, inv_count, training, C, S, amax_seg, nseg, vec, grad_x, am);
-    if (int e = check_launch("bnact_bwd_apply_pb")) return e;
-    return launch_amax_reduce(am, (long)B * nseg, s);
+                       beta, grad_gamma, grad_beta, slope, inv_count, training, C, S, amax_seg, nseg, vec, grad_x, am, 1);
+    return check_launch("bnact_bwd_apply_pb");
   }
   hipLaunchKernelGGL(bnact_bwd_apply_kernel, grid, dim3(kBnThreads), 0, s, x, grad_y, mean, rstd, gamma, beta, grad_gamma,
                      grad_beta, slope, inv_count, training, C, S, grad_x, gy_bstride);

@@ -18,7 +18,8 @@
 //   * split-K over P partitions of the strips; every workgroup writes its block to part[p] ([tap][co][ci]: 128-byte rows) and
 //     conv3d_wgrad_f16_reduce_kernel sums the partitions in a fixed order (deterministic, no atomics), scales back by
 //     2^-(sx + sgy) and transposes to (Co, Ci, 27).  grad_bias falls out of the grad_y rows a thread stages.
-// R must be a multiple of 16 (R = 16 and 32 are instantiated); anything else stays on the fp32-MFMA kernel of conv3d.hip.
+// R = 8, 12, 16 and 32 are instantiated (a z row shorter than the 16-deep k-step is padded with zeros IN LDS: R = 12, the Frustum
+// grids, wastes a quarter of the MFMA work, R = 8 half of it); anything else stays on the fp32-MFMA kernel of conv3d.hip.
 #include <algorithm>
 
 #include "common.h"
@@ -30,7 +31,8 @@ constexpr int kWgCo = 64, kWgCi = 32;
 
 template <int R>
 struct WgradLds {
-  static constexpr int RS = R + 24;                 // fp16 elements per LDS row: [8 pad | R data | 16 pad]; z = i - 8.  RS * 2 bytes
+  static constexpr int RP = (R + 15) / 16 * 16;     // z extent rounded up to whole 16-deep k-steps (the tail stays zero)
+  static constexpr int RS = RP + 24;                // fp16 elements per LDS row: [8 pad | RP data | 16 pad]; z = i - 8.  RS * 2 bytes
   static constexpr int ROWB = RS * 2;               //   = 28 / 20 dwords (R = 32 / 16): 16-byte reads of 16 rows hit 64 distinct banks
   static constexpr int XPL = 4 * 3 * kWgCi * ROWB;  // one fp16 plane of the x ring  [slot 4][dx 3][ci 32][row]
   static constexpr int GPL = 2 * kWgCo * ROWB;      // one fp16 plane of grad_y      [buffer 2][co 64][row]
@@ -43,7 +45,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_f16_kernel(const float *_
                                                                   const uint32_t *__restrict__ gy_absmax, int B, int Ci, int Co, int P,
                                                                   int citiles, float *__restrict__ part, float *__restrict__ gb_part) {
   using L = WgradLds<R>;
-  constexpr int QZ = R / 4, KS = R / 16, ROWB = L::ROWB;
+  constexpr int QZ = R / 4, KS = L::RP / 16, ROWB = L::ROWB;
   constexpr int XITEMS = 3 * kWgCi * QZ, GITEMS = kWgCo * QZ;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned char *xl = lds, *gl = lds + 2 * L::XPL;
@@ -284,9 +286,11 @@ static int launch_wgrad_f16(const float *x, const float *gy, const uint32_t *xa,
 
 using namespace pvcnn;
 
-// 0 when this shape is not served by the f16x2 kernel (R not 16 or 32): use pvcnn_conv3d_bwd_weight
+static bool wgrad_f16_serves(int R) { return R == 8 || R == 12 || R == 16 || R == 32; }
+
+// 0 when this shape is not served by the f16x2 kernel (R not 8, 12, 16 or 32): use pvcnn_conv3d_bwd_weight
 extern "C" size_t pvcnn_conv3d_bwd_weight_f16_workspace_bytes(int B, int Ci, int Co, int R) {
-  if (B <= 0 || Ci <= 0 || Co <= 0 || (R != 16 && R != 32)) return 0;
+  if (B <= 0 || Ci <= 0 || Co <= 0 || !wgrad_f16_serves(R)) return 0;
   const WgradPlan w = wgrad_f16_plan(B, Ci, Co, R);
   return (w.part_floats + w.gb_floats) * sizeof(float);
 }
@@ -294,7 +298,7 @@ extern "C" size_t pvcnn_conv3d_bwd_weight_f16_workspace_bytes(int B, int Ci, int
 extern "C" int pvcnn_conv3d_bwd_weight_f16(const float *x, const float *grad_y, const void *x_absmax, const void *gy_absmax, int B, int Ci,
                                            int Co, int R, float *grad_w, float *grad_bias, void *workspace, size_t workspace_bytes,
                                            void *stream) {
-  PVCNN_REQUIRE(B > 0 && Ci > 0 && Co > 0 && (R == 16 || R == 32), "bad size (R must be 16 or 32)");
+  PVCNN_REQUIRE(B > 0 && Ci > 0 && Co > 0 && wgrad_f16_serves(R), "bad size (R must be 8, 12, 16 or 32)");
   PVCNN_REQUIRE(x && grad_y && grad_w && x_absmax && gy_absmax, "null pointer");
   PVCNN_REQUIRE(aligned16(x) && aligned16(grad_y), "x and grad_y must be 16-byte aligned");
   PVCNN_REQUIRE(workspace && aligned16(workspace) && workspace_bytes >= pvcnn_conv3d_bwd_weight_f16_workspace_bytes(B, Ci, Co, R),
@@ -302,6 +306,10 @@ extern "C" int pvcnn_conv3d_bwd_weight_f16(const float *x, const float *grad_y, 
   hipStream_t s = static_cast<hipStream_t>(stream);
   const uint32_t *xa = static_cast<const uint32_t *>(x_absmax), *ga = static_cast<const uint32_t *>(gy_absmax);
   float *ws = static_cast<float *>(workspace);
-  return R == 32 ? launch_wgrad_f16<32>(x, grad_y, xa, ga, B, Ci, Co, grad_w, grad_bias, ws, s)
-                 : launch_wgrad_f16<16>(x, grad_y, xa, ga, B, Ci, Co, grad_w, grad_bias, ws, s);
+  switch (R) {
+    case 32: return launch_wgrad_f16<32>(x, grad_y, xa, ga, B, Ci, Co, grad_w, grad_bias, ws, s);
+    case 16: return launch_wgrad_f16<16>(x, grad_y, xa, ga, B, Ci, Co, grad_w, grad_bias, ws, s);
+    case 12: return launch_wgrad_f16<12>(x, grad_y, xa, ga, B, Ci, Co, grad_w, grad_bias, ws, s);
+    default: return launch_wgrad_f16<8>(x, grad_y, xa, ga, B, Ci, Co, grad_w, grad_bias, ws, s);
+  }
 }

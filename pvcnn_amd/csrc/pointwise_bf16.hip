@@ -376,9 +376,10 @@ extern "C" int pvcnn_pwconv_fwd_split(const float *x, const void *wts, const flo
   const int *wexp = nsplit == 2 ? reinterpret_cast<const int *>(static_cast<const char *>(wts) + pb_image_bytes(K, M, 2)) : nullptr;
 #define PVCNN_PB_LAUNCH(NSV, MBV) hipLaunchKernelGGL((pw_gemm_bf16_kernel<NSV, MBV>), grid, dim3(256), 0, s, x, w16, bias, y, K, M, N, tiles_n, (int)tiles_total, sp, am, wexp, amax_seg)
 #define PVCNN_PB_LAUNCH_PF(NSV, MBV, PFV) hipLaunchKernelGGL((pw_gemm_bf16_kernel<NSV, MBV, PFV>), grid, dim3(256), 0, s, x, w16, bias, y, K, M, N, tiles_n, (int)tiles_total, sp, am, wexp, amax_seg)
-  static const int pf = [] { const char *e = getenv("PVCNN_PW_PF"); return e ? atoi(e) : 1; }();   // EXPERIMENT (round 3): prefetch depth A/B
+  // prefetch depth of the wide f16x2 tile, measured (profiles/ab/r03c_pwbench_pf*.jsonl, 1472 -> 512 over 65 536 points): PF = 1 / 2 / 3
+  // = 0.576 / 0.538 / 0.523 ms forward, 1788 / 1820 / 1824 clouds/s in the step; PF = 2 is kept (232 VGPRs; PF = 3 needs 252 of 256)
   if (nsplit == 3)      { if (MB == 4) PVCNN_PB_LAUNCH(3, 4); else PVCNN_PB_LAUNCH(3, 2); }
-  else if (nsplit == 2) { if (MB == 4) { if (pf == 3) PVCNN_PB_LAUNCH_PF(2, 4, 3); else if (pf == 2) PVCNN_PB_LAUNCH_PF(2, 4, 2); else PVCNN_PB_LAUNCH(2, 4); } else PVCNN_PB_LAUNCH(2, 2); }
+  else if (nsplit == 2) { if (MB == 4) PVCNN_PB_LAUNCH_PF(2, 4, 2); else PVCNN_PB_LAUNCH(2, 2); }
   else                  { if (MB == 4) PVCNN_PB_LAUNCH(1, 4); else PVCNN_PB_LAUNCH(1, 2); }
 #undef PVCNN_PB_LAUNCH
 #undef PVCNN_PB_LAUNCH_PF

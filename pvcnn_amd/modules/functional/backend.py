@@ -554,9 +554,9 @@ class HipBackend:
         return self.conv3d_igemm_split(grad_y, self._conv_wsplit(weight, True, nsplit), None, ci, nsplit, False,
                                        amax if amax is not None else (self.conv_amax(grad_y) if int(nsplit) == 2 else None))
 
-    # ---- backward-weight in f16x2 (csrc/conv3d_wgrad_f16.hip): R = 16 and 32; other grids stay on the fp32-MFMA kernel ----
+    # ---- backward-weight in f16x2 (csrc/conv3d_wgrad_f16.hip): R = 8, 12, 16 and 32; other grids stay on the fp32-MFMA kernel ----
     def conv3d_backward_weight_f16_serves(self, x):
-        return x.dim() == 5 and x.shape[2] in (16, 32)
+        return x.dim() == 5 and x.shape[2] in (8, 12, 16, 32)
 
     def conv3d_backward_weight_f16(self, x, grad_y, x_amax=None, gy_amax=None, with_bias=False):
         """grad_w (Co,Ci,3,3,3) [, grad_bias]: x (B,Ci,R,R,R), grad_y (B,Co,R,R,R); *_amax = amax buffers of the two tensors (word [0],
@@ -564,7 +564,7 @@ class HipBackend:
         _f32(x, 'x'); _f32(grad_y, 'grad_y')
         b, ci, r = x.shape[0], x.shape[1], x.shape[2]
         co = grad_y.shape[1]
-        _shape(self.conv3d_backward_weight_f16_serves(x) and tuple(grad_y.shape) == (b, co, r, r, r), 'conv3d_backward_weight_f16: R must be 16 or 32')
+        _shape(self.conv3d_backward_weight_f16_serves(x) and tuple(grad_y.shape) == (b, co, r, r, r), 'conv3d_backward_weight_f16: R must be 8, 12, 16 or 32')
         x_amax = x_amax if x_amax is not None else self.absmax_bits(x)
         gy_amax = gy_amax if gy_amax is not None else self.absmax_bits(grad_y)
         gw = torch.empty((co, ci, 3, 3, 3), dtype=torch.float32, device=x.device)
@@ -691,11 +691,14 @@ class HipBackend:
 
     BNACT_AMAX_MAX_SEG = 256   # the apply passes emit amax buffers for segments up to this long
 
-    def bnact_forward(self, x, gamma, beta, running_mean, running_var, training, momentum, eps, slope, stats=None, amax_seg=0):
+    def bnact_forward(self, x, gamma, beta, running_mean, running_var, training, momentum, eps, slope, stats=None, amax_seg=0,
+                      y_amax=None):
         """x (B,C,S) -> (y, mean, rstd).  Training: batch statistics (running stats updated in place);
         eval: running statistics.  stats = (mean, rstd) already known (from a convolution epilogue +
         bn_finalize): only the normalise + activate pass runs.
-        amax_seg > 0: -> (y, mean, rstd, y_amax), y's amax buffer with segments of amax_seg positions emitted by the apply pass."""
+        amax_seg > 0: -> (y, mean, rstd, y_amax), y's amax buffer with segments of amax_seg positions emitted by the apply pass.
+        y_amax given: the buffer bn_finalize(..., zero_word=y_amax) already armed (its word [0] is zero: the pass then needs no
+        reduction launch behind it)."""
         _f32(x, 'x')
         b, c, s3 = x.shape
         dev = x.device
@@ -712,21 +715,28 @@ class HipBackend:
         ws = self._scratch(self.lib.pvcnn_bnact_workspace_bytes(b, c, s3), dev)
         nul = ctypes.c_void_p(None)
         amax_seg = int(amax_seg)
-        y_amax = (torch.empty((self.lib.pvcnn_absmax_tiles_count(b, s3, amax_seg),), dtype=torch.int32, device=dev) if amax_seg > 0 else None)
+        armed = y_amax is not None
+        if amax_seg > 0 and not armed:
+            y_amax = self.amax_buffer(b, s3, amax_seg, dev)
         with _Launch(x) as s:
             _lib.check(self.lib.pvcnn_bnact_fwd(_p(x), _p(gamma) if gamma is not None else nul, _p(beta) if beta is not None else nul,
                                                 _p(running_mean) if (training and running_mean is not None) else nul,
                                                 _p(running_var) if (training and running_var is not None) else nul,
                                                 b, c, s3, float(eps), float(momentum), float(slope), int(bool(training)),
-                                                _p(mean), _p(rstd), _p(y), _p(y_amax) if amax_seg > 0 else nul, amax_seg,
+                                                _p(mean), _p(rstd), _p(y), _p(y_amax) if amax_seg > 0 else nul, amax_seg, int(armed),
                                                 _p(ws), ws.numel(), s), 'bnact_forward')
         return (y, mean, rstd, y_amax) if amax_seg > 0 else (y, mean, rstd)
 
     has_devox_bnact = True
 
-    def bn_finalize(self, part, count, running_mean, running_var, momentum, eps, shift=None):
+    def amax_buffer(self, b, n, seg, device):
+        """Uninitialised amax buffer for a (b, C, n) tensor with segments of `seg` positions."""
+        return torch.empty((self.lib.pvcnn_absmax_tiles_count(int(b), int(n), int(seg)),), dtype=torch.int32, device=device)
+
+    def bn_finalize(self, part, count, running_mean, running_var, momentum, eps, shift=None, zero_word=None):
         """(C, nparts, 2) partial sums of (y - shift) from a convolution epilogue (shift = that convolution's bias, or None)
-        -> (mean, rstd) of y; running stats updated in place."""
+        -> (mean, rstd) of y; running stats updated in place.  zero_word: an amax buffer whose word [0] this launch zeroes (arming
+        it for the apply pass that follows: bnact_forward(..., y_amax=zero_word))."""
         c, nparts = part.shape[0], part.shape[1]
         dev = part.device
         mean = torch.empty((c,), dtype=torch.float32, device=dev)
@@ -736,7 +746,8 @@ class HipBackend:
             _lib.check(self.lib.pvcnn_bn_finalize(_p(part), c, nparts, float(count), float(eps), float(momentum),
                                                   _p(shift) if shift is not None else nul,
                                                   _p(running_mean) if running_mean is not None else nul,
-                                                  _p(running_var) if running_var is not None else nul, _p(mean), _p(rstd), s),
+                                                  _p(running_var) if running_var is not None else nul, _p(mean), _p(rstd),
+                                                  _p(zero_word) if zero_word is not None else nul, s),
                        'bn_finalize')
         return mean, rstd
 
@@ -798,7 +809,7 @@ class HipBackend:
         ws = self._scratch(self.lib.pvcnn_bnact_workspace_bytes(b, c, s3), dev)
         nul = ctypes.c_void_p(None)
         amax_seg = int(amax_seg)
-        gx_amax = (torch.empty((self.lib.pvcnn_absmax_tiles_count(b, s3, amax_seg),), dtype=torch.int32, device=dev) if amax_seg > 0 else None)
+        gx_amax = self.amax_buffer(b, s3, amax_seg, dev) if amax_seg > 0 else None
         with _Launch(x) as s:
             _lib.check(self.lib.pvcnn_bnact_bwd_strided(_p(x), _p(grad_y), gy_bstride, _p(gamma) if gamma is not None else nul,
                                                         _p(beta) if beta is not None else nul, _p(mean), _p(rstd), b, c, s3, float(slope),

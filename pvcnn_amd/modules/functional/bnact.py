@@ -29,6 +29,12 @@ def _rows(t, shape):
     return t.contiguous().view(shape[0], shape[1], -1)
 
 
+def _servable(x):
+    """The GPU path's kernels take fp32 tensors; under torch.autocast a half / bfloat16 tensor produced by a torch op in between is
+    cast up at the op boundary (custom_fwd(cast_inputs=float32) of every autograd node here), so it is served as well."""
+    return x.dtype == torch.float32 or (torch.is_autocast_enabled() and x.dtype in (torch.bfloat16, torch.float16))
+
+
 def _amax_seg_for(shape, is_cuda):
     """Segment length of the amax buffer (include/pvcnn_hip.h) the convolution NEXT TO a BatchNorm over a tensor of `shape` wants of
     that tensor, or 0: a cubic voxel grid (B,C,R,R,R) feeds / is fed by a 3x3x3 convolution in f16x2 arithmetic -> one z row (R);
@@ -72,13 +78,18 @@ class BatchNormAct(Function):
         x3 = x.contiguous().view(shape[0], shape[1], -1)
         w = weight.contiguous() if weight is not None else None
         b = bias.contiguous() if bias is not None else None
-        stats = None
+        stats = armed = None
         if training and stats_part is not None:   # partial sums from the producing convolution's epilogue
-            stats = native().bn_finalize(stats_part, x3.shape[0] * x3.shape[2], running_mean, running_var, momentum, eps, stats_shift)
+            if amax_seg:                          # the finalize launch also arms word [0] of the amax buffer the apply pass fills
+                armed = native().amax_buffer(x3.shape[0], x3.shape[2], amax_seg, x3.device)
+                stats = native().bn_finalize(stats_part, x3.shape[0] * x3.shape[2], running_mean, running_var, momentum, eps, stats_shift,
+                                             zero_word=armed)
+            else:
+                stats = native().bn_finalize(stats_part, x3.shape[0] * x3.shape[2], running_mean, running_var, momentum, eps, stats_shift)
         ctx.slope, ctx.training, ctx.shape = slope, training, shape
         if amax_seg:
             y, mean, rstd, amax = native().bnact_forward(x3, w, b, running_mean, running_var, training, momentum, eps, slope, stats=stats,
-                                                         amax_seg=amax_seg)
+                                                         amax_seg=amax_seg, y_amax=armed)
             ctx.save_for_backward(x3, w, b, mean, rstd)
             ctx.mark_non_differentiable(amax)
             ctx.set_materialize_grads(False)
@@ -127,7 +138,7 @@ def batch_norm_act(x, bn, slope, stats_part=None):
     use_batch_stats, momentum, rm, rv = _bn_mode(bn)
     part, shift = _split(stats_part)
     # the apply pass emits the f16x2 scale table of what it writes for the convolution that (usually) consumes it
-    seg = _amax_seg_for(x.shape, x.is_cuda) if x.dtype == torch.float32 else 0
+    seg = _amax_seg_for(x.shape, x.is_cuda)
     if seg:
         y, amax = BatchNormAct.apply(x, bn.weight, bn.bias, rm, rv, use_batch_stats, momentum, bn.eps, slope, part, shift, seg)
         return _cache.tag_amax(y, seg, amax)
@@ -190,9 +201,8 @@ def fusable_tail(layers, x):
     mods = list(layers)
     if _has_hooks(layers) or any(_has_hooks(m) for m in mods):   # hooks only fire through __call__: run module by module then
         return None
-    if (len(mods) >= 2 and x.is_cuda and x.dtype == torch.float32 and getattr(native(), 'has_devox_bnact', False)
-            and isinstance(mods[-2], nn.modules.batchnorm._BatchNorm) and _slope(mods[-1]) is not None
-            and not torch.is_autocast_enabled()):
+    if (len(mods) >= 2 and x.is_cuda and _servable(x) and getattr(native(), 'has_devox_bnact', False)
+            and isinstance(mods[-2], nn.modules.batchnorm._BatchNorm) and _slope(mods[-1]) is not None):
         return mods[-2], _slope(mods[-1])
     return None
 
@@ -238,16 +248,16 @@ def run_layers(layers, x, stop=None, tail_stats=False):
     while i < len(mods):
         m = mods[i]
         nxt = all_mods[i + 1] if i + 1 < len(all_mods) else None
-        want = fuse and x.dtype == torch.float32 and _wants_batch_stats(nxt) and not torch.is_autocast_enabled()
+        want = fuse and _servable(x) and _wants_batch_stats(nxt)
         part = None
-        if (pw and _is_pointwise(m) and x.dtype == torch.float32 and x.dim() == len(m.kernel_size) + 2 and x.numel() > 0
-                and not torch.is_autocast_enabled()):
-            from .pwconv import pointwise_conv
+        if pw and _is_pointwise(m) and _servable(x) and x.dim() == len(m.kernel_size) + 2 and x.numel() > 0:
+            from .pwconv import pointwise_conv, pw_nsplit
+            split = pw_nsplit(x, m.weight)        # decided HERE: inside the autograd node autocast is already switched off
             if want:
-                x, part = pointwise_conv(x, m.weight, m.bias, True)
+                x, part = pointwise_conv(x, m.weight, m.bias, True, split)
                 part = (part, m.bias)
             else:
-                x = pointwise_conv(x, m.weight, m.bias)
+                x = pointwise_conv(x, m.weight, m.bias, False, split)
             i += 1
         elif want and hasattr(m, 'forward_with_stats') and x.numel() > 0 and not hooked:
             res = m.forward_with_stats(x)
@@ -258,7 +268,7 @@ def run_layers(layers, x, stop=None, tail_stats=False):
                 x = res
             i += 1
         elif (fuse and isinstance(m, nn.modules.batchnorm._BatchNorm) and i + 1 < len(mods) and x.dim() >= 3
-                and x.dtype == torch.float32 and _slope(mods[i + 1]) is not None and x.numel() > 0):
+                and _servable(x) and _slope(mods[i + 1]) is not None and x.numel() > 0):
             x = batch_norm_act(x, m, _slope(mods[i + 1]), stats_part=carried)
             i += 2
         else:

@@ -4,18 +4,35 @@ The reference calls nn.Conv1d / nn.Conv2d (cuDNN / cuBLAS).  On gfx950 the three
 backward-weight + bias gradient) run directly on the channel-major (B, C, N) tensors: the large ones (>= 4.3 G multiply-adds)
 in "f16x2" arithmetic on the fp16 matrix cores (csrc/pointwise_bf16.hip, pointwise_wgrad_f16.hip: fp32 tensors, operands split
 into scaled fp16 hi + lo, fp32 accumulation), the small, launch-bound ones on the fp32-MFMA kernels of csrc/pointwise.hip."""
+import torch
 from torch.autograd import Function
 
 from . import _cache
 from ._autograd import native, amp_fwd, amp_bwd
 
-__all__ = ['pointwise_conv']
+__all__ = ['pointwise_conv', 'pw_nsplit']
+
+
+def pw_nsplit(x, weight):
+    """Arithmetic of one 1x1 convolution's forward / backward-data products, decided where it is CALLED (inside the autograd node
+    autocast is already switched off): 2 = f16x2 / 3 = bf16x3 (fp32-class, csrc/pointwise_bf16.hip; `backend.pw_math`), 1 = plain bf16
+    operands under torch.autocast(bfloat16), 0 = the fp32-MFMA kernels of csrc/pointwise.hip -- always for GEMMs below
+    `backend.pw_split_min_macs` multiply-adds: they are launch-bound, and the split kernels' extra launches cost more than they save."""
+    be = native()
+    if not getattr(be, 'has_pwconv_split', False):
+        return 0
+    macs = weight.shape[0] * weight.shape[1] * x.shape[0] * (x.numel() // max(x.shape[0] * x.shape[1], 1))
+    if macs < getattr(be, 'pw_split_min_macs', 0):
+        return 0
+    if torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16:
+        return 1
+    return getattr(be, 'PW_NSPLIT', {}).get(getattr(be, 'pw_math', 'fp32'), 0)
 
 
 class PointwiseConv(Function):
     @staticmethod
     @amp_fwd
-    def forward(ctx, x, weight, bias, want_stats=False):
+    def forward(ctx, x, weight, bias, want_stats=False, split=None):
         shape = x.shape
         x3 = x.contiguous().view(shape[0], shape[1], -1)
         w2 = weight.contiguous().view(weight.shape[0], weight.shape[1])
@@ -23,10 +40,8 @@ class PointwiseConv(Function):
         ctx.has_bias, ctx.x_shape, ctx.w_shape = bias is not None, shape, weight.shape
         b = bias.contiguous() if bias is not None else None
         be = native()
-        # the split products on the 16-bit matrix cores (csrc/pointwise_bf16.hip): 2 = f16x2, 3 = bf16x3, 0 = fp32 MFMA
-        ctx.split = getattr(be, 'PW_NSPLIT', {}).get(getattr(be, 'pw_math', 'fp32'), 0) if getattr(be, 'has_pwconv_split', False) else 0
-        if ctx.split and w2.shape[0] * w2.shape[1] * x3.shape[0] * x3.shape[2] < getattr(be, 'pw_split_min_macs', 0):
-            ctx.split = 0      # small GEMMs are launch-bound: the weight split and the absmax pass would cost more than they save
+        # the split products on the 16-bit matrix cores (csrc/pointwise_bf16.hip): 2 = f16x2, 3 = bf16x3, 1 = bf16, 0 = fp32 MFMA
+        ctx.split = int(split) if split is not None else pw_nsplit(x3, w2)
         ctx.x_amax = None
         if ctx.split == 2:     # the input's amax buffer (one scale per 256-point tile): left on it by its producer, else one read
             ctx.x_amax = _cache.amax_of(x, be.PW_AMAX_SEG)
@@ -46,11 +61,13 @@ class PointwiseConv(Function):
     def backward(ctx, grad_y, grad_part=None):
         x3, w2 = ctx.saved_tensors
         if grad_y is None:
-            return None, None, None, None
+            return None, None, None, None, None
         g3 = grad_y.contiguous().view(x3.shape[0], w2.shape[0], -1)
         be = native()
         f16 = ctx.split == 2
-        wgrad_f16 = f16 and ctx.needs_input_grad[1] and be.pwconv_backward_weight_f16_serves(x3)
+        # the f16x2 backward-weight kernel also serves the bf16 (autocast) mode: more accurate than bf16 operands, and far faster than
+        # the fp32-MFMA kernel on the large GEMMs this mode is chosen for
+        wgrad_f16 = ctx.split in (1, 2) and ctx.needs_input_grad[1] and be.pwconv_backward_weight_f16_serves(x3)
         # shared by both products; the BatchNorm backward that produced grad_y left it on the tensor (_cache.tag_amax)
         g_amax = None
         if f16 and (ctx.needs_input_grad[0] or wgrad_f16):
@@ -64,13 +81,14 @@ class PointwiseConv(Function):
         want_bias = ctx.has_bias and ctx.needs_input_grad[2]
         gw = gb = None
         if ctx.needs_input_grad[1]:
+            # (x_amax / g_amax None -- the bf16 mode measured neither: backward-weight takes the global maxima in one read each)
             res = (be.pwconv_backward_weight_f16(x3, g3, ctx.x_amax, g_amax, with_bias=want_bias) if wgrad_f16
                    else be.pwconv_backward_weight(x3, g3, with_bias=want_bias))
             gw, gb = res if want_bias else (res, None)
             gw = gw.view(ctx.w_shape)
         elif want_bias:
             gb = g3.sum(dim=(0, 2))
-        return gx, gw, gb, None
+        return gx, gw, gb, None, None
 
 
 pointwise_conv = PointwiseConv.apply

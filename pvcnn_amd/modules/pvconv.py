@@ -42,7 +42,8 @@ class _VoxelConv3d(nn.Conv3d):
         fast = (x.is_cuda and getattr(native(), 'has_conv3d', False) and self.kernel_size == (3, 3, 3)
                 and self.stride == (1, 1, 1) and self.padding == (1, 1, 1) and self.dilation == (1, 1, 1)
                 and self.groups == 1 and self.padding_mode == 'zeros' and x.dim() == 5
-                and x.shape[2] == x.shape[3] == x.shape[4] and x.dtype == torch.float32)
+                and x.shape[2] == x.shape[3] == x.shape[4] and self.weight.dtype == torch.float32
+                and (x.dtype == torch.float32 or (torch.is_autocast_enabled() and x.dtype in (torch.bfloat16, torch.float16))))
         if not fast:
             return self.forward(x)
         return voxel_conv3d(x, self.weight, self.bias, True, conv_nsplit())
@@ -85,7 +86,9 @@ class PVConv(nn.Module):
                                               addend=per_point)
             return fused, coords
         else:
-            grid = run_layers(self.voxel_layers, grid)     # = self.voxel_layers(grid), BN + LeakyReLU fused
+            # = self.voxel_layers(grid) with BN + LeakyReLU fused (a hooked Sequential goes through its own __call__)
+            hooked = bool(self.voxel_layers._forward_hooks or self.voxel_layers._forward_pre_hooks or self.voxel_layers._backward_hooks)
+            grid = self.voxel_layers(grid) if hooked else run_layers(self.voxel_layers, grid)
             per_point = self.point_features(features)
             from_voxels = F.trilinear_devoxelize(grid, grid_coords, self.resolution, self.training)
         return from_voxels + per_point, coords

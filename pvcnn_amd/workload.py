@@ -29,6 +29,43 @@ def _scaled(width, k):
     return int(k * width)
 
 
+class _TapAndPool(torch.autograd.Function):
+    """(x (B,C,N), winners (B,C)) -> (x, x[..., winners]): a per-point feature map that is BOTH kept as a tap of the classifier's
+    concatenation and max-pooled over the points (models/s3dis/pvcnn.py:41-45) as ONE autograd node.  With two separate consumers
+    autograd materialises the pool's gradient as a dense (B,C,N) tensor (a 268 MB zero fill + scatter at PVCNN's 1024 channels) and
+    then adds the two gradients with a full pass (another 3 x 268 MB); here the B*C pooled gradients are added into the tap's gradient
+    at the winner positions -- the very sum the reference's graph forms, one addition per winner, same rounding."""
+
+    @staticmethod
+    def forward(ctx, x, winners):
+        ctx.save_for_backward(winners)
+        ctx.npoints = x.shape[-1]
+        return x.view_as(x), x.gather(2, winners.unsqueeze(-1)).squeeze(-1)
+
+    @staticmethod
+    def backward(ctx, g_tap, g_pool):
+        (winners,) = ctx.saved_tensors
+        if g_tap is None and g_pool is None:
+            return None, None
+        if g_tap is None:
+            g = torch.zeros(g_pool.shape + (int(ctx.npoints),), dtype=g_pool.dtype, device=g_pool.device)
+        else:
+            # g_tap is this node's own slice of the concatenation's gradient (torch.cat's backward hands every input a disjoint
+            # view): adding in place keeps it a batch-strided view for the consumer (no copy) and touches B*C elements
+            g = g_tap
+        if g_pool is not None:
+            g.scatter_add_(2, winners.unsqueeze(-1), g_pool.unsqueeze(-1).to(g.dtype))
+        return g, None
+
+
+def tap_and_pool(x):
+    """-> (x as a tap, max over the points (B,C)).  The winners come from `x.max(dim=-1)` itself (ties: torch's rule)."""
+    if not (x.requires_grad and torch.is_grad_enabled()):
+        return x, x.max(dim=-1).values
+    winners = x.max(dim=-1).indices
+    return _TapAndPool.apply(x, winners)
+
+
 def _dense_bn_relu(cin, cout):
     return nn.Sequential(nn.Linear(cin, cout), nn.BatchNorm1d(cout), nn.ReLU(True))
 
@@ -96,8 +133,10 @@ class PVCNN(nn.Module):
         for stage in self.point_features:
             feats, _ = stage((feats, coords))
             taps.append(feats)
-        cloud = self.cloud_features(feats.max(dim=-1, keepdim=False).values)
-        taps.append(cloud.unsqueeze(-1).repeat([1, 1, coords.size(-1)]))
+        taps[-1], pooled = tap_and_pool(feats)             # the last stage's features: a tap AND the global max pool
+        cloud = self.cloud_features(pooled)
+        # (expand, not repeat: torch.cat reads the broadcast view -- the repeated (B,128,N) tensor is never written on its own)
+        taps.append(cloud.unsqueeze(-1).expand(-1, -1, coords.size(-1)))
         return self.classifier(torch.cat(taps, dim=1))
 
 

@@ -36,6 +36,9 @@ for (b, ci, co, n) in shapes:
     ax, ag = be.pw_amax(x), be.pw_amax(gy)
     wf, wb = be._pw_wsplit(w, False, 2), be._pw_wsplit(w, True, 2)
     f2 = t(lambda: be.pwconv_gemm_split(x, wf, bias, co, 2, False, ax))        # the GEMM launch alone
+    ax1 = be.absmax_bits(x)
+    f2s = t(lambda: be.pwconv_gemm_split(x, wf, bias, co, 2, False, ax1))      # ... with ONE scale for the tensor (amax_seg = 0)
+    tam = t(lambda: be.pw_amax(x))
     d2 = t(lambda: be.pwconv_gemm_split(gy, wb, None, ci, 2, False, ag))
     f2all = t(lambda: be.pwconv_forward_split(x, w, bias, 2))                  # + weight split + absmax
     e2 = ((be.pwconv_forward_split(x, w, bias, 2).double() - F.conv1d(x.double(), w.double().view(co, ci, 1), bias.double())).abs().max()
@@ -45,7 +48,7 @@ for (b, ci, co, n) in shapes:
     eg = ((be.pwconv_backward_weight_f16(x, gy, ax, ag).double() - gwr).abs().max() / gwr.abs().max()).item()
     print(json.dumps({'f16x2_wgrad_BCiCoN': [b, ci, co, n], 'bwd_w_ms': round(g2, 4), 'eff_TF': round(fl / g2 / 1e9, 1), 'err': eg}), flush=True)
     print(json.dumps({'f16x2_BCiCoN': [b, ci, co, n], 'fwd_ms': round(f2, 4), 'fwd_eff_TF': round(fl / f2 / 1e9, 1), 'bwd_data_ms': round(d2, 4),
-                      'fwd_with_split_and_absmax_ms': round(f2all, 4), 'err_f16x2': e2}), flush=True)
+                      'fwd_with_split_and_absmax_ms': round(f2all, 4), 'fwd_single_scale_ms': round(f2s, 4), 'amax_tiles_ms': round(tam, 4), 'err_f16x2': e2}), flush=True)
     f3 = t(lambda: be.pwconv_forward_split(x, w, bias, 3))
     d3 = t(lambda: be.pwconv_backward_data_split(gy, w, 3))
     f1 = t(lambda: be.pwconv_forward_split(x, w, bias, 1))
