@@ -114,7 +114,13 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_bf16_kernel(const float *__res
                                                               int N, int tiles_n, int tiles_total, float2 *__restrict__ stats_part,
                                                               const uint32_t *__restrict__ x_absmax, const int *__restrict__ wexp,
                                                               int amax_seg) {
-  constexpr int TM = 32 * MB, NBW = 2;
+  // Wave arrangement inside the 32*MB x 256 workgroup tile.  Each lane fetches its own A (weight) fragments from global memory:
+  // with the four waves side by side along the points (WM = 1) every wave pulls ALL 32*MB rows through the CU's vector-memory
+  // path -- at MB = 4 that is 48 KiB per chunk and workgroup (A four times + the x rows) = as many L1 cycles (64 B/clk) as the
+  // chunk has MFMA cycles: the kernel sat at 0.23 of the MFMA peak whatever was prefetched.  WM = 2 arranges the waves 2 x 2: a
+  // wave owns 32*MB/2 rows x 128 points, the A traffic halves (32 KiB: 2/3 of the MFMA time) and the B fragments -- LDS reads,
+  // which had headroom -- double.  Same products in the same order per output element: results are bit-identical.
+  constexpr int TM = 32 * MB, WM = (MB >= 4) ? 2 : 1, MBW = MB / WM, NBW = 2 * WM;
   constexpr int WBLK = NS * TM * kPbK;                          // bf16 elements of one (chunk, mtile) weight block
   __shared__ __attribute__((aligned(16))) uint32_t xs[NS * 8 * kPbN];       // [NS][8 channel pairs][256 points] words
 
@@ -129,21 +135,22 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_bf16_kernel(const float *__res
   const float x_scale = exp2_int(x_shift);
   const int b = tile / tiles_n, n0 = (tile - b * tiles_n) * kPbN, m0 = mt * TM;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, kh = lane >> 5;
+  const int wm = wave % WM, wn = wave / WM;                     // this wave's row group / point group
   const float *xb = x + (size_t)b * K * N;
   const int chunks = ceil_div(K, kPbK);
 
-  int a_off[MB];                                                // A fragment uint4 offsets inside one plane slab
+  int a_off[MBW];                                               // A fragment uint4 offsets inside one plane slab
 #pragma unroll
-  for (int mb = 0; mb < MB; ++mb) {
-    const int row = mb * 32 + j;
+  for (int mb = 0; mb < MBW; ++mb) {
+    const int row = (wm * MBW + mb) * 32 + j;
     a_off[mb] = (row * 8 + ((kh ^ ((row >> 3) & 1)) * 4)) >> 2;
   }
   int b_pt[NBW];                                                // this lane's point inside the tile, per column block
 #pragma unroll
-  for (int nb = 0; nb < NBW; ++nb) b_pt[nb] = wave * 64 + nb * 32 + j;
-  f32x16 acc[MB][NBW];
+  for (int nb = 0; nb < NBW; ++nb) b_pt[nb] = wn * (32 * NBW) + nb * 32 + j;
+  f32x16 acc[MBW][NBW];
 #pragma unroll
-  for (int mb = 0; mb < MB; ++mb)
+  for (int mb = 0; mb < MBW; ++mb)
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
@@ -187,11 +194,11 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_bf16_kernel(const float *__res
       }
     }
   };
-  uint4 af[MB][NS];
+  uint4 af[MBW][NS];
   auto load_a = [&](int chunk) {
     const uint4 *wq = reinterpret_cast<const uint4 *>(wts + ((size_t)chunk * mtiles + mt) * WBLK);
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
+    for (int mb = 0; mb < MBW; ++mb)
 #pragma unroll
       for (int s = 0; s < NS; ++s) af[mb][s] = wq[s * (TM * kPbK / 8) + a_off[mb]];
   };
@@ -238,7 +245,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_bf16_kernel(const float *__res
     __builtin_amdgcn_sched_barrier(0);
 #define PVCNN_PB_MFMA(SA, SB)                                                                                            \
     _Pragma("unroll") for (int nb = 0; nb < NBW; ++nb)                                                                   \
-    _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                                                                    \
+    _Pragma("unroll") for (int mb = 0; mb < MBW; ++mb)                                                                   \
       acc[mb][nb] = mfma16<NS>(af[mb][SA], bf[nb][SB], acc[mb][nb])
     if constexpr (NS == 1) {
       PVCNN_PB_MFMA(0, 0);
@@ -258,11 +265,12 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_bf16_kernel(const float *__res
 
   // ---- epilogue: D[i = m][j = point]; lanes = consecutive points (128-byte rows) ----
   const bool want_stats = stats_part != nullptr;
-  float2 *stat_lds = reinterpret_cast<float2 *>(xs);            // [4 waves][TM]
+  float2 *stat_lds = reinterpret_cast<float2 *>(xs);            // [4 / WM point groups][TM]
   if (want_stats) __syncthreads();
   float *yb = y + (size_t)b * M * N;
 #pragma unroll
-  for (int mb = 0; mb < MB; ++mb) {
+  for (int mbl = 0; mbl < MBW; ++mbl) {
+    const int mb = wm * MBW + mbl;                              // row block inside the workgroup tile
     float bv[16], unscale[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -276,11 +284,11 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_bf16_kernel(const float *__res
     for (int r = 0; r < 16; ++r) ss[r] = qq[r] = 0.0f;
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb) {
-      const int n = n0 + wave * 64 + nb * 32 + j;
+      const int n = n0 + wn * (32 * NBW) + nb * 32 + j;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        float v = acc[mb][nb][r];
+        float v = acc[mbl][nb][r];
         if constexpr (NS == 2) v = v * unscale[r] * x_unscale;  // powers of two: exact
         if (want_stats) {                                       // statistics of (y - bias), see bn_finalize_kernel
           const float mv = n < N ? v : 0.0f;
@@ -294,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_bf16_kernel(const float *__res
     if (want_stats) {
       const float st = half_wave_sum16(ss, j), qt = half_wave_sum16(qq, j);
       const int rr = (j >> 1) & 15;
-      if ((j & 1) == 0) stat_lds[wave * TM + mb * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * kh] = make_float2(st, qt);
+      if ((j & 1) == 0) stat_lds[wn * TM + mb * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * kh] = make_float2(st, qt);
     }
   }
   if (want_stats) {
@@ -302,7 +310,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_bf16_kernel(const float *__res
     if (tid < TM && m0 + tid < M) {
       float2 t = stat_lds[tid];
 #pragma unroll
-      for (int w = 1; w < 4; ++w) { t.x += stat_lds[w * TM + tid].x; t.y += stat_lds[w * TM + tid].y; }
+      for (int w = 1; w < 4 / WM; ++w) { t.x += stat_lds[w * TM + tid].x; t.y += stat_lds[w * TM + tid].y; }
       stats_part[(size_t)(m0 + tid) * tiles_total + tile] = t;
     }
   }
