@@ -240,7 +240,15 @@ __global__ __launch_bounds__(256, (NS == 3 || TX * TY * TZ == 512 || TZ <= 16) ?
                                                                    int amax_seg) {
   static_assert(TX * TY * TZ == 128 || TX * TY * TZ == 256 || TX * TY * TZ == 512, "a workgroup tile is 4 waves x NBW x 32 voxels");
   constexpr int HX = TX + 2, HY = TY + 2, HZ = TZ + 2, HS = HX * HY * HZ;
-  constexpr int NBW = TX * TY * TZ / 128;                       // 32-voxel MFMA column blocks per wave
+  // Wave arrangement inside the 64-channel x (TX*TY*TZ)-voxel workgroup tile.  Every lane fetches its own A (weight) fragments from
+  // global memory, once per tap.  With the four waves side by side along the voxels (WM = 1) each wave pulls all 64 rows: 4 KiB per
+  // tap and wave through the CU's vector-memory path (64 B/clk) against 6 / 12 MFMAs at a 128- / 256-voxel tile -- at R = 16 the L1
+  // path, not the matrix core, was the limit (0.33-0.40 of the MFMA peak whatever the prefetch depth).  WM = 2 arranges the waves
+  // 2 x 2: a wave owns 32 channels x half the voxels, the A traffic halves and the B fragments (LDS reads, which have headroom)
+  // double.  Only the 128-voxel tile is arranged so: at 256 voxels the wider B ring spills (measured by the compiler: 136-424 bytes
+  // of scratch), and the 512-voxel tile has 24 MFMAs per A fetch anyway.  Per output element the products and their order are the same.
+  constexpr int NB1 = TX * TY * TZ / 128;                       // 32-voxel column blocks per wave when the waves sit side by side
+  constexpr int WM = NB1 == 1 ? 2 : 1, MBW = 2 / WM, NBW = NB1 * WM;    // waves along the channels; row / column blocks per wave
   constexpr int WBLK = 3 * NS * kCoTileB * kKc;                 // bf16 elements of one (chunk, dxy, cotile) weight block
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
   uint32_t *xs = lds_u;                                         // [NS][HS][8] words (16 bf16 per voxel)
@@ -253,6 +261,7 @@ __global__ __launch_bounds__(256, (NS == 3 || TX * TY * TZ == 512 || TZ <= 16) ?
   const int cot = blockIdx.y, co0 = cot * kCoTileB, cotiles = gridDim.y;
   const int x0 = txi * TX, y0 = tyi * TY, z0 = tzi * TZ;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, kh = lane >> 5;
+  const int wm = wave % WM, wn = wave / WM;                     // this wave's channel group / voxel group
   const size_t RR = (size_t)R * R, S = RR * R;
   const float *xb = x + (size_t)b * Ci * S;
   const int chunks = ceil_div(Ci, kKc);
@@ -279,19 +288,19 @@ __global__ __launch_bounds__(256, (NS == 3 || TX * TY * TZ == 512 || TZ <= 16) ?
   int hb[NBW];                                                  // halo index of this lane's output voxel (tap 0,0,0 corner)
 #pragma unroll
   for (int nb = 0; nb < NBW; ++nb) {
-    const int m = wave * (32 * NBW) + nb * 32 + j;
+    const int m = wn * (32 * NBW) + nb * 32 + j;
     const int zt = m % TZ, yt = (m / TZ) % TY, xt = m / (TZ * TY);
     hb[nb] = (xt * HY + yt) * HZ + zt;
   }
-  int a_off[2];                                                 // A fragment word offsets inside one (dz, plane) slab
+  int a_off[MBW];                                               // A fragment word offsets inside one (dz, plane) slab
 #pragma unroll
-  for (int mb = 0; mb < 2; ++mb) {
-    const int row = mb * 32 + j;
+  for (int mb = 0; mb < MBW; ++mb) {
+    const int row = (wm * MBW + mb) * 32 + j;
     a_off[mb] = row * 8 + ((kh ^ ((row >> 3) & 1)) * 4);
   }
-  f32x16 acc[2][NBW];
+  f32x16 acc[MBW][NBW];
 #pragma unroll
-  for (int mb = 0; mb < 2; ++mb)
+  for (int mb = 0; mb < MBW; ++mb)
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
@@ -389,11 +398,11 @@ __global__ __launch_bounds__(256, (NS == 3 || TX * TY * TZ == 512 || TZ <= 16) ?
     // slab is 64 rows x 32 B: the 64 lanes of a wave read 2 KiB contiguous, L2-resident -- the whole image is a few hundred
     // KiB shared by every workgroup).  No LDS copy of the weights, no barriers inside the tap loop.
     const uint4 *wblk = reinterpret_cast<const uint4 *>(wts + (((size_t)chunk * 9) * cotiles + cot) * WBLK);
-    auto load_a = [&](int tap, uint4 (&af)[2][NS]) {
+    auto load_a = [&](int tap, uint4 (&af)[MBW][NS]) {
       const int dxy = tap / 3, dz = tap - dxy * 3;
       const uint4 *wq = wblk + (size_t)dxy * cotiles * (WBLK / 8);
 #pragma unroll
-      for (int mb = 0; mb < 2; ++mb)
+      for (int mb = 0; mb < MBW; ++mb)
 #pragma unroll
         for (int s = 0; s < NS; ++s) af[mb][s] = wq[((dz * NS + s) * kCoTileB * 8 + a_off[mb]) >> 2];
     };
@@ -402,7 +411,7 @@ __global__ __launch_bounds__(256, (NS == 3 || TX * TY * TZ == 512 || TZ <= 16) ?
     // hit: there the ring is three taps deep (48 more VGPRs, which the 256-voxel tiles have).
     constexpr int AD = (TZ <= 16 && NS != 3) ? 3 : 1;
     constexpr bool PIN = AD > 1, BPRE = PIN;                    // (pinning the R = 32 tiles changes nothing: 3 waves per SIMD hide it)
-    uint4 aq[AD + 1][2][NS], bq[2][NBW][NS];
+    uint4 aq[AD + 1][MBW][NS], bq[2][NBW][NS];
     auto load_b = [&](int tap, uint4 (&bf)[NBW][NS]) {
       const int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
       const int toff = (dx * HY + dy) * HZ + dz;
@@ -426,12 +435,12 @@ __global__ __launch_bounds__(256, (NS == 3 || TX * TY * TZ == 512 || TZ <= 16) ?
         load_b(tap, bq[tap & 1]);
       }
       if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);     // or the scheduler sinks the loads to just before their use
-      uint4 (&af)[2][NS] = aq[tap % (AD + 1)];
+      uint4 (&af)[MBW][NS] = aq[tap % (AD + 1)];
       uint4 (&bf)[NBW][NS] = bq[tap & 1];
       // consecutive MFMAs go to different accumulators (4 independent tiles between two partial products of one tile)
 #define PVCNN_MFMA4(SA, SB)                                                                                              \
       _Pragma("unroll") for (int nb = 0; nb < NBW; ++nb)                                                                 \
-      _Pragma("unroll") for (int mb = 0; mb < 2; ++mb)                                                                   \
+      _Pragma("unroll") for (int mb = 0; mb < MBW; ++mb)                                                                 \
         acc[mb][nb] = mfma16<NS>(af[mb][SA], bf[nb][SB], acc[mb][nb])
       if constexpr (NS == 1) {
         PVCNN_MFMA4(0, 0);
@@ -454,16 +463,17 @@ __global__ __launch_bounds__(256, (NS == 3 || TX * TY * TZ == 512 || TZ <= 16) ?
   bool vok[NBW];
 #pragma unroll
   for (int nb = 0; nb < NBW; ++nb) {
-    const int m = wave * (32 * NBW) + nb * 32 + j;
+    const int m = wn * (32 * NBW) + nb * 32 + j;
     const int zt = m % TZ, yt = (m / TZ) % TY, xt = m / (TZ * TY);
     const int gx = x0 + xt, gy = y0 + yt, gz = z0 + zt;
     vok[nb] = gx < R && gy < R && gz < R;
     voff[nb] = (size_t)gx * RR + (size_t)gy * R + gz;
   }
   const bool want_stats = stats_part != nullptr;
-  float2 *stat_lds = reinterpret_cast<float2 *>(lds_u);        // [4 waves][64 channels]
+  float2 *stat_lds = reinterpret_cast<float2 *>(lds_u);        // [4 / WM voxel groups][64 channels]
 #pragma unroll
-  for (int mb = 0; mb < 2; ++mb) {
+  for (int mbl = 0; mbl < MBW; ++mbl) {
+    const int mb = wm * MBW + mbl;                              // 32-channel row block inside the 64-channel tile
     float bv[16], unscale[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -480,7 +490,7 @@ __global__ __launch_bounds__(256, (NS == 3 || TX * TY * TZ == 512 || TZ <= 16) ?
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = co0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        float v = acc[mb][nb][r];
+        float v = acc[mbl][nb][r];
         if constexpr (NS == 2) v = v * unscale[r] * x_unscale;  // powers of two: exact
         if (want_stats) {                                       // statistics of (y - bias), see bn_finalize_kernel
           const float m = vok[nb] ? v : 0.0f;
@@ -493,7 +503,7 @@ __global__ __launch_bounds__(256, (NS == 3 || TX * TY * TZ == 512 || TZ <= 16) ?
     if (want_stats) {
       const float st = half_wave_sum16(ss, j), qt = half_wave_sum16(qq, j);
       const int rr = (j >> 1) & 15;
-      if ((j & 1) == 0) stat_lds[wave * kCoTileB + mb * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * kh] = make_float2(st, qt);
+      if ((j & 1) == 0) stat_lds[wn * kCoTileB + mb * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * kh] = make_float2(st, qt);
     }
   }
   if (want_stats) {
@@ -501,7 +511,7 @@ __global__ __launch_bounds__(256, (NS == 3 || TX * TY * TZ == 512 || TZ <= 16) ?
     if (tid < kCoTileB && co0 + tid < Co) {
       float2 t = stat_lds[tid];
 #pragma unroll
-      for (int w = 1; w < 4; ++w) { t.x += stat_lds[w * kCoTileB + tid].x; t.y += stat_lds[w * kCoTileB + tid].y; }
+      for (int w = 1; w < 4 / WM; ++w) { t.x += stat_lds[w * kCoTileB + tid].x; t.y += stat_lds[w * kCoTileB + tid].y; }
       stats_part[(size_t)(co0 + tid) * gridDim.x + blockIdx.x] = t;
     }
   }
