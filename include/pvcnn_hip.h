@@ -344,7 +344,7 @@ PVCNN_API int pvcnn_pwconv_fwd_stats(const float *x, const float *wt, int wt_row
  * bn_finalize adds it back to the mean -- a variance from E[a^2] - E[a]^2 stays accurate when the bias dwarfs the spread. */
 PVCNN_API int pvcnn_bn_finalize(const float *part, int C, long nparts, double count, float eps, float momentum, const float *shift,
                       float *running_mean, float *running_var, float *mean, float *rstd, void *zero_word /* NULL | one uint32 set to 0 */,
-                      void *stream);
+                      void *num_batches_tracked /* NULL | one int64 incremented by 1 (nn.BatchNorm's counter) */, void *stream);
 PVCNN_API int pvcnn_bn_stats(const float *x, float *running_mean, float *running_var, int B, int C, int S,
                    float eps, float momentum, float *mean, float *rstd, void *workspace,
                    size_t workspace_bytes, void *stream);

@@ -81,7 +81,7 @@ SIGNATURES = {
     'pvcnn_conv3d_fwd_stats': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     'pvcnn_pwconv_fwd_stats_parts': (_sz, [_i, _i]),
     'pvcnn_pwconv_fwd_stats': (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
-    'pvcnn_bn_finalize': (_i, [_vp, _i, ctypes.c_long, ctypes.c_double, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'pvcnn_bn_finalize': (_i, [_vp, _i, ctypes.c_long, ctypes.c_double, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'pvcnn_bn_stats': (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp, _sz, _vp]),
     'pvcnn_trilinear_devox_bnact_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'pvcnn_bnact_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _sz, _vp]),

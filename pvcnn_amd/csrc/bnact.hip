@@ -68,9 +68,11 @@ __global__ __launch_bounds__(kBnThreads) void bn_stats_kernel(const float *__res
 __global__ __launch_bounds__(64) void bn_finalize_kernel(const float2 *__restrict__ part, int nparts, double count, float eps,
                                                         float momentum, const float *__restrict__ shift, float *__restrict__ mean,
                                                         float *__restrict__ rstd, float *__restrict__ running_mean,
-                                                        float *__restrict__ running_var, uint32_t *__restrict__ zero_word) {
+                                                        float *__restrict__ running_var, uint32_t *__restrict__ zero_word,
+                                                        long long *__restrict__ counter) {
   const int c = blockIdx.x;
   if (zero_word != nullptr && c == 0 && threadIdx.x == 0) *zero_word = 0u;   // arms word [0] of the amax buffer the apply pass will fill
+  if (counter != nullptr && c == 0 && threadIdx.x == 0) *counter += 1;       // BatchNorm's num_batches_tracked (one launch less per layer)
   double s = 0.0, q = 0.0;
   for (int i = threadIdx.x; i < nparts; i += 64) { const float2 p = part[(size_t)c * nparts + i]; s += p.x; q += p.y; }
 #pragma unroll
@@ -348,7 +350,7 @@ extern "C" int pvcnn_bnact_fwd(const float *x, const float *gamma, const float *
     hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(kBnThreads), 0, s, x, C, S, slices, part, shift);
     if (int e = check_launch("bn_stats")) return e;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, s, part, B * slices, (double)B * S, eps, momentum, shift, mean, rstd,
-                       running_mean, running_var, static_cast<uint32_t *>(y_amax));
+                       running_mean, running_var, static_cast<uint32_t *>(y_amax), static_cast<long long *>(nullptr));
     if (int e = check_launch("bn_finalize")) return e;
     amax_zeroed = 1;
   }
@@ -369,11 +371,12 @@ extern "C" int pvcnn_bnact_fwd(const float *x, const float *gamma, const float *
 // mean / rstd (+ running statistics) from per-workgroup partials produced by a convolution epilogue
 // (pvcnn_conv3d_fwd_stats, pvcnn_pwconv_fwd_stats): part is (C, nparts) float2 {sum, sum of squares}.
 extern "C" int pvcnn_bn_finalize(const float *part, int C, long nparts, double count, float eps, float momentum, const float *shift,
-                                 float *running_mean, float *running_var, float *mean, float *rstd, void *zero_word, void *stream) {
+                                 float *running_mean, float *running_var, float *mean, float *rstd, void *zero_word,
+                                 void *num_batches_tracked, void *stream) {
   PVCNN_REQUIRE(C > 0 && nparts > 0 && nparts <= 0x7fffffffL && count > 0 && part && mean && rstd, "bad argument");
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, static_cast<hipStream_t>(stream),
                      reinterpret_cast<const float2 *>(part), (int)nparts, count, eps, momentum, shift, mean, rstd, running_mean,
-                     running_var, static_cast<uint32_t *>(zero_word));
+                     running_var, static_cast<uint32_t *>(zero_word), static_cast<long long *>(num_batches_tracked));
   return check_launch("bn_finalize");
 }
 
@@ -389,7 +392,7 @@ extern "C" int pvcnn_bn_stats(const float *x, float *running_mean, float *runnin
   hipLaunchKernelGGL(bn_stats_kernel, dim3(slices, B, C), dim3(kBnThreads), 0, s, x, C, S, slices, part, shift);
   if (int e = check_launch("bn_stats")) return e;
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, s, part, B * slices, (double)B * S, eps, momentum, shift, mean, rstd,
-                     running_mean, running_var, static_cast<uint32_t *>(nullptr));
+                     running_mean, running_var, static_cast<uint32_t *>(nullptr), static_cast<long long *>(nullptr));
   return check_launch("bn_finalize");
 }
 

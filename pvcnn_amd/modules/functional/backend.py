@@ -733,10 +733,11 @@ class HipBackend:
         """Uninitialised amax buffer for a (b, C, n) tensor with segments of `seg` positions."""
         return torch.empty((self.lib.pvcnn_absmax_tiles_count(int(b), int(n), int(seg)),), dtype=torch.int32, device=device)
 
-    def bn_finalize(self, part, count, running_mean, running_var, momentum, eps, shift=None, zero_word=None):
+    def bn_finalize(self, part, count, running_mean, running_var, momentum, eps, shift=None, zero_word=None, counter=None):
         """(C, nparts, 2) partial sums of (y - shift) from a convolution epilogue (shift = that convolution's bias, or None)
         -> (mean, rstd) of y; running stats updated in place.  zero_word: an amax buffer whose word [0] this launch zeroes (arming
-        it for the apply pass that follows: bnact_forward(..., y_amax=zero_word))."""
+        it for the apply pass that follows: bnact_forward(..., y_amax=zero_word)).  counter: the module's int64 num_batches_tracked,
+        incremented by the same launch."""
         c, nparts = part.shape[0], part.shape[1]
         dev = part.device
         mean = torch.empty((c,), dtype=torch.float32, device=dev)
@@ -747,7 +748,8 @@ class HipBackend:
                                                   _p(shift) if shift is not None else nul,
                                                   _p(running_mean) if running_mean is not None else nul,
                                                   _p(running_var) if running_var is not None else nul, _p(mean), _p(rstd),
-                                                  _p(zero_word) if zero_word is not None else nul, s),
+                                                  _p(zero_word) if zero_word is not None else nul,
+                                                  _p(counter) if counter is not None else nul, s),
                        'bn_finalize')
         return mean, rstd
 

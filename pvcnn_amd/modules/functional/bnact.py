@@ -72,7 +72,7 @@ class BatchNormAct(Function):
     @staticmethod
     @amp_fwd
     def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, slope, stats_part=None, stats_shift=None,
-                amax_seg=0):
+                amax_seg=0, counter=None):
         """-> y, or (y, y's amax buffer) when amax_seg > 0 (second output: not differentiable)."""
         shape = x.shape
         x3 = x.contiguous().view(shape[0], shape[1], -1)
@@ -83,9 +83,10 @@ class BatchNormAct(Function):
             if amax_seg:                          # the finalize launch also arms word [0] of the amax buffer the apply pass fills
                 armed = native().amax_buffer(x3.shape[0], x3.shape[2], amax_seg, x3.device)
                 stats = native().bn_finalize(stats_part, x3.shape[0] * x3.shape[2], running_mean, running_var, momentum, eps, stats_shift,
-                                             zero_word=armed)
+                                             zero_word=armed, counter=counter)
             else:
-                stats = native().bn_finalize(stats_part, x3.shape[0] * x3.shape[2], running_mean, running_var, momentum, eps, stats_shift)
+                stats = native().bn_finalize(stats_part, x3.shape[0] * x3.shape[2], running_mean, running_var, momentum, eps, stats_shift,
+                                             counter=counter)
         ctx.slope, ctx.training, ctx.shape = slope, training, shape
         if amax_seg:
             y, mean, rstd, amax = native().bnact_forward(x3, w, b, running_mean, running_var, training, momentum, eps, slope, stats=stats,
@@ -102,26 +103,33 @@ class BatchNormAct(Function):
     @amp_bwd
     def backward(ctx, grad_y, grad_amax=None):
         if grad_y is None:
-            return (None,) * 12
+            return (None,) * 13
         x3, w, b, mean, rstd = ctx.saved_tensors
         g3 = _rows(grad_y, ctx.shape)
         gx, gw, gb = _bnact_backward(x3, g3, w, b, mean, rstd, ctx.slope, ctx.training, ctx.shape)
         return (gx, gw if w is not None else None, gb if b is not None else None,
-                None, None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None, None)
 
 
-def _bn_mode(bn):
-    """-> (use_batch_stats, momentum, running_mean, running_var) of one forward call of module `bn`, with the
-    side effects torch.nn.BatchNorm has (num_batches_tracked)."""
+def _bn_mode(bn, finalize_counts=False):
+    """-> (use_batch_stats, momentum, running_mean, running_var, counter) of one forward call of module `bn`, with the side effects
+    torch.nn.BatchNorm has (num_batches_tracked).  finalize_counts: the statistics of this call come from a convolution epilogue and
+    are finalised by a kernel of ours -- that launch also increments num_batches_tracked (returned as `counter`; otherwise None and
+    the counter was incremented here, one tiny launch per BatchNorm and step)."""
     use_batch_stats = bn.training or bn.running_mean is None
     momentum = 0.0 if bn.momentum is None else bn.momentum
+    counter = None
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
-        if bn.momentum is None:                      # cumulative moving average
-            momentum = 1.0 / float(bn.num_batches_tracked)
+        nbt = bn.num_batches_tracked
+        if (finalize_counts and bn.momentum is not None and nbt.is_cuda and nbt.dtype == torch.int64 and nbt.numel() == 1):
+            counter = nbt
+        else:
+            nbt.add_(1)
+            if bn.momentum is None:                  # cumulative moving average
+                momentum = 1.0 / float(nbt)
     rm = bn.running_mean if (bn.track_running_stats or not use_batch_stats) else None
     rv = bn.running_var if (bn.track_running_stats or not use_batch_stats) else None
-    return use_batch_stats, momentum, rm, rv
+    return use_batch_stats, momentum, rm, rv, counter
 
 
 def _split(stats):
@@ -135,14 +143,14 @@ def _split(stats):
 def batch_norm_act(x, bn, slope, stats_part=None):
     """Apply BatchNorm module `bn` followed by LeakyReLU(slope) (slope = 0: ReLU) to x (B, C, ...).
     stats_part: (per-workgroup partial sums of x - shift written by the convolution that produced x, shift = its bias)."""
-    use_batch_stats, momentum, rm, rv = _bn_mode(bn)
+    use_batch_stats, momentum, rm, rv, counter = _bn_mode(bn, finalize_counts=stats_part is not None and bn.training)
     part, shift = _split(stats_part)
     # the apply pass emits the f16x2 scale table of what it writes for the convolution that (usually) consumes it
     seg = _amax_seg_for(x.shape, x.is_cuda)
     if seg:
-        y, amax = BatchNormAct.apply(x, bn.weight, bn.bias, rm, rv, use_batch_stats, momentum, bn.eps, slope, part, shift, seg)
+        y, amax = BatchNormAct.apply(x, bn.weight, bn.bias, rm, rv, use_batch_stats, momentum, bn.eps, slope, part, shift, seg, counter)
         return _cache.tag_amax(y, seg, amax)
-    return BatchNormAct.apply(x, bn.weight, bn.bias, rm, rv, use_batch_stats, momentum, bn.eps, slope, part, shift)
+    return BatchNormAct.apply(x, bn.weight, bn.bias, rm, rv, use_batch_stats, momentum, bn.eps, slope, part, shift, 0, counter)
 
 
 class BatchNormActDevoxelize(Function):
@@ -153,13 +161,14 @@ class BatchNormActDevoxelize(Function):
     @staticmethod
     @amp_fwd
     def forward(ctx, grid, coords, weight, bias, running_mean, running_var, use_batch_stats, momentum, eps, slope,
-                resolution, is_training, stats_part=None, stats_shift=None, addend=None):
+                resolution, is_training, stats_part=None, stats_shift=None, addend=None, counter=None):
         shape = grid.shape
         x3 = grid.contiguous().view(shape[0], shape[1], -1)
         w = weight.contiguous() if weight is not None else None
         b = bias.contiguous() if bias is not None else None
         if use_batch_stats and stats_part is not None:
-            mean, rstd = native().bn_finalize(stats_part, x3.shape[0] * x3.shape[2], running_mean, running_var, momentum, eps, stats_shift)
+            mean, rstd = native().bn_finalize(stats_part, x3.shape[0] * x3.shape[2], running_mean, running_var, momentum, eps, stats_shift,
+                                              counter=counter)
         elif use_batch_stats:
             mean, rstd = native().bn_stats(x3, running_mean, running_var, momentum, eps)
         else:
@@ -184,15 +193,15 @@ class BatchNormActDevoxelize(Function):
         g_act = ctx.taps.backward(_rows(grad_out, grad_out.shape))
         gx, gw, gb = _bnact_backward(x3, g_act.view(x3.shape), w, b, mean, rstd, ctx.slope, ctx.use_batch_stats, ctx.shape)
         return (gx, None, gw if w is not None else None, gb if b is not None else None,
-                None, None, None, None, None, None, None, None, None, None, grad_out if ctx.has_addend else None)
+                None, None, None, None, None, None, None, None, None, None, grad_out if ctx.has_addend else None, None)
 
 
 def batch_norm_act_devoxelize(grid, coords, bn, slope, resolution, is_training, stats_part=None, addend=None):
     """trilinear_devoxelize(act(bn(grid)), coords) [+ addend]: PVConv's tail (modules/pvconv.py:25-27,36-38) in one gather."""
-    use_batch_stats, momentum, rm, rv = _bn_mode(bn)
+    use_batch_stats, momentum, rm, rv, counter = _bn_mode(bn, finalize_counts=stats_part is not None and bn.training)
     part, shift = _split(stats_part)
     return BatchNormActDevoxelize.apply(grid, coords, bn.weight, bn.bias, rm, rv, use_batch_stats, momentum, bn.eps, slope,
-                                        resolution, is_training, part, shift, addend)
+                                        resolution, is_training, part, shift, addend, counter)
 
 
 def fusable_tail(layers, x):

@@ -39,7 +39,7 @@ def test_graphed_step_follows_the_eager_trajectory(hip):
     assert want[3] < want[0]                                  # it trains
     # the first replay sees the same weights as the eager twin's step 3 up to round-off; Adam's normalised updates then amplify
     # that round-off (near-zero gradients flip sign), so the bound loosens per step
-    for a, b, tol in zip(want[3:], got, (1e-4, 2e-3)):
+    for a, b, tol in zip(want[3:], got, (1e-4, 1e-2)):
         assert abs(a - b) <= tol * abs(a), (want, got)
     # new data goes INTO the static input tensors: the replay must see it (the per-coords plans are rebuilt inside the graph)
     x2, y2 = workload.make_s3dis_batch(2, 2048, device=DEV, seed=4)
