@@ -280,6 +280,7 @@ def main():
     ap.add_argument('--eager', action='store_true',
                     help='time the eagerly issued step (one Python thread issues every launch: host-bound) instead of the hipGraph replay')
     ap.add_argument('--graph', action='store_true', help='(default since round 3; accepted for older command lines)')
+    ap.add_argument('--torch-adam', action='store_true', help='torch.optim.Adam(fused=True) instead of pvcnn_amd.optim.FlatAdam')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -349,8 +350,14 @@ def main():
         metric = 'frustums/sec fwd+bwd, Frustum-PVCNN KITTI N=1024'
     model = model.to(dev).train()
     reducer = GradBucketReducer(model, bucket_mb=args.bucket_mb)
-    # one multi-tensor kernel per step; capturable: the step counter lives on the device (needed inside a hipGraph, harmless outside)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5, fused=True, capturable=True)
+    # Adam (lr 1e-3, weight decay 1e-5: configs/s3dis/__init__.py) on the reducer's flat buckets: one elementwise launch per bucket,
+    # step counter on the device (pvcnn_amd/optim.py; same arithmetic as torch.optim.Adam -- tests/test_gpu_optim.py).
+    # --torch-adam: torch's fused multi-tensor Adam over the ~100 parameter tensors instead (2 x 72 us per PVCNN step).
+    if args.torch_adam:
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5, fused=True, capturable=True)
+    else:
+        from pvcnn_amd.optim import FlatAdam
+        opt = FlatAdam(reducer, lr=1e-3, weight_decay=1e-5)
 
     clock = KernelClock(seam._backend)
     clock.install()

@@ -367,6 +367,13 @@ PVCNN_API int pvcnn_trilinear_devox_bwd_strided(const float *grad_y, long grad_y
                                       const float *wgts, int B, int C, int N, int R, float *grad_x,
                                       void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- the optimizer update of the training step on flat buffers (csrc/optim.hip) ----------------------------------------------
+ * replaces torch.optim.Adam's per-tensor update of train.py:96-119 (optimizer.step()) when the parameters share the flat layout of
+ * the gradient buckets (pvcnn_amd/dp.py): p, m (exp_avg), v (exp_avg_sq) updated in place, g read; arithmetic of torch.optim.Adam
+ * (no amsgrad; weight_decay added to the gradient), fp32.  `step`: one float in device memory = updates done so far (nothing is
+ * read back: graph-capturable); inc_step != 0 increments it behind this update (the last buffer of an optimizer step). */
+PVCNN_API int pvcnn_adam_step(float *p, const float *g, float *m, float *v, size_t n, float *step, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, int inc_step, void *stream);
 
 #ifdef __cplusplus
 }

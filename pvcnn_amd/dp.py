@@ -37,10 +37,11 @@ def shard_batch(global_batch, world_size, rank):
 
 
 class _Bucket:
-    __slots__ = ('flat', 'params', 'views', 'pending', 'work', 'packed')
+    __slots__ = ('flat', 'params', 'views', 'pending', 'work', 'packed', 'pflat')
 
     def __init__(self, flat, params):
         self.flat, self.params = flat, params
+        self.pflat = None                              # the parameters themselves in the same flat layout (flatten_parameters)
         self.views, off = [], 0
         for p in params:
             self.views.append(flat[off:off + p.numel()].view_as(p))
@@ -170,6 +171,23 @@ class GradBucketReducer:
         for b in self.buckets:
             for p in b.params:
                 p.grad = None
+
+    def flatten_parameters(self):
+        """Lay the PARAMETERS out like their gradients: one flat buffer per bucket, `p.data` becoming views of it (values kept).  An
+        optimizer can then update a whole bucket in one elementwise pass (pvcnn_amd.optim.FlatAdam) instead of walking ~100 tensors.
+        Call once, after the model sits on its device and before the optimizer / a graph capture is built."""
+        with torch.no_grad():
+            for b in self.buckets:
+                if b.pflat is not None:
+                    continue
+                b.pflat = torch.empty_like(b.flat)
+                off = 0
+                for p in b.params:
+                    view = b.pflat[off:off + p.numel()].view_as(p)
+                    view.copy_(p.data)
+                    p.data = view
+                    off += p.numel()
+        return self
 
     @property
     def gradient_bytes(self):

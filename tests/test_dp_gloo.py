@@ -316,3 +316,24 @@ def test_graphed_step_wants_a_capturable_optimizer_when_it_captures_the_update()
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     with pytest.raises(ValueError, match='capturable'):
         GraphedTrainStep(model, lambda: model(torch.randn(2, 6, 8)).sum(), opt, reducer, capture=True)
+
+
+def test_flatten_parameters_keeps_values_and_aliases_the_flat_buffers():
+    torch.manual_seed(2)
+    model = _net()
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    reducer = GradBucketReducer(model, bucket_mb=0.0005).flatten_parameters()
+    assert len(reducer.buckets) > 1
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, before[k])
+    for b in reducer.buckets:
+        lo, hi = b.pflat.data_ptr(), b.pflat.data_ptr() + b.pflat.numel() * 4
+        assert all(lo <= p.data_ptr() < hi for p in b.params)
+        b.pflat.add_(1.0)                              # an update of the flat buffer IS an update of the parameters
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, before[k] + 1.0)
+    x = torch.randn(2, 6, 8)
+    reducer.zero_grad()
+    model(x).sum().backward()                          # autograd still works on the re-seated parameters
+    reducer.finish()
+    assert all(p.grad is not None for p in model.parameters())
