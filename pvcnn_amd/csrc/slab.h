@@ -619,7 +619,20 @@ int launch_gather(const P &p, const float *src, float *dst, int B, int C, int L,
                   hipStream_t s, const char *what, const XF &xf = XF{}, int pshift = 0, const float *addend = nullptr) {
   if (B == 0 || C == 0 || J == 0) return 0;
   if (pshift > 0 && (size_t)(L + (L >> pshift)) * sizeof(float) > (size_t)kLdsBytesPerCU) pshift = 0;   // padding must not cost the LDS path
-  const SlabPlan pl = plan_slab(B, C, L, pshift);
+  SlabPlan pl = plan_slab(B, C, L, pshift);
+  if constexpr (P::kGridRows) {
+    // Small grids (R = 16: 17 KiB padded rows) with every point of the cloud resident in ONE 1024-thread workgroup: the generic plan
+    // above picks 256-thread single-row slabs, whose 16 points per thread re-derive their corner taps from the coordinates for EVERY
+    // channel (a (16,64,4096,16) devoxelization: 25 us for 42 MB, 0.27 of the HBM peak -- latency, not bandwidth).  The pipelined
+    // kernel below packs the taps once per workgroup and streams SEQ channel grids behind them with the next grid's loads in flight;
+    // it needs one row per slab, 1024 threads, J <= 4096.  SEQ: about one workgroup per CU (its 108 VGPRs allow no second one).
+    if (pl.lds && pshift > 0 && vec_ok && J <= 1024 * 4 && J > 1024 && pl.threads == 256 && (L & 3) == 0 && (L >> 2) <= 1024 * 8) {
+      pl.G = 1;
+      pl.threads = 1024;
+      pl.bytes = (size_t)(L + (L >> pshift)) * sizeof(float);
+      pl.seq = (int)std::min<long>(8, std::max<long>(1, (long)B * C / kNumCU));
+    }
+  }
   if (!pl.lds) {
     if (!XF::kIdentity || addend) {
       set_error("%s: row does not fit LDS; the fused transform / addend needs the LDS path", what);

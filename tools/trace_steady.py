@@ -2,7 +2,7 @@
 """Steady-state per-step kernel breakdown from a rocprofv3 kernel-trace CSV.
 
 usage: trace_steady.py <kernel_trace.csv> <timed_steps> [top] [skip_last]
-Training steps are delimited by the optimizer phase (runs of fused Adam's multi_tensor_apply kernels);
+Training steps are delimited by the optimizer phase (runs of fused Adam's multi_tensor_apply kernels, or of pvcnn_amd.optim.FlatAdam's kernels);
 the `timed_steps` complete steps before the last `skip_last` ones are aggregated, i.e. bench.py's timed region (bench.py runs
 min(steps, 20) fully instrumented steps AFTER it: skip_last = 20 for the default 100 steps)."""
 import csv
@@ -18,7 +18,8 @@ s_k = 'Start_Timestamp' if 'Start_Timestamp' in rows[0] else 'Start'
 e_k = 'End_Timestamp' if 'End_Timestamp' in rows[0] else 'End'
 rows.sort(key=lambda r: int(r[s_k]))
 # the optimizer's own launches: the gradient packing of pvcnn_amd/dp.py is a multi_tensor_apply kernel too (a copy functor)
-is_opt = ['multi_tensor_apply' in r[name_k] and ('FusedOptimizer' in r[name_k] or 'Adam' in r[name_k]) for r in rows]
+is_opt = [('multi_tensor_apply' in r[name_k] and ('FusedOptimizer' in r[name_k] or 'Adam' in r[name_k])) or 'pvcnn::adam_' in r[name_k]
+          for r in rows]      # torch's fused Adam, or pvcnn_amd.optim.FlatAdam (adam_flat_kernel ... adam_step_inc_kernel)
 ends = [i for i in range(len(rows)) if is_opt[i] and (i + 1 == len(rows) or not is_opt[i + 1])]   # last kernel of each optimizer phase
 if len(ends) < steps + 1 + skip:
     raise SystemExit(f'only {len(ends)} optimizer phases in the trace, need {steps + 1 + skip}')
