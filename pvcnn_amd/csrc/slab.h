@@ -529,6 +529,115 @@ __global__ __launch_bounds__(1024) void gather_lds_pipe_kernel(P p, XF xf, const
   }
 }
 
+// The same pipeline for SMALL grids (R = 16: 16 KiB rows): G channel rows per slab.  With one row per slab a CU has 16 KiB in
+// flight per HBM round trip (the pipelined kernel above at R = 16: 23 us for 42 MB, no better than the 256-thread slabs it
+// replaced); with G rows it has G times that, the corner taps of a point are expanded once per G channels, and the first slab's
+// grid loads are in flight together with the coordinate loads.  G = 2 (G = 4 spills ~70 registers at 1024 threads).  Requires L / 4 == 1024:
+// load u of a thread is quad `tid` of row u, so the row transform of load u is that of channel c0 + u.  Same expressions per
+// output element as gather_lds_kernel / gather_lds_pipe_kernel: bit-identical.
+template <class P, class XF, int G>
+__global__ __launch_bounds__(1024) void gather_lds_pipe_rows_kernel(P p, XF xf, const float *__restrict__ src, float *__restrict__ dst,
+                                                                int C, int L, int J, int SEQ, int pshift,
+                                                                const float *__restrict__ addend = nullptr) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int NC = P::NC, THREADS = 1024;
+  const int b = blockIdx.y;
+  const int jf = threadIdx.x * 4;
+  const bool has = jf < J;
+  const int Lp = L + (L >> pshift);
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const int voff = (int)threadIdx.x * 16;
+  float4 v[G];
+  auto issue = [&](int c0) {
+    const int rows = min(G, C - c0);
+    const uintptr_t rowp = reinterpret_cast<uintptr_t>(src + ((size_t)b * C + c0) * L);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)rowp), hi = __builtin_amdgcn_readfirstlane((uint32_t)(rowp >> 32));
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<void *>(((uintptr_t)hi << 32) | lo), /*stride*/ 0, /*bytes*/ rows * L * 4, 0x00020000);
+#pragma unroll
+    for (int u = 0; u < G; ++u) {                           // rows past C: the bounds check returns zeros
+      const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, u * THREADS * 16, 0);
+      v[u] = make_float4(__uint_as_float(raw.x), __uint_as_float(raw.y), __uint_as_float(raw.z), __uint_as_float(raw.w));
+    }
+  };
+  [[maybe_unused]] float raw[G][4];
+#pragma unroll
+  for (int u = 0; u < G; ++u) { raw[u][0] = raw[u][1] = 1.0f; raw[u][2] = raw[u][3] = 0.0f; }
+  auto fetch = [&](int c0) {
+    if constexpr (!XF::kIdentity) {
+#pragma unroll
+      for (int u = 0; u < G; ++u)
+        if (c0 + u < C) xf.fetch(c0 + u, raw[u]);
+    }
+  };
+  auto commit = [&]() {
+    const int i = (int)threadIdx.x * 4;
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      float scale = 1.0f, shift = 0.0f;
+      if constexpr (!XF::kIdentity) xf.combine(raw[u], scale, shift);
+      auto f = [&](float x) {
+        if constexpr (XF::kIdentity) return x; else return xf.apply(x, scale, shift);
+      };
+      float *d = lds + u * Lp + i + (i >> pshift);
+      d[0] = f(v[u].x); d[1] = f(v[u].y); d[2] = f(v[u].z); d[3] = f(v[u].w);
+    }
+  };
+  const int first = blockIdx.x * SEQ * G;
+  if (first < C) {                                          // the grid rows first: they are in flight while the taps are derived
+    fetch(first);
+    issue(first);
+  }
+  typename P::Packed pk[4];
+  if (has) p.pack4(b, jf, pk);
+  for (int sq = 0; sq < SEQ; ++sq) {
+    const int c0 = first + sq * G;
+    if (c0 >= C) break;
+    if (sq > 0) lds_barrier();                              // every wave is done reading the previous slab
+    commit();                                               // waits for this slab's loads only
+    lds_barrier();
+    if (sq + 1 < SEQ && c0 + G < C) {
+      fetch(c0 + G);
+      issue(c0 + G);
+    }
+    __builtin_amdgcn_sched_barrier(0);                      // keep the loads HERE
+    if (has) {
+      float r[G][4];
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        if constexpr (sizeof(typename P::Packed) == 16) {   // (see gather_lds_pipe_kernel: keep the expansion inside the slab loop)
+          uint4 &rw = reinterpret_cast<uint4 &>(pk[h]);
+          asm volatile("" : "+v"(rw.x), "+v"(rw.y), "+v"(rw.z), "+v"(rw.w));
+        }
+        Taps<NC> t;
+        p.unpack(pk[h], t);
+#pragma unroll
+        for (int u = 0; u < G; ++u) r[u][h] = combine<NC, P::kMaySkip, true>(t, lds + u * Lp, pshift);
+      }
+#pragma unroll
+      for (int u = 0; u < G; ++u) {
+        if (c0 + u < C) {
+          const size_t rowoff = ((size_t)b * C + c0 + u) * J;
+          float4 o = make_float4(r[u][0], r[u][1], r[u][2], r[u][3]);
+          if (addend) {
+            const float4 a = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(addend + rowoff) + (uint32_t)jf * 4u);
+            o.x = o.x + a.x; o.y = o.y + a.y; o.z = o.z + a.z; o.w = o.w + a.w;
+          }
+          *reinterpret_cast<float4 *>(reinterpret_cast<char *>(dst + rowoff) + (uint32_t)jf * 4u) = o;
+        }
+      }
+    }
+  }
+  // side outputs (devoxelize: inds / wgts) once per cloud -- LAST: four expanded tap sets are 64 registers, which the loop above
+  // (grid rows in flight + four rows of results) has no room for at 1024 threads
+  if (has && blockIdx.x == 0) {
+    Taps<NC> t[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) p.unpack(pk[h], t[h]);
+    p.post4(b, jf, t);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Direct (no-LDS) fallbacks for rows larger than LDS.  grid = (ceil(J/256), ceil(C/CT), B).
 // scatter_direct needs dst zeroed first (the launcher enqueues a hipMemsetAsync).
@@ -621,16 +730,20 @@ int launch_gather(const P &p, const float *src, float *dst, int B, int C, int L,
   if (pshift > 0 && (size_t)(L + (L >> pshift)) * sizeof(float) > (size_t)kLdsBytesPerCU) pshift = 0;   // padding must not cost the LDS path
   SlabPlan pl = plan_slab(B, C, L, pshift);
   if constexpr (P::kGridRows) {
-    // Small grids (R = 16: 17 KiB padded rows) with every point of the cloud resident in ONE 1024-thread workgroup: the generic plan
-    // above picks 256-thread single-row slabs, whose 16 points per thread re-derive their corner taps from the coordinates for EVERY
-    // channel (a (16,64,4096,16) devoxelization: 25 us for 42 MB, 0.27 of the HBM peak -- latency, not bandwidth).  The pipelined
-    // kernel below packs the taps once per workgroup and streams SEQ channel grids behind them with the next grid's loads in flight;
-    // it needs one row per slab, 1024 threads, J <= 4096.  SEQ: about one workgroup per CU (its 108 VGPRs allow no second one).
-    if (pl.lds && pshift > 0 && vec_ok && J <= 1024 * 4 && J > 1024 && pl.threads == 256 && (L & 3) == 0 && (L >> 2) <= 1024 * 8) {
-      pl.G = 1;
-      pl.threads = 1024;
-      pl.bytes = (size_t)(L + (L >> pshift)) * sizeof(float);
-      pl.seq = (int)std::min<long>(8, std::max<long>(1, (long)B * C / kNumCU));
+    // Small grids whose rows are exactly 1024 quads (R = 16) with every point of the cloud resident in ONE 1024-thread workgroup: the
+    // generic plan above picks 256-thread single-row slabs, whose 16 points per thread re-derive their corner taps from the
+    // coordinates for EVERY channel (a (16,64,4096,16) devoxelization: 25 us for 42 MB, 0.27 of the HBM peak -- latency, not
+    // bandwidth).  gather_lds_pipe_rows_kernel: G rows per slab, taps packed once per workgroup, SEQ slabs with the next one in flight.
+    static const bool pipe4 = [] { const char *e = getenv("PVCNN_GATHER_PIPE"); return !(e && e[0] == '0'); }();
+    if (pipe4 && pl.lds && pshift > 0 && vec_ok && J <= 1024 * 4 && J > 1024 && (L >> 2) == 1024 && aligned16(src) && C >= 4) {
+      constexpr int GR = 2;                                   // rows per slab (4 rows spill 70 registers at 1024 threads / 128 VGPRs)
+      const int slabs = ceil_div(C, GR);
+      const int seq = (int)std::min<long>(8, std::max<long>(1, (long)B * slabs / kNumCU));
+      const size_t bytes = (size_t)GR * (L + (L >> pshift)) * sizeof(float);
+      auto k = gather_lds_pipe_rows_kernel<P, XF, GR>;
+      if (int e = enable_big_lds(k, bytes)) { set_error("%s: LDS attribute: %d", what, e); return e; }
+      hipLaunchKernelGGL(k, dim3(ceil_div(slabs, seq), B), dim3(1024), bytes, s, p, xf, src, dst, C, L, J, seq, pshift, addend);
+      return check_launch(what);
     }
   }
   if (!pl.lds) {
