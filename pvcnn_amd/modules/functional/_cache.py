@@ -18,7 +18,7 @@ __all__ = ['memo', 'clear', 'enabled', 'tag_amax', 'amax_of']
 # re-entrant: a weak-reference callback (_drop) can fire from the garbage collector at any allocation, including inside
 # memo()'s own critical section on the same thread -- a plain Lock deadlocks there (seen in the GPU test-suite)
 _lock = threading.RLock()
-_entries = {}          # id(tensor) -> (weakref, version, dict)
+_entries = {}          # id(tensor) -> (weakref, (version, data_ptr, shape, stride), dict)
 enabled = True
 
 
@@ -29,18 +29,24 @@ def _drop(key, ref):
             del _entries[key]
 
 
+def _stamp(tensor):
+    """What must be unchanged for a memo entry of `tensor` to be valid: the in-place version counter AND where / how the tensor
+    views its storage (`t.data = other` or `set_()` re-seat a tensor without touching the counter)."""
+    return (tensor._version, tensor.data_ptr(), tuple(tensor.shape), tuple(tensor.stride()))
+
+
 def memo(tensor, key, make):
-    """make() computed once per (tensor object, tensor._version, key); the result is shared afterwards."""
+    """make() computed once per (tensor object, its version / storage view, key); the result is shared afterwards."""
     if not enabled:
         return make()
     tid = id(tensor)
     with _lock:
         ent = _entries.get(tid)
-        if ent is not None and (ent[0]() is not tensor or ent[1] != tensor._version):
+        if ent is not None and (ent[0]() is not tensor or ent[1] != _stamp(tensor)):
             ent = None
         if ent is None:
             ref = weakref.ref(tensor, lambda r, k=tid: _drop(k, r))
-            ent = (ref, tensor._version, {})
+            ent = (ref, _stamp(tensor), {})
             _entries[tid] = ent
         store = ent[2]
         if key in store:
@@ -75,6 +81,6 @@ def amax_of(tensor, seg):
         tid, key = id(tensor), ('amax', int(seg))
         with _lock:
             ent = _entries.get(tid)
-            if ent is not None and ent[0]() is tensor and ent[1] == tensor._version and key in ent[2]:
+            if ent is not None and ent[0]() is tensor and ent[1] == _stamp(tensor) and key in ent[2]:
                 return ent[2][key]
     return None

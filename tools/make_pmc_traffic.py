@@ -34,14 +34,16 @@ if not (vf and vw):
 if vf and vw:
     rows.append({'op': 'trilinear_devoxelize_fwd', 'shape_BCNR': [16, 64, 4096, 32], 'kernel_name': kf[:120], 'where': 'inside bench.py steps',
                  'FETCH_SIZE_KiB': round(vf['FETCH_SIZE'], 1), 'WRITE_SIZE_KiB': round(vw['WRITE_SIZE'], 1), 'dispatches': vf['dispatches']})
-for shp in ('16x64x4096x16', '16x128x4096x16', '16x64x4096x32'):
-    fo, wo = load(f'pmc_FETCH_SIZE_opbench_{shp}.json'), load(f'pmc_WRITE_SIZE_opbench_{shp}.json')
-    for op, needles in (('trilinear_devoxelize_bwd', ('segsum_tile_kernel',)), ('trilinear_devoxelize_fwd (op-level, unfused)', ('gather_lds_', 'TrilinearFromCoords'))):
-        kf, vf = pick(fo, *needles)
-        kw, vw = pick(wo, *needles)
-        if vf and vw:
-            rows.append({'op': op, 'shape_BCNR': [int(v) for v in shp.split('x')], 'kernel_name': kf[:120], 'where': 'tools/opbench.py',
-                         'FETCH_SIZE_KiB': round(vf['FETCH_SIZE'], 1), 'WRITE_SIZE_KiB': round(vw['WRITE_SIZE'], 1), 'dispatches': vf['dispatches']})
+# every other scatter / gather kernel of the step: averages over the launches of one kernel template (several shapes per step),
+# for the traffic / algorithmic ratio of the family -- the per-shape algorithmic bytes are in the bench line's `kernels`
+for op, needles in (('trilinear_devoxelize_fwd at R = 16 (3 launches per step: C = 64, 64, 128)', ('gather_lds_pipe_rows_kernel', 'TrilinearFromCoords')),
+                    ('trilinear_devoxelize_bwd + avg_voxelize_fwd applies (8 launches per step)', ('segsum_tile_kernel',)),
+                    ('avg_voxelize_bwd (3 launches per step)', ('gather_lds_kernel', 'VoxelMean'))):
+    kf, vf = pick(fb, *needles)
+    kw, vw = pick(wb, *needles)
+    if vf and vw:
+        rows.append({'op': op, 'kernel_name': kf[:120], 'where': 'inside bench.py steps (average over the launches of this template)',
+                     'FETCH_SIZE_KiB': round(vf['FETCH_SIZE'], 1), 'WRITE_SIZE_KiB': round(vw['WRITE_SIZE'], 1), 'dispatches': vf['dispatches']})
 print(json.dumps({'command': 'rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace (separate passes), tools/collect_evidence.sh',
                   'units': 'KiB per launch, averaged over dispatches; HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 on gfx950',
                   'kernels': rows}, indent=1))
