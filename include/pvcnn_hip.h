@@ -329,7 +329,9 @@ PVCNN_API int pvcnn_bnact_fwd(const float *x, const float *gamma, const float *b
  * (PVConv: the last BatchNorm3d + LeakyReLU of voxel_layers followed by the devoxelization, modules/pvconv.py:
  * 25-27,36).  Bit-identical to bnact_fwd followed by trilinear_devox_fwd.  Requires R^3 * 4 bytes <= 160 KiB.
  * addend (B,C,N) or NULL: outs = devoxelized + addend in the gather's store -- PVConv's "voxel branch + point branch"
- * (modules/pvconv.py:38) without a separate read-modify-write pass; one rounded fp32 addition, as in the reference. */
+ * (modules/pvconv.py:38) without a separate read-modify-write pass; one rounded fp32 addition, as in the reference.
+ * se_scale (B,C) or NULL: the squeeze-and-excitation factor of SE3d (modules/se.py:17) applied to the activated grid while it is
+ * staged, out = trilinear_devoxelize(leaky_relu(bn(feat)) * se_scale[b][c]) -- a second rounded multiplication, as in the reference. */
 /* Convolution forward WITH BatchNorm statistics: as pvcnn_conv3d_fwd / pvcnn_pwconv_fwd, and the epilogue also
  * writes per-workgroup partial (sum, sum of squares) of every output channel to stats_part -- (C, nparts) pairs of
  * floats, nparts = *_fwd_stats_parts(...) -- so the BatchNorm that follows needs no pass over y:
@@ -351,7 +353,7 @@ PVCNN_API int pvcnn_bn_stats(const float *x, float *running_mean, float *running
 PVCNN_API int pvcnn_trilinear_devox_bnact_fwd(const float *coords, const float *feat, const float *gamma,
                                     const float *beta, const float *mean, const float *rstd, float slope,
                                     int B, int C, int N, int R, int is_training, int32_t *inds, float *wgts,
-                                    const float *addend, float *outs, void *stream);
+                                    const float *addend, const float *se_scale, float *outs, void *stream);
 PVCNN_API int pvcnn_bnact_bwd(const float *x, const float *grad_y, const float *gamma, const float *beta,
                               const float *mean, const float *rstd, int B, int C, int S, float slope, int training,
                               float *grad_x, float *grad_gamma, float *grad_beta, void *workspace,
@@ -363,6 +365,21 @@ PVCNN_API int pvcnn_bnact_bwd_strided(const float *x, const float *grad_y, long 
                             const float *beta, const float *mean, const float *rstd, int B, int C, int S,
                             float slope, int training, float *grad_x, float *grad_gamma, float *grad_beta,
                             void *gx_amax, int amax_seg, void *workspace, size_t workspace_bytes, void *stream);
+/* The two halves of pvcnn_bnact_bwd_strided on their own, for callers that put something between them (PVConv's SE tail,
+ * pvcnn_amd/modules/functional/bnact.py: the per-(cloud, channel) sums feed the excitation's backward before the apply pass runs).
+ * partial_sums: part (C, B, slices) float pairs, slices = pvcnn_bnact_slices(S): per slice of row (b, c) the sums of g' and g' * xhat
+ *   with g' = grad_y * act'(z), z = gamma * xhat + beta, xhat = (x - mean) * rstd; grad_y = NULL means grad_y == 1 (then the two sums
+ *   are what SE3d's squeeze needs: sum act(z) = gamma * sum act'(z) xhat + beta * sum act'(z)).
+ * bwd_apply: grad_x = gamma * rstd * (g' - sum_beta * inv_count - xhat * sum_gamma * inv_count) [training] or gamma * rstd * g' [eval] with
+ *   g' = (grad_y * bc_mul[b][c] + bc_add[b][c]) * act'(z); bc_mul / bc_add (B,C) or NULL (1 / 0); sum_gamma / sum_beta (C) given by
+ *   the caller; gx_amax / amax_seg as in pvcnn_bnact_bwd_strided. */
+PVCNN_API int pvcnn_bnact_slices(int S);
+PVCNN_API int pvcnn_bnact_partial_sums(const float *x, const float *grad_y, long grad_y_batch_stride, const float *gamma, const float *beta,
+                             const float *mean, const float *rstd, int B, int C, int S, float slope, float *part, void *stream);
+PVCNN_API int pvcnn_bnact_bwd_apply(const float *x, const float *grad_y, long grad_y_batch_stride, const float *gamma, const float *beta,
+                          const float *mean, const float *rstd, const float *sum_gamma, const float *sum_beta, const float *bc_mul,
+                          const float *bc_add, int B, int C, int S, float slope, int training, float *grad_x, void *gx_amax,
+                          int amax_seg, void *stream);
 PVCNN_API int pvcnn_trilinear_devox_bwd_strided(const float *grad_y, long grad_y_batch_stride, const int32_t *inds,
                                       const float *wgts, int B, int C, int N, int R, float *grad_x,
                                       void *workspace, size_t workspace_bytes, void *stream);

@@ -140,10 +140,10 @@ __global__ __launch_bounds__(kBnThreads) void bnact_bwd_reduce_kernel(const floa
   const size_t goff = (size_t)b * gy_bstride + (size_t)c * S;   // grad_y: channels of a cloud contiguous, clouds gy_bstride apart
   const int lo = sl * kBnSlice, hi = min(S, lo + kBnSlice);
   float s = 0.f, q = 0.f;
-  if ((S & 3) == 0 && aligned16(x + off) && aligned16(gy + goff)) {
+  if ((S & 3) == 0 && aligned16(x + off) && (!gy || aligned16(gy + goff))) {
     for (int i = lo + threadIdx.x * 4; i < hi; i += kBnThreads * 4) {
       const float4 xv = *reinterpret_cast<const float4 *>(x + off + i);
-      const float4 gv = *reinterpret_cast<const float4 *>(gy + goff + i);
+      const float4 gv = gy ? *reinterpret_cast<const float4 *>(gy + goff + i) : make_float4(1.0f, 1.0f, 1.0f, 1.0f);
       const float xs_[4] = {xv.x, xv.y, xv.z, xv.w}, gs_[4] = {gv.x, gv.y, gv.z, gv.w};
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(kBnThreads) void bnact_bwd_reduce_kernel(const floa
     for (int i = lo + threadIdx.x; i < hi; i += kBnThreads) {
       const float xv = x[off + i];
       const float z = fmaf(xv, scale, shift);
-      const float g = gy[goff + i] * (z > 0.f ? 1.0f : slope);
+      const float g = (gy ? gy[goff + i] : 1.0f) * (z > 0.f ? 1.0f : slope);
       s += g;
       q += g * ((xv - m) * r);
     }
@@ -238,7 +238,8 @@ __global__ __launch_bounds__(256) void bnact_apply_pb_kernel(const float *__rest
                                                              const float *__restrict__ dgamma, const float *__restrict__ dbeta,
                                                              float slope, float inv_count, int training, int C, int S, int seg,
                                                              int nseg, int vec, float *__restrict__ out, uint32_t *__restrict__ amax,
-                                                             int global_by_atomic) {
+                                                             int global_by_atomic, const float *__restrict__ bc_mul = nullptr,
+                                                             const float *__restrict__ bc_add = nullptr) {
   __shared__ uint32_t seg_max[256];
   const int spb = seg >= 256 ? 1 : 256 / seg;                  // whole segments per workgroup (seg <= 256 enforced by the host)
   const int b = blockIdx.y, s0 = blockIdx.x * spb;
@@ -250,10 +251,12 @@ __global__ __launch_bounds__(256) void bnact_apply_pb_kernel(const float *__rest
   const float *gb = BWD ? gy + (size_t)b * gy_bstride + p0 : nullptr;
   float *ob = out + (size_t)b * C * S + p0;
   uint32_t mx[4] = {0u, 0u, 0u, 0u};
-  struct Par { float scale, shift, m, r, db, dg; };
+  struct Par { float scale, shift, m, r, db, dg, gmul, gadd; };
   auto par_of = [&](int c) {
     Par p;
     p.m = mean[c]; p.r = rstd[c];
+    p.gmul = (BWD && bc_mul) ? bc_mul[(size_t)b * C + c] : 1.0f;          // SE tail: g' = (grad_y * mul + add) * act'(z)
+    p.gadd = (BWD && bc_add) ? bc_add[(size_t)b * C + c] : 0.0f;
     p.scale = (gamma ? gamma[c] : 1.0f) * p.r;
     p.shift = (beta ? beta[c] : 0.0f) - p.m * p.scale;
     p.db = (BWD && training) ? dbeta[c] * inv_count : 0.0f;
@@ -263,7 +266,8 @@ __global__ __launch_bounds__(256) void bnact_apply_pb_kernel(const float *__rest
   auto one = [&](float xv, float gv, const Par &p) {
     if constexpr (BWD) {
       const float z = fmaf(xv, p.scale, p.shift);
-      const float g = gv * (z > 0.f ? 1.0f : slope);
+      const float gin = (bc_mul || bc_add) ? fmaf(gv, p.gmul, p.gadd) : gv;
+      const float g = gin * (z > 0.f ? 1.0f : slope);
       return p.scale * (g - p.db - ((xv - p.m) * p.r) * p.dg);
     } else {
       const float v = fmaf(xv, p.scale, p.shift);
@@ -444,4 +448,41 @@ extern "C" int pvcnn_bnact_bwd_strided(const float *x, const float *grad_y, long
                                        void *workspace, size_t workspace_bytes, void *stream) {
   return bnact_bwd_impl(x, grad_y, grad_y_batch_stride, gamma, beta, mean, rstd, B, C, S, slope, training, grad_x, grad_gamma,
                         grad_beta, workspace, workspace_bytes, stream, gx_amax, amax_seg);
+}
+
+extern "C" int pvcnn_bnact_slices(int S) { return S > 0 ? ceil_div(S, kBnSlice) : 0; }
+
+extern "C" int pvcnn_bnact_partial_sums(const float *x, const float *grad_y, long grad_y_batch_stride, const float *gamma, const float *beta,
+                                        const float *mean, const float *rstd, int B, int C, int S, float slope, float *part, void *stream) {
+  PVCNN_REQUIRE(B > 0 && C > 0 && S > 0 && x && mean && rstd && part, "bad argument");
+  PVCNN_REQUIRE(B <= 65535 && C <= 65535, "batch or channel count > 65535");
+  PVCNN_REQUIRE(!grad_y || grad_y_batch_stride >= (long)C * S, "grad_y batch stride smaller than one sample");
+  PVCNN_REQUIRE((reinterpret_cast<uintptr_t>(part) & 7) == 0, "part must be 8-byte aligned");
+  const int slices = ceil_div(S, kBnSlice);
+  hipLaunchKernelGGL(bnact_bwd_reduce_kernel, dim3(slices, B, C), dim3(kBnThreads), 0, static_cast<hipStream_t>(stream), x, grad_y, mean, rstd,
+                     gamma, beta, slope, C, S, slices, reinterpret_cast<float2 *>(part), grad_y ? grad_y_batch_stride : (long)C * S);
+  return check_launch("bnact_partial_sums");
+}
+
+extern "C" int pvcnn_bnact_bwd_apply(const float *x, const float *grad_y, long grad_y_batch_stride, const float *gamma, const float *beta,
+                                     const float *mean, const float *rstd, const float *sum_gamma, const float *sum_beta, const float *bc_mul,
+                                     const float *bc_add, int B, int C, int S, float slope, int training, float *grad_x, void *gx_amax,
+                                     int amax_seg, void *stream) {
+  PVCNN_REQUIRE(B > 0 && C > 0 && S > 0 && x && grad_y && mean && rstd && grad_x, "bad argument");
+  PVCNN_REQUIRE(!training || (sum_gamma && sum_beta), "training mode needs the two per-channel sums");
+  PVCNN_REQUIRE(B <= 65535 && C <= 65535, "batch or channel count > 65535");
+  PVCNN_REQUIRE(grad_y_batch_stride >= (long)C * S, "grad_y batch stride smaller than one sample");
+  PVCNN_REQUIRE(!gx_amax || (amax_seg > 0 && amax_seg <= 256), "amax_seg must be in 1..256");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  // the position-block-major pass (it carries the per-(cloud, channel) factors); without an amax request the table goes to a dummy
+  // segmentation of 256 positions that is simply not written out (amax == NULL is not supported by the kernel: give it scratch)
+  PVCNN_REQUIRE(gx_amax, "pvcnn_bnact_bwd_apply needs an amax buffer (pvcnn_absmax_tiles_count words)");
+  const int nseg = ceil_div(S, amax_seg), spb = amax_seg >= 256 ? 1 : 256 / amax_seg;
+  const int vec = (S % 4 == 0) && (amax_seg % 4 == 0) && (grad_y_batch_stride % 4 == 0) && aligned16(x) && aligned16(grad_y) && aligned16(grad_x);
+  uint32_t *am = static_cast<uint32_t *>(gx_amax);
+  hipLaunchKernelGGL(bnact_apply_pb_kernel<true>, dim3(ceil_div(nseg, spb), B), dim3(256), 0, s, x, grad_y, grad_y_batch_stride, mean, rstd, gamma,
+                     beta, sum_gamma, sum_beta, slope, (float)(1.0 / ((double)B * S)), training, C, S, amax_seg, nseg, vec, grad_x, am, 0, bc_mul,
+                     bc_add);
+  if (int e = check_launch("bnact_bwd_apply_pb")) return e;
+  return launch_amax_reduce(am, (long)B * nseg, s);
 }

@@ -525,7 +525,8 @@ __global__ __launch_bounds__(256, (NS == 3 || TX * TY * TZ == 512 || TZ <= 16) ?
 struct SplitTile { int tx, ty, tz; bool vec; };
 static SplitTile split_tiles(int B, int Co, int R, int nsplit) {
   const bool vec = R % 4 == 0 && R <= 32;
-  if (R <= 8) return {4, 8, 8, vec};
+  if (R <= 8)    // tiny grids (PVCNN++ at R = 8, B = 8: 16 tiles of 256 voxels per 64 channels): halve the tile while the chip is not full
+    return (long)B * ceil_div(R, 4) * ceil_div(R, 8) * ceil_div(Co, kCoTileB) < kNumCU ? SplitTile{2, 8, 8, vec} : SplitTile{4, 8, 8, vec};
   if (!vec) return {4, 4, 16, false};
   if (R <= 16)   // too few 256-voxel tiles to give every SIMD two waves (R = 16, B = 16: 256 per 64 channels): halve them
     return (long)B * ceil_div(R, 4) * ceil_div(R, 4) * ceil_div(Co, kCoTileB) < 768 ? SplitTile{2, 4, 16, true} : SplitTile{4, 4, 16, true};
@@ -656,6 +657,7 @@ static int conv3d_fwd_split_impl(const float *x, const void *wts, const float *b
 #define PVCNN_IGEMM(NS, TX, TY, TZ, VEC) launch_igemm_bf16<NS, TX, TY, TZ, VEC>(x, w16, bias, y, B, Ci, Co, R, s, sp, am, wexp, amax_seg)
 #define PVCNN_IGEMM_NS(TX, TY, TZ, VEC) (nsplit == 3 ? PVCNN_IGEMM(3, TX, TY, TZ, VEC) : nsplit == 2 ? PVCNN_IGEMM(2, TX, TY, TZ, VEC) : PVCNN_IGEMM(1, TX, TY, TZ, VEC))
 #define PVCNN_IGEMM_BIG(TX, TY, TZ) (nsplit == 2 ? PVCNN_IGEMM(2, TX, TY, TZ, true) : PVCNN_IGEMM(1, TX, TY, TZ, true))
+  if (t.tz == 8 && t.tx == 2) return t.vec ? PVCNN_IGEMM_NS(2, 8, 8, true) : PVCNN_IGEMM_NS(2, 8, 8, false);
   if (t.tz == 8) return t.vec ? PVCNN_IGEMM_NS(4, 8, 8, true) : PVCNN_IGEMM_NS(4, 8, 8, false);
   if (!t.vec) return PVCNN_IGEMM_NS(4, 4, 16, false);
   if (t.tz == 16) return t.tx == 2 ? PVCNN_IGEMM_NS(2, 4, 16, true) : PVCNN_IGEMM_NS(4, 4, 16, true);

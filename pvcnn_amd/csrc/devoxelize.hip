@@ -52,7 +52,7 @@ extern "C" int pvcnn_trilinear_devox_fwd(const float *coords, const float *feat,
 extern "C" int pvcnn_trilinear_devox_bnact_fwd(const float *coords, const float *feat, const float *gamma,
                                                const float *beta, const float *mean, const float *rstd, float slope, int B,
                                                int C, int N, int R, int is_training, int32_t *inds, float *wgts,
-                                               const float *addend, float *outs, void *stream) {
+                                               const float *addend, const float *se_scale, float *outs, void *stream) {
   PVCNN_REQUIRE(B >= 0 && C > 0 && N >= 0 && R > 0, "bad size");
   PVCNN_REQUIRE((long)R * R * R * sizeof(float) <= (size_t)kLdsBytesPerCU, "grid row does not fit LDS: use bnact_fwd + trilinear_devox_fwd");
   if (B == 0 || N == 0) return 0;
@@ -63,7 +63,7 @@ extern "C" int pvcnn_trilinear_devox_bnact_fwd(const float *coords, const float 
   TrilinearFromCoords p{coords, is_training ? inds : nullptr, is_training ? wgts : nullptr, N, R, R * R};
   bool vec = (N % 4 == 0) && aligned16(coords) && aligned16(outs) && (!addend || aligned16(addend));
   if (is_training) vec = vec && aligned16(inds) && aligned16(wgts);
-  const XfBnAct xf{gamma, beta, mean, rstd, slope};
+  const XfBnAct xf{gamma, beta, mean, rstd, slope, se_scale};
   return launch_gather(p, feat, outs, B, C, /*L=*/R * R * R, /*J=*/N, vec, s, "trilinear_devox_bnact_fwd", xf, grid_pad_shift(R), addend);
 }
 

@@ -269,24 +269,37 @@ __device__ __forceinline__ void slab_copy(float *dst, const float *src, int tota
 // the tensor that kernel would have written.
 struct XfNone {
   static constexpr bool kIdentity = true;
+  static constexpr int kRaw = 1;
+  __device__ __forceinline__ XfNone at(int) const { return *this; }
 };
+// `se` (optional, (B, C) row-major): the squeeze-and-excitation factor of SE3d (modules/se.py:17), y = act(bn(x)) * se[b][c] --
+// the multiplication is a SECOND rounded operation on the activated value, exactly like the reference's separate `inputs * fc(...)`.
 struct XfBnAct {
   static constexpr bool kIdentity = false;
+  static constexpr int kRaw = 5;
   const float *gamma, *beta, *mean, *rstd;   // per channel; gamma / beta may be null
   float slope;
+  const float *se = nullptr;                 // per (cloud, channel) excitation, or null; kernels take `xf.at(b)`: the cloud's row
+  __device__ __forceinline__ XfBnAct at(int b_times_C) const {
+    XfBnAct x = *this;
+    if (x.se) x.se += b_times_C;
+    return x;
+  }
   __device__ __forceinline__ void params(int c, float &scale, float &shift) const {
     scale = (gamma ? gamma[c] : 1.0f) * rstd[c];
     shift = (beta ? beta[c] : 0.0f) - mean[c] * scale;
   }
-  __device__ __forceinline__ float apply(float v, float scale, float shift) const {
+  __device__ __forceinline__ float mul(int c) const { return se ? se[c] : 1.0f; }
+  __device__ __forceinline__ float apply(float v, float scale, float shift, float m = 1.0f) const {
     v = fmaf(v, scale, shift);
-    return v > 0.f ? v : v * slope;
+    v = v > 0.f ? v : v * slope;
+    return se ? v * m : v;
   }
   // params() in two halves, for kernels that fetch a row's raw parameters one slab ahead and combine them when the row arrives
-  __device__ __forceinline__ void fetch(int c, float (&raw)[4]) const {
-    raw[0] = gamma ? gamma[c] : 1.0f; raw[1] = rstd[c]; raw[2] = beta ? beta[c] : 0.0f; raw[3] = mean[c];
+  __device__ __forceinline__ void fetch(int c, float (&raw)[5]) const {
+    raw[0] = gamma ? gamma[c] : 1.0f; raw[1] = rstd[c]; raw[2] = beta ? beta[c] : 0.0f; raw[3] = mean[c]; raw[4] = mul(c);
   }
-  __device__ __forceinline__ void combine(const float (&raw)[4], float &scale, float &shift) const {
+  __device__ __forceinline__ void combine(const float (&raw)[5], float &scale, float &shift) const {
     scale = raw[0] * raw[1];
     shift = raw[2] - raw[3] * scale;
   }
@@ -297,6 +310,7 @@ template <int THREADS, class XF>
 __device__ __forceinline__ void slab_copy_row_xf(float *dst, const float *src, int len, const XF &xf, int c) {
   float scale, shift;
   xf.params(c, scale, shift);
+  const float m = xf.mul(c);
   if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0 && (len & 3) == 0) {
     constexpr int kB = 8;
     const int nq = len >> 2;
@@ -309,11 +323,11 @@ __device__ __forceinline__ void slab_copy_row_xf(float *dst, const float *src, i
 #pragma unroll
       for (int u = 0; u < kB; ++u)
         if (q0 + u * THREADS < nq)
-          d4[q0 + u * THREADS] = make_float4(xf.apply(v[u].x, scale, shift), xf.apply(v[u].y, scale, shift),
-                                             xf.apply(v[u].z, scale, shift), xf.apply(v[u].w, scale, shift));
+          d4[q0 + u * THREADS] = make_float4(xf.apply(v[u].x, scale, shift, m), xf.apply(v[u].y, scale, shift, m),
+                                             xf.apply(v[u].z, scale, shift, m), xf.apply(v[u].w, scale, shift, m));
     }
   } else {
-    for (int i = threadIdx.x; i < len; i += THREADS) dst[i] = xf.apply(src[i], scale, shift);
+    for (int i = threadIdx.x; i < len; i += THREADS) dst[i] = xf.apply(src[i], scale, shift, m);
   }
 }
 
@@ -322,9 +336,10 @@ __device__ __forceinline__ void slab_copy_row_xf(float *dst, const float *src, i
 template <int THREADS, class XF>
 __device__ __forceinline__ void slab_copy_row_padded(float *dst, const float *src, int len, int pshift, const XF &xf, int c) {
   float scale = 1.0f, shift = 0.0f;
-  if constexpr (!XF::kIdentity) xf.params(c, scale, shift);
+  [[maybe_unused]] float m = 1.0f;
+  if constexpr (!XF::kIdentity) { xf.params(c, scale, shift); m = xf.mul(c); }
   auto f = [&](float v) {
-    if constexpr (XF::kIdentity) return v; else return xf.apply(v, scale, shift);
+    if constexpr (XF::kIdentity) return v; else return xf.apply(v, scale, shift, m);
   };
   if ((reinterpret_cast<uintptr_t>(src) & 15) == 0 && (len & 3) == 0) {
     constexpr int kB = 8;
@@ -370,6 +385,7 @@ __global__ __launch_bounds__(THREADS) void gather_lds_kernel(P p, XF xf, const f
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int NC = P::NC;
   const int b = blockIdx.y;
+  const XF xfb = xf.at(b * C);                          // (the transform's per-cloud part: the SE factors of cloud b)
   const bool side = (blockIdx.x == 0);
   constexpr bool resident = RESIDENT;                  // J <= THREADS * VEC
   const int jf = threadIdx.x * VEC;
@@ -389,7 +405,7 @@ __global__ __launch_bounds__(THREADS) void gather_lds_kernel(P p, XF xf, const f
     const int g = min(G, C - c0);
     if (sq > 0) lds_barrier();                         // all LDS reads of the previous slab are done (its output stores keep draining)
     const int Lp = PAD ? L + (L >> pshift) : L;            // LDS row length
-    slab_stage<THREADS, PAD>(lds, src + ((size_t)b * C + c0) * L, g, L, Lp, pshift, xf, c0);
+    slab_stage<THREADS, PAD>(lds, src + ((size_t)b * C + c0) * L, g, L, Lp, pshift, xfb, c0);
     __syncthreads();
     float *out = dst + ((size_t)b * C + c0) * J;
     // optional epilogue: out = gather + addend (PVConv's "devoxelized voxel branch + point branch", modules/pvconv.py:38,
@@ -439,6 +455,7 @@ __global__ __launch_bounds__(1024) void gather_lds_pipe_kernel(P p, XF xf, const
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int NC = P::NC, THREADS = 1024, kB = 8;
   const int b = blockIdx.y;
+  const XF xfb = xf.at(b * C);
   const int jf = threadIdx.x * 4;
   const bool has = jf < J;
   typename P::Packed pk[4];
@@ -472,11 +489,11 @@ __global__ __launch_bounds__(1024) void gather_lds_pipe_kernel(P p, XF xf, const
   // the row transform's raw parameters are fetched one slab ahead, BEFORE the row's own loads (so that waiting for them
   // never waits for the row), and combined into (scale, shift) when the row is committed
   float scale = 1.0f, shift = 0.0f;
-  [[maybe_unused]] float raw[4] = {1.0f, 1.0f, 0.0f, 0.0f};
+  [[maybe_unused]] float raw[XF::kRaw];
   auto commit = [&]() {
-    if constexpr (!XF::kIdentity) xf.combine(raw, scale, shift);
+    if constexpr (!XF::kIdentity) xfb.combine(raw, scale, shift);
     auto f = [&](float x) {
-      if constexpr (XF::kIdentity) return x; else return xf.apply(x, scale, shift);
+      if constexpr (XF::kIdentity) return x; else return xfb.apply(x, scale, shift, raw[4]);
     };
 #pragma unroll
     for (int u = 0; u < kB; ++u) {
@@ -490,7 +507,7 @@ __global__ __launch_bounds__(1024) void gather_lds_pipe_kernel(P p, XF xf, const
   };
   const int first = blockIdx.x * SEQ;
   if (first < C) {
-    if constexpr (!XF::kIdentity) xf.fetch(first, raw);
+    if constexpr (!XF::kIdentity) xfb.fetch(first, raw);
     issue(first);
   }
   for (int sq = 0; sq < SEQ; ++sq) {
@@ -500,7 +517,7 @@ __global__ __launch_bounds__(1024) void gather_lds_pipe_kernel(P p, XF xf, const
     commit();                                               // waits for this slab's loads only
     lds_barrier();                                          // slab visible (LDS-only: the previous outputs keep draining)
     if (sq + 1 < SEQ && c + 1 < C) {
-      if constexpr (!XF::kIdentity) xf.fetch(c + 1, raw);
+      if constexpr (!XF::kIdentity) xfb.fetch(c + 1, raw);
       issue(c + 1);
     }
     __builtin_amdgcn_sched_barrier(0);                      // keep the loads HERE: the scheduler sinks them to their first use
@@ -542,6 +559,7 @@ __global__ __launch_bounds__(1024) void gather_lds_pipe_rows_kernel(P p, XF xf, 
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int NC = P::NC, THREADS = 1024;
   const int b = blockIdx.y;
+  const XF xfb = xf.at(b * C);
   const int jf = threadIdx.x * 4;
   const bool has = jf < J;
   const int Lp = L + (L >> pshift);
@@ -560,14 +578,16 @@ __global__ __launch_bounds__(1024) void gather_lds_pipe_rows_kernel(P p, XF xf, 
       v[u] = make_float4(__uint_as_float(raw.x), __uint_as_float(raw.y), __uint_as_float(raw.z), __uint_as_float(raw.w));
     }
   };
-  [[maybe_unused]] float raw[G][4];
+  [[maybe_unused]] float raw[G][XF::kRaw];
 #pragma unroll
-  for (int u = 0; u < G; ++u) { raw[u][0] = raw[u][1] = 1.0f; raw[u][2] = raw[u][3] = 0.0f; }
+  for (int u = 0; u < G; ++u)
+#pragma unroll
+    for (int i = 0; i < XF::kRaw; ++i) raw[u][i] = (i < 2 || i == 4) ? 1.0f : 0.0f;
   auto fetch = [&](int c0) {
     if constexpr (!XF::kIdentity) {
 #pragma unroll
       for (int u = 0; u < G; ++u)
-        if (c0 + u < C) xf.fetch(c0 + u, raw[u]);
+        if (c0 + u < C) xfb.fetch(c0 + u, raw[u]);
     }
   };
   auto commit = [&]() {
@@ -575,9 +595,9 @@ __global__ __launch_bounds__(1024) void gather_lds_pipe_rows_kernel(P p, XF xf, 
 #pragma unroll
     for (int u = 0; u < G; ++u) {
       float scale = 1.0f, shift = 0.0f;
-      if constexpr (!XF::kIdentity) xf.combine(raw[u], scale, shift);
+      if constexpr (!XF::kIdentity) xfb.combine(raw[u], scale, shift);
       auto f = [&](float x) {
-        if constexpr (XF::kIdentity) return x; else return xf.apply(x, scale, shift);
+        if constexpr (XF::kIdentity) return x; else return xfb.apply(x, scale, shift, raw[u][XF::kRaw - 1]);
       };
       float *d = lds + u * Lp + i + (i >> pshift);
       d[0] = f(v[u].x); d[1] = f(v[u].y); d[2] = f(v[u].z); d[3] = f(v[u].w);

@@ -768,9 +768,10 @@ class HipBackend:
                                                float(momentum), _p(mean), _p(rstd), _p(ws), ws.numel(), s), 'bn_stats')
         return mean, rstd
 
-    def trilinear_devoxelize_bnact_forward(self, r, is_training, coords, features, gamma, beta, mean, rstd, slope, addend=None):
-        """trilinear_devoxelize_forward of leaky_relu(bn(features)) without materialising that tensor:
-        features (B,C,R^3) is the PRE-BatchNorm grid, mean / rstd (C) its statistics."""
+    def trilinear_devoxelize_bnact_forward(self, r, is_training, coords, features, gamma, beta, mean, rstd, slope, addend=None,
+                                           se_scale=None):
+        """trilinear_devoxelize_forward of leaky_relu(bn(features)) [* se_scale (B,C): SE3d's excitation] without materialising that
+        tensor: features (B,C,R^3) is the PRE-BatchNorm grid, mean / rstd (C) its statistics."""
         _f32(features, 'features'); _f32(coords, 'coords')
         r = int(r)
         _shape(features.dim() == 3 and coords.dim() == 3 and coords.shape[1] == 3
@@ -782,6 +783,9 @@ class HipBackend:
         if addend is not None:
             _f32(addend, 'addend')
             _shape(tuple(addend.shape) == (b, c, n), 'trilinear_devoxelize: addend (B,C,N) expected')
+        if se_scale is not None:
+            _f32(se_scale, 'se_scale')
+            _shape(tuple(se_scale.shape) == (b, c), 'trilinear_devoxelize: se_scale (B,C) expected')
         outs = torch.empty((b, c, n), dtype=torch.float32, device=dev)
         if is_training:
             inds = torch.empty((b, 8, n), dtype=torch.int32, device=dev)
@@ -795,9 +799,50 @@ class HipBackend:
                 _p(coords), _p(features), _p(gamma) if gamma is not None else nul, _p(beta) if beta is not None else nul,
                 _p(mean), _p(rstd), float(slope), b, c, n, r, int(bool(is_training)),
                 _p(inds) if is_training else None, _p(wgts) if is_training else None,
-                _p(addend) if addend is not None else None, _p(outs), s),
+                _p(addend) if addend is not None else None, _p(se_scale) if se_scale is not None else None, _p(outs), s),
                 'trilinear_devoxelize_bnact_forward')
         return [outs, inds, wgts]
+
+    # ---- the two halves of bnact_backward on their own (PVConv's SE tail puts the excitation's backward between them) ----
+    has_bnact_split_bwd = True
+
+    def bnact_partial_sums(self, x, grad_y, gamma, beta, mean, rstd, slope):
+        """-> (P, Q) (B,C) each: sums over the positions of g' and g' * xhat, g' = grad_y * act'(z) (grad_y None: == 1)."""
+        _f32(x, 'x')
+        b, c, s3 = x.shape
+        gy_bstride = _f32_rows(grad_y, 'grad_y') if grad_y is not None else c * s3
+        slices = self.lib.pvcnn_bnact_slices(s3)
+        part = torch.empty((c, b, slices, 2), dtype=torch.float32, device=x.device)
+        nul = ctypes.c_void_p(None)
+        with _Launch(x) as s:
+            _lib.check(self.lib.pvcnn_bnact_partial_sums(_p(x), _p(grad_y) if grad_y is not None else nul, gy_bstride,
+                                                         _p(gamma) if gamma is not None else nul, _p(beta) if beta is not None else nul,
+                                                         _p(mean), _p(rstd), b, c, s3, float(slope), _p(part), s), 'bnact_partial_sums')
+        sums = part.sum(dim=2)                                   # (C, B, 2): a few hundred values per channel at most
+        return sums[..., 0].t().contiguous(), sums[..., 1].t().contiguous()
+
+    def bnact_backward_apply(self, x, grad_y, gamma, beta, mean, rstd, sum_gamma, sum_beta, slope, training, bc_mul=None, bc_add=None,
+                             amax_seg=256):
+        """grad_x of BatchNorm + activation with the two per-channel sums GIVEN and g' = (grad_y * bc_mul[b][c] + bc_add[b][c]) * act'(z);
+        -> (grad_x, its amax buffer with segments of amax_seg positions)."""
+        _f32(x, 'x')
+        gy_bstride = _f32_rows(grad_y, 'grad_y')
+        b, c, s3 = x.shape
+        for t, name in ((bc_mul, 'bc_mul'), (bc_add, 'bc_add')):
+            if t is not None:
+                _f32(t, name)
+                _shape(tuple(t.shape) == (b, c), f'{name} (B,C) expected')
+        gx = torch.empty_like(x)
+        amax = self.amax_buffer(b, s3, amax_seg, x.device)
+        nul = ctypes.c_void_p(None)
+        with _Launch(x) as s:
+            _lib.check(self.lib.pvcnn_bnact_bwd_apply(_p(x), _p(grad_y), gy_bstride, _p(gamma) if gamma is not None else nul,
+                                                      _p(beta) if beta is not None else nul, _p(mean), _p(rstd),
+                                                      _p(sum_gamma) if sum_gamma is not None else nul, _p(sum_beta) if sum_beta is not None else nul,
+                                                      _p(bc_mul) if bc_mul is not None else nul, _p(bc_add) if bc_add is not None else nul,
+                                                      b, c, s3, float(slope), int(bool(training)), _p(gx), _p(amax), int(amax_seg), s),
+                       'bnact_backward_apply')
+        return gx, amax
 
     def bnact_backward(self, x, grad_y, gamma, beta, mean, rstd, slope, training, amax_seg=0):
         """-> (grad_x, grad_gamma, grad_beta [, grad_x's amax buffer with segments of amax_seg positions, emitted by the apply pass])."""

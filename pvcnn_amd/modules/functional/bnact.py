@@ -65,7 +65,7 @@ def _bnact_backward(x3, g3, w, b, mean, rstd, slope, training, shape):
     return gx.view(shape), gw, gb
 
 
-__all__ = ['batch_norm_act', 'batch_norm_act_devoxelize', 'fusable_tail', 'run_layers']
+__all__ = ['batch_norm_act', 'batch_norm_act_devoxelize', 'batch_norm_act_se_devoxelize', 'fusable_tail', 'run_layers']
 
 
 class BatchNormAct(Function):
@@ -204,15 +204,119 @@ def batch_norm_act_devoxelize(grid, coords, bn, slope, resolution, is_training, 
                                         resolution, is_training, part, shift, addend, counter)
 
 
+class BatchNormActSEDevoxelize(Function):
+    """trilinear_devoxelize(SE3d(leaky_relu(batch_norm(grid))), coords) [+ addend]: the tail of a PVConv WITH squeeze-and-excitation
+    (modules/pvconv.py:25-30,36-38, modules/se.py:6-17) as ONE node that touches the convolution's output three times in all:
+
+      forward : one reduction pass over the grid -> per (cloud, channel) A = sum act'(z), Ax = sum act'(z) * xhat (z = gamma * xhat +
+                beta, xhat = (x - mean) * rstd).  LeakyReLU is piecewise linear through 0, act(z) = z * act'(z), so the squeeze is
+                mean act(z) = (gamma * Ax + beta * A) / S -- no activated grid is written for it; the two tiny Linear layers + sigmoid
+                run on (B, C) numbers; the excitation rides on the gather's row transform (a second rounded multiplication, as in
+                the reference).  Neither act(bn(x)) nor its product with the excitation ever exists in memory.
+      backward: the devoxelize scatter gives g_y = dL/d(a * s); ONE reduction pass yields P = sum g_y act', Q = sum g_y act' xhat per
+                (cloud, channel): dL/ds = sum g_y a = gamma * Q + beta * P feeds the excitation's backward (tiny), whose dL/dmean
+                comes back as a per-(cloud, channel) constant gm; the BatchNorm sums follow WITHOUT another pass,
+                sum g' = s * P + gm * A, sum g' xhat = s * Q + gm * Ax with g' = (s * g_y + gm) * act'(z); one apply pass writes grad_x.
+    The reference's graph (activated grid, mean, product, devoxelize: 3 writes + 4 reads of the grid forward, as many backward)
+    computes the same numbers; summation order differs (<= 1e-6 relative), the discrete decisions (act' = sign of z) are the same."""
+
+    @staticmethod
+    @amp_fwd
+    def forward(ctx, grid, coords, weight, bias, running_mean, running_var, use_batch_stats, momentum, eps, slope,
+                resolution, is_training, stats_part, stats_shift, addend, counter, fc1, fc2):
+        be = native()
+        shape = grid.shape
+        x3 = grid.contiguous().view(shape[0], shape[1], -1)
+        nb, nc, s3 = x3.shape
+        w = weight.contiguous() if weight is not None else None
+        b = bias.contiguous() if bias is not None else None
+        if use_batch_stats and stats_part is not None:
+            mean, rstd = be.bn_finalize(stats_part, nb * s3, running_mean, running_var, momentum, eps, stats_shift, counter=counter)
+        elif use_batch_stats:
+            mean, rstd = be.bn_stats(x3, running_mean, running_var, momentum, eps)
+        else:
+            mean, rstd = running_mean.contiguous(), torch.rsqrt(running_var + eps)
+        # squeeze from the two sums (grad_y == 1 in the reduction kernel of the BatchNorm backward)
+        a_sum, ax_sum = be.bnact_partial_sums(x3, None, w, b, mean, rstd, slope)            # (B, C) each
+        gam = w if w is not None else torch.ones_like(mean)
+        bet = b if b is not None else torch.zeros_like(mean)
+        squeezed = (gam * ax_sum + bet * a_sum) / float(s3)
+        w1, w2 = fc1.contiguous(), fc2.contiguous()
+        hidden = torch.relu(squeezed @ w1.t())
+        excite = torch.sigmoid(hidden @ w2.t()).contiguous()                                 # (B, C)
+        r = int(resolution)
+        pts = coords.contiguous()
+        add = addend.contiguous() if addend is not None else None
+        ctx.has_addend = add is not None
+        if not is_training:
+            return be.trilinear_devoxelize_bnact_forward(r, False, pts, x3, w, b, mean, rstd, slope, add, se_scale=excite)[0]
+        taps = CornerTaps.of(coords, r)
+        out = taps.forward(lambda emit: be.trilinear_devoxelize_bnact_forward(r, emit, pts, x3, w, b, mean, rstd, slope, add, se_scale=excite))
+        ctx.save_for_backward(x3, w, b, mean, rstd, a_sum, ax_sum, squeezed, hidden, excite, w1, w2, taps.inds, taps.wgts)
+        ctx.taps = taps
+        ctx.slope, ctx.use_batch_stats, ctx.shape = slope, use_batch_stats, shape
+        return out
+
+    @staticmethod
+    @amp_bwd
+    def backward(ctx, grad_out):
+        be = native()
+        x3, w, b, mean, rstd, a_sum, ax_sum, squeezed, hidden, excite, w1, w2, _, _ = ctx.saved_tensors
+        nb, nc, s3 = x3.shape
+        g_y = ctx.taps.backward(_rows(grad_out, grad_out.shape)).view(x3.shape)             # dL/d(act(bn(x)) * excite)
+        p_sum, q_sum = be.bnact_partial_sums(x3, g_y, w, b, mean, rstd, ctx.slope)          # (B, C) each
+        gam = w if w is not None else torch.ones_like(mean)
+        bet = b if b is not None else torch.zeros_like(mean)
+        # excitation backward: s = sigmoid(relu(m W1^T) W2^T)
+        g_excite = gam * q_sum + bet * p_sum
+        g_pre2 = g_excite * excite * (1.0 - excite)
+        g_w2 = g_pre2.t() @ hidden
+        g_pre1 = (g_pre2 @ w2) * (hidden > 0).to(hidden.dtype)
+        g_w1 = g_pre1.t() @ squeezed
+        g_mean = ((g_pre1 @ w1) / float(s3)).contiguous()                                    # dL/d(squeezed) spread over the S voxels
+        # BatchNorm sums of g' = (excite * g_y + g_mean) * act'(z), from the four per-(cloud, channel) sums
+        sum_beta = (excite * p_sum + g_mean * a_sum).sum(dim=0).contiguous()
+        sum_gamma = (excite * q_sum + g_mean * ax_sum).sum(dim=0).contiguous()
+        seg = _amax_seg_for(ctx.shape, x3.is_cuda) or 256
+        gx, amax = be.bnact_backward_apply(x3, g_y, w, b, mean, rstd, sum_gamma, sum_beta, ctx.slope, ctx.use_batch_stats,
+                                           bc_mul=excite, bc_add=g_mean, amax_seg=seg)
+        gx = gx.view(ctx.shape)
+        if _amax_seg_for(ctx.shape, x3.is_cuda):
+            _cache.tag_amax(gx, seg, amax)
+        return (gx, None, sum_gamma if w is not None else None, sum_beta if b is not None else None,
+                None, None, None, None, None, None, None, None, None, None, grad_out if ctx.has_addend else None, None, g_w1, g_w2)
+
+
+def batch_norm_act_se_devoxelize(grid, coords, bn, slope, se, resolution, is_training, stats_part=None, addend=None):
+    """trilinear_devoxelize(se(act(bn(grid))), coords) [+ addend]: PVConv's tail with squeeze-and-excitation in one node."""
+    use_batch_stats, momentum, rm, rv, counter = _bn_mode(bn, finalize_counts=stats_part is not None and bn.training)
+    part, shift = _split(stats_part)
+    return BatchNormActSEDevoxelize.apply(grid, coords, bn.weight, bn.bias, rm, rv, use_batch_stats, momentum, bn.eps, slope,
+                                          resolution, is_training, part, shift, addend, counter, se.fc[0].weight, se.fc[2].weight)
+
+
+def _plain_se(m):
+    """True for the reference's SE3d layout (modules/se.py:9-14): Linear (no bias), ReLU, Linear (no bias), Sigmoid."""
+    fc = getattr(m, 'fc', None)
+    return (isinstance(fc, nn.Sequential) and len(fc) == 4 and isinstance(fc[0], nn.Linear) and fc[0].bias is None
+            and isinstance(fc[1], nn.ReLU) and isinstance(fc[2], nn.Linear) and fc[2].bias is None and isinstance(fc[3], nn.Sigmoid)
+            and not _has_hooks(fc) and not any(_has_hooks(f) for f in fc))
+
+
 def fusable_tail(layers, x):
-    """If the nn.Sequential ends in (BatchNorm, ReLU|LeakyReLU) and the GPU path can fuse that pair into the
-    devoxelize gather for tensor x (the Sequential's INPUT: same device / dtype), return (bn, slope)."""
+    """If the nn.Sequential ends in (BatchNorm, ReLU|LeakyReLU [, SE3d]) and the GPU path can fuse that tail into the
+    devoxelize gather for tensor x (the Sequential's INPUT: same device / dtype), return (bn, slope, se | None)."""
     mods = list(layers)
     if _has_hooks(layers) or any(_has_hooks(m) for m in mods):   # hooks only fire through __call__: run module by module then
         return None
-    if (len(mods) >= 2 and x.is_cuda and _servable(x) and getattr(native(), 'has_devox_bnact', False)
-            and isinstance(mods[-2], nn.modules.batchnorm._BatchNorm) and _slope(mods[-1]) is not None):
-        return mods[-2], _slope(mods[-1])
+    be = native()
+    if not (x.is_cuda and _servable(x) and getattr(be, 'has_devox_bnact', False)):
+        return None
+    if (len(mods) >= 3 and _plain_se(mods[-1]) and getattr(be, 'has_bnact_split_bwd', False)
+            and isinstance(mods[-3], nn.modules.batchnorm._BatchNorm) and _slope(mods[-2]) is not None):
+        return mods[-3], _slope(mods[-2]), mods[-1]
+    if len(mods) >= 2 and isinstance(mods[-2], nn.modules.batchnorm._BatchNorm) and _slope(mods[-1]) is not None:
+        return mods[-2], _slope(mods[-1]), None
     return None
 
 

@@ -13,7 +13,7 @@ import torch.nn as nn
 
 from . import functional as F
 from .functional._autograd import native
-from .functional.bnact import batch_norm_act_devoxelize, fusable_tail, run_layers
+from .functional.bnact import batch_norm_act_devoxelize, batch_norm_act_se_devoxelize, fusable_tail, run_layers
 from .functional.conv3d import conv_nsplit, voxel_conv3d
 from .se import SE3d
 from .shared_mlp import SharedMLP
@@ -77,13 +77,18 @@ class PVConv(nn.Module):
             # the last BatchNorm3d + LeakyReLU ride on the devoxelize gather: the activated grid is never written
             # (and the gather does not start on a grid whose write is still draining to HBM: 1.5x slower, see
             # tools/devox_after_writer.py)
-            bn, slope = tail
-            grid, stats_part = run_layers(self.voxel_layers, grid, stop=len(self.voxel_layers) - 2, tail_stats=True)
+            bn, slope, se = tail
+            ntail = 2 if se is None else 3
+            grid, stats_part = run_layers(self.voxel_layers, grid, stop=len(self.voxel_layers) - ntail, tail_stats=True)
             per_point = self.point_features(features)
             # ... and so does the sum with the point branch: added in the gather's store (one rounded addition, like the
             # reference's `voxel_features + point_features`, modules/pvconv.py:38)
-            fused = batch_norm_act_devoxelize(grid, grid_coords, bn, slope, self.resolution, self.training, stats_part,
-                                              addend=per_point)
+            if se is None:
+                fused = batch_norm_act_devoxelize(grid, grid_coords, bn, slope, self.resolution, self.training, stats_part,
+                                                  addend=per_point)
+            else:   # ... and SE3d: squeeze from one reduction pass over the convolution's output, excitation in the gather's staging
+                fused = batch_norm_act_se_devoxelize(grid, grid_coords, bn, slope, se, self.resolution, self.training, stats_part,
+                                                     addend=per_point)
             return fused, coords
         else:
             # = self.voxel_layers(grid) with BN + LeakyReLU fused (a hooked Sequential goes through its own __call__)

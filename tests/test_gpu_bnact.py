@@ -148,3 +148,57 @@ def test_batch_statistics_when_the_mean_dwarfs_the_spread(hip, path):
     assert _rel(bn.running_mean, bn_ref.running_mean) < 1e-6
     assert _rel(bn.running_var, bn_ref.running_var) < 1e-2, (bn.running_var[:4], bn_ref.running_var[:4])
     assert (got.double() - want).abs().max().item() < 2e-2 * want.abs().max().item()
+
+
+@pytest.mark.parametrize('r,cin,cout,n,normalize', [(16, 9, 32, 1024, True), (32, 16, 24, 2048, True), (8, 12, 64, 600, False), (12, 6, 16, 1000, True)])
+def test_se_tail_fused_into_the_gather_matches_the_separate_modules(hip, r, cin, cout, n, normalize):
+    """PVConv WITH squeeze-and-excitation (cfg3 / cfg4): BatchNorm3d + LeakyReLU + SE3d + devoxelize + point-branch sum as one node
+    (functional/bnact.py: BatchNormActSEDevoxelize) vs the same modules run one by one on the GPU.  Not bit-identical by construction:
+    the squeeze is ONE sum over the grid instead of the reference's mean of means, and the BatchNorm-backward sums are assembled from
+    per-(cloud, channel) partial sums -- 1e-5 of the tensor's largest entry, forward and every gradient, train and eval mode."""
+    import copy
+    from pvcnn_amd.modules import PVConv
+    from pvcnn_amd.modules.functional._autograd import native
+    torch.manual_seed(13)
+    dev = 'cuda:0'
+    fused = PVConv(cin, cout, 3, r, with_se=True, normalize=normalize).to(dev).train()
+    plain = copy.deepcopy(fused)
+    feats = torch.randn(3, cin, n, device=dev)
+    coords = torch.rand(3, 3, n, device=dev) * (1.0 if normalize else 0.9) * 2 - 1
+    if not normalize:
+        coords = coords * 0.5
+    wgt = torch.randn(3, cout, n, device=dev)
+    fa, fb = feats.clone().requires_grad_(), feats.clone().requires_grad_()
+    be = native()
+
+    def rel(a, b):
+        return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+    ya, _ = fused((fa, coords))
+    (ya * wgt).sum().backward()
+    try:
+        type(be).has_devox_bnact = False
+        yb, _ = plain((fb, coords))
+        (yb * wgt).sum().backward()
+    finally:
+        type(be).has_devox_bnact = True
+    assert rel(ya, yb) < 1e-5, rel(ya, yb)
+    assert rel(fa.grad, fb.grad) < 2e-5, rel(fa.grad, fb.grad)
+    for (na, pa), (nb, pb) in zip(fused.named_parameters(), plain.named_parameters()):
+        if pa.grad is None:
+            assert pb.grad is None
+            continue
+        # a bias in front of a train-mode BatchNorm has a zero true gradient: judged against its layer's weight gradient
+        scale = max(pb.grad.abs().max().item(), dict(plain.named_parameters())[na.replace('.bias', '.weight')].grad.abs().max().item()
+                    if na.endswith('.bias') else 0.0, 1e-30)
+        assert (pa.grad - pb.grad).abs().max().item() <= 3e-5 * scale, (na, (pa.grad - pb.grad).abs().max().item(), scale)
+    for (na, ba), (nb, bb) in zip(fused.named_buffers(), plain.named_buffers()):
+        assert torch.allclose(ba.float(), bb.float(), rtol=1e-6, atol=1e-7), na
+    fused.eval(); plain.eval()
+    with torch.no_grad():
+        ya, _ = fused((feats, coords))
+        try:
+            type(be).has_devox_bnact = False
+            yb, _ = plain((feats, coords))
+        finally:
+            type(be).has_devox_bnact = True
+    assert rel(ya, yb) < 1e-5

@@ -302,3 +302,95 @@ def test_bench_byte_formulas_reproduce_the_survey_totals():
     t = bench.pmc_traffic('trilinear_devoxelize_fwd', [16, 64, 4096, 32])
     assert t['traffic'] is not None and 1.0 <= t['traffic'] / (bench.bytes_devox_fwd(b, 64, n, s32) + 4 * b * 64 * n) <= 1.1
     assert bench.pmc_traffic('no_such_op', [1, 2, 3, 4]) == {'traffic': None}
+
+
+# ---- PVConv's tail with squeeze-and-excitation as one autograd node: the algebra, checked on the CPU ------------------------------
+class _SETailStandIn:
+    """The native calls of BatchNormActSEDevoxelize evaluated with torch (float64 friendly) + the CPU oracle's devoxelization."""
+
+    def __init__(self, oracle):
+        self.o = oracle
+
+    @staticmethod
+    def _z(x3, g, b, mean, rstd):
+        xhat = (x3 - mean.view(1, -1, 1)) * rstd.view(1, -1, 1)
+        gam = g if g is not None else torch.ones_like(mean)
+        bet = b if b is not None else torch.zeros_like(mean)
+        return xhat, xhat * gam.view(1, -1, 1) + bet.view(1, -1, 1)
+
+    def bn_stats(self, x3, rm, rv, momentum, eps):
+        mean = x3.mean(dim=(0, 2))
+        var = x3.var(dim=(0, 2), unbiased=False)
+        return mean, torch.rsqrt(var + eps)
+
+    def bnact_partial_sums(self, x3, gy, g, b, mean, rstd, slope):
+        xhat, z = self._z(x3, g, b, mean, rstd)
+        d = torch.where(z > 0, torch.ones_like(z), torch.full_like(z, slope)) * (gy if gy is not None else 1.0)
+        return d.sum(dim=2), (d * xhat).sum(dim=2)
+
+    def bnact_backward_apply(self, x3, gy, g, b, mean, rstd, sum_gamma, sum_beta, slope, training, bc_mul=None, bc_add=None, amax_seg=256):
+        xhat, z = self._z(x3, g, b, mean, rstd)
+        gin = gy * (bc_mul.unsqueeze(-1) if bc_mul is not None else 1.0) + (bc_add.unsqueeze(-1) if bc_add is not None else 0.0)
+        gp = gin * torch.where(z > 0, torch.ones_like(z), torch.full_like(z, slope))
+        scale = ((g if g is not None else torch.ones_like(mean)) * rstd).view(1, -1, 1)
+        inv = 1.0 / (x3.shape[0] * x3.shape[2])
+        if training:
+            gx = scale * (gp - (sum_beta * inv).view(1, -1, 1) - xhat * (sum_gamma * inv).view(1, -1, 1))
+        else:
+            gx = scale * gp
+        return gx, None
+
+    def trilinear_devoxelize_bnact_forward(self, r, is_training, coords, x3, g, b, mean, rstd, slope, addend=None, se_scale=None):
+        _, z = self._z(x3, g, b, mean, rstd)
+        a = torch.where(z > 0, z, z * slope)
+        if se_scale is not None:
+            a = a * se_scale.unsqueeze(-1)
+        out, inds, wgts = self.o.trilinear_devoxelize_forward(r, True, coords.float().contiguous(), a.float().contiguous())
+        out = out.to(x3.dtype)
+        if addend is not None:
+            out = out + addend
+        return [out, inds, wgts]
+
+    def trilinear_devoxelize_backward(self, grad, inds, wgts, r):
+        return self.o.trilinear_devoxelize_backward(grad.float().contiguous(), inds, wgts, r).to(grad.dtype)
+
+
+def test_se_tail_node_matches_the_modules_it_replaces(oracle, monkeypatch):
+    """BatchNormActSEDevoxelize (BatchNorm3d + LeakyReLU + SE3d + trilinear_devoxelize + point-branch sum as one node whose backward
+    derives every BatchNorm / excitation sum from TWO reduction passes) == the reference's module chain, output and every gradient."""
+    import torch.nn as nn
+    from pvcnn_amd.modules import SE3d
+    from pvcnn_amd.modules import functional as PF
+    from pvcnn_amd.modules.functional import backend as seam, bnact as bnact_mod
+    from pvcnn_amd.modules.functional.bnact import batch_norm_act_se_devoxelize
+    torch.manual_seed(9)
+    nb, nc, r, n = 2, 16, 6, 50
+    bn, act, se = nn.BatchNorm3d(nc, eps=1e-4), nn.LeakyReLU(0.1), SE3d(nc)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.5, 0.5)
+    grid = torch.randn(nb, nc, r, r, r)
+    coords = torch.rand(nb, 3, n) * (r - 1)
+    addend = torch.randn(nb, nc, n)
+    wgt = torch.randn(nb, nc, n)
+
+    # the module chain (with the oracle's devoxelization through the package's own autograd function)
+    monkeypatch.setattr(seam, '_backend', oracle)
+    g1, a1 = grid.clone().requires_grad_(), addend.clone().requires_grad_()
+    out1 = PF.trilinear_devoxelize(se(act(bn(g1))), coords, r, True) + a1
+    (out1 * wgt).sum().backward()
+    want = [g1.grad, a1.grad, bn.weight.grad, bn.bias.grad, se.fc[0].weight.grad, se.fc[2].weight.grad]
+    want = [t.clone() for t in want]
+    for p in list(bn.parameters()) + list(se.parameters()):
+        p.grad = None
+
+    monkeypatch.setattr(seam, '_backend', _SETailStandIn(oracle))
+    monkeypatch.setattr(bnact_mod, '_amax_seg_for', lambda shape, is_cuda: 0)
+    bn2 = nn.BatchNorm3d(nc, eps=1e-4)
+    bn2.load_state_dict({k: v for k, v in bn.state_dict().items() if 'running' not in k and 'num_batches' not in k}, strict=False)
+    g2, a2 = grid.clone().requires_grad_(), addend.clone().requires_grad_()
+    out2 = batch_norm_act_se_devoxelize(g2, coords, bn2, 0.1, se, r, True, stats_part=None, addend=a2)
+    assert torch.allclose(out2, out1, atol=2e-5), (out2 - out1).abs().max()
+    (out2 * wgt).sum().backward()
+    got = [g2.grad, a2.grad, bn2.weight.grad, bn2.bias.grad, se.fc[0].weight.grad, se.fc[2].weight.grad]
+    for name, a, b in zip(('grid', 'addend', 'bn.weight', 'bn.bias', 'fc1', 'fc2'), got, want):
+        assert a is not None and torch.allclose(a, b, rtol=2e-4, atol=2e-5), (name, (a - b).abs().max().item(), b.abs().max().item())
