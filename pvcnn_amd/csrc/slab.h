@@ -458,16 +458,6 @@ __global__ __launch_bounds__(1024) void gather_lds_pipe_kernel(P p, XF xf, const
   const XF xfb = xf.at(b * C);
   const int jf = threadIdx.x * 4;
   const bool has = jf < J;
-  typename P::Packed pk[4];
-  if (has) {
-    p.pack4(b, jf, pk);
-    if (blockIdx.x == 0) {                                  // side outputs (devoxelize: inds / wgts) once per cloud
-      Taps<NC> t[4];
-#pragma unroll
-      for (int v = 0; v < 4; ++v) p.unpack(pk[v], t[v]);
-      p.post4(b, jf, t);
-    }
-  }
   const int nq = L >> 2;                                    // <= THREADS * kB quads (checked by the launcher)
   float4 v[kB];
   // loads through a buffer descriptor: ONE per-lane offset register (tid * 16) for all eight loads, the rest of the address
@@ -506,10 +496,12 @@ __global__ __launch_bounds__(1024) void gather_lds_pipe_kernel(P p, XF xf, const
     }
   };
   const int first = blockIdx.x * SEQ;
-  if (first < C) {
-    if constexpr (!XF::kIdentity) xfb.fetch(first, raw);
+  if (first < C) {                                          // the first grid's loads go out BEFORE the taps are derived: the
+    if constexpr (!XF::kIdentity) xfb.fetch(first, raw);    // coordinate loads and the tap arithmetic run under them
     issue(first);
   }
+  typename P::Packed pk[4];
+  if (has) p.pack4(b, jf, pk);
   for (int sq = 0; sq < SEQ; ++sq) {
     const int c = first + sq;
     if (c >= C) break;
@@ -543,6 +535,14 @@ __global__ __launch_bounds__(1024) void gather_lds_pipe_kernel(P p, XF xf, const
       }
       *reinterpret_cast<float4 *>(reinterpret_cast<char *>(dst + rowoff) + (uint32_t)jf * 4u) = make_float4(r[0], r[1], r[2], r[3]);
     }
+  }
+  // side outputs (devoxelize: inds / wgts) once per cloud -- last: four expanded tap sets (64 registers) have no room while a grid's
+  // loads are in flight
+  if (has && blockIdx.x == 0) {
+    Taps<NC> t[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) p.unpack(pk[v], t[v]);
+    p.post4(b, jf, t);
   }
 }
 
