@@ -252,6 +252,8 @@ PVCNN_API int pvcnn_conv3d_bwd_weight(const float *x, const float *grad_y, int B
  */
 PVCNN_API size_t pvcnn_conv3d_weight_split_bytes(int Co, int Ci, int for_bwd_data, int nsplit);
 PVCNN_API int pvcnn_conv3d_weight_split(const float *w, int Co, int Ci, int for_bwd_data, int nsplit, void *wts, void *stream);
+/* both f16x2 images (for_bwd_data = 0 and 1) of one weight in ONE launch: a training step needs both, the weights do not change in between */
+PVCNN_API int pvcnn_conv3d_weight_split_pair(const float *w, int Co, int Ci, void *wts_fwd, void *wts_bwd, void *stream);
 PVCNN_API size_t pvcnn_conv3d_fwd_split_stats_parts(int B, int Co, int R, int nsplit);
 PVCNN_API int pvcnn_absmax_bits(const float *x, size_t n, void *out, void *stream);
 PVCNN_API size_t pvcnn_absmax_tiles_count(int B, long L, int seg);      /* 1 + T words */
@@ -292,6 +294,7 @@ PVCNN_API int pvcnn_pwconv_bwd_weight(const float *x, const float *grad_y, int B
  * with which grad_x = pwconv_fwd_split(grad_y, wts, NULL, B, K = Co, M = Ci, ...). */
 PVCNN_API size_t pvcnn_pwconv_weight_split_bytes(int Co, int Ci, int for_bwd_data, int nsplit);
 PVCNN_API int pvcnn_pwconv_weight_split(const float *w, int Co, int Ci, int for_bwd_data, int nsplit, void *wts, void *stream);
+PVCNN_API int pvcnn_pwconv_weight_split_pair(const float *w, int Co, int Ci, void *wts_fwd, void *wts_bwd, void *stream);
 PVCNN_API size_t pvcnn_pwconv_fwd_split_stats_parts(int B, int N);
 PVCNN_API int pvcnn_pwconv_fwd_split(const float *x, const void *wts, const float *bias, int B, int K, int M, int N, int nsplit,
                            const void *x_absmax, int amax_seg /* 0 | 256 */, float *y, float *stats_part, void *stream);

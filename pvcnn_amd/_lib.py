@@ -58,6 +58,7 @@ SIGNATURES = {
     'pvcnn_conv3d_bwd_weight': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     'pvcnn_conv3d_weight_split_bytes': (_sz, [_i, _i, _i, _i]),
     'pvcnn_conv3d_weight_split': (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    'pvcnn_conv3d_weight_split_pair': (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     'pvcnn_conv3d_fwd_split_stats_parts': (_sz, [_i, _i, _i, _i]),
     'pvcnn_absmax_bits': (_i, [_vp, _sz, _vp, _vp]),
     'pvcnn_absmax_tiles_count': (_sz, [_i, ctypes.c_long, _i]),
@@ -69,6 +70,7 @@ SIGNATURES = {
     'pvcnn_pwconv_fwd': (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
     'pvcnn_pwconv_weight_split_bytes': (_sz, [_i, _i, _i, _i]),
     'pvcnn_pwconv_weight_split': (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    'pvcnn_pwconv_weight_split_pair': (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     'pvcnn_pwconv_fwd_split_stats_parts': (_sz, [_i, _i]),
     'pvcnn_pwconv_fwd_split': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
     'pvcnn_pwconv_bwd_weight_f16_workspace_bytes': (_sz, [_i, _i, _i, _i]),

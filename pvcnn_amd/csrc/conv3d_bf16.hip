@@ -162,11 +162,11 @@ __global__ __launch_bounds__(1024) void absmax_tiles_reduce_kernel(uint32_t *__r
 
 // f16x2 weights: one workgroup per (padded) output channel finds the row maximum, then writes the row's hi / lo planes in the
 // image layout below and the row's shift to wexp[co].
-__global__ __launch_bounds__(256) void conv3d_weight_split_f16_kernel(const float *__restrict__ w, int Co, int Ci, int for_bwd_data,
-                                                                      uint16_t *__restrict__ wts, int *__restrict__ wexp) {
+__device__ __forceinline__ void conv3d_weight_split_f16_row(const float *__restrict__ w, int Co, int Ci, int for_bwd_data,
+                                                            uint16_t *__restrict__ wts, int *__restrict__ wexp, int co) {
   const int CiE = for_bwd_data ? Co : Ci, CoE = for_bwd_data ? Ci : Co;
   const int chunks = ceil_div(CiE, 16), cotiles = ceil_div(CoE, 64);
-  const int co = blockIdx.x, cot = co >> 6, co_l = co & 63, tid = threadIdx.x;
+  const int cot = co >> 6, co_l = co & 63, tid = threadIdx.x;
   auto load = [&](int ci, int tap) { return for_bwd_data ? w[((size_t)ci * Ci + co) * 27 + (26 - tap)] : w[((size_t)co * Ci + ci) * 27 + tap]; };
   __shared__ uint32_t red[4];
   uint32_t m = 0;
@@ -192,6 +192,19 @@ __global__ __launch_bounds__(256) void conv3d_weight_split_f16_kernel(const floa
 #pragma unroll
     for (int s = 0; s < 2; ++s) img[((size_t)(dz * 2 + s) * 64 + co_l) * 8 + pos] = p[s];
   }
+}
+
+__global__ __launch_bounds__(256) void conv3d_weight_split_f16_kernel(const float *__restrict__ w, int Co, int Ci, int for_bwd_data,
+                                                                      uint16_t *__restrict__ wts, int *__restrict__ wexp) {
+  conv3d_weight_split_f16_row(w, Co, Ci, for_bwd_data, wts, wexp, blockIdx.x);
+}
+
+// forward AND backward-data image of one weight in one launch (a training step needs both; the weights do not change in between)
+__global__ __launch_bounds__(256) void conv3d_weight_split_f16_pair_kernel(const float *__restrict__ w, int Co, int Ci, int rows_fwd,
+                                                                           uint16_t *__restrict__ wts_f, int *__restrict__ wexp_f,
+                                                                           uint16_t *__restrict__ wts_b, int *__restrict__ wexp_b) {
+  if ((int)blockIdx.x < rows_fwd) conv3d_weight_split_f16_row(w, Co, Ci, 0, wts_f, wexp_f, blockIdx.x);
+  else conv3d_weight_split_f16_row(w, Co, Ci, 1, wts_b, wexp_b, blockIdx.x - rows_fwd);
 }
 
 // ---- weights: (Co, Ci, 27) fp32 -> [chunk][dxy][cotile][dz][plane][64 co][16 ci (halves swizzled)] bf16 ----
@@ -627,6 +640,18 @@ extern "C" int pvcnn_conv3d_weight_split(const float *w, int Co, int Ci, int for
   if (nsplit == 1) hipLaunchKernelGGL(conv3d_weight_split_kernel<1>, grid, dim3(256), 0, s, w, Co, Ci, for_bwd_data, static_cast<uint16_t *>(wts));
   else             hipLaunchKernelGGL(conv3d_weight_split_kernel<3>, grid, dim3(256), 0, s, w, Co, Ci, for_bwd_data, static_cast<uint16_t *>(wts));
   return check_launch("conv3d_weight_split");
+}
+
+// both f16x2 images of w (forward + backward-data) in one launch; buffers sized by pvcnn_conv3d_weight_split_bytes(.., 0 / 1, 2)
+extern "C" int pvcnn_conv3d_weight_split_pair(const float *w, int Co, int Ci, void *wts_fwd, void *wts_bwd, void *stream) {
+  PVCNN_REQUIRE(w && wts_fwd && wts_bwd && Co > 0 && Ci > 0, "bad argument");
+  PVCNN_REQUIRE(aligned16(wts_fwd) && aligned16(wts_bwd), "images must be 16-byte aligned");
+  const int rows_f = ceil_div(Co, kCoTileB) * kCoTileB, rows_b = ceil_div(Ci, kCoTileB) * kCoTileB;
+  int *wexp_f = reinterpret_cast<int *>(static_cast<char *>(wts_fwd) + weight_image_bytes(Ci, Co, 2));
+  int *wexp_b = reinterpret_cast<int *>(static_cast<char *>(wts_bwd) + weight_image_bytes(Co, Ci, 2));
+  hipLaunchKernelGGL(conv3d_weight_split_f16_pair_kernel, dim3(rows_f + rows_b), dim3(256), 0, static_cast<hipStream_t>(stream), w, Co, Ci,
+                     rows_f, static_cast<uint16_t *>(wts_fwd), wexp_f, static_cast<uint16_t *>(wts_bwd), wexp_b);
+  return check_launch("conv3d_weight_split_pair");
 }
 
 extern "C" size_t pvcnn_conv3d_fwd_split_stats_parts(int B, int Co, int R, int nsplit) {

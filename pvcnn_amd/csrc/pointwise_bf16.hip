@@ -75,11 +75,11 @@ __global__ __launch_bounds__(256) void pw_weight_split_kernel(const float *__res
 
 // f16x2 image: one workgroup per (padded) output row finds the row's max |w|, scales by the power of two of scale_shift and writes the
 // fp16 hi / lo planes; wexp[row] = the shift (the epilogue scales back per output channel).
-__global__ __launch_bounds__(256) void pw_weight_split_f16_kernel(const float *__restrict__ w, int Co, int Ci, int for_bwd_data, int TM,
-                                                                  uint16_t *__restrict__ wts, int *__restrict__ wexp) {
+__device__ __forceinline__ void pw_weight_split_f16_row(const float *__restrict__ w, int Co, int Ci, int for_bwd_data, int TM,
+                                                        uint16_t *__restrict__ wts, int *__restrict__ wexp, int m) {
   const int KE = for_bwd_data ? Co : Ci, ME = for_bwd_data ? Ci : Co;
   const int chunks = ceil_div(KE, kPbK), mtiles = ceil_div(ME, TM);
-  const int m = blockIdx.x, mt = m / TM, row = m - mt * TM, tid = threadIdx.x;
+  const int mt = m / TM, row = m - mt * TM, tid = threadIdx.x;
   auto load = [&](int k) { return for_bwd_data ? w[(size_t)k * Ci + m] : w[(size_t)m * Ci + k]; };
   __shared__ uint32_t red[4];
   uint32_t mx = 0;
@@ -102,6 +102,19 @@ __global__ __launch_bounds__(256) void pw_weight_split_f16_kernel(const float *_
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) img[((size_t)s2 * TM + row) * 8 + word] = p[s2];
   }
+}
+
+__global__ __launch_bounds__(256) void pw_weight_split_f16_kernel(const float *__restrict__ w, int Co, int Ci, int for_bwd_data, int TM,
+                                                                  uint16_t *__restrict__ wts, int *__restrict__ wexp) {
+  pw_weight_split_f16_row(w, Co, Ci, for_bwd_data, TM, wts, wexp, blockIdx.x);
+}
+
+// forward AND backward-data image of one weight in one launch
+__global__ __launch_bounds__(256) void pw_weight_split_f16_pair_kernel(const float *__restrict__ w, int Co, int Ci, int rows_fwd, int TM_f,
+                                                                       int TM_b, uint16_t *__restrict__ wts_f, int *__restrict__ wexp_f,
+                                                                       uint16_t *__restrict__ wts_b, int *__restrict__ wexp_b) {
+  if ((int)blockIdx.x < rows_fwd) pw_weight_split_f16_row(w, Co, Ci, 0, TM_f, wts_f, wexp_f, blockIdx.x);
+  else pw_weight_split_f16_row(w, Co, Ci, 1, TM_b, wts_b, wexp_b, blockIdx.x - rows_fwd);
 }
 
 // f16x2 operand scale: amax_seg = 0 -> one scale for the whole tensor (x_absmax[0]); amax_seg = 256 -> x_absmax is an "amax buffer"
@@ -353,6 +366,19 @@ extern "C" int pvcnn_pwconv_weight_split(const float *w, int Co, int Ci, int for
   if (nsplit == 1) hipLaunchKernelGGL(pw_weight_split_kernel<1>, grid, dim3(256), 0, s, w, Co, Ci, for_bwd_data, TM, static_cast<uint16_t *>(wts));
   else             hipLaunchKernelGGL(pw_weight_split_kernel<3>, grid, dim3(256), 0, s, w, Co, Ci, for_bwd_data, TM, static_cast<uint16_t *>(wts));
   return check_launch("pwconv_weight_split");
+}
+
+// both f16x2 images of w (forward + backward-data) in one launch; buffers sized by pvcnn_pwconv_weight_split_bytes(.., 0 / 1, 2)
+extern "C" int pvcnn_pwconv_weight_split_pair(const float *w, int Co, int Ci, void *wts_fwd, void *wts_bwd, void *stream) {
+  PVCNN_REQUIRE(w && wts_fwd && wts_bwd && Co > 0 && Ci > 0, "bad argument");
+  PVCNN_REQUIRE(aligned16(wts_fwd) && aligned16(wts_bwd), "images must be 16-byte aligned");
+  const int TM_f = 32 * pb_mb(Co), TM_b = 32 * pb_mb(Ci);
+  const int rows_f = ceil_div(Co, TM_f) * TM_f, rows_b = ceil_div(Ci, TM_b) * TM_b;
+  int *wexp_f = reinterpret_cast<int *>(static_cast<char *>(wts_fwd) + pb_image_bytes(Ci, Co, 2));
+  int *wexp_b = reinterpret_cast<int *>(static_cast<char *>(wts_bwd) + pb_image_bytes(Co, Ci, 2));
+  hipLaunchKernelGGL(pw_weight_split_f16_pair_kernel, dim3(rows_f + rows_b), dim3(256), 0, static_cast<hipStream_t>(stream), w, Co, Ci, rows_f,
+                     TM_f, TM_b, static_cast<uint16_t *>(wts_fwd), wexp_f, static_cast<uint16_t *>(wts_bwd), wexp_b);
+  return check_launch("pwconv_weight_split_pair");
 }
 
 extern "C" size_t pvcnn_pwconv_fwd_split_stats_parts(int B, int N) {

@@ -13,7 +13,7 @@ by a later tensor can never hit a stale entry.
 import threading
 import weakref
 
-__all__ = ['memo', 'clear', 'enabled', 'tag_amax', 'amax_of']
+__all__ = ['memo', 'forget', 'clear', 'enabled', 'tag_amax', 'amax_of']
 
 # re-entrant: a weak-reference callback (_drop) can fire from the garbage collector at any allocation, including inside
 # memo()'s own critical section on the same thread -- a plain Lock deadlocks there (seen in the GPU test-suite)
@@ -55,6 +55,14 @@ def memo(tensor, key, make):
     with _lock:
         store.setdefault(key, value)
         return store[key]
+
+
+def forget(tensor, key):
+    """Drop one memoised product of `tensor` (its owner found it stale)."""
+    with _lock:
+        ent = _entries.get(id(tensor))
+        if ent is not None and ent[0]() is tensor:
+            ent[2].pop(key, None)
 
 
 def clear():

@@ -520,6 +520,29 @@ class HipBackend:
             _lib.check(self.lib.pvcnn_conv3d_weight_split(_p(weight), co, ci, int(for_bwd_data), int(nsplit), _p(wts), s), 'conv3d_weight_split')
         return wts
 
+    def conv_weight_images(self, weight, nsplit):
+        """(forward image, backward-data image) of a Conv3d weight; f16x2: both from ONE launch (a training step needs both and the
+        weights do not change between its forward and its backward)."""
+        co, ci = weight.shape[0], weight.shape[1]
+        if int(nsplit) != 2:
+            return self._conv_wsplit(weight, False, nsplit), self._conv_wsplit(weight, True, nsplit)
+        wf = torch.empty((self.lib.pvcnn_conv3d_weight_split_bytes(co, ci, 0, 2),), dtype=torch.uint8, device=weight.device)
+        wb = torch.empty((self.lib.pvcnn_conv3d_weight_split_bytes(co, ci, 1, 2),), dtype=torch.uint8, device=weight.device)
+        with _Launch(weight) as s:
+            _lib.check(self.lib.pvcnn_conv3d_weight_split_pair(_p(weight), co, ci, _p(wf), _p(wb), s), 'conv3d_weight_split_pair')
+        return wf, wb
+
+    def pw_weight_images(self, weight, nsplit):
+        """(forward image, backward-data image) of a 1x1 convolution weight (Co, Ci); f16x2: one launch."""
+        co, ci = weight.shape
+        if int(nsplit) != 2:
+            return self._pw_wsplit(weight, False, nsplit), self._pw_wsplit(weight, True, nsplit)
+        wf = torch.empty((self.lib.pvcnn_pwconv_weight_split_bytes(co, ci, 0, 2),), dtype=torch.uint8, device=weight.device)
+        wb = torch.empty((self.lib.pvcnn_pwconv_weight_split_bytes(co, ci, 1, 2),), dtype=torch.uint8, device=weight.device)
+        with _Launch(weight) as s:
+            _lib.check(self.lib.pvcnn_pwconv_weight_split_pair(_p(weight), co, ci, _p(wf), _p(wb), s), 'pwconv_weight_split_pair')
+        return wf, wb
+
     def conv3d_forward_split(self, x, weight, bias, nsplit, want_stats=False, amax=None):
         _f32(x, 'x'); _f32(weight, 'weight')
         _shape(x.dim() == 5 and weight.dim() == 5 and tuple(weight.shape[2:]) == (3, 3, 3) and weight.shape[1] == x.shape[1]

@@ -46,13 +46,22 @@ class VoxelConv3d(Function):
             if ctx.x_amax is None:
                 ctx.x_amax = be.conv_amax(x)
         kw = {'amax': ctx.x_amax} if ctx.nsplit == 2 else {}
+        # the pre-split weight images: when the input wants a gradient the backward-data image is made by the SAME launch as the
+        # forward one and kept for backward (the values backward must use are the ones saved now, not a later state of the weight)
+        ctx.w_bwd_image = None
+        if ctx.nsplit and hasattr(be, 'conv_weight_images') and ctx.needs_input_grad[0]:
+            w_image, ctx.w_bwd_image = be.conv_weight_images(weight, ctx.nsplit)
+            run = lambda **k: be.conv3d_igemm_split(x, w_image, b, weight.shape[0], ctx.nsplit, amax=ctx.x_amax, **k)
+        elif ctx.nsplit:
+            run = lambda **k: be.conv3d_forward_split(x, weight, b, ctx.nsplit, **kw, **k)
+        else:
+            run = lambda **k: be.conv3d_forward(x, weight, b, **k)
         if want_stats:   # second output: BatchNorm partial sums from the epilogue (not differentiable)
-            y, part = (be.conv3d_forward_split(x, weight, b, ctx.nsplit, want_stats=True, **kw) if ctx.nsplit
-                       else be.conv3d_forward(x, weight, b, want_stats=True))
+            y, part = run(want_stats=True)
             ctx.mark_non_differentiable(part)
             ctx.set_materialize_grads(False)     # no zero tensor for the (non-existent) gradient of `part`
             return y, part
-        return be.conv3d_forward_split(x, weight, b, ctx.nsplit, **kw) if ctx.nsplit else be.conv3d_forward(x, weight, b)
+        return run()
 
     @staticmethod
     @amp_bwd
@@ -74,8 +83,11 @@ class VoxelConv3d(Function):
                 g_amax = be.conv_amax(grad_y)
         gx = None
         if ctx.needs_input_grad[0]:
-            gx = (be.conv3d_backward_data_split(grad_y, weight, ctx.nsplit, **({'amax': g_amax} if f16 else {})) if ctx.nsplit
-                  else be.conv3d_backward_data(grad_y, weight))
+            if ctx.nsplit and ctx.w_bwd_image is not None:     # a convolution with Ci and Co exchanged on the flipped weights (forward's image)
+                gx = be.conv3d_igemm_split(grad_y, ctx.w_bwd_image, None, weight.shape[1], ctx.nsplit, False, g_amax)
+            else:
+                gx = (be.conv3d_backward_data_split(grad_y, weight, ctx.nsplit, **({'amax': g_amax} if f16 else {})) if ctx.nsplit
+                      else be.conv3d_backward_data(grad_y, weight))
         want_bias = ctx.has_bias and ctx.needs_input_grad[2]
         gw = gb = None
         if ctx.needs_input_grad[1]:

@@ -48,7 +48,15 @@ class PointwiseConv(Function):
             if ctx.x_amax is None:
                 ctx.x_amax = be.pw_amax(x3)
         akw = {'amax': ctx.x_amax} if ctx.split == 2 else {}
-        run = (lambda **kw: be.pwconv_forward_split(x3, w2, b, ctx.split, **akw, **kw)) if ctx.split else (lambda **kw: be.pwconv_forward(x3, w2, b, **kw))
+        # forward + backward-data weight images from one launch when the input wants a gradient (see functional/conv3d.py)
+        ctx.w_bwd_image = None
+        if ctx.split and hasattr(be, 'pw_weight_images') and ctx.needs_input_grad[0]:
+            w_image, ctx.w_bwd_image = be.pw_weight_images(w2, ctx.split)
+            run = lambda **kw: be.pwconv_gemm_split(x3, w_image, b, w2.shape[0], ctx.split, amax=ctx.x_amax, **kw)
+        elif ctx.split:
+            run = lambda **kw: be.pwconv_forward_split(x3, w2, b, ctx.split, **akw, **kw)
+        else:
+            run = lambda **kw: be.pwconv_forward(x3, w2, b, **kw)
         if want_stats:   # second output: BatchNorm partial sums from the epilogue (not differentiable)
             y, part = run(want_stats=True)
             ctx.mark_non_differentiable(part)
@@ -76,8 +84,11 @@ class PointwiseConv(Function):
                 g_amax = be.pw_amax(g3)
         gx = None
         if ctx.needs_input_grad[0]:
-            gx = (be.pwconv_backward_data_split(g3, w2, ctx.split, **({'amax': g_amax} if f16 else {})) if ctx.split
-                  else be.pwconv_backward_data(g3, w2)).view(ctx.x_shape)
+            if ctx.split and ctx.w_bwd_image is not None:
+                gx = be.pwconv_gemm_split(g3, ctx.w_bwd_image, None, w2.shape[1], ctx.split, False, g_amax).view(ctx.x_shape)
+            else:
+                gx = (be.pwconv_backward_data_split(g3, w2, ctx.split, **({'amax': g_amax} if f16 else {})) if ctx.split
+                      else be.pwconv_backward_data(g3, w2)).view(ctx.x_shape)
         want_bias = ctx.has_bias and ctx.needs_input_grad[2]
         gw = gb = None
         if ctx.needs_input_grad[1]:

@@ -64,7 +64,7 @@ class Voxelization(nn.Module):
         be = native()
         normalize = bool(self.normalize)
         if self.single_launch:
-            return _cache.memo(coords, ('vox1', self.r, normalize, float(self.eps)),
+            return self._fresh(coords, ('vox1', self.r, normalize, float(self.eps)),
                                lambda: be.voxel_coords(coords.detach().contiguous(), self.r, normalize, self.eps))
 
         def tail():
@@ -74,7 +74,22 @@ class Voxelization(nn.Module):
             if not batch_strided_ok(c):
                 c = c.contiguous()
             return be.voxel_coords_tail(c, mean.contiguous(), radius.contiguous() if radius is not None else None, self.r, self.eps)
-        return _cache.memo(coords, ('vox', self.r, normalize, float(self.eps)), tail)
+        return self._fresh(coords, ('vox', self.r, normalize, float(self.eps)), tail)
+
+    @staticmethod
+    def _fresh(coords, key, make):
+        """memo(coords, key) of a (norm_coords, vox_coords) pair that is handed OUT of this module (forward returns norm_coords): the
+        entry also records both tensors' in-place version counters, and a caller that modified one of them in place gets a recomputed
+        pair next time instead of its own edit (the other layers at this resolution share the pair)."""
+        def stamped():
+            norm, vox = make()
+            return norm, vox, norm._version, vox._version
+        for _ in range(2):
+            norm, vox, vn, vv = _cache.memo(coords, key, stamped)
+            if norm._version == vn and vox._version == vv:
+                return norm, vox
+            _cache.forget(coords, key)
+        return norm, vox
 
     def forward(self, features, coords):
         be = native()
