@@ -387,6 +387,13 @@ PVCNN_API int pvcnn_trilinear_devox_bwd_strided(const float *grad_y, long grad_y
                                       const float *wgts, int B, int C, int N, int R, float *grad_x,
                                       void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- concatenation of per-point feature maps along the channels: torch.cat(features, dim=1) of models/s3dis/pvcnn.py:45 (and
+ * models/shapenet/pvcnn.py:41) in one pass that also emits the amax buffer (256-point segments) of its output, i.e. the f16x2 scale
+ * table of the classifier GEMM that consumes it.  nsrc <= 8 sources; source i has channels[i] channels, its clouds are bstrides[i]
+ * elements apart and pstrides[i] is 1 (rows of N points) or 0 (one value per (cloud, channel), broadcast over the points). */
+PVCNN_API int pvcnn_concat_points(const float *const *srcs, const long *bstrides, const int *channels, const int *pstrides, int nsrc, int B,
+                        int N, float *out, void *out_amax, void *stream);
+
 /* ---- the optimizer update of the training step on flat buffers (csrc/optim.hip) ----------------------------------------------
  * replaces torch.optim.Adam's per-tensor update of train.py:96-119 (optimizer.step()) when the parameters share the flat layout of
  * the gradient buckets (pvcnn_amd/dp.py): p, m (exp_avg), v (exp_avg_sq) updated in place, g read; arithmetic of torch.optim.Adam

@@ -486,3 +486,98 @@ extern "C" int pvcnn_bnact_bwd_apply(const float *x, const float *grad_y, long g
   if (int e = check_launch("bnact_bwd_apply_pb")) return e;
   return launch_amax_reduce(am, (long)B * nseg, s);
 }
+
+// ---- concatenation of per-point feature maps along the channels (torch.cat(taps, dim=1) of models/s3dis/pvcnn.py:45) -------------
+// Position-block-major like the BatchNorm apply passes: a workgroup owns 256 points of one cloud and walks all channels of all
+// sources, so the amax buffer of the OUTPUT (the f16x2 scale table of the classifier GEMM that consumes it: one maximum per 256
+// points) falls out of the copy -- torch's cat (0.20 ms for PVCNN's 386 MB) plus a separate amax pass (0.07 ms) become one kernel.
+// A source may be a broadcast over the points (point stride 0: the cloud descriptor of models/s3dis/pvcnn.py:44).
+namespace pvcnn {
+constexpr int kCatMaxSrc = 8;
+struct CatSources {
+  const float *p[kCatMaxSrc];
+  long bstride[kCatMaxSrc];     // elements between clouds
+  int c0[kCatMaxSrc + 1];       // first output channel of each source (c0[n] = total)
+  int pstride[kCatMaxSrc];      // 1: (B, C, N) rows; 0: one value per (cloud, channel), broadcast over the points
+  int n;
+};
+
+__global__ __launch_bounds__(256) void concat_points_kernel(CatSources src, int N, int vec, float *__restrict__ out,
+                                                            uint32_t *__restrict__ amax) {
+  __shared__ uint32_t wave_max[4];
+  const int b = blockIdx.y, p0 = blockIdx.x * 256;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, pos = p0 + 4 * lane;
+  const int Ctot = src.c0[src.n];
+  float *ob = out + (size_t)b * Ctot * N;
+  uint32_t m = 0;
+  using v4f = __attribute__((ext_vector_type(4))) float;
+  for (int s = 0; s < src.n; ++s) {
+    const int cb = src.c0[s], cn = src.c0[s + 1] - cb;
+    const float *sp = src.p[s] + (size_t)b * src.bstride[s];
+    if (src.pstride[s] == 0) {                               // broadcast rows
+      for (int c = wave; c < cn; c += 4) {
+        const float v = sp[c];
+        m = max(m, __float_as_uint(fabsf(v)));
+        if (vec && pos < N) { v4f o = {v, v, v, v}; __builtin_nontemporal_store(o, reinterpret_cast<v4f *>(ob + (size_t)(cb + c) * N + pos)); }
+        else for (int i = 0; i < 4; ++i) if (pos + i < N) ob[(size_t)(cb + c) * N + pos + i] = v;
+      }
+    } else if (vec) {
+      if (pos < N)
+        for (int c0 = wave; c0 < cn; c0 += 16) {             // four rows in flight per wave
+          float4 v[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (c0 + 4 * u < cn) v[u] = *reinterpret_cast<const float4 *>(sp + (size_t)(c0 + 4 * u) * N + pos);
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (c0 + 4 * u < cn) {
+              m = max(max(m, __float_as_uint(fabsf(v[u].x))), max(__float_as_uint(fabsf(v[u].y)), max(__float_as_uint(fabsf(v[u].z)), __float_as_uint(fabsf(v[u].w)))));
+              v4f o = {v[u].x, v[u].y, v[u].z, v[u].w};
+              __builtin_nontemporal_store(o, reinterpret_cast<v4f *>(ob + (size_t)(cb + c0 + 4 * u) * N + pos));
+            }
+        }
+    } else {
+      for (int c = wave; c < cn; c += 4)
+        for (int i = 0; i < 4; ++i)
+          if (pos + i < N) {
+            const float v = sp[(size_t)c * N + pos + i];
+            m = max(m, __float_as_uint(fabsf(v)));
+            ob[(size_t)(cb + c) * N + pos + i] = v;
+          }
+    }
+  }
+  if (amax != nullptr) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+    if (lane == 0) wave_max[wave] = m;
+    lds_barrier();
+    if (tid == 0) amax[1 + (size_t)b * gridDim.x + blockIdx.x] = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
+  }
+}
+}  // namespace pvcnn
+
+// out (B, sum C_i, N) = concatenation of nsrc <= 8 sources along the channels; source i: srcs[i] with channels[i] channels, clouds
+// bstrides[i] elements apart, pstrides[i] = 1 ((C_i, N) rows contiguous within a cloud) or 0 (one value per (cloud, channel), broadcast).
+// out_amax: NULL, or pvcnn_absmax_tiles_count(B, N, 256) words = the amax buffer of `out` with 256-point segments.
+extern "C" int pvcnn_concat_points(const float *const *srcs, const long *bstrides, const int *channels, const int *pstrides, int nsrc, int B,
+                                   int N, float *out, void *out_amax, void *stream) {
+  PVCNN_REQUIRE(srcs && bstrides && channels && pstrides && out && nsrc > 0 && nsrc <= kCatMaxSrc && B > 0 && N > 0, "bad argument");
+  PVCNN_REQUIRE(B <= 65535, "batch > 65535");
+  CatSources cs{};
+  cs.n = nsrc;
+  bool vec = (N % 4 == 0) && aligned16(out);
+  int c = 0;
+  for (int i = 0; i < nsrc; ++i) {
+    PVCNN_REQUIRE(srcs[i] && channels[i] > 0 && (pstrides[i] == 0 || pstrides[i] == 1), "bad source");
+    cs.p[i] = srcs[i]; cs.bstride[i] = bstrides[i]; cs.pstride[i] = pstrides[i]; cs.c0[i] = c;
+    c += channels[i];
+    if (pstrides[i] == 1) vec = vec && aligned16(srcs[i]) && (bstrides[i] % 4 == 0);
+  }
+  cs.c0[nsrc] = c;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int blocks = ceil_div(N, 256);
+  hipLaunchKernelGGL(concat_points_kernel, dim3(blocks, B), dim3(256), 0, s, cs, N, vec ? 1 : 0, out, static_cast<uint32_t *>(out_amax));
+  if (int e = check_launch("concat_points")) return e;
+  if (out_amax != nullptr) return launch_amax_reduce(static_cast<uint32_t *>(out_amax), (long)B * blocks, s);
+  return 0;
+}

@@ -826,6 +826,35 @@ class HipBackend:
                 'trilinear_devoxelize_bnact_forward')
         return [outs, inds, wgts]
 
+    # ---- torch.cat(features, dim=1) of the classifier input + the amax buffer of its output in one pass (csrc/bnact.hip) ----
+    has_concat_points = True
+
+    def concat_points(self, tensors, want_amax=True):
+        """tensors: (B, C_i, N) float32, each with contiguous rows inside a cloud (a channel slice is fine) or broadcast over the points
+        (stride 0 along N, contiguous (B, C_i)) -> (out (B, sum C_i, N), its amax buffer with 256-point segments | None)."""
+        _shape(0 < len(tensors) <= 8, 'concat_points: 1..8 sources')
+        b, n = tensors[0].shape[0], tensors[0].shape[2]
+        ptrs, bstr, chans, pstr = [], [], [], []
+        for t in tensors:
+            _dev(t, 'source')
+            _shape(t.dim() == 3 and t.dtype == torch.float32 and t.shape[0] == b and t.shape[2] == n, 'concat_points: (B, C_i, N) float sources expected')
+            c = t.shape[1]
+            if n > 1 and t.stride(2) == 0:
+                _shape(t.stride(1) == 1 or c == 1, 'concat_points: a broadcast source must be contiguous over (B, C)')
+                pstr.append(0); bstr.append(t.stride(0) if b > 1 else c)
+            else:
+                _shape((n == 1 or t.stride(2) == 1) and (c == 1 or t.stride(1) == n), 'concat_points: rows must be contiguous inside a cloud')
+                pstr.append(1); bstr.append(t.stride(0) if b > 1 else c * n)
+            ptrs.append(t.data_ptr()); chans.append(c)
+        k = len(tensors)
+        out = torch.empty((b, sum(chans), n), dtype=torch.float32, device=tensors[0].device)
+        amax = self.amax_buffer(b, n, self.PW_AMAX_SEG, out.device) if want_amax else None
+        with _Launch(out) as s:
+            _lib.check(self.lib.pvcnn_concat_points((ctypes.c_void_p * k)(*ptrs), (ctypes.c_long * k)(*bstr), (ctypes.c_int * k)(*chans),
+                                                    (ctypes.c_int * k)(*pstr), k, b, n, _p(out), _p(amax) if want_amax else None, s),
+                       'concat_points')
+        return out, amax
+
     # ---- the two halves of bnact_backward on their own (PVConv's SE tail puts the excitation's backward between them) ----
     has_bnact_split_bwd = True
 

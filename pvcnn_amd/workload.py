@@ -58,6 +58,55 @@ class _TapAndPool(torch.autograd.Function):
         return g, None
 
 
+class _ConcatPoints(torch.autograd.Function):
+    """torch.cat(taps, dim=1) of the classifier input (models/s3dis/pvcnn.py:45) as one kernel that ALSO emits the f16x2 scale table of
+    its output (csrc/bnact.hip: concat_points_kernel) -- the first classifier GEMM then needs no pass of its own over the 386 MB it
+    reads.  Backward hands every source its channel slice of the gradient as a view (what torch.cat's backward does); a source that
+    was broadcast over the points gets the slice summed over them (expand's backward)."""
+
+    @staticmethod
+    def forward(ctx, *taps):
+        from .modules.functional import _cache
+        from .modules.functional._autograd import native
+        be = native()
+        ctx.splits = [t.shape[1] for t in taps]
+        ctx.broadcast = [t.shape[2] > 1 and t.stride(2) == 0 for t in taps]
+        out, amax = be.concat_points([t.detach() for t in taps])
+        ctx.mark_non_differentiable(amax)
+        ctx.set_materialize_grads(False)
+        return out, amax
+
+    @staticmethod
+    def backward(ctx, grad, _grad_amax=None):
+        if grad is None:
+            return (None,) * len(ctx.splits)
+        grads, off = [], 0
+        for c, bc in zip(ctx.splits, ctx.broadcast):
+            g = grad.narrow(1, off, c)
+            grads.append(g.sum(dim=2, keepdim=True).expand(-1, -1, grad.shape[2]) if bc else g)
+            off += c
+        return tuple(grads)
+
+
+def concat_points(taps):
+    """torch.cat(taps, dim=1); on the GPU path one kernel that also tags the result with its f16x2 scale table."""
+    from .modules.functional import _cache
+    from .modules.functional._autograd import native
+    be = native()
+    ok = (getattr(be, 'has_concat_points', False) and len(taps) <= 8 and all(t.is_cuda and t.dtype == torch.float32 and t.dim() == 3 for t in taps)
+          and not torch.is_autocast_enabled())
+    if not ok:
+        return torch.cat(taps, dim=1)
+    ok = all((t.shape[2] > 1 and t.stride(2) == 0 and (t.stride(1) == 1 or t.shape[1] == 1)) or
+             ((t.shape[2] == 1 or t.stride(2) == 1) and (t.shape[1] == 1 or t.stride(1) == t.shape[2])) for t in taps)
+    if not ok:
+        return torch.cat(taps, dim=1)
+    out, amax = _ConcatPoints.apply(*taps)
+    if getattr(be, 'pw_math', '') == 'f16x2':
+        _cache.tag_amax(out, be.PW_AMAX_SEG, amax)
+    return out
+
+
 def tap_and_pool(x):
     """-> (x as a tap, max over the points (B,C)).  The winners come from `x.max(dim=-1)` itself (ties: torch's rule)."""
     if not (x.requires_grad and torch.is_grad_enabled()):
@@ -137,7 +186,7 @@ class PVCNN(nn.Module):
         cloud = self.cloud_features(pooled)
         # (expand, not repeat: torch.cat reads the broadcast view -- the repeated (B,128,N) tensor is never written on its own)
         taps.append(cloud.unsqueeze(-1).expand(-1, -1, coords.size(-1)))
-        return self.classifier(torch.cat(taps, dim=1))
+        return self.classifier(concat_points(taps))
 
 
 class PVCNN2(nn.Module):
@@ -244,8 +293,9 @@ class PVCNNShapeNet(nn.Module):
         for stage in self.point_features:
             feats, _ = stage((feats, coords))
             taps.append(feats)
-        taps.append(feats.max(dim=-1, keepdim=True).values.repeat([1, 1, coords.size(-1)]))
-        return self.classifier(torch.cat(taps, dim=1))
+        taps[-1], pooled = tap_and_pool(feats)             # the last stage's features: a tap AND the global max pool
+        taps.append(pooled.unsqueeze(-1).expand(-1, -1, coords.size(-1)))
+        return self.classifier(concat_points(taps))
 
 
 class _FrustumSegmentation(nn.Module):
