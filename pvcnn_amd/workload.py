@@ -61,8 +61,7 @@ class _TapAndPool(torch.autograd.Function):
 class _ConcatPoints(torch.autograd.Function):
     """torch.cat(taps, dim=1) of the classifier input (models/s3dis/pvcnn.py:45) as one kernel that ALSO emits the f16x2 scale table of
     its output (csrc/bnact.hip: concat_points_kernel) -- the first classifier GEMM then needs no pass of its own over the 386 MB it
-    reads.  Backward hands every source its channel slice of the gradient as a view (what torch.cat's backward does); a source that
-    was broadcast over the points gets the slice summed over them (expand's backward)."""
+    reads.  Backward hands every source its channel slice of the gradient as a view (what torch.cat's backward does)."""
 
     @staticmethod
     def forward(ctx, *taps):
@@ -70,7 +69,6 @@ class _ConcatPoints(torch.autograd.Function):
         from .modules.functional._autograd import native
         be = native()
         ctx.splits = [t.shape[1] for t in taps]
-        ctx.broadcast = [t.shape[2] > 1 and t.stride(2) == 0 for t in taps]
         out, amax = be.concat_points([t.detach() for t in taps])
         ctx.mark_non_differentiable(amax)
         ctx.set_materialize_grads(False)
@@ -81,9 +79,8 @@ class _ConcatPoints(torch.autograd.Function):
         if grad is None:
             return (None,) * len(ctx.splits)
         grads, off = [], 0
-        for c, bc in zip(ctx.splits, ctx.broadcast):
-            g = grad.narrow(1, off, c)
-            grads.append(g.sum(dim=2, keepdim=True).expand(-1, -1, grad.shape[2]) if bc else g)
+        for c in ctx.splits:
+            grads.append(grad.narrow(1, off, c))        # a broadcast source: expand's own backward sums its slice over the points
             off += c
         return tuple(grads)
 
