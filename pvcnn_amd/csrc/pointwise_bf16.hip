@@ -117,11 +117,78 @@ __global__ __launch_bounds__(256) void pw_weight_split_f16_pair_kernel(const flo
   else pw_weight_split_f16_row(w, Co, Ci, 1, TM_b, wts_b, wexp_b, blockIdx.x - rows_fwd);
 }
 
+// ---- epilogue shared by the 1x1 GEMM kernels: D[i = m][j = point]; lanes = consecutive points (128-byte rows); bias; the optional
+// BatchNorm partial sums of (y - bias).  `lds` = the workgroup's staging buffer (>= 4 / WM * TM float pairs), free by now.
+template <int NS, int MB, int WM>
+__device__ __forceinline__ void pb_epilogue(f32x16 (&acc)[MB / WM][2 * WM], uint32_t *lds, const float *__restrict__ bias,
+                                            float *__restrict__ y, int M, int N, int b, int n0, int m0, int tile, int tiles_total,
+                                            float2 *__restrict__ stats_part, const int *__restrict__ wexp, int x_shift) {
+  constexpr int TM = 32 * MB, MBW = MB / WM, NBW = 2 * WM;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, kh = lane >> 5;
+  const int wm = wave % WM, wn = wave / WM;
+  uint32_t *xs = lds;
+  const bool want_stats = stats_part != nullptr;
+  float2 *stat_lds = reinterpret_cast<float2 *>(xs);            // [4 / WM point groups][TM]
+  if (want_stats) __syncthreads();
+  float *yb = y + (size_t)b * M * N;
+#pragma unroll
+  for (int mbl = 0; mbl < MBW; ++mbl) {
+    const int mb = wm * MBW + mbl;                              // row block inside the workgroup tile
+    float bv[16], unscale[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+      bv[r] = (bias != nullptr && m < M) ? bias[m] : 0.0f;
+      if constexpr (NS == 2) unscale[r] = exp2_int(-wexp[m]);   // wexp covers the padded rows of the tile
+    }
+    const float x_unscale = exp2_int(-x_shift);
+    float ss[16], qq[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ss[r] = qq[r] = 0.0f;
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb) {
+      const int n = n0 + wn * (32 * NBW) + nb * 32 + j;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        float v = acc[mbl][nb][r];
+        if constexpr (NS == 2) v = v * unscale[r] * x_unscale;  // powers of two: exact
+        if (want_stats) {                                       // statistics of (y - bias), see bn_finalize_kernel
+          const float mv = n < N ? v : 0.0f;
+          ss[r] += mv;
+          qq[r] += mv * mv;
+        }
+        v += bv[r];
+        if (n < N && m < M) yb[(size_t)m * N + n] = v;
+      }
+    }
+    if (want_stats) {
+      const float st = half_wave_sum16(ss, j), qt = half_wave_sum16(qq, j);
+      const int rr = (j >> 1) & 15;
+      if ((j & 1) == 0) stat_lds[wn * TM + mb * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * kh] = make_float2(st, qt);
+    }
+  }
+  if (want_stats) {
+    __syncthreads();
+    if (tid < TM && m0 + tid < M) {
+      float2 t = stat_lds[tid];
+#pragma unroll
+      for (int w = 1; w < 4 / WM; ++w) { t.x += stat_lds[w * TM + tid].x; t.y += stat_lds[w * TM + tid].y; }
+      stats_part[(size_t)(m0 + tid) * tiles_total + tile] = t;
+    }
+  }
+}
+
 // f16x2 operand scale: amax_seg = 0 -> one scale for the whole tensor (x_absmax[0]); amax_seg = 256 -> x_absmax is an "amax buffer"
 // (include/pvcnn_hip.h) with one maximum per 256-point tile behind the global one: every workgroup scales by ITS tile's maximum.
 // (A 256-channel tile, MB = 8 with the accumulators in AGPRs, was built and measured in round 3: 0.196 vs 0.154 ms at 128 -> 1024,
 // 1730 vs 1760 clouds/s in the step -- removed.)
-template <int NS, int MB, int PF = 1>
+// VEC (N % 4 == 0, N >= 4, x 16-byte aligned): the chunk loop is STRAIGHT-LINE code -- every row load is issued unconditionally from a
+// clamped address (rows >= K read row K - 1: their weights in the image are zero; the points of a ragged last tile read the last
+// quad: those columns are never stored), the next weight fragments from a clamped chunk.  With branches around the loads the
+// compiler cannot count the loads in flight and waits with vmcnt(0) in front of the first MFMA of every chunk -- i.e. for the
+// prefetch it has just issued (ISA of round 3: the whole HBM latency was exposed once per chunk).
+template <int NS, int MB, int PF = 1, bool VEC = false>
 __global__ __launch_bounds__(256, 2) void pw_gemm_bf16_kernel(const float *__restrict__ x, const uint16_t *__restrict__ wts,
                                                               const float *__restrict__ bias, float *__restrict__ y, int K, int M,
                                                               int N, int tiles_n, int tiles_total, float2 *__restrict__ stats_part,
@@ -182,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_bf16_kernel(const float *__res
   // that the ring indices are compile-time).  With PF = 1 every workgroup on the chip alternates "burst of loads" / "multiply":
   // the loads of chunk i + 1 have only chunk i's MFMAs (~0.3 us) to land in.
   float4 va_[PF][ITEMS], vb_[PF][ITEMS];
-  const bool vec = (N % 4 == 0) && aligned16(xb) && (n0 + kPbN <= N);
+  const bool vec = !VEC && (N % 4 == 0) && aligned16(xb) && (n0 + kPbN <= N);
   auto load_x = [&](int chunk, float4 (&va)[ITEMS], float4 (&vb)[ITEMS]) {
     const int c0 = chunk * kPbK;
 #pragma unroll
@@ -190,6 +257,12 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_bf16_kernel(const float *__res
       const int e = u * 256 + tid;
       const int q = e & 63, kp = e >> 6;                        // 64 point quads x 8 channel pairs
       const int c = c0 + 2 * kp, n = n0 + 4 * q;
+      if constexpr (VEC) {
+        const float *col = xb + min(n, N - 4);
+        va[u] = *reinterpret_cast<const float4 *>(col + (size_t)min(c, K - 1) * N);
+        vb[u] = *reinterpret_cast<const float4 *>(col + (size_t)min(c + 1, K - 1) * N);
+        continue;
+      }
       va[u] = vb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (vec) {
         if (c < K) va[u] = *reinterpret_cast<const float4 *>(xb + (size_t)c * N + n);
@@ -227,6 +300,8 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_bf16_kernel(const float *__res
     float4 (&va)[ITEMS] = va_[d];
     float4 (&vb)[ITEMS] = vb_[d];
     __syncthreads();                                            // previous chunk's fragment reads are done
+    // VEC: a padding chunk (chunk >= chunks) holds clamped rows, not zeros, and meets the previous chunk's weights: scaled to zero
+    const float cs = (VEC && chunk >= chunks) ? 0.0f : x_scale;
 #pragma unroll
     for (int u = 0; u < ITEMS; ++u) {
       const int e = u * 256 + tid;
@@ -236,7 +311,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_bf16_kernel(const float *__res
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         uint32_t pw[NS];
-        if constexpr (NS == 2) split_pair<NS>(a[t] * x_scale, bq[t] * x_scale, pw);
+        if constexpr (NS == 2 || VEC) split_pair<NS>(a[t] * cs, bq[t] * cs, pw);
         else split_pair<NS>(a[t], bq[t], pw);
 #pragma unroll
         for (int s = 0; s < NS; ++s) w[s][t] = pw[s];
@@ -272,61 +347,153 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_bf16_kernel(const float *__res
     }
 #undef PVCNN_PB_MFMA
     __builtin_amdgcn_sched_barrier(0);
-    if (chunk + 1 < chunks) load_a(chunk + 1);                  // overwrites af once this chunk's MFMAs have been issued
+    if constexpr (VEC) load_a(min(chunk + 1, chunks - 1));      // overwrites af once this chunk's MFMAs have been issued
+    else if (chunk + 1 < chunks) load_a(chunk + 1);
   }
   }
 
-  // ---- epilogue: D[i = m][j = point]; lanes = consecutive points (128-byte rows) ----
-  const bool want_stats = stats_part != nullptr;
-  float2 *stat_lds = reinterpret_cast<float2 *>(xs);            // [4 / WM point groups][TM]
-  if (want_stats) __syncthreads();
-  float *yb = y + (size_t)b * M * N;
+  pb_epilogue<NS, MB, WM>(acc, xs, bias, y, M, N, b, n0, m0, tile, tiles_total, stats_part, wexp, x_shift);
+}
+
+// The wide f16x2 tile (NS = 2, MB = 4, vector loads) with the conversion INSIDE the multiply phase: the staging buffer is double-
+// buffered (2 x 16 KiB) and a chunk costs ONE barrier.  In iteration c a wave reads its B fragments of tile c, then issues the 24
+// MFMAs of chunk c with the fp32 -> fp16 hi / lo conversion of the rows of chunk c + 1 (in registers since the previous iteration)
+// scheduled BETWEEN them (two vector-ALU instructions per MFMA: the matrix pipe is busy 32 cycles per instruction, the conversions
+// are free), stores the converted tile into the other buffer, requests the rows of chunk c + 3 and meets the other waves.  Every
+// load has a whole chunk to land: the weight fragments of chunk c + 1 are requested in front of chunk c's MFMAs (second register set),
+// and the loop is straight-line code, so the compiler's vmcnt waits leave the younger loads in flight.  (pw_gemm_bf16_kernel converts between two barriers and relies on the co-resident workgroup to fill the
+// matrix pipe meanwhile.)  Same products in the same order per output element: bit-identical to pw_gemm_bf16_kernel<2, 4>.
+__global__ __launch_bounds__(256, 2) void pw_gemm_f16_pipe_kernel(const float *__restrict__ x, const uint16_t *__restrict__ wts,
+                                                                  const float *__restrict__ bias, float *__restrict__ y, int K, int M,
+                                                                  int N, int tiles_n, int tiles_total, float2 *__restrict__ stats_part,
+                                                                  const uint32_t *__restrict__ x_absmax, const int *__restrict__ wexp,
+                                                                  int amax_seg) {
+  constexpr int NS = 2, MB = 4, TM = 32 * MB, WM = 2, MBW = MB / WM, NBW = 2 * WM, WBLK = NS * TM * kPbK;
+  constexpr int ITEMS = (kPbK / 2) * (kPbN / 4) / 256, TILE = NS * 8 * kPbN;
+  // two tiles [plane][kh][128-point block][h][128 points][2 words], channel pair = 4 kh + 2 h + word: a staging thread owns 4 channels
+  // x 4 points = two 16-byte stores of 8 consecutive words per plane; a lane's B fragment (the 8 channels 8 kh .. 8 kh + 7 of its
+  // point) = its h = 0 and h = 1 word pairs, 1 KiB apart = ONE ds_read2_b64 that lands in the four registers of the MFMA operand
+  __shared__ __attribute__((aligned(16))) uint32_t xs[2 * TILE];
+  const int mtiles = ceil_div(M, TM);
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;                    // XCD-aware tile order, as in pw_gemm_bf16_kernel
+  const int tile = (slot / mtiles) * 8 + xcd, mt = slot - (slot / mtiles) * mtiles;
+  if (tile >= tiles_total) return;
+  const int x_shift = scale_shift(amax_seg > 0 ? x_absmax[1 + tile] : *x_absmax);
+  const float x_scale = exp2_int(x_shift);
+  const int b = tile / tiles_n, n0 = (tile - b * tiles_n) * kPbN, m0 = mt * TM;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, kh = lane >> 5;
+  const int wm = wave % WM, wn = wave / WM;
+  const float *xb = x + (size_t)b * K * N;
+  const int chunks = ceil_div(K, kPbK);
+
+  int a_off[MBW];
 #pragma unroll
-  for (int mbl = 0; mbl < MBW; ++mbl) {
-    const int mb = wm * MBW + mbl;                              // row block inside the workgroup tile
-    float bv[16], unscale[16];
+  for (int mb = 0; mb < MBW; ++mb) {
+    const int row = (wm * MBW + mb) * 32 + j;
+    a_off[mb] = (row * 8 + ((kh ^ ((row >> 3) & 1)) * 4)) >> 2;
+  }
+  f32x16 acc[MBW][NBW];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-      bv[r] = (bias != nullptr && m < M) ? bias[m] : 0.0f;
-      if constexpr (NS == 2) unscale[r] = exp2_int(-wexp[m]);   // wexp covers the padded rows of the tile
+  for (int mb = 0; mb < MBW; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.0f;
+
+  // a thread's items: channel pairs 2 * wave and 2 * wave + 1 of point quad `lane`, the same positions in every chunk (a wave
+  // instruction reads one whole 1 KiB channel row)
+  static_assert(ITEMS == 2, "two channel pairs per thread");
+  const float *col = xb + min(n0 + 4 * lane, N - 4);
+  const int kp0 = 2 * wave, st = ((((wave >> 1) * 2 + (lane >> 5)) * 2 + (wave & 1)) * 128 + ((4 * lane) & 127)) * 2;
+  auto load_x = [&](int chunk, float4 (&va)[ITEMS], float4 (&vb)[ITEMS]) {   // rows >= K: row K - 1 (zero weights / zero scale)
+#pragma unroll
+    for (int u = 0; u < ITEMS; ++u) {
+      const int c = chunk * kPbK + 2 * (kp0 + u);
+      va[u] = *reinterpret_cast<const float4 *>(col + (size_t)min(c, K - 1) * N);
+      vb[u] = *reinterpret_cast<const float4 *>(col + (size_t)min(c + 1, K - 1) * N);
     }
-    const float x_unscale = exp2_int(-x_shift);
-    float ss[16], qq[16];
+  };
+  uint4 af_[2][MBW][NS];                                        // two sets: the next chunk's fragments are requested a whole chunk ahead
+  auto load_a = [&](int chunk, uint4 (&af)[MBW][NS]) {
+    const uint4 *wq = reinterpret_cast<const uint4 *>(wts + ((size_t)chunk * mtiles + mt) * WBLK);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) ss[r] = qq[r] = 0.0f;
+    for (int mb = 0; mb < MBW; ++mb)
 #pragma unroll
-    for (int nb = 0; nb < NBW; ++nb) {
-      const int n = n0 + wn * (32 * NBW) + nb * 32 + j;
+      for (int s = 0; s < NS; ++s) af[mb][s] = wq[s * (TM * kPbK / 8) + a_off[mb]];
+  };
+  // w[s][h] = words (point 2h, pair 0), (point 2h, pair 1), (point 2h + 1, pair 0), (point 2h + 1, pair 1) of plane s
+  auto convert = [&](const float4 (&va)[ITEMS], const float4 (&vb)[ITEMS], float cs, uint4 (&w)[NS][2]) {
+    uint32_t t4[NS][ITEMS][4];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        float v = acc[mbl][nb][r];
-        if constexpr (NS == 2) v = v * unscale[r] * x_unscale;  // powers of two: exact
-        if (want_stats) {                                       // statistics of (y - bias), see bn_finalize_kernel
-          const float mv = n < N ? v : 0.0f;
-          ss[r] += mv;
-          qq[r] += mv * mv;
-        }
-        v += bv[r];
-        if (n < N && m < M) yb[(size_t)m * N + n] = v;
+    for (int u = 0; u < ITEMS; ++u) {
+      const float a[4] = {va[u].x, va[u].y, va[u].z, va[u].w}, bq[4] = {vb[u].x, vb[u].y, vb[u].z, vb[u].w};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        uint32_t pw[NS];
+        split_pair<NS>(a[t] * cs, bq[t] * cs, pw);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) t4[s][u][t] = pw[s];
       }
     }
-    if (want_stats) {
-      const float st = half_wave_sum16(ss, j), qt = half_wave_sum16(qq, j);
-      const int rr = (j >> 1) & 15;
-      if ((j & 1) == 0) stat_lds[wn * TM + mb * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * kh] = make_float2(st, qt);
-    }
-  }
-  if (want_stats) {
-    __syncthreads();
-    if (tid < TM && m0 + tid < M) {
-      float2 t = stat_lds[tid];
 #pragma unroll
-      for (int w = 1; w < 4 / WM; ++w) { t.x += stat_lds[w * TM + tid].x; t.y += stat_lds[w * TM + tid].y; }
-      stats_part[(size_t)(m0 + tid) * tiles_total + tile] = t;
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) w[s][h] = make_uint4(t4[s][0][2 * h], t4[s][1][2 * h], t4[s][0][2 * h + 1], t4[s][1][2 * h + 1]);
+  };
+  auto store = [&](int buf, const uint4 (&w)[NS][2]) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) *reinterpret_cast<uint4 *>(xs + buf * TILE + s * 8 * kPbN + st + 4 * h) = w[s][h];
+  };
+
+  float4 va_[2][ITEMS], vb_[2][ITEMS];
+  uint4 w[NS][2];
+  load_x(0, va_[0], vb_[0]);
+  load_x(1, va_[1], vb_[1]);
+  load_a(0, af_[0]);
+  convert(va_[0], vb_[0], x_scale, w);
+  store(0, w);
+  load_x(2, va_[0], vb_[0]);
+  __syncthreads();
+  // the chunk count is padded to even (ring / buffer indices are compile-time): the padding chunk's tile was converted with scale 0
+  for (int chunk0 = 0; chunk0 < chunks; chunk0 += 2) {
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      const int chunk = chunk0 + d;
+      // tile `chunk` is published in buffer d; ring slot d ^ 1 holds the rows of chunk + 1 (landed), slot d those of chunk + 2
+      uint4 bf[NBW][NS];
+#pragma unroll
+      for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          const uint32_t *c2 = xs + d * TILE + ((((s * 2 + kh) * 2 + wn) * 2) * 128 + nb * 32 + j) * 2;
+          const uint2 lo = *reinterpret_cast<const uint2 *>(c2), hi = *reinterpret_cast<const uint2 *>(c2 + 256);
+          bf[nb][s] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+      load_a(min(chunk + 1, chunks - 1), af_[d ^ 1]);
+      uint4 (&af)[MBW][NS] = af_[d];
+      __builtin_amdgcn_sched_barrier(0);
+      convert(va_[d ^ 1], vb_[d ^ 1], chunk + 1 < chunks ? x_scale : 0.0f, w);
+#define PVCNN_PB_MFMA(SA, SB)                                                                                            \
+      _Pragma("unroll") for (int nb = 0; nb < NBW; ++nb)                                                                 \
+      _Pragma("unroll") for (int mb = 0; mb < MBW; ++mb)                                                                 \
+        acc[mb][nb] = mfma16<NS>(af[mb][SA], bf[nb][SB], acc[mb][nb])
+      PVCNN_PB_MFMA(1, 0); PVCNN_PB_MFMA(0, 1);                         // lo x hi, hi x lo, then hi x hi
+      PVCNN_PB_MFMA(0, 0);
+#undef PVCNN_PB_MFMA
+#pragma unroll
+      for (int i = 0; i < 3 * MBW * NBW; ++i) {                         // 1 MFMA, 2 vector-ALU, 24 times
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      store(d ^ 1, w);
+      load_x(chunk + 3, va_[d ^ 1], vb_[d ^ 1]);
+      __syncthreads();
     }
   }
+  pb_epilogue<NS, MB, WM>(acc, xs, bias, y, M, N, b, n0, m0, tile, tiles_total, stats_part, wexp, x_shift);
 }
 
 static int pb_mb(int M) { return M > 64 ? 4 : 2; }
@@ -408,12 +575,27 @@ extern "C" int pvcnn_pwconv_fwd_split(const float *x, const void *wts, const flo
   float2 *sp = reinterpret_cast<float2 *>(stats_part);
   const uint32_t *am = static_cast<const uint32_t *>(x_absmax);
   const int *wexp = nsplit == 2 ? reinterpret_cast<const int *>(static_cast<const char *>(wts) + pb_image_bytes(K, M, 2)) : nullptr;
-#define PVCNN_PB_LAUNCH(NSV, MBV) hipLaunchKernelGGL((pw_gemm_bf16_kernel<NSV, MBV>), grid, dim3(256), 0, s, x, w16, bias, y, K, M, N, tiles_n, (int)tiles_total, sp, am, wexp, amax_seg)
-#define PVCNN_PB_LAUNCH_PF(NSV, MBV, PFV) hipLaunchKernelGGL((pw_gemm_bf16_kernel<NSV, MBV, PFV>), grid, dim3(256), 0, s, x, w16, bias, y, K, M, N, tiles_n, (int)tiles_total, sp, am, wexp, amax_seg)
+  const bool vec = N % 4 == 0 && N >= 4 && aligned16(x);       // straight-line chunk loop (see the kernel)
+#define PVCNN_PB_LAUNCH_PF(NSV, MBV, PFV)                                                                                            \
+  do {                                                                                                                               \
+    if (vec) hipLaunchKernelGGL((pw_gemm_bf16_kernel<NSV, MBV, PFV, true>), grid, dim3(256), 0, s, x, w16, bias, y, K, M, N, tiles_n, \
+                                (int)tiles_total, sp, am, wexp, amax_seg);                                                           \
+    else hipLaunchKernelGGL((pw_gemm_bf16_kernel<NSV, MBV, PFV, false>), grid, dim3(256), 0, s, x, w16, bias, y, K, M, N, tiles_n,    \
+                            (int)tiles_total, sp, am, wexp, amax_seg);                                                               \
+  } while (0)
+#define PVCNN_PB_LAUNCH(NSV, MBV) PVCNN_PB_LAUNCH_PF(NSV, MBV, 1)
   // prefetch depth of the wide f16x2 tile, measured (profiles/ab/r03c_pwbench_pf*.jsonl, 1472 -> 512 over 65 536 points): PF = 1 / 2 / 3
   // = 0.576 / 0.538 / 0.523 ms forward, 1788 / 1820 / 1824 clouds/s in the step; PF = 2 is kept (232 VGPRs; PF = 3 needs 252 of 256)
   if (nsplit == 3)      { if (MB == 4) PVCNN_PB_LAUNCH(3, 4); else PVCNN_PB_LAUNCH(3, 2); }
-  else if (nsplit == 2) { if (MB == 4) PVCNN_PB_LAUNCH_PF(2, 4, 2); else PVCNN_PB_LAUNCH(2, 2); }
+  else if (nsplit == 2) {
+    // measured (profiles/ab/r03k_*, 1472 -> 512 over 65 536 points, forward): round-3 start 0.483 ms; straight-line chunk loop
+    // (VEC) 0.347 ms; + conversion between the MFMAs, one barrier per chunk (pipe kernel) 0.306 ms; the step 1925 -> 2103 -> 2108 clouds/s
+    if (MB == 4 && vec)
+      hipLaunchKernelGGL(pw_gemm_f16_pipe_kernel, grid, dim3(256), 0, s, x, w16, bias, y, K, M, N, tiles_n, (int)tiles_total, sp, am, wexp,
+                         amax_seg);
+    else if (MB == 4) PVCNN_PB_LAUNCH_PF(2, 4, 2);
+    else PVCNN_PB_LAUNCH(2, 2);
+  }
   else                  { if (MB == 4) PVCNN_PB_LAUNCH(1, 4); else PVCNN_PB_LAUNCH(1, 2); }
 #undef PVCNN_PB_LAUNCH
 #undef PVCNN_PB_LAUNCH_PF

@@ -102,7 +102,8 @@ def test_pointwise_conv_is_deterministic(hip):
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize('b,ci,co,n', [(2, 9, 64, 4096), (3, 64, 128, 1000), (1, 130, 70, 513), (2, 1472, 512, 2048), (1, 16, 13, 7), (2, 128, 1024, 1024)])
+@pytest.mark.parametrize('b,ci,co,n', [(2, 9, 64, 4096), (3, 64, 128, 1000), (1, 130, 70, 513), (2, 1472, 512, 2048), (1, 16, 13, 7), (2, 128, 1024, 1024),
+                                      (1, 130, 200, 516), (2, 24, 128, 260), (1, 8, 96, 4), (2, 40, 129, 252)])
 def test_pointwise_gemm_on_the_bf16_matrix_cores(hip, b, ci, co, n):
     """csrc/pointwise_bf16.hip (opt-in, `pw_math = 'bf16x3'`): the exact three-way bf16 split meets the same 1e-5 bar as the
     fp32-MFMA kernels -- forward with bias and BatchNorm epilogue statistics, backward-data -- for ragged K, M and N;
@@ -129,7 +130,9 @@ def test_pointwise_gemm_on_the_bf16_matrix_cores(hip, b, ci, co, n):
     assert _rel(hip.pwconv_backward_data_split(gy * 1e-9, w * 1e3, 2), torch.einsum('oc,bon->bcn', w.double() * 1e3, gy.double() * 1e-9)) < 1e-5
 
 
-@pytest.mark.parametrize('b,ci,co,n', [(2, 9, 64, 4096), (3, 64, 128, 1000), (1, 130, 70, 516), (2, 1472, 512, 1024), (1, 16, 13, 8), (16, 128, 1024, 512)])
+@pytest.mark.parametrize('b,ci,co,n', [(2, 9, 64, 4096), (3, 64, 128, 1000), (1, 130, 70, 516), (2, 1472, 512, 1024), (1, 16, 13, 8), (16, 128, 1024, 512),
+                                      (2, 512, 256, 1000), (1, 250, 200, 516), (3, 700, 450, 36), (1, 256, 256, 4),
+                                      (2, 1472, 512, 16384), (5, 450, 700, 16388)])   # the last two: the 256 x 192 and 256 x 256 tiles
 def test_pointwise_backward_weight_f16x2(hip, b, ci, co, n):
     """csrc/pointwise_wgrad_f16.hip: grad_w and grad_bias at the 1e-5 bar (vs fp64), bit-reproducible, ragged M / K / N tails,
     gradients far below fp16's range."""
