@@ -47,7 +47,7 @@ extern "C" {
 #define PVCNN_API
 #endif
 
-#define PVCNN_ABI_VERSION 5
+#define PVCNN_ABI_VERSION 6
 #define PVCNN_OK 0
 #define PVCNN_ERR_INVALID_ARGUMENT (-1)
 
@@ -318,8 +318,9 @@ PVCNN_API int pvcnn_pwconv_bwd_weight_f16(const float *x, const float *grad_y, c
  *      resp. grad_x) with segments of amax_seg positions, emitted by the apply pass itself -- the f16x2 convolution that consumes
  *      that tensor needs no pass of its own over it.  Requires amax_seg <= 256.  Word [0] (the global maximum) is accumulated with
  *      one atomic per workgroup when it was zeroed beforehand: by the call's own finalize kernel (training != 0, and always in
- *      bwd), or -- amax_zeroed != 0 -- by the pvcnn_bn_finalize call that produced mean / rstd (its zero_word argument); with
- *      training == 0 and amax_zeroed == 0 a one-workgroup reduction of the table is launched behind the pass instead.
+ *      bwd), or -- amax_zeroed != 0 -- by the pvcnn_bn_finalize call that produced mean / rstd (its zero_words argument, the WHOLE
+ *      buffer: on small position counts the pass splits the channels over several workgroups whose table entries meet by atomic
+ *      maxima); with training == 0 and amax_zeroed == 0 a one-workgroup reduction of the table is launched behind the pass instead.
  */
 PVCNN_API size_t pvcnn_bnact_workspace_bytes(int B, int C, int S);
 PVCNN_API int pvcnn_bnact_fwd(const float *x, const float *gamma, const float *beta, float *running_mean,
@@ -348,7 +349,8 @@ PVCNN_API int pvcnn_pwconv_fwd_stats(const float *x, const float *wt, int wt_row
 /* The epilogue partials are sums of (y - bias) and (y - bias)^2: pass the convolution's bias as `shift` (NULL = no bias) and
  * bn_finalize adds it back to the mean -- a variance from E[a^2] - E[a]^2 stays accurate when the bias dwarfs the spread. */
 PVCNN_API int pvcnn_bn_finalize(const float *part, int C, long nparts, double count, float eps, float momentum, const float *shift,
-                      float *running_mean, float *running_var, float *mean, float *rstd, void *zero_word /* NULL | one uint32 set to 0 */,
+                      float *running_mean, float *running_var, float *mean, float *rstd,
+                      void *zero_words /* NULL | the amax buffer the apply pass that follows will fill: */, long zero_count /* its words, set to 0 */,
                       void *num_batches_tracked /* NULL | one int64 incremented by 1 (nn.BatchNorm's counter) */, void *stream);
 PVCNN_API int pvcnn_bn_stats(const float *x, float *running_mean, float *running_var, int B, int C, int S,
                    float eps, float momentum, float *mean, float *rstd, void *workspace,

@@ -16,7 +16,7 @@ import torch  # noqa: F401  (must be imported before the dlopen, see above)
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 LIB_PATH = os.path.join(_CSRC, 'libpvcnn_hip.so')
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
 
@@ -83,7 +83,7 @@ SIGNATURES = {
     'pvcnn_conv3d_fwd_stats': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     'pvcnn_pwconv_fwd_stats_parts': (_sz, [_i, _i]),
     'pvcnn_pwconv_fwd_stats': (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
-    'pvcnn_bn_finalize': (_i, [_vp, _i, ctypes.c_long, ctypes.c_double, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'pvcnn_bn_finalize': (_i, [_vp, _i, ctypes.c_long, ctypes.c_double, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_long, _vp, _vp]),
     'pvcnn_bn_stats': (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp, _sz, _vp]),
     'pvcnn_trilinear_devox_bnact_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     'pvcnn_bnact_slices': (_i, [_i]),

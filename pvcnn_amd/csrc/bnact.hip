@@ -69,9 +69,12 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(const float2 *__restric
                                                         float momentum, const float *__restrict__ shift, float *__restrict__ mean,
                                                         float *__restrict__ rstd, float *__restrict__ running_mean,
                                                         float *__restrict__ running_var, uint32_t *__restrict__ zero_word,
-                                                        long long *__restrict__ counter) {
+                                                        long zero_count, long long *__restrict__ counter) {
   const int c = blockIdx.x;
-  if (zero_word != nullptr && c == 0 && threadIdx.x == 0) *zero_word = 0u;   // arms word [0] of the amax buffer the apply pass will fill
+  // arms the amax buffer the apply pass will fill by atomic maxima (word [0] and, when that pass splits the channels over several
+  // workgroups, the table behind it)
+  if (zero_word != nullptr)
+    for (long i = (long)c * 64 + threadIdx.x; i < zero_count; i += (long)gridDim.x * 64) zero_word[i] = 0u;
   if (counter != nullptr && c == 0 && threadIdx.x == 0) *counter += 1;       // BatchNorm's num_batches_tracked (one launch less per layer)
   double s = 0.0, q = 0.0;
   for (int i = threadIdx.x; i < nparts; i += 64) { const float2 p = part[(size_t)c * nparts + i]; s += p.x; q += p.y; }
@@ -169,9 +172,10 @@ __global__ __launch_bounds__(kBnThreads) void bnact_bwd_reduce_kernel(const floa
 // grid = C: dbeta = sum g', dgamma = sum g' xhat (fp64 combine)
 __global__ __launch_bounds__(64) void bnact_bwd_finalize_kernel(const float2 *__restrict__ part, int nparts,
                                                                float *__restrict__ dgamma, float *__restrict__ dbeta,
-                                                               uint32_t *__restrict__ zero_word) {
+                                                               uint32_t *__restrict__ zero_word, long zero_count) {
   const int c = blockIdx.x;
-  if (zero_word != nullptr && c == 0 && threadIdx.x == 0) *zero_word = 0u;   // arms word [0] of grad_x's amax buffer (apply pass)
+  if (zero_word != nullptr)                                     // arms grad_x's amax buffer (apply pass), see bn_finalize_kernel
+    for (long i = (long)c * 64 + threadIdx.x; i < zero_count; i += (long)gridDim.x * 64) zero_word[i] = 0u;
   double s = 0.0, q = 0.0;
   for (int i = threadIdx.x; i < nparts; i += 64) { const float2 p = part[(size_t)c * nparts + i]; s += p.x; q += p.y; }
 #pragma unroll
@@ -231,6 +235,11 @@ __global__ __launch_bounds__(kBnThreads) void bnact_bwd_apply_kernel(const float
 // consumes it) -- falls out of the pass: per-lane maxima of four positions, combined across waves and positions with ds_max_u32,
 // every table entry written by exactly one workgroup.  The arithmetic is the expressions of bnact_apply_kernel /
 // bnact_bwd_apply_kernel above, element for element (same bits).
+// Channel groups (gridDim.z > 1, `cgroup` channels each): at S = 4096 (the R = 16 grids, every per-point tensor) there are only
+// B * S / 256 = 256 position blocks, one workgroup per CU with four rows in flight per wave -- 16 KiB in flight per CU, a latency-bound
+// 2 TB/s on the 1024-channel tensor.  With the channels split over gridDim.z workgroups (and eight rows in flight per wave) the chip is
+// full; the table entries are then maxima over the groups: atomicMax into a table zeroed by the finalize kernel (`table_by_atomic`;
+// order-independent, deterministic).
 template <bool BWD>
 __global__ __launch_bounds__(256) void bnact_apply_pb_kernel(const float *__restrict__ x, const float *__restrict__ gy, long gy_bstride,
                                                              const float *__restrict__ mean, const float *__restrict__ rstd,
@@ -239,12 +248,14 @@ __global__ __launch_bounds__(256) void bnact_apply_pb_kernel(const float *__rest
                                                              float slope, float inv_count, int training, int C, int S, int seg,
                                                              int nseg, int vec, float *__restrict__ out, uint32_t *__restrict__ amax,
                                                              int global_by_atomic, const float *__restrict__ bc_mul = nullptr,
-                                                             const float *__restrict__ bc_add = nullptr) {
+                                                             const float *__restrict__ bc_add = nullptr, int cgroup = 0x7fffffff,
+                                                             int table_by_atomic = 0) {
   __shared__ uint32_t seg_max[256];
   const int spb = seg >= 256 ? 1 : 256 / seg;                  // whole segments per workgroup (seg <= 256 enforced by the host)
   const int b = blockIdx.y, s0 = blockIdx.x * spb;
   const int p0 = s0 * seg, span = min(spb * seg, S - p0);
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, pos = 4 * lane;
+  const int cbeg = (int)blockIdx.z * min(cgroup, C), cend = min(C, cbeg + min(cgroup, C));
   if (tid < spb) seg_max[tid] = 0u;
   __syncthreads();
   const float *xb = x + (size_t)b * C * S + p0;
@@ -277,21 +288,22 @@ __global__ __launch_bounds__(256) void bnact_apply_pb_kernel(const float *__rest
   if (pos < span) {
     if (vec) {
       using v4f = __attribute__((ext_vector_type(4))) float;
-      for (int c0 = wave; c0 < C; c0 += 16) {                  // channels c0, c0 + 4, c0 + 8, c0 + 12: four rows in flight
-        float4 xv[4], gv[4];
+      constexpr int RF = 8;                                    // rows in flight per wave: channels c0, c0 + 4, ..., c0 + 4 (RF - 1)
+      for (int c0 = cbeg + wave; c0 < cend; c0 += 4 * RF) {
+        float4 xv[RF], gv[RF];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < RF; ++u) {
           const int c = c0 + 4 * u;
           xv[u] = gv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (c < C) {
+          if (c < cend) {
             xv[u] = *reinterpret_cast<const float4 *>(xb + (size_t)c * S + pos);
             if constexpr (BWD) gv[u] = *reinterpret_cast<const float4 *>(gb + (size_t)c * S + pos);
           }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < RF; ++u) {
           const int c = c0 + 4 * u;
-          if (c < C) {
+          if (c < cend) {
             const Par p = par_of(c);
             const float o0 = one(xv[u].x, gv[u].x, p), o1 = one(xv[u].y, gv[u].y, p), o2 = one(xv[u].z, gv[u].z, p), o3 = one(xv[u].w, gv[u].w, p);
             mx[0] = max(mx[0], __float_as_uint(fabsf(o0))); mx[1] = max(mx[1], __float_as_uint(fabsf(o1)));
@@ -302,7 +314,7 @@ __global__ __launch_bounds__(256) void bnact_apply_pb_kernel(const float *__rest
         }
       }
     } else {
-      for (int c = wave; c < C; c += 4) {
+      for (int c = cbeg + wave; c < cend; c += 4) {
         const Par p = par_of(c);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -318,7 +330,10 @@ __global__ __launch_bounds__(256) void bnact_apply_pb_kernel(const float *__rest
       if (pos + i < span) atomicMax(&seg_max[(pos + i) / seg], mx[i]);
   }
   lds_barrier();                                                // LDS only: the streaming stores above need not have drained
-  if (tid < spb && s0 + tid < nseg) amax[1 + (size_t)b * nseg + s0 + tid] = seg_max[tid];
+  if (tid < spb && s0 + tid < nseg) {
+    if (table_by_atomic) { if (seg_max[tid] != 0u) atomicMax(&amax[1 + (size_t)b * nseg + s0 + tid], seg_max[tid]); }
+    else amax[1 + (size_t)b * nseg + s0 + tid] = seg_max[tid];
+  }
   // word [0], the tensor's maximum: zeroed by the finalize kernel that ran before this pass -> one fire-and-forget atomic per
   // workgroup (order-independent: deterministic); otherwise the host launches the table reduction behind this kernel
   if (global_by_atomic && tid == 0) {
@@ -331,6 +346,13 @@ __global__ __launch_bounds__(256) void bnact_apply_pb_kernel(const float *__rest
 }  // namespace pvcnn
 
 using namespace pvcnn;
+
+// channel groups of the position-block-major apply pass (see the kernel): enough workgroups for ~4 per CU, >= 32 channels each
+static int pb_channel_groups(long position_blocks, int C) {
+  int g = 1;
+  while (position_blocks * g < 4 * kNumCU && C / (2 * g) >= 32) g *= 2;
+  return g;
+}
 
 extern "C" size_t pvcnn_bnact_workspace_bytes(int B, int C, int S) {
   if (B <= 0 || C <= 0 || S <= 0) return 16;
@@ -354,7 +376,8 @@ extern "C" int pvcnn_bnact_fwd(const float *x, const float *gamma, const float *
     hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(kBnThreads), 0, s, x, C, S, slices, part, shift);
     if (int e = check_launch("bn_stats")) return e;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, s, part, B * slices, (double)B * S, eps, momentum, shift, mean, rstd,
-                       running_mean, running_var, static_cast<uint32_t *>(y_amax), static_cast<long long *>(nullptr));
+                       running_mean, running_var, static_cast<uint32_t *>(y_amax), y_amax ? 1 + (long)B * ceil_div(S, amax_seg) : 0L,
+                       static_cast<long long *>(nullptr));
     if (int e = check_launch("bn_finalize")) return e;
     amax_zeroed = 1;
   }
@@ -363,8 +386,10 @@ extern "C" int pvcnn_bnact_fwd(const float *x, const float *gamma, const float *
     const int nseg = ceil_div(S, amax_seg), spb = amax_seg >= 256 ? 1 : 256 / amax_seg;
     const int vec = (S % 4 == 0) && (amax_seg % 4 == 0) && aligned16(x) && aligned16(y);
     uint32_t *am = static_cast<uint32_t *>(y_amax);
-    hipLaunchKernelGGL(bnact_apply_pb_kernel<false>, dim3(ceil_div(nseg, spb), B), dim3(256), 0, s, x, nullptr, 0L, mean, rstd, gamma, beta,
-                       nullptr, nullptr, slope, 0.0f, 0, C, S, amax_seg, nseg, vec, y, am, amax_zeroed ? 1 : 0);
+    const int groups = amax_zeroed ? pb_channel_groups((long)ceil_div(nseg, spb) * B, C) : 1;
+    hipLaunchKernelGGL(bnact_apply_pb_kernel<false>, dim3(ceil_div(nseg, spb), B, groups), dim3(256), 0, s, x, nullptr, 0L, mean, rstd, gamma,
+                       beta, nullptr, nullptr, slope, 0.0f, 0, C, S, amax_seg, nseg, vec, y, am, amax_zeroed ? 1 : 0, nullptr, nullptr,
+                       ceil_div(C, groups), groups > 1 ? 1 : 0);
     if (int e = check_launch("bnact_apply_pb")) return e;
     return amax_zeroed ? 0 : launch_amax_reduce(am, (long)B * nseg, s);
   }
@@ -375,12 +400,13 @@ extern "C" int pvcnn_bnact_fwd(const float *x, const float *gamma, const float *
 // mean / rstd (+ running statistics) from per-workgroup partials produced by a convolution epilogue
 // (pvcnn_conv3d_fwd_stats, pvcnn_pwconv_fwd_stats): part is (C, nparts) float2 {sum, sum of squares}.
 extern "C" int pvcnn_bn_finalize(const float *part, int C, long nparts, double count, float eps, float momentum, const float *shift,
-                                 float *running_mean, float *running_var, float *mean, float *rstd, void *zero_word,
+                                 float *running_mean, float *running_var, float *mean, float *rstd, void *zero_words, long zero_count,
                                  void *num_batches_tracked, void *stream) {
   PVCNN_REQUIRE(C > 0 && nparts > 0 && nparts <= 0x7fffffffL && count > 0 && part && mean && rstd, "bad argument");
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, static_cast<hipStream_t>(stream),
                      reinterpret_cast<const float2 *>(part), (int)nparts, count, eps, momentum, shift, mean, rstd, running_mean,
-                     running_var, static_cast<uint32_t *>(zero_word), static_cast<long long *>(num_batches_tracked));
+                     running_var, static_cast<uint32_t *>(zero_words), zero_words ? zero_count : 0L,
+                     static_cast<long long *>(num_batches_tracked));
   return check_launch("bn_finalize");
 }
 
@@ -396,7 +422,7 @@ extern "C" int pvcnn_bn_stats(const float *x, float *running_mean, float *runnin
   hipLaunchKernelGGL(bn_stats_kernel, dim3(slices, B, C), dim3(kBnThreads), 0, s, x, C, S, slices, part, shift);
   if (int e = check_launch("bn_stats")) return e;
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, s, part, B * slices, (double)B * S, eps, momentum, shift, mean, rstd,
-                     running_mean, running_var, static_cast<uint32_t *>(nullptr), static_cast<long long *>(nullptr));
+                     running_mean, running_var, static_cast<uint32_t *>(nullptr), 0L, static_cast<long long *>(nullptr));
   return check_launch("bn_finalize");
 }
 
@@ -417,15 +443,17 @@ static int bnact_bwd_impl(const float *x, const float *grad_y, long gy_bstride, 
                      slices, part, gy_bstride);
   if (int e = check_launch("bnact_bwd_reduce")) return e;
   hipLaunchKernelGGL(bnact_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, part, B * slices, grad_gamma, grad_beta,
-                     static_cast<uint32_t *>(gx_amax));
+                     static_cast<uint32_t *>(gx_amax), gx_amax ? 1 + (long)B * ceil_div(S, amax_seg) : 0L);
   if (int e = check_launch("bnact_bwd_finalize")) return e;
   const float inv_count = (float)(1.0 / ((double)B * S));
   if (gx_amax != nullptr) {                                     // position-block-major pass that also emits grad_x's amax buffer
     const int nseg = ceil_div(S, amax_seg), spb = amax_seg >= 256 ? 1 : 256 / amax_seg;
     const int vec = (S % 4 == 0) && (amax_seg % 4 == 0) && (gy_bstride % 4 == 0) && aligned16(x) && aligned16(grad_y) && aligned16(grad_x);
     uint32_t *am = static_cast<uint32_t *>(gx_amax);
-    hipLaunchKernelGGL(bnact_apply_pb_kernel<true>, dim3(ceil_div(nseg, spb), B), dim3(256), 0, s, x, grad_y, gy_bstride, mean, rstd, gamma,
-                       beta, grad_gamma, grad_beta, slope, inv_count, training, C, S, amax_seg, nseg, vec, grad_x, am, 1);
+    const int groups = pb_channel_groups((long)ceil_div(nseg, spb) * B, C);
+    hipLaunchKernelGGL(bnact_apply_pb_kernel<true>, dim3(ceil_div(nseg, spb), B, groups), dim3(256), 0, s, x, grad_y, gy_bstride, mean, rstd,
+                       gamma, beta, grad_gamma, grad_beta, slope, inv_count, training, C, S, amax_seg, nseg, vec, grad_x, am, 1, nullptr,
+                       nullptr, ceil_div(C, groups), groups > 1 ? 1 : 0);
     return check_launch("bnact_bwd_apply_pb");
   }
   hipLaunchKernelGGL(bnact_bwd_apply_kernel, grid, dim3(kBnThreads), 0, s, x, grad_y, mean, rstd, gamma, beta, grad_gamma,

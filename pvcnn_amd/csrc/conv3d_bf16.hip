@@ -530,6 +530,232 @@ __global__ __launch_bounds__(256, (NS == 3 || TX * TY * TZ == 512 || TZ <= 16) ?
   }
 }
 
+// ---- the 128-voxel f16x2 tile (TX x TY x 16, R = 16 grids), pipelined ----------------------------------------------------------
+// conv3d_igemm_bf16_kernel stages a chunk between two barriers -- request the rows, wait, convert, store, barrier -- and starts the 27
+// taps with the weight fragments' latency exposed; with two workgroups of 162 MFMAs per wave and chunk on a CU that sequence was as
+// long as the multiply phase (counters, round 3: MFMA pipe 49 % busy, 60 % of the LDS cycles bank conflicts of the 4-byte staging
+// stores, whose lanes are 32 words apart).  Here:
+//   * the tile is double-buffered (2 x 27 KiB) and a chunk costs ONE barrier: the rows of chunk c + 1 are converted and stored between
+//     the MFMAs of taps 1..8 of chunk c (they were requested during the taps 24..26 of chunk c - 1 and sit in registers), the rows
+//     of chunk c + 2 are requested at tap 24 -- behind the chunk's last weight-fragment request, so that the in-order wait for a
+//     fragment never waits for a row;
+//   * a staging thread owns 8 channels x 4 z voxels of one (x, y) row: 16-byte LDS stores of one voxel's four channel pairs, and the
+//     z voxels of a quad are rotated by the quad index in LDS (position 4q + ((i + q) & 3)) so that the four quads of a row store
+//     to four different bank groups;
+//   * lanes are mapped to voxels by the hardware's ds_read_b128 service groups ({0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} of a half
+//     wave): each group reads one whole z row (16 consecutive voxels = 64 distinct banks);
+//   * straight-line code: every load is issued unconditionally from a clamped address (rows outside the grid are scaled by zero;
+//     Ci % 16 == 0 is required, other layers stay on conv3d_igemm_bf16_kernel), so the compiler's vmcnt waits leave the younger
+//     loads in flight; weights and rows are addressed as uniform base + one 32-bit lane offset, LDS fragments as lane base + immediate.
+// Same products in the same order per output element as conv3d_igemm_bf16_kernel<2, TX, TY, 16, true>.
+template <int TX, int TY>
+__global__ __launch_bounds__(256, 2) void conv3d_igemm_f16_pipe_kernel(const float *__restrict__ x, const uint16_t *__restrict__ wts,
+                                                                       const float *__restrict__ bias, float *__restrict__ y, int Ci, int Co,
+                                                                       int R, int tiles_x, int tiles_y, float2 *__restrict__ stats_part,
+                                                                       const uint32_t *__restrict__ x_absmax, const int *__restrict__ wexp,
+                                                                       int amax_seg) {
+  constexpr int NS = 2, TZ = 16, HX = TX + 2, HY = TY + 2, HZ = TZ + 2, HS = HX * HY * HZ, TILE = NS * HS * 8;
+  static_assert(TX * TY * TZ == 128, "4 waves, 2 x 2: 32 channels x 64 voxels each");
+  constexpr int NBW = 2, WBLK = 3 * NS * kCoTileB * kKc;
+  constexpr int ITEMS = 2 * HX * HY * (TZ / 4);                 // (channel octet, hx, hy, z quad)
+  static_assert(ITEMS <= 256, "one staging item per thread");
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
+  // two tiles [plane][channel half kh][halo voxel][4 words]: a lane's B fragment (8 channels of one voxel) is 16 bytes, 16 consecutive
+  // voxels are 256 contiguous bytes (64 banks once), and a tap is a compile-time byte offset from the lane's base address
+  unsigned char *xs = reinterpret_cast<unsigned char *>(lds_u);
+  constexpr int TILEB = TILE * 4, HALFB = HS * 16;              // bytes of a tile / of one (plane, kh) slab
+
+  int bid = blockIdx.x;
+  const int tyi = bid % tiles_y; bid /= tiles_y;
+  const int txi = bid % tiles_x; bid /= tiles_x;
+  const int b = bid;
+  const int cot = blockIdx.y, co0 = cot * kCoTileB, cotiles = gridDim.y;
+  const int x0 = txi * TX, y0 = tyi * TY;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, kh = lane >> 5;
+  const int wm = wave & 1, wn = wave >> 1;
+  const size_t RR = (size_t)R * R, S = RR * R;
+  const float *xb = x + (size_t)b * Ci * S;
+  const int chunks = ceil_div(Ci, kKc);
+  uint32_t tm = 0;
+  if (amax_seg > 0) {                                           // max over the z rows of the halo tile: uniform scalar loads
+    const int lenx = min(HX, R), leny = min(HY, R);
+    const int sx = min(max(x0 - 1, 0), R - lenx), sy = min(max(y0 - 1, 0), R - leny);
+    const uint32_t *tab = x_absmax + 1 + ((size_t)b * R + sx) * R + sy;
+    for (int ix = 0; ix < lenx; ++ix)
+      for (int iy = 0; iy < leny; ++iy) tm = max(tm, tab[(size_t)ix * R + iy]);
+  } else {
+    tm = *x_absmax;
+  }
+  const int x_shift = scale_shift(tm);
+  const float x_scale = exp2_int(x_shift);
+
+  // lane -> voxel of a 32-voxel column block (two z rows): the two ds_read_b128 service groups of a half wave read one row each
+  const int jj = j < 4 ? j : j < 12 ? 16 + (j - 4) : j < 16 ? j - 8 : j < 20 ? 24 + (j - 16) : j < 28 ? 8 + (j - 20) : 28 + (j - 28);
+  // z position in LDS: the voxels of quad q rotated by q;  pos(hz) for hz = zt + dz, dz = 0, 1, 2
+  auto zpos = [](int hz) { const int z = hz - 1; return hz == 0 ? 0 : 1 + ((z & ~3) | ((z + (z >> 2)) & 3)); };
+  uint32_t bbase[NBW][3];                                       // byte offset of the lane's fragment for tap (0, 0, dz) inside plane 0
+  const int zt = jj & 15;
+#pragma unroll
+  for (int nb = 0; nb < NBW; ++nb) {
+    const int m = wn * (32 * NBW) + nb * 32 + jj;
+    const int yt = (m / TZ) % TY, xt = m / (TZ * TY);
+#pragma unroll
+    for (int dz = 0; dz < 3; ++dz) bbase[nb][dz] = (uint32_t)(kh * HS + (xt * HY + yt) * HZ + zpos(zt + dz)) * 16u;
+  }
+  const int a_row = wm * 32 + j;
+  const uint32_t a_off = (uint32_t)(a_row * 8 + ((kh ^ ((a_row >> 3) & 1)) * 4)) * 4u;      // bytes inside one (dz, plane) slab of the image
+  f32x16 acc[NBW];
+#pragma unroll
+  for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nb][r] = 0.0f;
+
+  // staging item of this thread: channel octet cg, halo row (hx, hy), z quad q
+  const bool has_item = tid < ITEMS;
+  const int e = has_item ? tid : 0;
+  const int q = e & 3, hy = (e >> 2) % HY, hx = ((e >> 2) / HY) % HX, cg = (e >> 2) / (HY * HX);
+  const int gx = x0 + hx - 1, gy = y0 + hy - 1;
+  const bool inside = has_item && (unsigned)gx < (unsigned)R && (unsigned)gy < (unsigned)R && 4 * q < R;     // (R = 12: quad 3 is padding)
+  const float item_scale = inside ? x_scale : 0.0f;
+  // (uniform channel base + 32-bit per-thread offset: one address register for the eight rows)
+  const uint32_t xoff = (uint32_t)(((size_t)cg * 8 * S + (size_t)min(max(gx, 0), R - 1) * RR + (size_t)min(max(gy, 0), R - 1) * R + min(4 * q, R - 4)) *
+                                   sizeof(float));
+  const uint32_t st0 = (uint32_t)(cg * HS + (hx * HY + hy) * HZ + 1 + 4 * q) * 16u;     // this thread's quad inside plane 0, bytes
+  auto load_x = [&](int chunk, float4 (&v)[8]) {
+    const int c0 = chunk * kKc;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)                                   // Ci % 16 == 0 (host): no channel clamp
+      v[k] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(xb + (size_t)(c0 + k) * S) + xoff);
+  };
+  auto convert_store = [&](const float4 (&v)[8], int i, float sc, int buf) {        // z voxel 4q + i of the item
+    uint32_t w[NS][4];
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2) {
+      const float a = i == 0 ? v[2 * k2].x : i == 1 ? v[2 * k2].y : i == 2 ? v[2 * k2].z : v[2 * k2].w;
+      const float c = i == 0 ? v[2 * k2 + 1].x : i == 1 ? v[2 * k2 + 1].y : i == 2 ? v[2 * k2 + 1].z : v[2 * k2 + 1].w;
+      uint32_t pw[NS];
+      split_pair<NS>(a * sc, c * sc, pw);
+      w[0][k2] = pw[0]; w[1][k2] = pw[1];
+    }
+    if (has_item) {
+      unsigned char *dst = xs + buf * TILEB + st0 + (uint32_t)((i + q) & 3) * 16u;       // rotated inside the quad by q
+#pragma unroll
+      for (int s = 0; s < NS; ++s) *reinterpret_cast<uint4 *>(dst + s * 2 * HALFB) = make_uint4(w[s][0], w[s][1], w[s][2], w[s][3]);
+    }
+  };
+
+  // the z halo (positions 0 and HZ - 1 of every row) is padding in both tiles
+  for (int z = tid; z < 2 * NS * 2 * HX * HY * 2 * 4; z += 256) {
+    const int w = z & 3, side = (z >> 2) & 1, row = (z >> 3) % (HX * HY), slab = (z >> 3) / (HX * HY);   // slab: (buffer, plane, kh)
+    lds_u[(slab * HS + row * HZ + side * (HZ - 1)) * 4 + w] = 0u;
+  }
+  float4 xr[8];
+  load_x(0, xr);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) convert_store(xr, i, item_scale, 0);
+  load_x(min(1, chunks - 1), xr);
+  __syncthreads();
+
+  constexpr int AD = 3;
+  for (int chunk = 0; chunk < chunks; ++chunk) {
+    const int d = chunk & 1;
+    const unsigned char *xt_ = xs + d * TILEB;
+    const float next_scale = chunk + 1 < chunks ? item_scale : 0.0f;
+    const char *wblk = reinterpret_cast<const char *>(wts + (((size_t)chunk * 9) * cotiles + cot) * WBLK);
+    auto load_a = [&](int tap, uint4 (&af)[NS]) {              // uniform tap base + the lane's 32-bit offset
+      const int dxy = tap / 3, dz = tap - dxy * 3;
+      const char *wq = wblk + ((size_t)dxy * cotiles * WBLK + (size_t)dz * NS * kCoTileB * kKc) * sizeof(uint16_t);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) af[s] = *reinterpret_cast<const uint4 *>(wq + s * (kCoTileB * kKc * 2) + a_off);
+    };
+    auto load_b = [&](int tap, uint4 (&bf)[NBW][NS]) {
+      const int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
+#pragma unroll
+      for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+          bf[nb][s] = *reinterpret_cast<const uint4 *>(xt_ + bbase[nb][dz] + (s * 2 * HALFB + (dx * HY + dy) * HZ * 16));
+    };
+    uint4 aq[AD + 1][NS], bq[2][NBW][NS];
+#pragma unroll
+    for (int t = 0; t < AD; ++t) load_a(t, aq[t]);
+    load_b(0, bq[0]);
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) {
+      if (tap + AD < 27) load_a(tap + AD, aq[(tap + AD) % (AD + 1)]);
+      if (tap + 1 < 27) load_b(tap + 1, bq[(tap + 1) & 1]);
+      if (tap == 24) load_x(min(chunk + 2, chunks - 1), xr);    // behind the chunk's last fragment request
+      __builtin_amdgcn_sched_barrier(0);
+      if (tap >= 1 && tap <= 7 && (tap & 1)) convert_store(xr, tap >> 1, next_scale, d ^ 1);      // taps 1, 3, 5, 7: z voxel 0..3
+      uint4 (&af)[NS] = aq[tap % (AD + 1)];
+      uint4 (&bf)[NBW][NS] = bq[tap & 1];
+#pragma unroll
+      for (int nb = 0; nb < NBW; ++nb) acc[nb] = mfma16<NS>(af[1], bf[nb][0], acc[nb]);       // lo x hi
+#pragma unroll
+      for (int nb = 0; nb < NBW; ++nb) acc[nb] = mfma16<NS>(af[0], bf[nb][1], acc[nb]);       // hi x lo
+#pragma unroll
+      for (int nb = 0; nb < NBW; ++nb) acc[nb] = mfma16<NS>(af[0], bf[nb][0], acc[nb]);       // hi x hi
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: D[i = co][j = voxel]; lane -> voxel jj, register r -> co row ----
+  float *yb = y + (size_t)b * Co * S;
+  size_t voff[NBW];
+  bool vok[NBW];
+#pragma unroll
+  for (int nb = 0; nb < NBW; ++nb) {
+    const int m = wn * (32 * NBW) + nb * 32 + jj;
+    const int yt = (m / TZ) % TY, xt = m / (TZ * TY);
+    const int ox = x0 + xt, oy = y0 + yt;
+    vok[nb] = ox < R && oy < R && zt < R;
+    voff[nb] = (size_t)ox * RR + (size_t)oy * R + zt;
+  }
+  const bool want_stats = stats_part != nullptr;
+  float2 *stat_lds = reinterpret_cast<float2 *>(lds_u);        // [2 voxel groups][64 channels]
+  {
+    const int mb = wm;
+    float bv[16], unscale[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+      bv[r] = (bias != nullptr && co < Co) ? bias[co] : 0.0f;
+      unscale[r] = exp2_int(-wexp[co]);                         // wexp covers the padded rows of the tile
+    }
+    const float x_unscale = exp2_int(-x_shift);
+    float ss[16], qq[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ss[r] = qq[r] = 0.0f;
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        float v = acc[nb][r] * unscale[r] * x_unscale;          // powers of two: exact
+        if (want_stats) {
+          const float m = vok[nb] ? v : 0.0f;
+          ss[r] += m;
+          qq[r] += m * m;
+        }
+        v += bv[r];
+        if (vok[nb] && co < Co) yb[(size_t)co * S + voff[nb]] = v;
+      }
+    if (want_stats) {
+      const float st2 = half_wave_sum16(ss, j), qt = half_wave_sum16(qq, j);
+      const int rr = (j >> 1) & 15;
+      if ((j & 1) == 0) stat_lds[wn * kCoTileB + mb * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * kh] = make_float2(st2, qt);
+    }
+  }
+  if (want_stats) {
+    __syncthreads();
+    if (tid < kCoTileB && co0 + tid < Co) {
+      float2 t = stat_lds[tid];
+      t.x += stat_lds[kCoTileB + tid].x; t.y += stat_lds[kCoTileB + tid].y;
+      stats_part[(size_t)(co0 + tid) * gridDim.x + blockIdx.x] = t;
+    }
+  }
+}
+
 // Workgroup tile and staging path.  Vector staging (whole z rows as 16-byte loads) needs R % 4 == 0 and a tile that spans z:
 // tz = 8 / 16 / 32 for R <= 8 / 16 / 32.  At 16 < R <= 32 a 512-voxel tile (a wave owns 64 channels x 128 voxels: every weight
 // fragment feeds four MFMA column blocks, the halo overhead drops from 3.0x to 2.25x) when that still leaves two workgroups for
@@ -545,6 +771,17 @@ static SplitTile split_tiles(int B, int Co, int R, int nsplit) {
     return (long)B * ceil_div(R, 4) * ceil_div(R, 4) * ceil_div(Co, kCoTileB) < 768 ? SplitTile{2, 4, 16, true} : SplitTile{4, 4, 16, true};
   const bool big = nsplit != 3 && (long)B * ceil_div(R, 4) * ceil_div(R, 4) * ceil_div(Co, kCoTileB) >= 512;
   return big ? SplitTile{4, 4, 32, true} : SplitTile{2, 4, 32, true};
+}
+
+template <int TX, int TY>
+static int launch_igemm_f16_pipe(const float *x, const uint16_t *wts, const float *bias, float *y, int B, int Ci, int Co, int R, hipStream_t s,
+                                 float2 *stats_part, const uint32_t *x_absmax, const int *wexp, int amax_seg) {
+  constexpr int HS = (TX + 2) * (TY + 2) * 18;
+  const size_t lds = (size_t)2 * 2 * HS * 8 * sizeof(uint32_t);                  // two tiles of two planes
+  const int tx = ceil_div(R, TX), ty = ceil_div(R, TY);
+  hipLaunchKernelGGL((conv3d_igemm_f16_pipe_kernel<TX, TY>), dim3((unsigned)((long)B * tx * ty), ceil_div(Co, kCoTileB)), dim3(256), lds, s, x,
+                     wts, bias, y, Ci, Co, R, tx, ty, stats_part, x_absmax, wexp, amax_seg);
+  return check_launch("conv3d_igemm_f16_pipe");
 }
 
 template <int NS, int TX, int TY, int TZ, bool VEC>
@@ -685,6 +922,8 @@ static int conv3d_fwd_split_impl(const float *x, const void *wts, const float *b
   if (t.tz == 8 && t.tx == 2) return t.vec ? PVCNN_IGEMM_NS(2, 8, 8, true) : PVCNN_IGEMM_NS(2, 8, 8, false);
   if (t.tz == 8) return t.vec ? PVCNN_IGEMM_NS(4, 8, 8, true) : PVCNN_IGEMM_NS(4, 8, 8, false);
   if (!t.vec) return PVCNN_IGEMM_NS(4, 4, 16, false);
+  // the pipelined 128-voxel kernel (f16x2 only).  Round 3, 64 -> 64 at 16^3 x 16: see profiles/ab/r03u_convbench.jsonl
+  if (t.tz == 16 && t.tx == 2 && nsplit == 2 && Ci % kKc == 0) return launch_igemm_f16_pipe<2, 4>(x, w16, bias, y, B, Ci, Co, R, s, sp, am, wexp, amax_seg);
   if (t.tz == 16) return t.tx == 2 ? PVCNN_IGEMM_NS(2, 4, 16, true) : PVCNN_IGEMM_NS(4, 4, 16, true);
   return t.tx == 4 ? PVCNN_IGEMM_BIG(4, 4, 32) : PVCNN_IGEMM_NS(2, 4, 32, true);
 #undef PVCNN_IGEMM_BIG

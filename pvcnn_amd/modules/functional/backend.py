@@ -720,7 +720,7 @@ class HipBackend:
         eval: running statistics.  stats = (mean, rstd) already known (from a convolution epilogue +
         bn_finalize): only the normalise + activate pass runs.
         amax_seg > 0: -> (y, mean, rstd, y_amax), y's amax buffer with segments of amax_seg positions emitted by the apply pass.
-        y_amax given: the buffer bn_finalize(..., zero_word=y_amax) already armed (its word [0] is zero: the pass then needs no
+        y_amax given: the buffer bn_finalize(..., zero_word=y_amax) already armed (all of it is zero: the pass then needs no
         reduction launch behind it)."""
         _f32(x, 'x')
         b, c, s3 = x.shape
@@ -758,8 +758,8 @@ class HipBackend:
 
     def bn_finalize(self, part, count, running_mean, running_var, momentum, eps, shift=None, zero_word=None, counter=None):
         """(C, nparts, 2) partial sums of (y - shift) from a convolution epilogue (shift = that convolution's bias, or None)
-        -> (mean, rstd) of y; running stats updated in place.  zero_word: an amax buffer whose word [0] this launch zeroes (arming
-        it for the apply pass that follows: bnact_forward(..., y_amax=zero_word)).  counter: the module's int64 num_batches_tracked,
+        -> (mean, rstd) of y; running stats updated in place.  zero_word: an amax buffer this launch zeroes (arming it for the
+        apply pass that follows, which fills it by atomic maxima: bnact_forward(..., y_amax=zero_word)).  counter: the module's int64 num_batches_tracked,
         incremented by the same launch."""
         c, nparts = part.shape[0], part.shape[1]
         dev = part.device
@@ -772,6 +772,7 @@ class HipBackend:
                                                   _p(running_mean) if running_mean is not None else nul,
                                                   _p(running_var) if running_var is not None else nul, _p(mean), _p(rstd),
                                                   _p(zero_word) if zero_word is not None else nul,
+                                                  zero_word.numel() if zero_word is not None else 0,
                                                   _p(counter) if counter is not None else nul, s),
                        'bn_finalize')
         return mean, rstd

@@ -15,7 +15,11 @@ CASES = [(2, 9, 64, 32), (1, 5, 7, 12), (2, 64, 64, 16), (1, 16, 130, 8), (1, 3,
          (1, 1, 1, 1), (1, 2, 3, 2),
          (2, 8, 32, 16),     # vector staging with a partial 64-wide output tile (Co % 4 == 0, Co < 64): PVCNN++ widths
          (2, 16, 96, 8),     # R = 8: half tile (2,8,8), Co = 64 + 32
-         (20, 32, 64, 16)]   # enough workgroups for the full 256-voxel tile at R = 16
+         (20, 32, 64, 16),
+         (2, 32, 40, 12),    # the pipelined 128-voxel f16x2 kernel (Ci % 16 == 0) on a Frustum grid: the fourth z quad of a row is padding
+         (1, 16, 64, 16),    # ... with a single chunk
+         (2, 48, 64, 16),    # ... three chunks
+         (52, 16, 64, 16)]   # enough workgroups (>= 768) for the 256-voxel tile at R = 16
 
 
 def _rel(a, b):
