@@ -639,7 +639,13 @@ class HipBackend:
     # arithmetic of the SharedMLP forward / backward-data products: 'fp32' (pointwise.hip), 'f16x2' or 'bf16x3' (pointwise_bf16.hip)
     pw_math = os.environ.get('PVCNN_PW_MATH', 'f16x2')
     PW_NSPLIT = {'f16x2': 2, 'bf16x3': 3, 'fp32': 0}
-    pw_split_min_macs = 1 << 32     # K * M * B * N below which the split path is not worth its two extra launches (4.3 G multiply-adds)
+    # K * M * B * N below which the split forward / backward-data path is not worth its extra launches (weight images, an amax pass
+    # when the producer left no table).  Round 3, after the straight-line / pipelined kernels: a sweep of the threshold from 2^32
+    # (round 2) down to "always" on one box -- PVCNN 2121 -> 2157, PVCNN++ 429 -> 484, ShapeNet 1418 -> 1497 clouds/s, Frustum
+    # 3763 -> 4095 frustums/s, flat below 2^24 (profiles/ab/r03w_*).  Backward-weight has its own bar: the f16x2 kernel writes
+    # 128 x 128 partial tiles per partition of the points, a loss on small weight matrices (64 x 64: 0.17 vs 0.05 ms).
+    pw_split_min_macs = 1 << 24
+    pw_wgrad_f16_min_macs = 1 << 32
 
     def _pw_wsplit(self, weight, for_bwd_data, nsplit):
         co, ci = weight.shape

@@ -75,7 +75,8 @@ class PointwiseConv(Function):
         f16 = ctx.split == 2
         # the f16x2 backward-weight kernel also serves the bf16 (autocast) mode: more accurate than bf16 operands, and far faster than
         # the fp32-MFMA kernel on the large GEMMs this mode is chosen for
-        wgrad_f16 = ctx.split in (1, 2) and ctx.needs_input_grad[1] and be.pwconv_backward_weight_f16_serves(x3)
+        wgrad_f16 = (ctx.split in (1, 2) and ctx.needs_input_grad[1] and be.pwconv_backward_weight_f16_serves(x3)
+                     and x3.shape[0] * x3.shape[2] * w2.shape[0] * w2.shape[1] >= getattr(be, 'pw_wgrad_f16_min_macs', 0))
         # shared by both products; the BatchNorm backward that produced grad_y left it on the tensor (_cache.tag_amax)
         g_amax = None
         if f16 and (ctx.needs_input_grad[0] or wgrad_f16):
