@@ -38,9 +38,11 @@ def _servable(x):
 def _amax_seg_for(shape, is_cuda):
     """Segment length of the amax buffer (include/pvcnn_hip.h) the convolution NEXT TO a BatchNorm over a tensor of `shape` wants of
     that tensor, or 0: a cubic voxel grid (B,C,R,R,R) feeds / is fed by a 3x3x3 convolution in f16x2 arithmetic -> one z row (R);
-    point features (B,C,N) / (B,C,M,U) a 1x1 GEMM -> its 256-point tile.  0 when that arithmetic is off (no table is needed)."""
+    point features (B,C,N) / (B,C,M,U) a 1x1 GEMM -> its 256-point tile.  0 when that arithmetic is off (no table is needed).
+    Under bf16 autocast the forward / backward-data products need no scales, but the backward-weight kernels are the f16x2 ones and take
+    word [0] of the same buffers (else: one global-maximum pass + memset per operand and layer, 0.4 ms per Frustum-PVCNN step)."""
     be = native()
-    if not is_cuda or torch.is_autocast_enabled():
+    if not is_cuda:
         return 0
     cap = getattr(be, 'BNACT_AMAX_MAX_SEG', 0)
     if len(shape) == 5 and shape[2] == shape[3] == shape[4]:

@@ -41,9 +41,9 @@ class VoxelConv3d(Function):
         # f16x2: the input's amax buffer (its power-of-two scales, one per z row) -- left on the tensor by the BatchNorm pass that
         # wrote it (_cache.tag_amax), else measured here in one read -- is reused by backward-weight
         ctx.x_amax = None
-        if ctx.nsplit == 2:
+        if ctx.nsplit in (1, 2):
             ctx.x_amax = _cache.amax_of(given, x.shape[2])
-            if ctx.x_amax is None:
+            if ctx.x_amax is None and ctx.nsplit == 2:           # (bf16 mode: only backward-weight wants it, and measures it itself)
                 ctx.x_amax = be.conv_amax(x)
         kw = {'amax': ctx.x_amax} if ctx.nsplit == 2 else {}
         # the pre-split weight images: when the input wants a gradient the backward-data image is made by the SAME launch as the
@@ -77,9 +77,9 @@ class VoxelConv3d(Function):
         wgrad_f16 = ctx.nsplit in (1, 2) and ctx.needs_input_grad[1] and be.conv3d_backward_weight_f16_serves(x)
         # shared by both products; the BatchNorm backward that produced grad_y left it on the tensor (_cache.tag_amax)
         g_amax = None
-        if f16 and (ctx.needs_input_grad[0] or wgrad_f16):
+        if (f16 and (ctx.needs_input_grad[0] or wgrad_f16)) or (ctx.nsplit == 1 and wgrad_f16):
             g_amax = _cache.amax_of(received, grad_y.shape[2])
-            if g_amax is None:
+            if g_amax is None and f16:
                 g_amax = be.conv_amax(grad_y)
         gx = None
         if ctx.needs_input_grad[0]:

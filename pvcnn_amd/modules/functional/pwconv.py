@@ -43,9 +43,9 @@ class PointwiseConv(Function):
         # the split products on the 16-bit matrix cores (csrc/pointwise_bf16.hip): 2 = f16x2, 3 = bf16x3, 1 = bf16, 0 = fp32 MFMA
         ctx.split = int(split) if split is not None else pw_nsplit(x3, w2)
         ctx.x_amax = None
-        if ctx.split == 2:     # the input's amax buffer (one scale per 256-point tile): left on it by its producer, else one read
+        if ctx.split in (1, 2):     # the input's amax buffer (one scale per 256-point tile): left on it by its producer, else one read
             ctx.x_amax = _cache.amax_of(x, be.PW_AMAX_SEG)
-            if ctx.x_amax is None:
+            if ctx.x_amax is None and ctx.split == 2:             # (bf16 mode: only backward-weight wants it, and measures it itself)
                 ctx.x_amax = be.pw_amax(x3)
         akw = {'amax': ctx.x_amax} if ctx.split == 2 else {}
         # forward + backward-data weight images from one launch when the input wants a gradient (see functional/conv3d.py)
@@ -79,9 +79,9 @@ class PointwiseConv(Function):
                      and x3.shape[0] * x3.shape[2] * w2.shape[0] * w2.shape[1] >= getattr(be, 'pw_wgrad_f16_min_macs', 0))
         # shared by both products; the BatchNorm backward that produced grad_y left it on the tensor (_cache.tag_amax)
         g_amax = None
-        if f16 and (ctx.needs_input_grad[0] or wgrad_f16):
+        if (f16 and (ctx.needs_input_grad[0] or wgrad_f16)) or (ctx.split == 1 and wgrad_f16):
             g_amax = _cache.amax_of(grad_y, be.PW_AMAX_SEG)
-            if g_amax is None:
+            if g_amax is None and f16:
                 g_amax = be.pw_amax(g3)
         gx = None
         if ctx.needs_input_grad[0]:

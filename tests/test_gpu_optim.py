@@ -39,8 +39,11 @@ def test_flat_adam_matches_torch_adam(hip, wd, bucket_mb):
 
 
 def test_flat_adam_trains_a_graphed_step(hip):
-    """The whole step -- zero_grad, forward, loss, backward, FlatAdam -- captured in a hipGraph and replayed: the loss goes down and the
-    replays continue the eager trajectory of the same optimizer."""
+    """The whole step -- zero_grad, forward, loss, backward, FlatAdam -- captured in a hipGraph and replayed: the loss goes down, the
+    replays continue the eager trajectory of the SAME optimizer (1e-4: the one atomics-based vendor kernel of the step, the last
+    Conv1d's backward-weight, is the only difference), and stay near torch.optim.Adam's.  eps = 1e-3: with Adam's default 1e-8 the
+    first updates are lr * sign(gradient) for every parameter, gradients at rounding level included, and the trajectories of two
+    implementations that round differently drift apart by 1 % within four steps (measured) -- a property of the test net, not of the step."""
     import torch.nn.functional as tf
     from pvcnn_amd import workload
     from pvcnn_amd.dp import GradBucketReducer
@@ -52,19 +55,21 @@ def test_flat_adam_trains_a_graphed_step(hip):
         if isinstance(m, nn.Dropout):
             m.p = 0.0
     x, y = workload.make_s3dis_batch(2, 1024, device=DEV, seed=3)
-    twin = copy.deepcopy(model)
-    red, red2 = GradBucketReducer(model), GradBucketReducer(twin)
-    opt, opt2 = FlatAdam(red, lr=1e-3), torch.optim.Adam(twin.parameters(), lr=1e-3)
+    twin, twin2 = copy.deepcopy(model), copy.deepcopy(model)
+    red, red2, red3 = GradBucketReducer(model), GradBucketReducer(twin), GradBucketReducer(twin2)
+    opt, opt2, opt3 = FlatAdam(red, lr=1e-3, eps=1e-3), torch.optim.Adam(twin.parameters(), lr=1e-3, eps=1e-3), FlatAdam(red3, lr=1e-3, eps=1e-3)
 
-    def eager():
-        red2.zero_grad()
-        loss = tf.cross_entropy(twin(x), y)
+    def eager(net, reducer, optimizer):
+        reducer.zero_grad()
+        loss = tf.cross_entropy(net(x), y)
         loss.backward()
-        red2.finish()
-        opt2.step()
+        reducer.finish()
+        optimizer.step()
         return loss.item()
-    want = [eager() for _ in range(5)]
+    want = [eager(twin, red2, opt2) for _ in range(5)]          # torch.optim.Adam
+    same = [eager(twin2, red3, opt3) for _ in range(5)]         # FlatAdam, eager
     step = GraphedTrainStep(model, lambda: tf.cross_entropy(model(x), y), opt, red, warmup=3)
     got = [step().item() for _ in range(2)]
     assert want[4] < want[0]
-    assert abs(got[0] - want[3]) <= 1e-4 * abs(want[3]) and abs(got[1] - want[4]) <= 1e-2 * abs(want[4]), (want, got)
+    assert abs(got[0] - same[3]) <= 1e-4 * abs(same[3]) and abs(got[1] - same[4]) <= 1e-4 * abs(same[4]), (same, got)
+    assert abs(got[0] - want[3]) <= 1e-3 * abs(want[3]) and abs(got[1] - want[4]) <= 1e-2 * abs(want[4]), (want, got)
