@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Steady-state per-step kernel breakdown from a rocprofv3 kernel-trace CSV.
 
-usage: trace_steady.py <kernel_trace.csv> <timed_steps> [top] [skip_last]
+usage: trace_steady.py <kernel_trace.csv> <timed_steps> [top] [skip_last] [--by-grid <substring>]
+(--by-grid: the kernels whose name contains <substring>, broken down by launch grid -- one line per layer shape)
 Training steps are delimited by the optimizer phase (runs of fused Adam's multi_tensor_apply kernels, or of pvcnn_amd.optim.FlatAdam's kernels);
 the `timed_steps` complete steps before the last `skip_last` ones are aggregated, i.e. bench.py's timed region (bench.py runs
 min(steps, 20) fully instrumented steps AFTER it: skip_last = 20 for the default 100 steps)."""
@@ -9,6 +10,9 @@ import csv
 import sys
 from collections import defaultdict
 
+by_grid = None
+if '--by-grid' in sys.argv:
+    i = sys.argv.index('--by-grid'); by_grid = sys.argv[i + 1]; del sys.argv[i:i + 2]
 path, steps = sys.argv[1], int(sys.argv[2])
 top = int(sys.argv[3]) if len(sys.argv) > 3 else 40
 skip = int(sys.argv[4]) if len(sys.argv) > 4 else 0
@@ -38,3 +42,15 @@ mine = sum(v[1] for k, v in agg.items() if 'pvcnn::' in k) / 1e6
 print(f'hand-written pvcnn:: kernels: {mine / steps:.3f} ms/step ({100 * mine / busy:.1f}% of kernel time)')
 for name, (calls, ns) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]:
     print('%8.3f ms/step %5.1f%%  calls/step=%6.1f avg=%8.1f us  %s' % (ns / 1e6 / steps, 100 * ns / 1e6 / busy, calls / steps, ns / 1e3 / calls, name[:110]))
+
+if by_grid:
+    gk = [k for k in ('Grid_Size_X', 'Grid_Size_Y', 'Grid_Size_Z') if k in rows[0]]
+    g = defaultdict(lambda: [0, 0])
+    for r in steady:
+        if by_grid in r[name_k]:
+            a = g[(r[name_k][:70], tuple(int(r[k]) for k in gk))]
+            a[0] += 1
+            a[1] += int(r[e_k]) - int(r[s_k])
+    print(f'--- kernels matching "{by_grid}" by launch grid (threads) ---')
+    for (name, grid), (calls, ns) in sorted(g.items(), key=lambda kv: -kv[1][1]):
+        print('%8.3f ms/step  calls/step=%5.1f avg=%8.1f us  grid=%s  %s' % (ns / 1e6 / steps, calls / steps, ns / 1e3 / calls, grid, name))
