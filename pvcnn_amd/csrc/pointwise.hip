@@ -466,20 +466,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
   }
 }
 
+// out[e] = sum over the P partial tiles: a workgroup owns 32 consecutive elements, its eight 32-lane groups take every eighth partial
+// (eight loads in flight each) and meet in LDS in a fixed order -- deterministic.  (First version: one thread per element walking all
+// P partials: 16 workgroups for a 64 x 64 weight and 512 partials, 14 us per launch, 8 launches per PVCNN step.)
 __global__ __launch_bounds__(256) void pw_reduce_kernel(const float *__restrict__ part, int n, int P, float *__restrict__ out) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= n) return;
+  __shared__ float red[8][32];
+  const int l = threadIdx.x & 31, g = threadIdx.x >> 5, e = blockIdx.x * 32 + l;
   float s = 0.0f;
-  int p = 0;
-  for (; p + 8 <= P; p += 8) {
-    float v[8];
+  if (e < n) {
+    int p = g;
+    for (; p + 56 < P; p += 64) {
+      float v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(p + u) * n + e];
+      for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(p + 8 * u) * n + e];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) s += v[u];
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; p < P; p += 8) s += part[(size_t)p * n + e];
   }
-  for (; p < P; ++p) s += part[(size_t)p * n + e];
-  out[e] = s;
+  red[g][l] = s;
+  __syncthreads();
+  if (g == 0 && e < n) {
+    float t = red[0][l];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) t += red[i][l];
+    out[e] = t;
+  }
 }
 
 inline bool pw_wgrad_small(int K, int M, int N) { return (long)M * K <= 128L * 128L && N % kPwSmC == 0; }
@@ -597,10 +609,10 @@ extern "C" int pvcnn_pwconv_bwd_weight(const float *x, const float *grad_y, int 
   }
   if (int rc = check_launch("pwconv_wgrad")) return rc;
   const int n = M * K;
-  hipLaunchKernelGGL(pw_reduce_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, part, n, PT, grad_w);
+  hipLaunchKernelGGL(pw_reduce_kernel, dim3(ceil_div(n, 32)), dim3(256), 0, s, part, n, PT, grad_w);
   if (int rc = check_launch("pwconv_wgrad_reduce")) return rc;
   if (grad_bias) {
-    hipLaunchKernelGGL(pw_reduce_kernel, dim3(ceil_div(M, 256)), dim3(256), 0, s, bias_part, M, P, grad_bias);
+    hipLaunchKernelGGL(pw_reduce_kernel, dim3(ceil_div(M, 32)), dim3(256), 0, s, bias_part, M, P, grad_bias);
     return check_launch("pwconv_bias_reduce");
   }
   return 0;

@@ -1,5 +1,5 @@
 #!/bin/bash
-R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/r03y; mkdir -p $O
+R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/r03za; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 (cd $R; timeout 300 python -m pytest tests/test_gpu_optim.py tests/test_gpu_graph.py -m gpu -q -p no:cacheprovider 2>&1 | tail -2)
 rm -rf /tmp/kt; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python $R/bench.py --no-cpu-baseline > $O/log 2>&1
