@@ -448,6 +448,10 @@ __global__ __launch_bounds__(THREADS) void gather_lds_kernel(P p, XF xf, const f
 // current slab is gathered; to make room the four points of a thread are expanded one at a time.  Same expressions, same order:
 // bit-identical to gather_lds_kernel<P, 4, 1024, true, XF, true> (tools/pipecheck*.py: 7 ragged shapes x training / eval x plain /
 // BatchNorm / addend) and 36.3 us on the same box (profiles/ab/r02_pipecheck_*).  PVCNN_GATHER_PIPE=0 selects the classic kernel.
+// (Round 3: a 512-thread variant with TWO grids in flight -- 2 x 16 x 16-byte loads per thread, the slab loop unrolled so that the
+// compiler's vmcnt waits leave the younger grid in flight -- measured 35.1 vs 35.2 us at (16,64,4096,32): with half the waves the LDS
+// write and gather phases take twice as long, and the fixed part of the launch (one slab per CU alone costs 9 us; eight slabs per
+// workgroup reach 0.69 of the HBM peak where four reach 0.55) is untouched.  Removed.)
 template <class P, class XF>
 __global__ __launch_bounds__(1024) void gather_lds_pipe_kernel(P p, XF xf, const float *__restrict__ src, float *__restrict__ dst,
                                                                int C, int L, int J, int SEQ, int pshift,
@@ -508,6 +512,11 @@ __global__ __launch_bounds__(1024) void gather_lds_pipe_kernel(P p, XF xf, const
     if (sq > 0) lds_barrier();                              // every wave is done reading the previous slab
     commit();                                               // waits for this slab's loads only
     lds_barrier();                                          // slab visible (LDS-only: the previous outputs keep draining)
+    // this slab's addend quad is requested BEFORE the next grid: loads return in order -- behind the eight grid loads it made the
+    // first store of the slab wait for the whole next grid (vmcnt(0))
+    const size_t rowoff = ((size_t)b * C + c) * J;
+    float4 add = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (addend) add = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(addend + rowoff) + (uint32_t)min(jf, max(J - 4, 0)) * 4u);
     if (sq + 1 < SEQ && c + 1 < C) {
       if constexpr (!XF::kIdentity) xfb.fetch(c + 1, raw);
       issue(c + 1);
@@ -528,11 +537,7 @@ __global__ __launch_bounds__(1024) void gather_lds_pipe_kernel(P p, XF xf, const
         r[h] = combine<NC, P::kMaySkip, true>(t, lds, pshift);
       }
       // uniform row base + the thread's 32-bit byte offset (jf * 4): no 64-bit per-lane addresses live across the loop
-      const size_t rowoff = ((size_t)b * C + c) * J;
-      if (addend) {
-        const float4 a = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(addend + rowoff) + (uint32_t)jf * 4u);
-        r[0] = r[0] + a.x; r[1] = r[1] + a.y; r[2] = r[2] + a.z; r[3] = r[3] + a.w;
-      }
+      if (addend) { r[0] = r[0] + add.x; r[1] = r[1] + add.y; r[2] = r[2] + add.z; r[3] = r[3] + add.w; }
       *reinterpret_cast<float4 *>(reinterpret_cast<char *>(dst + rowoff) + (uint32_t)jf * 4u) = make_float4(r[0], r[1], r[2], r[3]);
     }
   }

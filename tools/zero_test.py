@@ -1,21 +1,46 @@
-import sys, torch
-sys.path.insert(0, '.')
+#!/usr/bin/env python3
+"""Is a matrix-core kernel limited by the power envelope or by its schedule?  Same binary, three input fills: random normal, zeros,
+0/1 integers.  A kernel that runs much faster on zeros is at the power-limited MFMA rate (profiles/ab/r03v_mfma_power_limit.md)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
 from pvcnn_amd.modules.functional.backend import HipBackend
 be = HipBackend(); dev = 'cuda:0'
+
+
 def t(fn, n=20):
-    for _ in range(5): fn()
+    for _ in range(5):
+        fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(n): fn()
+    for _ in range(n):
+        fn()
     e1.record(); e1.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
+
+
+def fill(kind, *shape, scale=1.0):
+    if kind == 'randn':
+        return torch.randn(*shape, device=dev) * scale
+    if kind == 'zeros':
+        return torch.zeros(*shape, device=dev)
+    return torch.randint(0, 2, shape, device=dev).float()
+
+
 for (b, ci, co, r) in [(16, 64, 64, 16), (16, 128, 128, 16), (16, 64, 64, 32)]:
     for kind in ('randn', 'zeros', 'small-int'):
-        if kind == 'randn': x = torch.randn(b, ci, r, r, r, device=dev); w = torch.randn(co, ci, 3, 3, 3, device=dev) * 0.1
-        elif kind == 'zeros': x = torch.zeros(b, ci, r, r, r, device=dev); w = torch.zeros(co, ci, 3, 3, 3, device=dev)
-        else: x = torch.randint(0, 2, (b, ci, r, r, r), device=dev).float(); w = torch.randint(0, 2, (co, ci, 3, 3, 3), device=dev).float()
-        ax = be.conv_amax(x)
+        x, w, gy = fill(kind, b, ci, r, r, r), fill(kind, co, ci, 3, 3, 3, scale=0.1), fill(kind, b, co, r, r, r)
+        ax, ag = be.conv_amax(x), be.conv_amax(gy)
         wf = be._conv_wsplit(w, False, 2)
-        us = t(lambda: be.conv3d_igemm_split(x, wf, None, co, 2, False, ax))
-        print(b, ci, co, r, kind, round(us, 1), 'us', flush=True)
+        f = t(lambda: be.conv3d_igemm_split(x, wf, None, co, 2, False, ax))
+        g = t(lambda: be.conv3d_backward_weight_f16(x, gy, ax, ag))
+        print('conv3d', (b, ci, co, r), kind, 'fwd %.1f us' % f, 'bwd-weight %.1f us' % g, flush=True)
+for (b, ci, co, n) in [(16, 1472, 512, 4096), (16, 128, 1024, 4096)]:
+    for kind in ('randn', 'zeros', 'small-int'):
+        x, w, gy = fill(kind, b, ci, n), fill(kind, co, ci, scale=0.1), fill(kind, b, co, n)
+        ax, ag = be.pw_amax(x), be.pw_amax(gy)
+        wf = be._pw_wsplit(w, False, 2)
+        f = t(lambda: be.pwconv_gemm_split(x, wf, None, co, 2, False, ax))
+        g = t(lambda: be.pwconv_backward_weight_f16(x, gy, ax, ag))
+        print('1x1', (b, ci, co, n), kind, 'fwd %.1f us' % f, 'bwd-weight %.1f us' % g, flush=True)
