@@ -394,3 +394,76 @@ def test_se_tail_node_matches_the_modules_it_replaces(oracle, monkeypatch):
     got = [g2.grad, a2.grad, bn2.weight.grad, bn2.bias.grad, se.fc[0].weight.grad, se.fc[2].weight.grad]
     for name, a, b in zip(('grid', 'addend', 'bn.weight', 'bn.bias', 'fc1', 'fc2'), got, want):
         assert a is not None and torch.allclose(a, b, rtol=2e-4, atol=2e-5), (name, (a - b).abs().max().item(), b.abs().max().item())
+
+
+# ---- which kernels a 1x1 convolution takes: the two size bars of functional/pwconv.py ------------------------------------------------
+class _PwRouteStandIn:
+    """torch stand-ins for the 1x1 kernels that record which of them a layer took."""
+    has_pwconv_split = True
+    pw_math = 'f16x2'
+    PW_NSPLIT = {'f16x2': 2, 'bf16x3': 3, 'fp32': 0}
+    PW_AMAX_SEG = 256
+    pw_split_min_macs = 1 << 12
+    pw_wgrad_f16_min_macs = 1 << 16
+
+    def __init__(self):
+        self.calls = []
+
+    def pw_amax(self, x3):
+        self.calls.append('pw_amax')
+        return x3.abs().amax().reshape(1).view(torch.int32)
+
+    def pwconv_forward(self, x3, w2, b):
+        self.calls.append('forward_fp32')
+        return torch.einsum('oc,bcn->bon', w2, x3) + (b.view(1, -1, 1) if b is not None else 0)
+
+    def pwconv_forward_split(self, x3, w2, b, nsplit, amax=None):
+        self.calls.append(f'forward_split{nsplit}')
+        return torch.einsum('oc,bcn->bon', w2, x3) + (b.view(1, -1, 1) if b is not None else 0)
+
+    def pwconv_backward_data(self, g3, w2):
+        self.calls.append('bwd_data_fp32')
+        return torch.einsum('oc,bon->bcn', w2, g3)
+
+    def pwconv_backward_data_split(self, g3, w2, nsplit, amax=None):
+        self.calls.append(f'bwd_data_split{nsplit}')
+        return torch.einsum('oc,bon->bcn', w2, g3)
+
+    def pwconv_backward_weight_f16_serves(self, x3):
+        return x3.shape[2] % 4 == 0
+
+    def pwconv_backward_weight_f16(self, x3, g3, x_amax, g_amax, with_bias=False):
+        self.calls.append('wgrad_f16')
+        gw = torch.einsum('bon,bcn->oc', g3, x3)
+        return (gw, g3.sum(dim=(0, 2))) if with_bias else gw
+
+    def pwconv_backward_weight(self, x3, g3, with_bias=False):
+        self.calls.append('wgrad_fp32')
+        gw = torch.einsum('bon,bcn->oc', g3, x3)
+        return (gw, g3.sum(dim=(0, 2))) if with_bias else gw
+
+
+def test_pointwise_conv_routes_by_the_two_size_bars(monkeypatch):
+    """functional/pwconv.py: forward / backward-data take the split (f16x2) kernels from `pw_split_min_macs` multiply-adds up, the
+    backward-weight its f16x2 kernel only from `pw_wgrad_f16_min_macs` up (it writes 128 x 128 partial tiles per partition: a loss
+    on small weight matrices) -- and the results are the plain convolution's either way."""
+    from pvcnn_amd.modules.functional import backend as seam
+    from pvcnn_amd.modules.functional.pwconv import pointwise_conv, pw_nsplit
+    fake = _PwRouteStandIn()
+    monkeypatch.setattr(seam, '_backend', fake)
+    torch.manual_seed(3)
+    for (b, ci, co, n), want in (((1, 4, 4, 64), ['forward_fp32', 'bwd_data_fp32', 'wgrad_fp32']),                    # 1 Ki MACs
+                                 ((2, 8, 8, 64), ['pw_amax', 'forward_split2', 'pw_amax', 'bwd_data_split2', 'wgrad_fp32']),   # 8 Ki
+                                 ((2, 32, 32, 64), ['pw_amax', 'forward_split2', 'pw_amax', 'bwd_data_split2', 'wgrad_f16'])):  # 128 Ki
+        x = torch.randn(b, ci, n, requires_grad=True)
+        w = torch.randn(co, ci, 1, requires_grad=True)
+        bias = torch.randn(co, requires_grad=True)
+        assert pw_nsplit(x, w.view(co, ci)) == (2 if b * ci * co * n >= fake.pw_split_min_macs else 0)
+        fake.calls.clear()
+        y = pointwise_conv(x, w, bias)
+        gy = torch.randn_like(y)
+        y.backward(gy)
+        assert fake.calls == want, (fake.calls, want)
+        x2, w2, b2 = x.detach().clone().requires_grad_(), w.detach().clone().requires_grad_(), bias.detach().clone().requires_grad_()
+        torch.nn.functional.conv1d(x2, w2, b2).backward(gy)
+        assert torch.allclose(x.grad, x2.grad, atol=1e-5) and torch.allclose(w.grad, w2.grad, atol=1e-4) and torch.allclose(bias.grad, b2.grad, atol=1e-4)
