@@ -39,7 +39,11 @@ struct WgradLds {
   static constexpr int BYTES = 2 * XPL + 2 * GPL;
 };
 
-template <int R>
+// PACK (Ci <= 10, the first layer of a network: 9 input channels): the MFMA's 32 columns hold (dx, ci) -- 3 x Ci <= 30 of them --
+// instead of 32 input channels of which Ci exist, so a workgroup has 6 units (dy; 32-row co block) instead of 18: a third of the
+// MFMAs (the unpacked kernel took 0.18 ms at Ci = 9 against 0.35 ms at Ci = 64, for a seventh of the work).  Waves 0..5 take one
+// unit each; all eight waves stage.
+template <int R, bool PACK = false>
 __global__ __launch_bounds__(512, 2) void conv3d_wgrad_f16_kernel(const float *__restrict__ x, const float *__restrict__ gy,
                                                                   const uint32_t *__restrict__ x_absmax,
                                                                   const uint32_t *__restrict__ gy_absmax, int B, int Ci, int Co, int P,
@@ -61,8 +65,10 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_f16_kernel(const float *_
   for (int e = tid; e < L::BYTES / 4; e += 512) reinterpret_cast<uint32_t *>(lds)[e] = 0u;    // z halos stay zero for good
   __syncthreads();
 
-  // units of this wave: u = wave, wave + 8, wave + 16 (< 18);  u -> (dxy = u % 9, mb = u / 9)
-  const int nunits = wave < 2 ? 3 : 2;
+  // units of this wave: u = wave, wave + 8, wave + 16 (< 18);  u -> (dxy = u % 9, mb = u / 9)   [PACK: unit = wave < 6 -> (dy = u % 3, mb = u / 3)]
+  const int nunits = PACK ? (wave < 6 ? 1 : 0) : (wave < 2 ? 3 : 2);
+  // PACK: column j of the MFMA = (dx = j / Ci, ci = j % Ci); columns >= 3 Ci read a row of a channel that does not exist (zeros)
+  const int pdx = PACK ? (j < 3 * Ci ? j / Ci : 0) : 0, pci = PACK ? (j < 3 * Ci ? j - (j / Ci) * Ci : kWgCi - 1) : 0;
   f32x16 acc[3][3];
 #pragma unroll
   for (int u = 0; u < 3; ++u)
@@ -122,12 +128,13 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_f16_kernel(const float *_
 #pragma unroll
           for (int u = 0; u < 3; ++u) {
             if (u < nunits) {
-              const int unit = wave + 8 * u, dxy = unit % 9, mb = unit / 9, dx = dxy / 3, dy = dxy - dx * 3;
+              const int unit = wave + 8 * u, dxy = unit % 9, mb = PACK ? unit / 3 : unit / 9, dx = PACK ? pdx : dxy / 3,
+                        dy = PACK ? unit % 3 : dxy - (dxy / 3) * 3;
               const int slot = (t + dy - 1) & 3;
               uint4 bw[2][3];                                    // [hi, lo][dz]
 #pragma unroll
               for (int pl = 0; pl < 2; ++pl) {
-                const unsigned char *row = xl + pl * L::XPL + ((slot * 3 + dx) * kWgCi + j) * ROWB + (z8 + 6) * 2;
+                const unsigned char *row = xl + pl * L::XPL + ((slot * 3 + dx) * kWgCi + (PACK ? pci : j)) * ROWB + (z8 + 6) * 2;
                 const uint32_t d0 = *reinterpret_cast<const uint32_t *>(row);
                 const uint4 m = *reinterpret_cast<const uint4 *>(row + 4);
                 const uint32_t d5 = *reinterpret_cast<const uint32_t *>(row + 20);
@@ -170,14 +177,14 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_f16_kernel(const float *_
 #pragma unroll
   for (int u = 0; u < 3; ++u) {
     if (u < nunits) {
-      const int unit = wave + 8 * u, dxy = unit % 9, mb = unit / 9;
+      const int unit = wave + 8 * u, dxy = PACK ? pdx * 3 + unit % 3 : unit % 9, mb = PACK ? unit / 3 : unit / 9;
 #pragma unroll
       for (int dz = 0; dz < 3; ++dz) {
         const int tap = dxy * 3 + dz;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int co = co0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-          pp[((size_t)tap * CoP + co) * CiP + ci0 + j] = acc[u][dz][r];
+          if (!PACK || j < 3 * Ci) pp[((size_t)tap * CoP + co) * CiP + ci0 + (PACK ? pci : j)] = acc[u][dz][r];
         }
       }
     }
@@ -269,7 +276,8 @@ static int launch_wgrad_f16(const float *x, const float *gy, const uint32_t *xa,
                             float *gb, float *ws, hipStream_t s) {
   const WgradPlan w = wgrad_f16_plan(B, Ci, Co, R);
   float *part = ws, *gb_part = ws + w.part_floats;
-  auto k = conv3d_wgrad_f16_kernel<R>;
+  const bool pack = 3 * Ci <= kWgCi && (R == 32 || R == 16);     // (instantiated for the grids a network's first layer has)
+  auto k = pack ? conv3d_wgrad_f16_kernel<R, (R == 32 || R == 16)> : conv3d_wgrad_f16_kernel<R, false>;
   const int lds = WgradLds<R>::BYTES;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e != hipSuccess) { set_error("conv3d_wgrad_f16: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }

@@ -177,7 +177,8 @@ def test_conv3d_is_deterministic(hip):
 
 
 @pytest.mark.parametrize('b,ci,co,r', [(2, 9, 64, 32), (2, 64, 64, 16), (3, 40, 70, 16), (1, 33, 130, 32), (1, 1, 1, 16), (20, 64, 128, 16),
-                                       (4, 64, 64, 12), (3, 33, 70, 12), (2, 64, 128, 8), (5, 7, 9, 8)])
+                                       (4, 64, 64, 12), (3, 33, 70, 12), (2, 64, 128, 8), (5, 7, 9, 8),
+                                       (2, 10, 64, 16), (1, 3, 40, 32), (16, 9, 64, 32)])   # Ci <= 10: the (dx, ci)-packed kernel
 def test_conv3d_backward_weight_f16x2(hip, b, ci, co, r):
     """csrc/conv3d_wgrad_f16.hip: grad_w and grad_bias within the 1e-5 bar of the fp32-MFMA kernel (vs fp64), bit-reproducible,
     for ragged channel counts (zero-padded 64 x 32 blocks), several strips per workgroup, gradients far below fp16's range."""
