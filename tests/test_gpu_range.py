@@ -161,7 +161,8 @@ def test_channels_seven_decades_apart(hip):
 
 
 @pytest.mark.parametrize('shape,seg', [((16, 64, 32, 32, 32), 32), ((3, 24, 16, 16, 16), 16), ((2, 10, 12, 12, 12), 12),
-                                       ((4, 64, 4096), 256), ((2, 7, 1001), 256), ((3, 130, 2, 600), 256)])
+                                       ((4, 64, 4096), 256), ((2, 7, 1001), 256), ((3, 130, 2, 600), 256),
+                                       ((2, 512, 1024), 256)])    # (the S <= 4096 shapes split their channels over 2-4 workgroups)
 def test_batchnorm_apply_passes_emit_the_buffer_and_the_same_bits(hip, shape, seg):
     """The position-block-major apply passes (csrc/bnact.hip) write bit for bit what the classic passes write, forward and backward
     (batch-strided gradient included), and the amax buffer they emit equals absmax_tiles of that output."""
