@@ -17,14 +17,11 @@
 //     optional BatchNorm partial sums of (y - bias) ride on the epilogue.
 // Backward-data is the same kernel on the transposed weights (for_bwd_data image), x = grad_y.
 //
-// STATUS: correct (<= 1e-5 vs fp64, tests/test_gpu_pwconv.py) but NOT the default: at PVCNN's layer shapes it is 0.9-1.14x the
-// fp32-MFMA kernels of pointwise.hip (classifier 1472->512 over 65 536 points: 0.69 vs 0.77 ms forward).  Unlike the 3x3x3
-// convolution, where every staged and converted element is reused by 27 taps x 64 channels, a 1x1 GEMM reuses it by the M tile
-// only (128), and the per-chunk phase "convert + LDS + barrier" (0.29 ms in total at this shape, measured with NS = 1) does not
-// overlap the MFMA phase (0.37 ms at the sustained 1.6 PF) of the co-resident workgroup -- the two add up.  Tried without effect:
-// one-chunk-ahead register prefetch of x and of the weight fragments, 32-channel stages (spills at 2 waves per SIMD, slower at 1),
-// XCD-aware tile order (L2 hit rate 75 %: x is fetched from HBM once), issue priority for the multiplying wave.  Selected with
-// `backend.pw_math = 'bf16x3'`.
+// History of the "convert + LDS + barrier" phase that does not overlap the MFMA phase (0.29 of 0.69 ms at the classifier shape in the
+// bf16x3 form, round 2): one-chunk-ahead register prefetch, 32-channel stages, XCD-aware tile order (kept: x is fetched from HBM
+// once) and issue priorities did not move it; round 3 found the cause in the ISA -- the compiler drained every load (vmcnt(0)) in front
+// of each chunk's first MFMA because the prefetch sat behind bounds checks -- and moved the conversion between the MFMAs
+// (pw_gemm_f16_pipe_kernel below).  Arithmetic is selected with `backend.pw_math` (f16x2 default, bf16x3, fp32).
 #include <algorithm>
 #include <stdlib.h>
 

@@ -1,9 +1,10 @@
 """pointwise_conv: the kernel-size-1 Conv1d / Conv2d of SharedMLP (reference: modules/shared_mlp.py:9-25).
 
 The reference calls nn.Conv1d / nn.Conv2d (cuDNN / cuBLAS).  On gfx950 the three GEMMs (forward, backward-data,
-backward-weight + bias gradient) run directly on the channel-major (B, C, N) tensors: the large ones (>= 4.3 G multiply-adds)
-in "f16x2" arithmetic on the fp16 matrix cores (csrc/pointwise_bf16.hip, pointwise_wgrad_f16.hip: fp32 tensors, operands split
-into scaled fp16 hi + lo, fp32 accumulation), the small, launch-bound ones on the fp32-MFMA kernels of csrc/pointwise.hip."""
+backward-weight + bias gradient) run directly on the channel-major (B, C, N) tensors in "f16x2" arithmetic on the fp16 matrix
+cores (csrc/pointwise_bf16.hip, pointwise_wgrad_f16.hip: fp32 tensors, operands split into scaled fp16 hi + lo, fp32 accumulation)
+-- forward / backward-data from `backend.pw_split_min_macs` (16.8 M) multiply-adds up, backward-weight from
+`backend.pw_wgrad_f16_min_macs` (4.3 G) -- and on the fp32-MFMA kernels of csrc/pointwise.hip below those bars."""
 import torch
 from torch.autograd import Function
 
