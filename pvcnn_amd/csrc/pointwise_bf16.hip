@@ -360,12 +360,14 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_bf16_kernel(const float *__res
 // load has a whole chunk to land: the weight fragments of chunk c + 1 are requested in front of chunk c's MFMAs (second register set),
 // and the loop is straight-line code, so the compiler's vmcnt waits leave the younger loads in flight.  (pw_gemm_bf16_kernel converts between two barriers and relies on the co-resident workgroup to fill the
 // matrix pipe meanwhile.)  Same products in the same order per output element: bit-identical to pw_gemm_bf16_kernel<2, 4>.
+template <int NS>   // 2 = f16x2; 1 = plain bf16 operands (torch.autocast): one plane, one product -- the conversion is then the longer phase
 __global__ __launch_bounds__(256, 2) void pw_gemm_f16_pipe_kernel(const float *__restrict__ x, const uint16_t *__restrict__ wts,
                                                                   const float *__restrict__ bias, float *__restrict__ y, int K, int M,
                                                                   int N, int tiles_n, int tiles_total, float2 *__restrict__ stats_part,
                                                                   const uint32_t *__restrict__ x_absmax, const int *__restrict__ wexp,
                                                                   int amax_seg) {
-  constexpr int NS = 2, MB = 4, TM = 32 * MB, WM = 2, MBW = MB / WM, NBW = 2 * WM, WBLK = NS * TM * kPbK;
+  static_assert(NS == 1 || NS == 2, "f16x2 or bf16");
+  constexpr int MB = 4, TM = 32 * MB, WM = 2, MBW = MB / WM, NBW = 2 * WM, WBLK = NS * TM * kPbK;
   constexpr int ITEMS = (kPbK / 2) * (kPbN / 4) / 256, TILE = NS * 8 * kPbN;
   // two tiles [plane][kh][128-point block][h][128 points][2 words], channel pair = 4 kh + 2 h + word: a staging thread owns 4 channels
   // x 4 points = two 16-byte stores of 8 consecutive words per plane; a lane's B fragment (the 8 channels 8 kh .. 8 kh + 7 of its
@@ -375,7 +377,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_f16_pipe_kernel(const float *_
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;                    // XCD-aware tile order, as in pw_gemm_bf16_kernel
   const int tile = (slot / mtiles) * 8 + xcd, mt = slot - (slot / mtiles) * mtiles;
   if (tile >= tiles_total) return;
-  const int x_shift = scale_shift(amax_seg > 0 ? x_absmax[1 + tile] : *x_absmax);
+  const int x_shift = NS == 2 ? scale_shift(amax_seg > 0 ? x_absmax[1 + tile] : *x_absmax) : 0;
   const float x_scale = exp2_int(x_shift);
   const int b = tile / tiles_n, n0 = (tile - b * tiles_n) * kPbN, m0 = mt * TM;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, kh = lane >> 5;
@@ -476,13 +478,17 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_f16_pipe_kernel(const float *_
       _Pragma("unroll") for (int nb = 0; nb < NBW; ++nb)                                                                 \
       _Pragma("unroll") for (int mb = 0; mb < MBW; ++mb)                                                                 \
         acc[mb][nb] = mfma16<NS>(af[mb][SA], bf[nb][SB], acc[mb][nb])
-      PVCNN_PB_MFMA(1, 0); PVCNN_PB_MFMA(0, 1);                         // lo x hi, hi x lo, then hi x hi
-      PVCNN_PB_MFMA(0, 0);
+      if constexpr (NS == 2) {
+        PVCNN_PB_MFMA(1, 0); PVCNN_PB_MFMA(0, 1);                       // lo x hi, hi x lo, then hi x hi
+        PVCNN_PB_MFMA(0, 0);
+      } else {
+        PVCNN_PB_MFMA(0, 0);
+      }
 #undef PVCNN_PB_MFMA
 #pragma unroll
-      for (int i = 0; i < 3 * MBW * NBW; ++i) {                         // 1 MFMA, 2 vector-ALU, 24 times
+      for (int i = 0; i < (NS == 2 ? 3 : 1) * MBW * NBW; ++i) {         // 1 MFMA, 2 (bf16: 4) vector-ALU; 24 (8) times
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, NS == 2 ? 2 : 4, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
       store(d ^ 1, w);
@@ -588,11 +594,14 @@ extern "C" int pvcnn_pwconv_fwd_split(const float *x, const void *wts, const flo
     // measured (profiles/ab/r03k_*, 1472 -> 512 over 65 536 points, forward): round-3 start 0.483 ms; straight-line chunk loop
     // (VEC) 0.347 ms; + conversion between the MFMAs, one barrier per chunk (pipe kernel) 0.306 ms; the step 1925 -> 2103 -> 2108 clouds/s
     if (MB == 4 && vec)
-      hipLaunchKernelGGL(pw_gemm_f16_pipe_kernel, grid, dim3(256), 0, s, x, w16, bias, y, K, M, N, tiles_n, (int)tiles_total, sp, am, wexp,
+      hipLaunchKernelGGL(pw_gemm_f16_pipe_kernel<2>, grid, dim3(256), 0, s, x, w16, bias, y, K, M, N, tiles_n, (int)tiles_total, sp, am, wexp,
                          amax_seg);
     else if (MB == 4) PVCNN_PB_LAUNCH_PF(2, 4, 2);
     else PVCNN_PB_LAUNCH(2, 2);
   }
+  else if (MB == 4 && vec)   // bf16 operands (autocast): the same pipelined structure with one plane
+    hipLaunchKernelGGL(pw_gemm_f16_pipe_kernel<1>, grid, dim3(256), 0, s, x, w16, bias, y, K, M, N, tiles_n, (int)tiles_total, sp, am, wexp,
+                       amax_seg);
   else                  { if (MB == 4) PVCNN_PB_LAUNCH(1, 4); else PVCNN_PB_LAUNCH(1, 2); }
 #undef PVCNN_PB_LAUNCH
 #undef PVCNN_PB_LAUNCH_PF
