@@ -536,14 +536,19 @@ __global__ __launch_bounds__(256) void concat_points_kernel(CatSources src, int 
   const int b = blockIdx.y, p0 = blockIdx.x * 256;
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, pos = p0 + 4 * lane;
   const int Ctot = src.c0[src.n];
+  // channel groups (gridDim.z > 1): with few position blocks (ShapeNet: 8 clouds x 2048 points = 64 workgroups walking ~2700
+  // channels each: 1.7 TB/s) the concatenated channel range is split over gridDim.z workgroups; their table entries meet by atomicMax
+  // in a table the host zeroed
+  const int cgroup = ceil_div(Ctot, (int)gridDim.z), gbeg = (int)blockIdx.z * cgroup, gend = min(Ctot, gbeg + cgroup);
   float *ob = out + (size_t)b * Ctot * N;
   uint32_t m = 0;
   using v4f = __attribute__((ext_vector_type(4))) float;
   for (int s = 0; s < src.n; ++s) {
-    const int cb = src.c0[s], cn = src.c0[s + 1] - cb;
+    const int cb = src.c0[s], lo = max(gbeg, cb) - cb, cn = min(gend, src.c0[s + 1]) - cb;      // this group's rows [lo, cn) of source s
+    if (lo >= cn) continue;
     const float *sp = src.p[s] + (size_t)b * src.bstride[s];
     if (src.pstride[s] == 0) {                               // broadcast rows
-      for (int c = wave; c < cn; c += 4) {
+      for (int c = lo + wave; c < cn; c += 4) {
         const float v = sp[c];
         m = max(m, __float_as_uint(fabsf(v)));
         if (vec && pos < N) { v4f o = {v, v, v, v}; __builtin_nontemporal_store(o, reinterpret_cast<v4f *>(ob + (size_t)(cb + c) * N + pos)); }
@@ -551,13 +556,13 @@ __global__ __launch_bounds__(256) void concat_points_kernel(CatSources src, int 
       }
     } else if (vec) {
       if (pos < N)
-        for (int c0 = wave; c0 < cn; c0 += 16) {             // four rows in flight per wave
-          float4 v[4];
+        for (int c0 = lo + wave; c0 < cn; c0 += 32) {        // eight rows in flight per wave
+          float4 v[8];
 #pragma unroll
-          for (int u = 0; u < 4; ++u)
+          for (int u = 0; u < 8; ++u)
             if (c0 + 4 * u < cn) v[u] = *reinterpret_cast<const float4 *>(sp + (size_t)(c0 + 4 * u) * N + pos);
 #pragma unroll
-          for (int u = 0; u < 4; ++u)
+          for (int u = 0; u < 8; ++u)
             if (c0 + 4 * u < cn) {
               m = max(max(m, __float_as_uint(fabsf(v[u].x))), max(__float_as_uint(fabsf(v[u].y)), max(__float_as_uint(fabsf(v[u].z)), __float_as_uint(fabsf(v[u].w)))));
               v4f o = {v[u].x, v[u].y, v[u].z, v[u].w};
@@ -565,7 +570,7 @@ __global__ __launch_bounds__(256) void concat_points_kernel(CatSources src, int 
             }
         }
     } else {
-      for (int c = wave; c < cn; c += 4)
+      for (int c = lo + wave; c < cn; c += 4)
         for (int i = 0; i < 4; ++i)
           if (pos + i < N) {
             const float v = sp[(size_t)c * N + pos + i];
@@ -579,7 +584,11 @@ __global__ __launch_bounds__(256) void concat_points_kernel(CatSources src, int 
     for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
     if (lane == 0) wave_max[wave] = m;
     lds_barrier();
-    if (tid == 0) amax[1 + (size_t)b * gridDim.x + blockIdx.x] = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
+    if (tid == 0) {
+      const uint32_t t = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
+      if (gridDim.z > 1) { if (t != 0u) atomicMax(&amax[1 + (size_t)b * gridDim.x + blockIdx.x], t); }
+      else amax[1 + (size_t)b * gridDim.x + blockIdx.x] = t;
+    }
   }
 }
 }  // namespace pvcnn
@@ -604,7 +613,13 @@ extern "C" int pvcnn_concat_points(const float *const *srcs, const long *bstride
   cs.c0[nsrc] = c;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int blocks = ceil_div(N, 256);
-  hipLaunchKernelGGL(concat_points_kernel, dim3(blocks, B), dim3(256), 0, s, cs, N, vec ? 1 : 0, out, static_cast<uint32_t *>(out_amax));
+  int groups = 1;                                            // ~4 workgroups per CU, >= 64 channels each
+  while ((long)blocks * B * groups < 4 * kNumCU && c / (2 * groups) >= 64) groups *= 2;
+  if (groups > 1 && out_amax != nullptr) {
+    hipError_t e = hipMemsetAsync(out_amax, 0, (1 + (size_t)B * blocks) * sizeof(uint32_t), s);
+    if (e != hipSuccess) { set_error("concat_points: memset: %s", hipGetErrorString(e)); return (int)e; }
+  }
+  hipLaunchKernelGGL(concat_points_kernel, dim3(blocks, B, groups), dim3(256), 0, s, cs, N, vec ? 1 : 0, out, static_cast<uint32_t *>(out_amax));
   if (int e = check_launch("concat_points")) return e;
   if (out_amax != nullptr) return launch_amax_reduce(static_cast<uint32_t *>(out_amax), (long)B * blocks, s);
   return 0;
