@@ -3,9 +3,9 @@
 PVCNN exercises PVConv (voxelize / Conv3d / devoxelize / SharedMLP); PVCNN++ adds the set-abstraction
 and feature-propagation stages (FPS, ball_query, grouping, 3-NN interpolation) with autograd.
 Index-producing ops are bit-exact, so both stacks build the same neighbourhoods; features then differ
-only by Conv/BatchNorm/GEMM summation order (MIOpen/rocBLAS/MFMA vs torch-CPU): tolerance 2e-3 on
-O(1) logits.  A point whose normalised coordinate sits within an ulp of a .5 voxel boundary may round
-differently on the two devices (torch's mean/norm reductions differ), hence the 99.5 % criterion."""
+only by Conv/BatchNorm/GEMM summation order (this package's MFMA kernels vs torch-CPU).  Measured on MI355X (round 3, three
+seeds per network, `tools/models_dev.py`): EVERY logit within 1e-7 * (1 + |logit|) of the CPU stack; the bar here is 2e-6, on
+every element (rounds 1-2 asserted 99.5 % of the elements within 2e-3)."""
 import pytest
 import torch
 import torch.nn.functional as tf
@@ -37,7 +37,7 @@ def test_network_eval_logits_match_cpu_oracle(hip, oracle, name, n, batch):
         finally:
             seam._backend = prev
     assert got.shape == want.shape == (batch, 13, n)
-    assert _close_fraction(got, want, 2e-3) > 0.995
+    assert _close_fraction(got, want, 2e-6) == 1.0, ((got - want).abs() / (1 + want.abs())).max().item()
 
 
 @pytest.mark.parametrize('name,n', [('PVCNN', 2048), ('PVCNN2', 2048)])
@@ -61,9 +61,15 @@ def test_network_training_step_is_reproducible(hip, name, n):
     net.load_state_dict(bn_state)                # restore BN running stats touched by the first pass
     l2, g2 = grads()
     assert all(torch.isfinite(g).all() for g in g1) and len(g1) > 10
-    # the forward pass is bit-reproducible (hand-written kernels are atomic-free, MIOpen forward is
-    # deterministic for fixed shapes); in the backward pass MIOpen's split-K weight-gradient kernels of
-    # the 1x1 convolutions (igemm_wrw_*_gkgs: global atomics) perturb the last bits of a few tensors
+    # every kernel of this package is atomic-free in floating point: the loss and every gradient are BIT-reproducible -- except the
+    # weight gradient of the one layer still on the vendor library, the classifier's last plain nn.Conv1d (MIOpen's
+    # igemm_wrw_*: global atomics), which moves by ~5e-7 of its largest entry from run to run
     assert l1 == l2
-    for a, b in zip(g1, g2):
-        assert torch.allclose(a, b, rtol=1e-4, atol=1e-7)
+    vendor = {id(m.weight) for m in net.modules() if type(m) is torch.nn.Conv1d and not any(m is c for mlp in net.modules()
+              if type(mlp).__name__ == 'SharedMLP' for c in mlp.modules())}
+    params = [p for p in net.parameters() if p.grad is not None]
+    for p, a, b in zip(params, g1, g2):
+        if id(p) in vendor:
+            assert (a - b).abs().max().item() <= 1e-5 * a.abs().max().item()
+        else:
+            assert torch.equal(a, b), (tuple(p.shape), (a - b).abs().max().item())
