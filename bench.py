@@ -502,7 +502,9 @@ def main():
                 'unit': 'TFLOP/s', 'frac': mfma['frac_of_peak'], 'avg_us': mfma['avg_us'], 'algorithmic_GFLOP': mfma['GFLOP'],
                 'effective_fp32_TFLOPs': mfma['effective_TFLOPs'], 'x_fp32_mfma_peak_157TF': mfma['x_fp32_mfma_peak'],
                 'note': 'achieved = MFMA flops actually executed (f16x2: 3 fp16 partial products per fp32 product; bf16x3: 6) / launch time; '
-                        'effective = algorithmic 2*B*R^3*27*Ci*Co / launch time'},
+                        'effective = algorithmic 2*B*R^3*27*Ci*Co / launch time; the dense MFMA kernels run at the rate the matrix cores '
+                        'sustain inside the power budget (~1400 TFLOP/s executed on random data; zeros run 18-30 % faster: '
+                        'profiles/ab/r03v_mfma_power_limit.md)'},
             'kernels': kernels,
         }
         if graph_error:
