@@ -47,7 +47,7 @@ extern "C" {
 #define PVCNN_API
 #endif
 
-#define PVCNN_ABI_VERSION 6
+#define PVCNN_ABI_VERSION 7
 #define PVCNN_OK 0
 #define PVCNN_ERR_INVALID_ARGUMENT (-1)
 
@@ -379,6 +379,19 @@ PVCNN_API int pvcnn_bnact_bwd_strided(const float *x, const float *grad_y, long 
  *   g' = (grad_y * bc_mul[b][c] + bc_add[b][c]) * act'(z); bc_mul / bc_add (B,C) or NULL (1 / 0); sum_gamma / sum_beta (C) given by
  *   the caller; gx_amax / amax_seg as in pvcnn_bnact_bwd_strided. */
 PVCNN_API int pvcnn_bnact_slices(int S);
+/* The excitation of SE3d (modules/se.py:6-17: Linear(C, H, bias=False) + ReLU + Linear(H, C, bias=False) + Sigmoid on the squeezed
+ * (B, C) descriptor) between the two reduction passes of PVConv's fused squeeze-and-excitation tail, and its backward.
+ * fwd: a_sum / ax_sum (B, C) = the sums of act'(z) and act'(z) * xhat over the grid (pvcnn_bnact_partial_sums with grad_y NULL);
+ *      squeezed = (gamma * ax_sum + beta * a_sum) * inv_s, hidden = relu(squeezed W1^T) (B, H), excite = sigmoid(hidden W2^T) (B, C).
+ * bwd: p_sum / q_sum (B, C) = the sums of g_y act'(z) and g_y act'(z) xhat; -> g_w1 (H, C), g_w2 (C, H), g_mean (B, C) = dL/dsqueezed
+ *      * inv_s, and the BatchNorm backward's per-channel sums sum_beta / sum_gamma (C) of g' = (excite g_y + g_mean) act'(z).
+ *      workspace: B * (C + H) floats.  C <= 2048, H <= 256.  Deterministic (sums over the clouds in cloud order). */
+PVCNN_API int pvcnn_se_excite_fwd(const float *a_sum, const float *ax_sum, const float *gamma, const float *beta, const float *w1,
+                        const float *w2, int B, int C, int H, float inv_s, float *squeezed, float *hidden, float *excite, void *stream);
+PVCNN_API int pvcnn_se_excite_bwd(const float *p_sum, const float *q_sum, const float *a_sum, const float *ax_sum, const float *gamma,
+                        const float *beta, const float *squeezed, const float *hidden, const float *excite, const float *w1,
+                        const float *w2, int B, int C, int H, float inv_s, float *g_w1, float *g_w2, float *g_mean, float *sum_beta,
+                        float *sum_gamma, float *workspace, void *stream);
 PVCNN_API int pvcnn_bnact_partial_sums(const float *x, const float *grad_y, long grad_y_batch_stride, const float *gamma, const float *beta,
                              const float *mean, const float *rstd, int B, int C, int S, float slope, float *part, void *stream);
 PVCNN_API int pvcnn_bnact_bwd_apply(const float *x, const float *grad_y, long grad_y_batch_stride, const float *gamma, const float *beta,

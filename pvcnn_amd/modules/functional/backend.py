@@ -865,6 +865,43 @@ class HipBackend:
     # ---- the two halves of bnact_backward on their own (PVConv's SE tail puts the excitation's backward between them) ----
     has_bnact_split_bwd = True
 
+    has_se_excite = True
+
+    def se_excite_forward(self, a_sum, ax_sum, gamma, beta, w1, w2, s3):
+        """-> (squeezed (B,C), hidden (B,H), excite (B,C)): SE3d's two Linear layers + ReLU + Sigmoid on the squeeze, one launch."""
+        b, c = a_sum.shape
+        h = w1.shape[0]
+        _shape(tuple(w1.shape) == (h, c) and tuple(w2.shape) == (c, h) and c <= 2048 and h <= 256, 'se_excite: W1 (H,C), W2 (C,H), C <= 2048, H <= 256')
+        dev = a_sum.device
+        squeezed = torch.empty((b, c), dtype=torch.float32, device=dev)
+        hidden = torch.empty((b, h), dtype=torch.float32, device=dev)
+        excite = torch.empty((b, c), dtype=torch.float32, device=dev)
+        nul = ctypes.c_void_p(None)
+        with _Launch(a_sum) as s:
+            _lib.check(self.lib.pvcnn_se_excite_fwd(_p(a_sum), _p(ax_sum), _p(gamma) if gamma is not None else nul,
+                                                    _p(beta) if beta is not None else nul, _p(w1), _p(w2), b, c, h, 1.0 / float(s3),
+                                                    _p(squeezed), _p(hidden), _p(excite), s), 'se_excite_fwd')
+        return squeezed, hidden, excite
+
+    def se_excite_backward(self, p_sum, q_sum, a_sum, ax_sum, gamma, beta, squeezed, hidden, excite, w1, w2, s3):
+        """-> (g_w1 (H,C), g_w2 (C,H), g_mean (B,C), sum_beta (C), sum_gamma (C)), two launches."""
+        b, c = p_sum.shape
+        h = w1.shape[0]
+        dev = p_sum.device
+        g_w1 = torch.empty((h, c), dtype=torch.float32, device=dev)
+        g_w2 = torch.empty((c, h), dtype=torch.float32, device=dev)
+        g_mean = torch.empty((b, c), dtype=torch.float32, device=dev)
+        sum_beta = torch.empty((c,), dtype=torch.float32, device=dev)
+        sum_gamma = torch.empty((c,), dtype=torch.float32, device=dev)
+        ws = torch.empty((b * (c + h),), dtype=torch.float32, device=dev)
+        nul = ctypes.c_void_p(None)
+        with _Launch(p_sum) as s:
+            _lib.check(self.lib.pvcnn_se_excite_bwd(_p(p_sum), _p(q_sum), _p(a_sum), _p(ax_sum), _p(gamma) if gamma is not None else nul,
+                                                    _p(beta) if beta is not None else nul, _p(squeezed), _p(hidden), _p(excite), _p(w1), _p(w2),
+                                                    b, c, h, 1.0 / float(s3), _p(g_w1), _p(g_w2), _p(g_mean), _p(sum_beta), _p(sum_gamma),
+                                                    _p(ws), s), 'se_excite_bwd')
+        return g_w1, g_w2, g_mean, sum_beta, sum_gamma
+
     def bnact_partial_sums(self, x, grad_y, gamma, beta, mean, rstd, slope):
         """-> (P, Q) (B,C) each: sums over the positions of g' and g' * xhat, g' = grad_y * act'(z) (grad_y None: == 1)."""
         _f32(x, 'x')

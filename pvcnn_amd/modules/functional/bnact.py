@@ -240,12 +240,15 @@ class BatchNormActSEDevoxelize(Function):
             mean, rstd = running_mean.contiguous(), torch.rsqrt(running_var + eps)
         # squeeze from the two sums (grad_y == 1 in the reduction kernel of the BatchNorm backward)
         a_sum, ax_sum = be.bnact_partial_sums(x3, None, w, b, mean, rstd, slope)            # (B, C) each
-        gam = w if w is not None else torch.ones_like(mean)
-        bet = b if b is not None else torch.zeros_like(mean)
-        squeezed = (gam * ax_sum + bet * a_sum) / float(s3)
         w1, w2 = fc1.contiguous(), fc2.contiguous()
-        hidden = torch.relu(squeezed @ w1.t())
-        excite = torch.sigmoid(hidden @ w2.t()).contiguous()                                 # (B, C)
+        if getattr(be, 'has_se_excite', False) and nc <= 2048 and w1.shape[0] <= 256:
+            squeezed, hidden, excite = be.se_excite_forward(a_sum, ax_sum, w, b, w1, w2, s3)      # one launch (csrc/se.hip)
+        else:
+            gam = w if w is not None else torch.ones_like(mean)
+            bet = b if b is not None else torch.zeros_like(mean)
+            squeezed = (gam * ax_sum + bet * a_sum) / float(s3)
+            hidden = torch.relu(squeezed @ w1.t())
+            excite = torch.sigmoid(hidden @ w2.t()).contiguous()                             # (B, C)
         r = int(resolution)
         pts = coords.contiguous()
         add = addend.contiguous() if addend is not None else None
@@ -267,18 +270,22 @@ class BatchNormActSEDevoxelize(Function):
         nb, nc, s3 = x3.shape
         g_y = ctx.taps.backward(_rows(grad_out, grad_out.shape)).view(x3.shape)             # dL/d(act(bn(x)) * excite)
         p_sum, q_sum = be.bnact_partial_sums(x3, g_y, w, b, mean, rstd, ctx.slope)          # (B, C) each
-        gam = w if w is not None else torch.ones_like(mean)
-        bet = b if b is not None else torch.zeros_like(mean)
-        # excitation backward: s = sigmoid(relu(m W1^T) W2^T)
-        g_excite = gam * q_sum + bet * p_sum
-        g_pre2 = g_excite * excite * (1.0 - excite)
-        g_w2 = g_pre2.t() @ hidden
-        g_pre1 = (g_pre2 @ w2) * (hidden > 0).to(hidden.dtype)
-        g_w1 = g_pre1.t() @ squeezed
-        g_mean = ((g_pre1 @ w1) / float(s3)).contiguous()                                    # dL/d(squeezed) spread over the S voxels
-        # BatchNorm sums of g' = (excite * g_y + g_mean) * act'(z), from the four per-(cloud, channel) sums
-        sum_beta = (excite * p_sum + g_mean * a_sum).sum(dim=0).contiguous()
-        sum_gamma = (excite * q_sum + g_mean * ax_sum).sum(dim=0).contiguous()
+        if getattr(be, 'has_se_excite', False) and nc <= 2048 and w1.shape[0] <= 256:
+            # excitation backward + the BatchNorm sums below in two launches (csrc/se.hip)
+            g_w1, g_w2, g_mean, sum_beta, sum_gamma = be.se_excite_backward(p_sum, q_sum, a_sum, ax_sum, w, b, squeezed, hidden, excite, w1, w2, s3)
+        else:
+            gam = w if w is not None else torch.ones_like(mean)
+            bet = b if b is not None else torch.zeros_like(mean)
+            # excitation backward: s = sigmoid(relu(m W1^T) W2^T)
+            g_excite = gam * q_sum + bet * p_sum
+            g_pre2 = g_excite * excite * (1.0 - excite)
+            g_w2 = g_pre2.t() @ hidden
+            g_pre1 = (g_pre2 @ w2) * (hidden > 0).to(hidden.dtype)
+            g_w1 = g_pre1.t() @ squeezed
+            g_mean = ((g_pre1 @ w1) / float(s3)).contiguous()                                # dL/d(squeezed) spread over the S voxels
+            # BatchNorm sums of g' = (excite * g_y + g_mean) * act'(z), from the four per-(cloud, channel) sums
+            sum_beta = (excite * p_sum + g_mean * a_sum).sum(dim=0).contiguous()
+            sum_gamma = (excite * q_sum + g_mean * ax_sum).sum(dim=0).contiguous()
         seg = _amax_seg_for(ctx.shape, x3.is_cuda) or 256
         gx, amax = be.bnact_backward_apply(x3, g_y, w, b, mean, rstd, sum_gamma, sum_beta, ctx.slope, ctx.use_batch_stats,
                                            bc_mul=excite, bc_add=g_mean, amax_seg=seg)

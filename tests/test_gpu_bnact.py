@@ -202,3 +202,44 @@ def test_se_tail_fused_into_the_gather_matches_the_separate_modules(hip, r, cin,
         finally:
             type(be).has_devox_bnact = True
     assert rel(ya, yb) < 1e-5
+
+
+@pytest.mark.parametrize('b,c,h,affine', [(8, 64, 8, True), (64, 1024, 128, True), (3, 100, 12, False), (1, 2048, 256, True), (5, 16, 2, True)])
+def test_se_excitation_kernels_match_the_torch_chain(hip, b, c, h, affine):
+    """pvcnn_se_excite_fwd / _bwd (csrc/se.hip) vs the same algebra written with torch ops in fp64 (SE3d, reference modules/se.py:6-17,
+    between the sums of BatchNormActSEDevoxelize): 1e-5 of each tensor's largest entry; and run twice -> the same bits (sums in cloud order)."""
+    torch.manual_seed(5)
+    dev = 'cuda:0'
+    s3 = 4096
+    a_sum, ax_sum, p_sum, q_sum = (torch.randn(b, c, device=dev) * s3 ** 0.5 for _ in range(4))
+    gam = torch.randn(c, device=dev) if affine else None
+    bet = torch.randn(c, device=dev) if affine else None
+    w1 = torch.randn(h, c, device=dev) / c ** 0.5 * 8
+    w2 = torch.randn(c, h, device=dev) / h ** 0.5
+    sq, hd, ex = hip.se_excite_forward(a_sum, ax_sum, gam, bet, w1, w2, s3)
+    out = hip.se_excite_backward(p_sum, q_sum, a_sum, ax_sum, gam, bet, sq, hd, ex, w1, w2, s3)
+    again = hip.se_excite_backward(p_sum, q_sum, a_sum, ax_sum, gam, bet, sq, hd, ex, w1, w2, s3)
+    for x, y in zip(out, again):
+        assert torch.equal(x, y)
+    d = torch.float64
+    g = gam.to(d) if affine else torch.ones(c, device=dev, dtype=d)
+    bt = bet.to(d) if affine else torch.zeros(c, device=dev, dtype=d)
+    A, AX, P, Q, W1, W2 = (t.to(d) for t in (a_sum, ax_sum, p_sum, q_sum, w1, w2))
+    sq_r = (g * AX + bt * A) / s3
+    pre1 = sq_r @ W1.t()
+    hd_r = torch.relu(pre1)
+    ex_r = torch.sigmoid(hd_r @ W2.t())
+    g_ex = g * Q + bt * P
+    g_pre2 = g_ex * ex_r * (1 - ex_r)
+    g_w2 = g_pre2.t() @ hd_r
+    g_pre1 = (g_pre2 @ W2) * (hd.to(d) > 0)               # the kernel's own relu mask: a hidden unit at 0 +- 1 ulp may sit on either side
+    g_w1 = g_pre1.t() @ sq_r
+    g_mean = (g_pre1 @ W1) / s3
+    sb = (ex_r * P + g_mean * A).sum(0)
+    sg = (ex_r * Q + g_mean * AX).sum(0)
+
+    def rel(x, y):
+        return ((x.to(d) - y).abs().max() / y.abs().max().clamp_min(1e-300)).item()
+    assert rel(sq, sq_r) < 1e-6 and rel(hd, hd_r) < 1e-5 and rel(ex, ex_r) < 1e-5
+    for name, x, y in zip(('g_w1', 'g_w2', 'g_mean', 'sum_beta', 'sum_gamma'), out, (g_w1, g_w2, g_mean, sb, sg)):
+        assert rel(x, y) < 1e-5, (name, rel(x, y))
