@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from pvcnn_amd.modules.functional.backend import HipBackend
 be = HipBackend()
-for (b, n, m) in [(8, 8192, 1024), (8, 1024, 256), (16, 4096, 1024), (64, 2048, 512)]:
+for (b, n, m) in [(8, 8192, 1024), (8, 1024, 256), (8, 256, 64), (8, 64, 16), (16, 4096, 1024), (64, 2048, 512), (8, 16384, 1024)]:
     c = torch.rand(b, 3, n, device='cuda:0')
     for _ in range(2): be.furthest_point_sampling(c, m)
     torch.cuda.synchronize()
