@@ -149,7 +149,7 @@ def test_gather_fwd_bwd(hip, oracle, gen, b, c, n, m):
 
 
 FPS_CASES = [(2, 8192, 1024), (2, 1024, 256), (3, 256, 64), (2, 64, 16), (1, 1000, 100), (1, 5000, 50),
-             (1, 17, 17), (1, 20000, 40), (1, 700, 1)]
+             (1, 17, 17), (1, 20000, 40), (1, 700, 1), (1, 3000, 64), (2, 12000, 64), (1, 16000, 32)]   # every launch shape of fps.hip
 
 
 @pytest.mark.parametrize('b,n,m', FPS_CASES)
@@ -158,11 +158,14 @@ def test_fps(hip, oracle, gen, b, n, m):
     assert torch.equal(hip.furthest_point_sampling(pts.to(DEV), m).cpu(), oracle.furthest_point_sampling(pts, m))
 
 
-def test_fps_tie_rule_lattice(hip, oracle):
-    # integer lattice: masses of exactly equidistant candidates -> the (k mod 512, k) rule decides every step
-    g = torch.arange(12, dtype=torch.float32)
-    pts = torch.stack(torch.meshgrid(g, g, g, indexing='ij')).reshape(1, 3, -1).contiguous()   # N = 1728 > 512
-    assert torch.equal(hip.furthest_point_sampling(pts.to(DEV), 200).cpu(), oracle.furthest_point_sampling(pts, 200))
+@pytest.mark.parametrize('side,m', [(12, 200), (8, 100), (20, 150), (6, 216)])
+def test_fps_tie_rule_lattice(hip, oracle, side, m):
+    # integer lattice: masses of exactly equidistant candidates -> the (k mod 512, k) rule decides every step.  N = 1728 and 8000:
+    # ties between the lanes and waves of a 512-thread workgroup; N = 512 and 216: between the lanes of the one-wave kernel
+    # (fps.hip: these steps leave the float-maximum path for the 64-bit key reduction)
+    g = torch.arange(side, dtype=torch.float32)
+    pts = torch.stack(torch.meshgrid(g, g, g, indexing='ij')).reshape(1, 3, -1).contiguous()
+    assert torch.equal(hip.furthest_point_sampling(pts.to(DEV), m).cpu(), oracle.furthest_point_sampling(pts, m))
 
 
 @pytest.mark.parametrize('b,c,m,n', [(2, 128, 1024, 8192), (2, 256, 64, 256), (2, 512, 16, 64), (1, 7, 2, 33),
