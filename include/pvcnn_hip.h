@@ -379,16 +379,26 @@ PVCNN_API int pvcnn_bnact_bwd_strided(const float *x, const float *grad_y, long 
  *   g' = (grad_y * bc_mul[b][c] + bc_add[b][c]) * act'(z); bc_mul / bc_add (B,C) or NULL (1 / 0); sum_gamma / sum_beta (C) given by
  *   the caller; gx_amax / amax_seg as in pvcnn_bnact_bwd_strided. */
 PVCNN_API int pvcnn_bnact_slices(int S);
+/* The max over the K neighbours of a centre (modules/pointnet.py:85: `mlp(grouper(...)).max(dim=-1).values` on (B, C, M, K)) and its
+ * backward, one streaming pass each.  x: (rows, K) contiguous, 16-byte aligned, rows = B * C * M; K in {4, 8, 16, 32, 64}
+ * (pvcnn_neighbor_max_supported; other K: the caller keeps torch's reduction).  out (rows) = the maxima, winners (rows) = their k
+ * (ties: the smallest k; a NaN wins against numbers, like torch.max).  bwd: grad_x (rows, K) = grad_out at the winner, 0 elsewhere. */
+PVCNN_API int pvcnn_neighbor_max_supported(int K);
+PVCNN_API int pvcnn_neighbor_max_fwd(const float *x, long rows, int K, float *out, unsigned char *winners, void *stream);
+PVCNN_API int pvcnn_neighbor_max_bwd(const float *grad_out, const unsigned char *winners, long rows, int K, float *grad_x, void *stream);
+
 /* The excitation of SE3d (modules/se.py:6-17: Linear(C, H, bias=False) + ReLU + Linear(H, C, bias=False) + Sigmoid on the squeezed
  * (B, C) descriptor) between the two reduction passes of PVConv's fused squeeze-and-excitation tail, and its backward.
- * fwd: a_sum / ax_sum (B, C) = the sums of act'(z) and act'(z) * xhat over the grid (pvcnn_bnact_partial_sums with grad_y NULL);
- *      squeezed = (gamma * ax_sum + beta * a_sum) * inv_s, hidden = relu(squeezed W1^T) (B, H), excite = sigmoid(hidden W2^T) (B, C).
- * bwd: p_sum / q_sum (B, C) = the sums of g_y act'(z) and g_y act'(z) xhat; -> g_w1 (H, C), g_w2 (C, H), g_mean (B, C) = dL/dsqueezed
- *      * inv_s, and the BatchNorm backward's per-channel sums sum_beta / sum_gamma (C) of g' = (excite g_y + g_mean) act'(z).
- *      workspace: B * (C + H) floats.  C <= 2048, H <= 256.  Deterministic (sums over the clouds in cloud order). */
-PVCNN_API int pvcnn_se_excite_fwd(const float *a_sum, const float *ax_sum, const float *gamma, const float *beta, const float *w1,
-                        const float *w2, int B, int C, int H, float inv_s, float *squeezed, float *hidden, float *excite, void *stream);
-PVCNN_API int pvcnn_se_excite_bwd(const float *p_sum, const float *q_sum, const float *a_sum, const float *ax_sum, const float *gamma,
+ * part: (C, B, slices, 2) as pvcnn_bnact_partial_sums writes it (slices = pvcnn_bnact_slices(S)); the sums over the slices are taken here.
+ * fwd: part from grad_y == NULL -> a_sum / ax_sum (B, C) = the sums of act'(z) and act'(z) * xhat over the grid (outputs, kept for the
+ *      backward); squeezed = (gamma * ax_sum + beta * a_sum) * inv_s, hidden = relu(squeezed W1^T) (B, H), excite = sigmoid(hidden W2^T) (B, C).
+ * bwd: part from grad_y = g_y -> P / Q = the sums of g_y act'(z) and g_y act'(z) xhat; -> g_w1 (H, C), g_w2 (C, H), g_mean (B, C) =
+ *      dL/dsqueezed * inv_s, and the BatchNorm backward's per-channel sums sum_beta / sum_gamma (C) of g' = (excite g_y + g_mean) act'(z).
+ *      workspace: B * (3 C + H) floats.  C <= 2048, H <= 256.  Deterministic (sums over slices and clouds in index order). */
+PVCNN_API int pvcnn_se_excite_fwd(const float *part, int slices, const float *gamma, const float *beta, const float *w1, const float *w2,
+                        int B, int C, int H, float inv_s, float *a_sum, float *ax_sum, float *squeezed, float *hidden, float *excite,
+                        void *stream);
+PVCNN_API int pvcnn_se_excite_bwd(const float *part, int slices, const float *a_sum, const float *ax_sum, const float *gamma,
                         const float *beta, const float *squeezed, const float *hidden, const float *excite, const float *w1,
                         const float *w2, int B, int C, int H, float inv_s, float *g_w1, float *g_w2, float *g_mean, float *sum_beta,
                         float *sum_gamma, float *workspace, void *stream);

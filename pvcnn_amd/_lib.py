@@ -18,7 +18,7 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 LIB_PATH = os.path.join(_CSRC, 'libpvcnn_hip.so')
 ABI_VERSION = 7
 
-_vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+_vp, _i, _f, _sz, _l = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_long
 
 # name -> (restype, argtypes); mirrors include/pvcnn_hip.h one to one
 SIGNATURES = {
@@ -87,8 +87,11 @@ SIGNATURES = {
     'pvcnn_bn_stats': (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp, _sz, _vp]),
     'pvcnn_trilinear_devox_bnact_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     'pvcnn_bnact_slices': (_i, [_i]),
-    'pvcnn_se_excite_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
-    'pvcnn_se_excite_bwd': (_i, [_vp] * 11 + [_i, _i, _i, _f] + [_vp] * 7),
+    'pvcnn_neighbor_max_supported': (_i, [_i]),
+    'pvcnn_neighbor_max_fwd': (_i, [_vp, _l, _i, _vp, _vp, _vp]),
+    'pvcnn_neighbor_max_bwd': (_i, [_vp, _vp, _l, _i, _vp, _vp]),
+    'pvcnn_se_excite_fwd': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'pvcnn_se_excite_bwd': (_i, [_vp, _i] + [_vp] * 9 + [_i, _i, _i, _f] + [_vp] * 7),
     'pvcnn_bnact_partial_sums': (_i, [_vp, _vp, ctypes.c_long, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp]),
     'pvcnn_bnact_bwd_apply': (_i, [_vp, _vp, ctypes.c_long, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _i, _vp]),
     'pvcnn_bnact_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -7,7 +7,9 @@
 // and its backward.  These are (B, C) x (C, H) products with B = 8..64, C <= 1024: as torch ops they were ~9 launches forward and
 // ~28 backward per squeeze-and-excitation block, 4.8 us each -- 2.3 of PVCNN++'s 16 ms step, 0.8 of ShapeNet-PVCNN's 5 ms.  Here:
 // one launch forward (a workgroup per cloud), two backward (per cloud: the chain through the two layers; per 64 channels: the sums
-// over the clouds -- weight gradients and the two BatchNorm sums -- in cloud order: deterministic).
+// over the clouds -- weight gradients and the two BatchNorm sums -- in cloud order: deterministic).  The inputs are the reduction
+// pass's partial sums as it writes them, `part` (C, B, slices, 2) (pvcnn_bnact_partial_sums): the sum over the slices happens here,
+// in slice order (as torch ops: a sum + two transposing copies per pass, 78 more launches per PVCNN++ step).
 #include "common.h"
 
 namespace pvcnn {
@@ -20,8 +22,17 @@ __device__ __forceinline__ float se_wave_sum(float v) {
   return v;
 }
 
+// (first, second) sums of channel c, cloud b over the slices of the reduction pass
+__device__ __forceinline__ float2 se_slice_sum(const float2 *__restrict__ part, int B, int slices, int b, int c) {
+  const float2 *p = part + ((size_t)c * B + b) * slices;
+  float2 t = p[0];
+  for (int s = 1; s < slices; ++s) { t.x += p[s].x; t.y += p[s].y; }
+  return t;
+}
+
 // grid = B, block = 256
-__global__ __launch_bounds__(256) void se_excite_fwd_kernel(const float *__restrict__ a_sum, const float *__restrict__ ax_sum,
+__global__ __launch_bounds__(256) void se_excite_fwd_kernel(const float2 *__restrict__ part, int B, int slices,
+                                                            float *__restrict__ a_sum, float *__restrict__ ax_sum,
                                                             const float *__restrict__ gamma, const float *__restrict__ beta,
                                                             const float *__restrict__ w1, const float *__restrict__ w2, int C, int H,
                                                             float inv_s, float *__restrict__ squeezed, float *__restrict__ hidden,
@@ -30,7 +41,10 @@ __global__ __launch_bounds__(256) void se_excite_fwd_kernel(const float *__restr
   const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   for (int c = tid; c < C; c += 256) {
     const float g = gamma ? gamma[c] : 1.0f, bt = beta ? beta[c] : 0.0f;
-    const float v = (g * ax_sum[(size_t)b * C + c] + bt * a_sum[(size_t)b * C + c]) * inv_s;
+    const float2 t = se_slice_sum(part, B, slices, b, c);
+    a_sum[(size_t)b * C + c] = t.x;
+    ax_sum[(size_t)b * C + c] = t.y;
+    const float v = (g * t.y + bt * t.x) * inv_s;
     sq[c] = v;
     squeezed[(size_t)b * C + c] = v;
   }
@@ -52,7 +66,8 @@ __global__ __launch_bounds__(256) void se_excite_fwd_kernel(const float *__restr
 
 // backward, per cloud (grid = B): g_excite = gamma * Q + beta * P;  g_pre2 = g_excite * e (1 - e);  g_pre1 = (g_pre2 W2) * [hidden > 0];
 // g_mean = g_pre1 W1 / S  (the gradient of the squeeze, spread over the S voxels).  g_pre2 / g_pre1 go to `ws` for the second launch.
-__global__ __launch_bounds__(256) void se_excite_bwd_chain_kernel(const float *__restrict__ p_sum, const float *__restrict__ q_sum,
+__global__ __launch_bounds__(256) void se_excite_bwd_chain_kernel(const float2 *__restrict__ part, int B, int slices,
+                                                                  float *__restrict__ p_sum, float *__restrict__ q_sum,
                                                                   const float *__restrict__ gamma, const float *__restrict__ beta,
                                                                   const float *__restrict__ hidden, const float *__restrict__ excite,
                                                                   const float *__restrict__ w1, const float *__restrict__ w2, int C, int H,
@@ -62,7 +77,10 @@ __global__ __launch_bounds__(256) void se_excite_bwd_chain_kernel(const float *_
   const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   for (int c = tid; c < C; c += 256) {
     const float g = gamma ? gamma[c] : 1.0f, bt = beta ? beta[c] : 0.0f, e = excite[(size_t)b * C + c];
-    const float v = (g * q_sum[(size_t)b * C + c] + bt * p_sum[(size_t)b * C + c]) * e * (1.0f - e);
+    const float2 t = se_slice_sum(part, B, slices, b, c);                 // P = sum g_y act', Q = sum g_y act' xhat
+    p_sum[(size_t)b * C + c] = t.x;
+    q_sum[(size_t)b * C + c] = t.y;
+    const float v = (g * t.y + bt * t.x) * e * (1.0f - e);
     gp2[c] = v;
     g_pre2[(size_t)b * C + c] = v;
   }
@@ -120,27 +138,29 @@ __global__ __launch_bounds__(256) void se_excite_bwd_sums_kernel(const float *__
 
 using namespace pvcnn;
 
-extern "C" int pvcnn_se_excite_fwd(const float *a_sum, const float *ax_sum, const float *gamma, const float *beta, const float *w1,
-                                   const float *w2, int B, int C, int H, float inv_s, float *squeezed, float *hidden, float *excite,
-                                   void *stream) {
-  PVCNN_REQUIRE(B > 0 && C > 0 && H > 0 && C <= kSeMaxC && H <= kSeMaxH, "bad size (C <= 2048, H <= 256)");
-  PVCNN_REQUIRE(a_sum && ax_sum && w1 && w2 && squeezed && hidden && excite, "null pointer");
-  hipLaunchKernelGGL(se_excite_fwd_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), a_sum, ax_sum, gamma, beta, w1, w2, C, H,
-                     inv_s, squeezed, hidden, excite);
+extern "C" int pvcnn_se_excite_fwd(const float *part, int slices, const float *gamma, const float *beta, const float *w1, const float *w2,
+                                   int B, int C, int H, float inv_s, float *a_sum, float *ax_sum, float *squeezed, float *hidden,
+                                   float *excite, void *stream) {
+  PVCNN_REQUIRE(B > 0 && C > 0 && H > 0 && slices > 0 && C <= kSeMaxC && H <= kSeMaxH, "bad size (C <= 2048, H <= 256)");
+  PVCNN_REQUIRE(part && a_sum && ax_sum && w1 && w2 && squeezed && hidden && excite, "null pointer");
+  PVCNN_REQUIRE((reinterpret_cast<uintptr_t>(part) & 7) == 0, "part must be 8-byte aligned");
+  hipLaunchKernelGGL(se_excite_fwd_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), reinterpret_cast<const float2 *>(part), B,
+                     slices, a_sum, ax_sum, gamma, beta, w1, w2, C, H, inv_s, squeezed, hidden, excite);
   return check_launch("se_excite_fwd");
 }
 
-extern "C" int pvcnn_se_excite_bwd(const float *p_sum, const float *q_sum, const float *a_sum, const float *ax_sum, const float *gamma,
+extern "C" int pvcnn_se_excite_bwd(const float *part, int slices, const float *a_sum, const float *ax_sum, const float *gamma,
                                    const float *beta, const float *squeezed, const float *hidden, const float *excite, const float *w1,
                                    const float *w2, int B, int C, int H, float inv_s, float *g_w1, float *g_w2, float *g_mean,
-                                   float *sum_beta, float *sum_gamma, float *workspace /* B * (C + H) floats */, void *stream) {
-  PVCNN_REQUIRE(B > 0 && C > 0 && H > 0 && C <= kSeMaxC && H <= kSeMaxH, "bad size (C <= 2048, H <= 256)");
-  PVCNN_REQUIRE(p_sum && q_sum && a_sum && ax_sum && squeezed && hidden && excite && w1 && w2 && g_w1 && g_w2 && g_mean && sum_beta &&
-                    sum_gamma && workspace, "null pointer");
+                                   float *sum_beta, float *sum_gamma, float *workspace /* B * (3 C + H) floats */, void *stream) {
+  PVCNN_REQUIRE(B > 0 && C > 0 && H > 0 && slices > 0 && C <= kSeMaxC && H <= kSeMaxH, "bad size (C <= 2048, H <= 256)");
+  PVCNN_REQUIRE(part && a_sum && ax_sum && squeezed && hidden && excite && w1 && w2 && g_w1 && g_w2 && g_mean && sum_beta && sum_gamma &&
+                    workspace, "null pointer");
+  PVCNN_REQUIRE((reinterpret_cast<uintptr_t>(part) & 7) == 0, "part must be 8-byte aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  float *g_pre2 = workspace, *g_pre1 = workspace + (size_t)B * C;
-  hipLaunchKernelGGL(se_excite_bwd_chain_kernel, dim3(B), dim3(256), 0, s, p_sum, q_sum, gamma, beta, hidden, excite, w1, w2, C, H, inv_s,
-                     g_pre2, g_pre1, g_mean);
+  float *g_pre2 = workspace, *p_sum = workspace + (size_t)B * C, *q_sum = workspace + (size_t)2 * B * C, *g_pre1 = workspace + (size_t)3 * B * C;
+  hipLaunchKernelGGL(se_excite_bwd_chain_kernel, dim3(B), dim3(256), 0, s, reinterpret_cast<const float2 *>(part), B, slices, p_sum, q_sum, gamma,
+                     beta, hidden, excite, w1, w2, C, H, inv_s, g_pre2, g_pre1, g_mean);
   if (int e = check_launch("se_excite_bwd_chain")) return e;
   hipLaunchKernelGGL(se_excite_bwd_sums_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, s, p_sum, q_sum, a_sum, ax_sum, squeezed, hidden, excite,
                      g_pre2, g_pre1, g_mean, B, C, H, g_w1, g_w2, sum_beta, sum_gamma);

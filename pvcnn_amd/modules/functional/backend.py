@@ -73,6 +73,19 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None and t.numel() > 0 else ctypes.c_void_p(None)
 
 
+_DUMMIES = {}
+
+
+def _dummies(dev):
+    """The 1-element (inds, wgts) the devoxelize forward returns when it does not emit them (trilinear_devox.cpp:45-53): one zeroed
+    pair per device, made once -- a training step asks for them once per PVConv layer behind the first of a resolution (two fill
+    launches each)."""
+    key = (dev.type, dev.index)
+    if key not in _DUMMIES:
+        _DUMMIES[key] = (torch.zeros((1,), dtype=torch.int32, device=dev), torch.zeros((1,), dtype=torch.float32, device=dev))
+    return _DUMMIES[key]
+
+
 class _Launch:
     """Device guard + current stream of the tensor's device for one native call."""
 
@@ -252,8 +265,7 @@ class HipBackend:
             inds = torch.empty((b, 8, n), dtype=torch.int32, device=dev)
             wgts = torch.empty((b, 8, n), dtype=torch.float32, device=dev)
         else:   # 1-element dummies, like trilinear_devox.cpp:45-53
-            inds = torch.zeros((1,), dtype=torch.int32, device=dev)
-            wgts = torch.zeros((1,), dtype=torch.float32, device=dev)
+            inds, wgts = _dummies(dev)
         with _Launch(features) as s:
             _lib.check(self.lib.pvcnn_trilinear_devox_fwd(_p(coords), _p(features), b, c, n, r, int(bool(is_training)),
                                                           _p(inds) if is_training else None,
@@ -821,8 +833,7 @@ class HipBackend:
             inds = torch.empty((b, 8, n), dtype=torch.int32, device=dev)
             wgts = torch.empty((b, 8, n), dtype=torch.float32, device=dev)
         else:
-            inds = torch.zeros((1,), dtype=torch.int32, device=dev)
-            wgts = torch.zeros((1,), dtype=torch.float32, device=dev)
+            inds, wgts = _dummies(dev)
         nul = ctypes.c_void_p(None)
         with _Launch(features) as s:
             _lib.check(self.lib.pvcnn_trilinear_devox_bnact_fwd(
@@ -865,45 +876,72 @@ class HipBackend:
     # ---- the two halves of bnact_backward on their own (PVConv's SE tail puts the excitation's backward between them) ----
     has_bnact_split_bwd = True
 
+    # ---- max over the neighbours of a centre (modules/pointnet.py:85) ------------------------------------------------
+    has_neighbor_max = True
+
+    def neighbor_max_supported(self, k):
+        return bool(self.lib.pvcnn_neighbor_max_supported(int(k)))
+
+    def neighbor_max_forward(self, x):
+        """x (..., K) contiguous -> (max over K (...), winners (...) uint8)."""
+        _f32(x, 'x')
+        k = x.shape[-1]
+        rows = x.numel() // k
+        out = torch.empty(x.shape[:-1], dtype=torch.float32, device=x.device)
+        winners = torch.empty(x.shape[:-1], dtype=torch.uint8, device=x.device)
+        with _Launch(x) as s:
+            _lib.check(self.lib.pvcnn_neighbor_max_fwd(_p(x), rows, k, _p(out), _p(winners), s), 'neighbor_max_forward')
+        return out, winners
+
+    def neighbor_max_backward(self, grad_out, winners, k):
+        """-> grad_x (..., K): grad_out at the winner, zeros elsewhere (one write pass)."""
+        _f32(grad_out, 'grad_out')
+        _shape(grad_out.shape == winners.shape and winners.dtype == torch.uint8 and winners.is_contiguous(), 'neighbor_max: winners (...) uint8 expected')
+        gx = torch.empty(tuple(grad_out.shape) + (int(k),), dtype=torch.float32, device=grad_out.device)
+        with _Launch(grad_out) as s:
+            _lib.check(self.lib.pvcnn_neighbor_max_bwd(_p(grad_out), _p(winners), grad_out.numel(), int(k), _p(gx), s), 'neighbor_max_backward')
+        return gx
+
     has_se_excite = True
 
-    def se_excite_forward(self, a_sum, ax_sum, gamma, beta, w1, w2, s3):
-        """-> (squeezed (B,C), hidden (B,H), excite (B,C)): SE3d's two Linear layers + ReLU + Sigmoid on the squeeze, one launch."""
-        b, c = a_sum.shape
+    def se_excite_forward(self, part, gamma, beta, w1, w2, s3):
+        """part (C,B,slices,2) from bnact_partial_sums_raw(grad_y=None) -> (a_sum (B,C), ax_sum (B,C), squeezed (B,C), hidden (B,H),
+        excite (B,C)): the slice sums + SE3d's two Linear layers + ReLU + Sigmoid on the squeeze, one launch."""
+        c, b, slices, _ = part.shape
         h = w1.shape[0]
         _shape(tuple(w1.shape) == (h, c) and tuple(w2.shape) == (c, h) and c <= 2048 and h <= 256, 'se_excite: W1 (H,C), W2 (C,H), C <= 2048, H <= 256')
-        dev = a_sum.device
-        squeezed = torch.empty((b, c), dtype=torch.float32, device=dev)
+        dev = part.device
+        a_sum, ax_sum, squeezed, excite = (torch.empty((b, c), dtype=torch.float32, device=dev) for _ in range(4))
         hidden = torch.empty((b, h), dtype=torch.float32, device=dev)
-        excite = torch.empty((b, c), dtype=torch.float32, device=dev)
         nul = ctypes.c_void_p(None)
-        with _Launch(a_sum) as s:
-            _lib.check(self.lib.pvcnn_se_excite_fwd(_p(a_sum), _p(ax_sum), _p(gamma) if gamma is not None else nul,
-                                                    _p(beta) if beta is not None else nul, _p(w1), _p(w2), b, c, h, 1.0 / float(s3),
-                                                    _p(squeezed), _p(hidden), _p(excite), s), 'se_excite_fwd')
-        return squeezed, hidden, excite
+        with _Launch(part) as s:
+            _lib.check(self.lib.pvcnn_se_excite_fwd(_p(part), slices, _p(gamma) if gamma is not None else nul, _p(beta) if beta is not None else nul,
+                                                    _p(w1), _p(w2), b, c, h, 1.0 / float(s3), _p(a_sum), _p(ax_sum), _p(squeezed), _p(hidden),
+                                                    _p(excite), s), 'se_excite_fwd')
+        return a_sum, ax_sum, squeezed, hidden, excite
 
-    def se_excite_backward(self, p_sum, q_sum, a_sum, ax_sum, gamma, beta, squeezed, hidden, excite, w1, w2, s3):
-        """-> (g_w1 (H,C), g_w2 (C,H), g_mean (B,C), sum_beta (C), sum_gamma (C)), two launches."""
-        b, c = p_sum.shape
+    def se_excite_backward(self, part, a_sum, ax_sum, gamma, beta, squeezed, hidden, excite, w1, w2, s3):
+        """part (C,B,slices,2) from bnact_partial_sums_raw(grad_y) -> (g_w1 (H,C), g_w2 (C,H), g_mean (B,C), sum_beta (C), sum_gamma (C)),
+        two launches."""
+        c, b, slices, _ = part.shape
         h = w1.shape[0]
-        dev = p_sum.device
+        dev = part.device
         g_w1 = torch.empty((h, c), dtype=torch.float32, device=dev)
         g_w2 = torch.empty((c, h), dtype=torch.float32, device=dev)
         g_mean = torch.empty((b, c), dtype=torch.float32, device=dev)
         sum_beta = torch.empty((c,), dtype=torch.float32, device=dev)
         sum_gamma = torch.empty((c,), dtype=torch.float32, device=dev)
-        ws = torch.empty((b * (c + h),), dtype=torch.float32, device=dev)
+        ws = torch.empty((b * (3 * c + h),), dtype=torch.float32, device=dev)
         nul = ctypes.c_void_p(None)
-        with _Launch(p_sum) as s:
-            _lib.check(self.lib.pvcnn_se_excite_bwd(_p(p_sum), _p(q_sum), _p(a_sum), _p(ax_sum), _p(gamma) if gamma is not None else nul,
+        with _Launch(part) as s:
+            _lib.check(self.lib.pvcnn_se_excite_bwd(_p(part), slices, _p(a_sum), _p(ax_sum), _p(gamma) if gamma is not None else nul,
                                                     _p(beta) if beta is not None else nul, _p(squeezed), _p(hidden), _p(excite), _p(w1), _p(w2),
                                                     b, c, h, 1.0 / float(s3), _p(g_w1), _p(g_w2), _p(g_mean), _p(sum_beta), _p(sum_gamma),
                                                     _p(ws), s), 'se_excite_bwd')
         return g_w1, g_w2, g_mean, sum_beta, sum_gamma
 
-    def bnact_partial_sums(self, x, grad_y, gamma, beta, mean, rstd, slope):
-        """-> (P, Q) (B,C) each: sums over the positions of g' and g' * xhat, g' = grad_y * act'(z) (grad_y None: == 1)."""
+    def bnact_partial_sums_raw(self, x, grad_y, gamma, beta, mean, rstd, slope):
+        """-> part (C,B,slices,2): per slice of positions the sums of g' and g' * xhat, g' = grad_y * act'(z) (grad_y None: == 1)."""
         _f32(x, 'x')
         b, c, s3 = x.shape
         gy_bstride = _f32_rows(grad_y, 'grad_y') if grad_y is not None else c * s3
@@ -914,7 +952,11 @@ class HipBackend:
             _lib.check(self.lib.pvcnn_bnact_partial_sums(_p(x), _p(grad_y) if grad_y is not None else nul, gy_bstride,
                                                          _p(gamma) if gamma is not None else nul, _p(beta) if beta is not None else nul,
                                                          _p(mean), _p(rstd), b, c, s3, float(slope), _p(part), s), 'bnact_partial_sums')
-        sums = part.sum(dim=2)                                   # (C, B, 2): a few hundred values per channel at most
+        return part
+
+    def bnact_partial_sums(self, x, grad_y, gamma, beta, mean, rstd, slope):
+        """-> (P, Q) (B,C) each: sums over the positions of g' and g' * xhat, g' = grad_y * act'(z) (grad_y None: == 1)."""
+        sums = self.bnact_partial_sums_raw(x, grad_y, gamma, beta, mean, rstd, slope).sum(dim=2)   # (C, B, 2)
         return sums[..., 0].t().contiguous(), sums[..., 1].t().contiguous()
 
     def bnact_backward_apply(self, x, grad_y, gamma, beta, mean, rstd, sum_gamma, sum_beta, slope, training, bc_mul=None, bc_add=None,

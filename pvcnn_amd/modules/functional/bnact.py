@@ -239,11 +239,13 @@ class BatchNormActSEDevoxelize(Function):
         else:
             mean, rstd = running_mean.contiguous(), torch.rsqrt(running_var + eps)
         # squeeze from the two sums (grad_y == 1 in the reduction kernel of the BatchNorm backward)
-        a_sum, ax_sum = be.bnact_partial_sums(x3, None, w, b, mean, rstd, slope)            # (B, C) each
         w1, w2 = fc1.contiguous(), fc2.contiguous()
-        if getattr(be, 'has_se_excite', False) and nc <= 2048 and w1.shape[0] <= 256:
-            squeezed, hidden, excite = be.se_excite_forward(a_sum, ax_sum, w, b, w1, w2, s3)      # one launch (csrc/se.hip)
+        fused_se = getattr(be, 'has_se_excite', False) and nc <= 2048 and w1.shape[0] <= 256
+        if fused_se:     # the slice sums of the pass + the excitation: one launch (csrc/se.hip)
+            part = be.bnact_partial_sums_raw(x3, None, w, b, mean, rstd, slope)
+            a_sum, ax_sum, squeezed, hidden, excite = be.se_excite_forward(part, w, b, w1, w2, s3)
         else:
+            a_sum, ax_sum = be.bnact_partial_sums(x3, None, w, b, mean, rstd, slope)        # (B, C) each
             gam = w if w is not None else torch.ones_like(mean)
             bet = b if b is not None else torch.zeros_like(mean)
             squeezed = (gam * ax_sum + bet * a_sum) / float(s3)
@@ -269,11 +271,12 @@ class BatchNormActSEDevoxelize(Function):
         x3, w, b, mean, rstd, a_sum, ax_sum, squeezed, hidden, excite, w1, w2, _, _ = ctx.saved_tensors
         nb, nc, s3 = x3.shape
         g_y = ctx.taps.backward(_rows(grad_out, grad_out.shape)).view(x3.shape)             # dL/d(act(bn(x)) * excite)
-        p_sum, q_sum = be.bnact_partial_sums(x3, g_y, w, b, mean, rstd, ctx.slope)          # (B, C) each
         if getattr(be, 'has_se_excite', False) and nc <= 2048 and w1.shape[0] <= 256:
-            # excitation backward + the BatchNorm sums below in two launches (csrc/se.hip)
-            g_w1, g_w2, g_mean, sum_beta, sum_gamma = be.se_excite_backward(p_sum, q_sum, a_sum, ax_sum, w, b, squeezed, hidden, excite, w1, w2, s3)
+            # the slice sums P, Q + the excitation backward + the BatchNorm sums below in two launches (csrc/se.hip)
+            part = be.bnact_partial_sums_raw(x3, g_y, w, b, mean, rstd, ctx.slope)
+            g_w1, g_w2, g_mean, sum_beta, sum_gamma = be.se_excite_backward(part, a_sum, ax_sum, w, b, squeezed, hidden, excite, w1, w2, s3)
         else:
+            p_sum, q_sum = be.bnact_partial_sums(x3, g_y, w, b, mean, rstd, ctx.slope)      # (B, C) each
             gam = w if w is not None else torch.ones_like(mean)
             bet = b if b is not None else torch.zeros_like(mean)
             # excitation backward: s = sigmoid(relu(m W1^T) W2^T)

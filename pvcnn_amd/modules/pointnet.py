@@ -11,6 +11,7 @@ import torch.nn as nn
 
 from . import functional as F
 from .ball_query import BallQuery
+from .functional.pooling import neighbor_max
 from .shared_mlp import SharedMLP
 
 __all__ = ['PointNetAModule', 'PointNetSAModule', 'PointNetFPModule']
@@ -64,7 +65,8 @@ class PointNetSAModule(nn.Module):
     def forward(self, inputs):
         features, coords = inputs
         centers = F.furthest_point_sample(coords, self.num_centers)
-        pooled = [mlp(grouper(coords, centers, features)).max(dim=-1).values
+        # (the max over the neighbours: one streaming pass each way on the GPU, csrc/pool.hip; elsewhere torch.max itself)
+        pooled = [neighbor_max(mlp(grouper(coords, centers, features)))
                   for grouper, mlp in zip(self.groupers, self.mlps)]
         return (torch.cat(pooled, dim=1) if len(pooled) > 1 else pooled[0]), centers
 

@@ -204,27 +204,31 @@ def test_se_tail_fused_into_the_gather_matches_the_separate_modules(hip, r, cin,
     assert rel(ya, yb) < 1e-5
 
 
-@pytest.mark.parametrize('b,c,h,affine', [(8, 64, 8, True), (64, 1024, 128, True), (3, 100, 12, False), (1, 2048, 256, True), (5, 16, 2, True)])
-def test_se_excitation_kernels_match_the_torch_chain(hip, b, c, h, affine):
+@pytest.mark.parametrize('b,c,h,slices,affine', [(8, 64, 8, 8, True), (64, 1024, 128, 1, True), (3, 100, 12, 3, False), (1, 2048, 256, 2, True), (5, 16, 2, 1, True)])
+def test_se_excitation_kernels_match_the_torch_chain(hip, b, c, h, slices, affine):
     """pvcnn_se_excite_fwd / _bwd (csrc/se.hip) vs the same algebra written with torch ops in fp64 (SE3d, reference modules/se.py:6-17,
-    between the sums of BatchNormActSEDevoxelize): 1e-5 of each tensor's largest entry; and run twice -> the same bits (sums in cloud order)."""
+    between the sums of BatchNormActSEDevoxelize), from the reduction pass's partial sums (C, B, slices, 2): 1e-5 of each tensor's
+    largest entry; and run twice -> the same bits (sums in slice and cloud order)."""
     torch.manual_seed(5)
     dev = 'cuda:0'
     s3 = 4096
-    a_sum, ax_sum, p_sum, q_sum = (torch.randn(b, c, device=dev) * s3 ** 0.5 for _ in range(4))
+    part_a = torch.randn(c, b, slices, 2, device=dev) * (s3 / slices) ** 0.5
+    part_p = torch.randn(c, b, slices, 2, device=dev) * (s3 / slices) ** 0.5
     gam = torch.randn(c, device=dev) if affine else None
     bet = torch.randn(c, device=dev) if affine else None
     w1 = torch.randn(h, c, device=dev) / c ** 0.5 * 8
     w2 = torch.randn(c, h, device=dev) / h ** 0.5
-    sq, hd, ex = hip.se_excite_forward(a_sum, ax_sum, gam, bet, w1, w2, s3)
-    out = hip.se_excite_backward(p_sum, q_sum, a_sum, ax_sum, gam, bet, sq, hd, ex, w1, w2, s3)
-    again = hip.se_excite_backward(p_sum, q_sum, a_sum, ax_sum, gam, bet, sq, hd, ex, w1, w2, s3)
+    a_sum, ax_sum, sq, hd, ex = hip.se_excite_forward(part_a, gam, bet, w1, w2, s3)
+    out = hip.se_excite_backward(part_p, a_sum, ax_sum, gam, bet, sq, hd, ex, w1, w2, s3)
+    again = hip.se_excite_backward(part_p, a_sum, ax_sum, gam, bet, sq, hd, ex, w1, w2, s3)
     for x, y in zip(out, again):
         assert torch.equal(x, y)
     d = torch.float64
     g = gam.to(d) if affine else torch.ones(c, device=dev, dtype=d)
     bt = bet.to(d) if affine else torch.zeros(c, device=dev, dtype=d)
-    A, AX, P, Q, W1, W2 = (t.to(d) for t in (a_sum, ax_sum, p_sum, q_sum, w1, w2))
+    sa, sp = part_a.to(d).sum(2), part_p.to(d).sum(2)                      # (C, B, 2)
+    A, AX, P, Q = sa[..., 0].t(), sa[..., 1].t(), sp[..., 0].t(), sp[..., 1].t()
+    W1, W2 = w1.to(d), w2.to(d)
     sq_r = (g * AX + bt * A) / s3
     pre1 = sq_r @ W1.t()
     hd_r = torch.relu(pre1)
@@ -240,6 +244,7 @@ def test_se_excitation_kernels_match_the_torch_chain(hip, b, c, h, affine):
 
     def rel(x, y):
         return ((x.to(d) - y).abs().max() / y.abs().max().clamp_min(1e-300)).item()
+    assert rel(a_sum, A) < 1e-6 and rel(ax_sum, AX) < 1e-6
     assert rel(sq, sq_r) < 1e-6 and rel(hd, hd_r) < 1e-5 and rel(ex, ex_r) < 1e-5
     for name, x, y in zip(('g_w1', 'g_w2', 'g_mean', 'sum_beta', 'sum_gamma'), out, (g_w1, g_w2, g_mean, sb, sg)):
         assert rel(x, y) < 1e-5, (name, rel(x, y))

@@ -184,6 +184,31 @@ def test_three_nn_interpolate(hip, oracle, gen, b, c, m, n):
                        oracle.three_nearest_neighbors_interpolate_backward(g, o_idx, o_w, m))
 
 
+@pytest.mark.parametrize('shape', [(8, 64, 1024, 32), (2, 5, 33, 32), (1, 3, 7, 4), (2, 4, 9, 8), (3, 2, 5, 16), (1, 2, 3, 64)])
+def test_neighbor_max_is_torch_max(hip, gen, shape):
+    """csrc/pool.hip vs `x.max(dim=-1)` of torch on the same device (modules/pointnet.py:85 of the reference): values and winners
+    bit-identical -- on ReLU outputs, i.e. with rows that are all zeros and rows with several equal maxima (first index wins) --
+    and the backward equal to torch's fill + scatter."""
+    from pvcnn_amd.modules.functional.pooling import neighbor_max
+    x = torch.relu(torch.randn(*shape, generator=gen)).mul(4).round().div(4).to(DEV)        # coarse values: many ties
+    x[0, 0, 0, :] = 0.0
+    out, winners = hip.neighbor_max_forward(x)
+    ref = x.max(dim=-1)
+    assert torch.equal(out, ref.values)
+    assert torch.equal(winners.long(), ref.indices)
+    g = torch.randn(shape[:-1], generator=gen).to(DEV)
+    want = torch.zeros_like(x).scatter_(-1, ref.indices.unsqueeze(-1), g.unsqueeze(-1))
+    assert torch.equal(hip.neighbor_max_backward(g, winners, shape[-1]), want)
+    xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+    (neighbor_max(xa) * g).sum().backward()
+    (xb.max(dim=-1).values * g).sum().backward()
+    assert torch.equal(xa.grad, xb.grad)
+    x[-1, -1, -1, 1] = float('nan')                                                         # a NaN wins, like torch.max
+    assert torch.isnan(hip.neighbor_max_forward(x)[0][-1, -1, -1]) and hip.neighbor_max_forward(x)[1][-1, -1, -1].item() == 1
+    odd = torch.randn(2, 3, 5, 12, generator=gen).to(DEV)                                   # K = 12: not covered -> torch.max itself
+    assert not hip.neighbor_max_supported(12) and torch.equal(neighbor_max(odd), odd.max(dim=-1).values)
+
+
 def test_empty_inputs(hip):
     z = torch.zeros
     assert hip.avg_voxelize_forward(z(0, 4, 16, device=DEV), z(0, 3, 16, dtype=torch.int32, device=DEV), 4)[0].shape == (0, 4, 64)
