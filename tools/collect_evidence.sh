@@ -24,6 +24,7 @@ python $R/tools/make_pmc_traffic.py $O > $O/pmc_traffic.json
 (cd $R && python tools/opbench.py 2>/dev/null | grep median > $O/opbench.jsonl; python tools/opbench.py --kind surface 2>/dev/null | grep median >> $O/opbench.jsonl
  python tools/convcheck.py --time --no-check --shapes 16x9x64x32,16x64x64x32,16x64x64x16,16x64x128x16,16x128x128x16,32x64x64x12,32x64x64x16,32x64x128x12 2>/dev/null | grep "time_\|absmax" > $O/convbench.jsonl
  python tools/pwbench.py 2>/dev/null | grep "^{" > $O/pwbench.jsonl
+ python tools/fpsbench.py 2>/dev/null | grep "^{" > $O/fpsbench.jsonl
  PVCNN_CONV_MATH=fp32 PVCNN_PW_MATH=fp32 timeout 300 python bench.py --no-cpu-baseline --steps 40 --warmup 10 2>/dev/null | tail -1 > $O/bench_fp32_mfma.json
  timeout 300 python bench.py --no-cpu-baseline --torch-adam --steps 40 --warmup 10 2>/dev/null | tail -1 > $O/bench_torch_adam.json
  timeout 120 python tools/step_profile.py --rows 70 > $O/step_profile.txt 2>/dev/null)
