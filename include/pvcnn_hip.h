@@ -387,6 +387,11 @@ PVCNN_API int pvcnn_neighbor_max_supported(int K);
 PVCNN_API int pvcnn_neighbor_max_fwd(const float *x, long rows, int K, float *out, unsigned char *winners, void *stream);
 PVCNN_API int pvcnn_neighbor_max_bwd(const float *grad_out, const unsigned char *winners, long rows, int K, float *grad_x, void *stream);
 
+/* arg-max over long rows: the global max-pool over the points of a cloud (models/s3dis/pvcnn.py:41-43, `features.max(dim=-1)` on
+ * (B, C, N)).  x: (rows, K) contiguous, 16-byte aligned, K % 4 == 0; winners (rows) int64 = the first index of the row maximum (a NaN
+ * wins against numbers), values (rows) = the maxima or NULL. */
+PVCNN_API int pvcnn_row_argmax(const float *x, long rows, int K, long long *winners, float *values, void *stream);
+
 /* The excitation of SE3d (modules/se.py:6-17: Linear(C, H, bias=False) + ReLU + Linear(H, C, bias=False) + Sigmoid on the squeezed
  * (B, C) descriptor) between the two reduction passes of PVConv's fused squeeze-and-excitation tail, and its backward.
  * part: (C, B, slices, 2) as pvcnn_bnact_partial_sums writes it (slices = pvcnn_bnact_slices(S)); the sums over the slices are taken here.

@@ -90,6 +90,7 @@ SIGNATURES = {
     'pvcnn_neighbor_max_supported': (_i, [_i]),
     'pvcnn_neighbor_max_fwd': (_i, [_vp, _l, _i, _vp, _vp, _vp]),
     'pvcnn_neighbor_max_bwd': (_i, [_vp, _vp, _l, _i, _vp, _vp]),
+    'pvcnn_row_argmax': (_i, [_vp, _l, _i, _vp, _vp, _vp]),
     'pvcnn_se_excite_fwd': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     'pvcnn_se_excite_bwd': (_i, [_vp, _i] + [_vp] * 9 + [_i, _i, _i, _f] + [_vp] * 7),
     'pvcnn_bnact_partial_sums': (_i, [_vp, _vp, ctypes.c_long, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp]),

@@ -71,6 +71,46 @@ __global__ __launch_bounds__(256) void neighbor_max_bwd_kernel(const float *__re
   }
 }
 
+// arg-max over a LONG row (the global max-pool over the N points of a cloud, models/s3dis/pvcnn.py:41-43: `features.max(dim=-1)` on
+// (B, C, N)): a wave per row, 1 KiB contiguous per load instruction, eight loads in flight, then a 6-step butterfly.  Same tie / NaN
+// rule as above.  K % 4 == 0 (16-byte rows).
+__global__ __launch_bounds__(256) void row_argmax_kernel(const float *__restrict__ x, long rows, int K, long long *__restrict__ winners,
+                                                         float *__restrict__ values) {
+  constexpr int U = 8;
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;                                // (wave-uniform)
+  const float4 *r4 = reinterpret_cast<const float4 *>(x + row * K);
+  const int quads = K >> 2;
+  float b = 0.0f;
+  int k = -1;                                             // -1: nothing yet (loses against everything)
+  for (int q0 = 0; q0 < quads; q0 += 64 * U) {
+    float4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = r4[min(q0 + u * 64 + lane, quads - 1)];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int q = q0 + u * 64 + lane;
+      if (q < quads) {
+        const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (k < 0 || pool_better(e[i], 4 * q + i, b, k)) { b = e[i]; k = 4 * q + i; }
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float bo = __shfl_xor(b, o);
+    const int ko = __shfl_xor(k, o);
+    if (ko >= 0 && (k < 0 || pool_better(bo, ko, b, k))) { b = bo; k = ko; }
+  }
+  if (lane == 0) {
+    winners[row] = k;
+    if (values) values[row] = b;
+  }
+}
+
 static int lanes_per_row(int K) { return (K >= 4 && K <= 64 && K % 4 == 0 && ((K / 4) & (K / 4 - 1)) == 0) ? K / 4 : 0; }
 
 }  // namespace pvcnn
@@ -117,4 +157,15 @@ extern "C" int pvcnn_neighbor_max_bwd(const float *grad_out, const unsigned char
     default: hipLaunchKernelGGL(neighbor_max_bwd_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, s, grad_out, winners, rows, g4); break;
   }
   return check_launch("neighbor_max_bwd");
+}
+
+extern "C" int pvcnn_row_argmax(const float *x, long rows, int K, long long *winners, float *values, void *stream) {
+  PVCNN_REQUIRE(rows >= 0 && K > 0, "negative size");
+  if (rows == 0) return 0;
+  PVCNN_REQUIRE(K % 4 == 0, "K must be a multiple of 4 (16-byte rows)");
+  PVCNN_REQUIRE(x && winners && aligned16(x), "null or misaligned pointer");
+  const long blocks = (rows + 3) / 4;
+  PVCNN_REQUIRE(blocks <= 0x7fffffffL, "tensor too large");
+  hipLaunchKernelGGL(row_argmax_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, rows, K, winners, values);
+  return check_launch("row_argmax");
 }

@@ -902,6 +902,17 @@ class HipBackend:
             _lib.check(self.lib.pvcnn_neighbor_max_bwd(_p(grad_out), _p(winners), grad_out.numel(), int(k), _p(gx), s), 'neighbor_max_backward')
         return gx
 
+    def row_argmax(self, x, with_values=False):
+        """x (..., K) contiguous, K % 4 == 0 -> winners (...) int64 [, values (...)]: `x.max(dim=-1)` for long rows, one read."""
+        _f32(x, 'x')
+        k = x.shape[-1]
+        _shape(k % 4 == 0 and k > 0, 'row_argmax: the last dimension must be a multiple of 4')
+        winners = torch.empty(x.shape[:-1], dtype=torch.int64, device=x.device)
+        values = torch.empty(x.shape[:-1], dtype=torch.float32, device=x.device) if with_values else None
+        with _Launch(x) as s:
+            _lib.check(self.lib.pvcnn_row_argmax(_p(x), x.numel() // k, k, _p(winners), _p(values), s), 'row_argmax')
+        return (winners, values) if with_values else winners
+
     has_se_excite = True
 
     def se_excite_forward(self, part, gamma, beta, w1, w2, s3):

@@ -209,6 +209,21 @@ def test_neighbor_max_is_torch_max(hip, gen, shape):
     assert not hip.neighbor_max_supported(12) and torch.equal(neighbor_max(odd), odd.max(dim=-1).values)
 
 
+@pytest.mark.parametrize('shape', [(16, 1024, 4096), (2, 3, 100), (1, 5, 8), (2, 2, 4100), (3, 1, 2048), (1, 2, 4)])
+def test_row_argmax_is_torch_max(hip, gen, shape):
+    """csrc/pool.hip row_argmax_kernel (the global max-pool over the points, models/s3dis/pvcnn.py:41-43) vs `x.max(dim=-1)`:
+    the same winners and values on ReLU outputs (all-zero rows, repeated maxima: the first index), and a NaN wins."""
+    x = torch.relu(torch.randn(*shape, generator=gen)).mul(2).round().div(2).to(DEV)
+    x[0, 0, :] = 0.0
+    winners, values = hip.row_argmax(x, with_values=True)
+    ref = x.max(dim=-1)
+    assert torch.equal(winners, ref.indices) and torch.equal(values, ref.values)
+    if shape[-1] > 5:
+        x[-1, -1, 5] = float('nan')
+        w2, v2 = hip.row_argmax(x, with_values=True)
+        assert w2[-1, -1].item() == 5 and torch.isnan(v2[-1, -1])
+
+
 def test_empty_inputs(hip):
     z = torch.zeros
     assert hip.avg_voxelize_forward(z(0, 4, 16, device=DEV), z(0, 3, 16, dtype=torch.int32, device=DEV), 4)[0].shape == (0, 4, 64)
