@@ -321,12 +321,20 @@ PVCNN_API int pvcnn_pwconv_bwd_weight_f16(const float *x, const float *grad_y, c
  *      bwd), or -- amax_zeroed != 0 -- by the pvcnn_bn_finalize call that produced mean / rstd (its zero_words argument, the WHOLE
  *      buffer: on small position counts the pass splits the channels over several workgroups whose table entries meet by atomic
  *      maxima); with training == 0 and amax_zeroed == 0 a one-workgroup reduction of the table is launched behind the pass instead.
+ * drop_seed / drop_p (pvcnn_bnact_fwd, pvcnn_bnact_bwd_strided; NULL / 0: off): the nn.Dropout(p) that follows the pair in the
+ *      classifier heads (models/utils.py:15-36), fused: fwd writes y = keep ? act(bn(x)) / (1 - p) : 0 (and y's amax buffer of THAT
+ *      tensor), bwd takes grad_y as the gradient of the dropped tensor.  keep(e) of element e is a pure function of (e, *drop_seed):
+ *      16 bits of a 32-bit integer mixer, recomputed in every pass, never stored (P(keep) = 1 - round(p * 65536) / 65536).
+ *      drop_seed: ONE int64 in device memory, drawn by the caller per forward call and handed to the matching backward call.
+ *      Requires y_amax / gx_amax (the position-block-major passes) and B * C * S < 2^33.  pvcnn_dropout_keep_mask writes keep(e) for
+ *      e = 0 .. numel - 1 as bytes (tests; not on the training path).
  */
+PVCNN_API int pvcnn_dropout_keep_mask(const void *drop_seed, float drop_p, long numel, unsigned char *keep, void *stream);
 PVCNN_API size_t pvcnn_bnact_workspace_bytes(int B, int C, int S);
 PVCNN_API int pvcnn_bnact_fwd(const float *x, const float *gamma, const float *beta, float *running_mean,
                               float *running_var, int B, int C, int S, float eps, float momentum, float slope,
                               int training, float *mean, float *rstd, float *y, void *y_amax, int amax_seg, int amax_zeroed,
-                              void *workspace, size_t workspace_bytes, void *stream);
+                              void *workspace, size_t workspace_bytes, const void *drop_seed, float drop_p, void *stream);
 /* Batch statistics only (training): mean / rstd per channel + running-stat update; the first half of bnact_fwd.
  * Used with pvcnn_trilinear_devox_bnact_fwd, which applies BatchNorm + LeakyReLU while it stages the voxel
  * grid into LDS -- out = trilinear_devoxelize(leaky_relu(bn(feat))) without writing the activated grid
@@ -369,7 +377,8 @@ PVCNN_API int pvcnn_bnact_bwd(const float *x, const float *grad_y, const float *
 PVCNN_API int pvcnn_bnact_bwd_strided(const float *x, const float *grad_y, long grad_y_batch_stride, const float *gamma,
                             const float *beta, const float *mean, const float *rstd, int B, int C, int S,
                             float slope, int training, float *grad_x, float *grad_gamma, float *grad_beta,
-                            void *gx_amax, int amax_seg, void *workspace, size_t workspace_bytes, void *stream);
+                            void *gx_amax, int amax_seg, void *workspace, size_t workspace_bytes, const void *drop_seed,
+                            float drop_p, void *stream);
 /* The two halves of pvcnn_bnact_bwd_strided on their own, for callers that put something between them (PVConv's SE tail,
  * pvcnn_amd/modules/functional/bnact.py: the per-(cloud, channel) sums feed the excitation's backward before the apply pass runs).
  * partial_sums: part (C, B, slices) float pairs, slices = pvcnn_bnact_slices(S): per slice of row (b, c) the sums of g' and g' * xhat

@@ -78,7 +78,8 @@ SIGNATURES = {
     'pvcnn_pwconv_bwd_weight_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'pvcnn_pwconv_bwd_weight': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     'pvcnn_bnact_workspace_bytes': (_sz, [_i, _i, _i]),
-    'pvcnn_bnact_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _f, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
+    'pvcnn_bnact_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _f, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _sz, _vp, _f, _vp]),
+    'pvcnn_dropout_keep_mask': (_i, [_vp, _f, _l, _vp, _vp]),
     'pvcnn_conv3d_fwd_stats_parts': (_sz, [_i, _i, _i]),
     'pvcnn_conv3d_fwd_stats': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     'pvcnn_pwconv_fwd_stats_parts': (_sz, [_i, _i]),
@@ -96,7 +97,7 @@ SIGNATURES = {
     'pvcnn_bnact_partial_sums': (_i, [_vp, _vp, ctypes.c_long, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp]),
     'pvcnn_bnact_bwd_apply': (_i, [_vp, _vp, ctypes.c_long, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _i, _vp]),
     'pvcnn_bnact_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
-    'pvcnn_bnact_bwd_strided': (_i, [_vp, _vp, ctypes.c_long, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
+    'pvcnn_bnact_bwd_strided': (_i, [_vp, _vp, ctypes.c_long, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp, _f, _vp]),
     'pvcnn_concat_points': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     'pvcnn_adam_step': (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _f, _f, _f, _f, _f, _i, _vp]),
     'pvcnn_trilinear_devox_bwd_strided': (_i, [_vp, ctypes.c_long, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),

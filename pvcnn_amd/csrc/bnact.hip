@@ -126,15 +126,48 @@ __global__ __launch_bounds__(kBnThreads) void bnact_apply_kernel(const float *__
   }
 }
 
+// ---- nn.Dropout behind a BatchNorm + ReLU pair (the classifier heads: models/utils.py:15-36, `[SharedMLP, Dropout(p), ...]`) fused
+// into the pair's passes: y = keep ? act(bn(x)) / (1 - p) : 0 in the apply pass, grad' = keep ? grad / (1 - p) : 0 on load in the two
+// backward passes.  keep(e) of element e of the (B, C, S) tensor is a pure function of (e, key): 16 bits of a 32-bit integer mixer
+// (two multiply-xorshift rounds) over (e >> 1) ^ key -- recomputed wherever it is needed, never stored; the key is one int64 in
+// device memory drawn by the caller per forward call (torch's generator: seeded by torch.manual_seed, graph-capture safe).
+// As torch ops the dropout is a read + write of the activated tensor forward and again backward (+ a mask): 0.15 ms per PVCNN step.
+struct Drop { const unsigned long long *key; uint32_t thr; float scale; };   // keep iff random16 >= thr; thr = round(p * 65536)
+
+__device__ __forceinline__ uint32_t drop_mix(uint32_t pair, uint32_t k0, uint32_t k1) {
+  uint32_t x = pair ^ k0;
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x += k1; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+// factors (scale or 0) of the four consecutive elements e0 .. e0 + 3, e0 % 4 == 0
+__device__ __forceinline__ void drop_factors4(size_t e0, uint32_t k0, uint32_t k1, uint32_t thr, float scale, float (&f)[4]) {
+  const uint32_t h0 = drop_mix((uint32_t)(e0 >> 1), k0, k1), h1 = drop_mix((uint32_t)(e0 >> 1) + 1u, k0, k1);
+  f[0] = (h0 & 0xffffu) >= thr ? scale : 0.0f; f[1] = (h0 >> 16) >= thr ? scale : 0.0f;
+  f[2] = (h1 & 0xffffu) >= thr ? scale : 0.0f; f[3] = (h1 >> 16) >= thr ? scale : 0.0f;
+}
+__device__ __forceinline__ float drop_factor1(size_t e, uint32_t k0, uint32_t k1, uint32_t thr, float scale) {
+  const uint32_t h = drop_mix((uint32_t)(e >> 1), k0, k1);
+  return ((e & 1) ? (h >> 16) : (h & 0xffffu)) >= thr ? scale : 0.0f;
+}
+
+__global__ __launch_bounds__(256) void dropout_keep_mask_kernel(Drop d, long numel, unsigned char *__restrict__ keep) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  const unsigned long long key = *d.key;
+  if (e < numel) keep[e] = drop_factor1((size_t)e, (uint32_t)key, (uint32_t)(key >> 32), d.thr, 1.0f) != 0.0f;
+}
+
 // grid = (slices, B, C): partial (sum g', sum g' * xhat),  g' = gy * act'(z),  z = scale*x + shift
+template <bool DROP = false>
 __global__ __launch_bounds__(kBnThreads) void bnact_bwd_reduce_kernel(const float *__restrict__ x, const float *__restrict__ gy,
                                                                      const float *__restrict__ mean,
                                                                      const float *__restrict__ rstd,
                                                                      const float *__restrict__ gamma,
                                                                      const float *__restrict__ beta, float slope, int C,
                                                                      int S, int slices, float2 *__restrict__ part,
-                                                                     long gy_bstride) {
+                                                                     long gy_bstride, Drop drop = Drop{nullptr, 0u, 1.0f}) {
   __shared__ float sm[16];
+  uint32_t k0 = 0u, k1 = 0u;
+  if constexpr (DROP) { const unsigned long long key = *drop.key; k0 = (uint32_t)key; k1 = (uint32_t)(key >> 32); }
   const int sl = blockIdx.x, b = blockIdx.y, c = blockIdx.z;
   const float m = mean[c], r = rstd[c];
   const float scale = (gamma ? gamma[c] : 1.0f) * r;
@@ -147,7 +180,14 @@ __global__ __launch_bounds__(kBnThreads) void bnact_bwd_reduce_kernel(const floa
     for (int i = lo + threadIdx.x * 4; i < hi; i += kBnThreads * 4) {
       const float4 xv = *reinterpret_cast<const float4 *>(x + off + i);
       const float4 gv = gy ? *reinterpret_cast<const float4 *>(gy + goff + i) : make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-      const float xs_[4] = {xv.x, xv.y, xv.z, xv.w}, gs_[4] = {gv.x, gv.y, gv.z, gv.w};
+      const float xs_[4] = {xv.x, xv.y, xv.z, xv.w};
+      float gs_[4] = {gv.x, gv.y, gv.z, gv.w};
+      if constexpr (DROP) {
+        float f[4];
+        drop_factors4(off + i, k0, k1, drop.thr, drop.scale, f);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) gs_[u] *= f[u];
+      }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const float z = fmaf(xs_[u], scale, shift);
@@ -160,7 +200,9 @@ __global__ __launch_bounds__(kBnThreads) void bnact_bwd_reduce_kernel(const floa
     for (int i = lo + threadIdx.x; i < hi; i += kBnThreads) {
       const float xv = x[off + i];
       const float z = fmaf(xv, scale, shift);
-      const float g = (gy ? gy[goff + i] : 1.0f) * (z > 0.f ? 1.0f : slope);
+      float gin = gy ? gy[goff + i] : 1.0f;
+      if constexpr (DROP) gin *= drop_factor1(off + i, k0, k1, drop.thr, drop.scale);
+      const float g = gin * (z > 0.f ? 1.0f : slope);
       s += g;
       q += g * ((xv - m) * r);
     }
@@ -240,7 +282,7 @@ __global__ __launch_bounds__(kBnThreads) void bnact_bwd_apply_kernel(const float
 // 2 TB/s on the 1024-channel tensor.  With the channels split over gridDim.z workgroups (and eight rows in flight per wave) the chip is
 // full; the table entries are then maxima over the groups: atomicMax into a table zeroed by the finalize kernel (`table_by_atomic`;
 // order-independent, deterministic).
-template <bool BWD>
+template <bool BWD, bool DROP = false>
 __global__ __launch_bounds__(256) void bnact_apply_pb_kernel(const float *__restrict__ x, const float *__restrict__ gy, long gy_bstride,
                                                              const float *__restrict__ mean, const float *__restrict__ rstd,
                                                              const float *__restrict__ gamma, const float *__restrict__ beta,
@@ -249,8 +291,10 @@ __global__ __launch_bounds__(256) void bnact_apply_pb_kernel(const float *__rest
                                                              int nseg, int vec, float *__restrict__ out, uint32_t *__restrict__ amax,
                                                              int global_by_atomic, const float *__restrict__ bc_mul = nullptr,
                                                              const float *__restrict__ bc_add = nullptr, int cgroup = 0x7fffffff,
-                                                             int table_by_atomic = 0) {
+                                                             int table_by_atomic = 0, Drop drop = Drop{nullptr, 0u, 1.0f}) {
   __shared__ uint32_t seg_max[256];
+  uint32_t k0 = 0u, k1 = 0u;
+  if constexpr (DROP) { const unsigned long long key = *drop.key; k0 = (uint32_t)key; k1 = (uint32_t)(key >> 32); }
   const int spb = seg >= 256 ? 1 : 256 / seg;                  // whole segments per workgroup (seg <= 256 enforced by the host)
   const int b = blockIdx.y, s0 = blockIdx.x * spb;
   const int p0 = s0 * seg, span = min(spb * seg, S - p0);
@@ -274,17 +318,21 @@ __global__ __launch_bounds__(256) void bnact_apply_pb_kernel(const float *__rest
     p.dg = (BWD && training) ? dgamma[c] * inv_count : 0.0f;
     return p;
   };
-  auto one = [&](float xv, float gv, const Par &p) {
+  // kf: the dropout factor of the element (1 / (1 - p) or 0; DROP only): on the OUTPUT forward, on the incoming gradient backward
+  auto one = [&](float xv, float gv, const Par &p, float kf) {
     if constexpr (BWD) {
       const float z = fmaf(xv, p.scale, p.shift);
-      const float gin = (bc_mul || bc_add) ? fmaf(gv, p.gmul, p.gadd) : gv;
+      float gin = (bc_mul || bc_add) ? fmaf(gv, p.gmul, p.gadd) : gv;
+      if constexpr (DROP) gin *= kf;
       const float g = gin * (z > 0.f ? 1.0f : slope);
       return p.scale * (g - p.db - ((xv - p.m) * p.r) * p.dg);
     } else {
       const float v = fmaf(xv, p.scale, p.shift);
-      return v > 0.f ? v : v * slope;
+      const float a = v > 0.f ? v : v * slope;
+      if constexpr (DROP) return a * kf; else return a;
     }
   };
+  const size_t ebase = (size_t)b * C * S + p0;                  // linear index of (b, channel 0, position p0)
   if (pos < span) {
     if (vec) {
       using v4f = __attribute__((ext_vector_type(4))) float;
@@ -305,7 +353,10 @@ __global__ __launch_bounds__(256) void bnact_apply_pb_kernel(const float *__rest
           const int c = c0 + 4 * u;
           if (c < cend) {
             const Par p = par_of(c);
-            const float o0 = one(xv[u].x, gv[u].x, p), o1 = one(xv[u].y, gv[u].y, p), o2 = one(xv[u].z, gv[u].z, p), o3 = one(xv[u].w, gv[u].w, p);
+            float kf[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+            if constexpr (DROP) drop_factors4(ebase + (size_t)c * S + pos, k0, k1, drop.thr, drop.scale, kf);
+            const float o0 = one(xv[u].x, gv[u].x, p, kf[0]), o1 = one(xv[u].y, gv[u].y, p, kf[1]), o2 = one(xv[u].z, gv[u].z, p, kf[2]),
+                        o3 = one(xv[u].w, gv[u].w, p, kf[3]);
             mx[0] = max(mx[0], __float_as_uint(fabsf(o0))); mx[1] = max(mx[1], __float_as_uint(fabsf(o1)));
             mx[2] = max(mx[2], __float_as_uint(fabsf(o2))); mx[3] = max(mx[3], __float_as_uint(fabsf(o3)));
             v4f ov = {o0, o1, o2, o3};
@@ -319,7 +370,8 @@ __global__ __launch_bounds__(256) void bnact_apply_pb_kernel(const float *__rest
 #pragma unroll
         for (int i = 0; i < 4; ++i)
           if (pos + i < span) {
-            const float o = one(xb[(size_t)c * S + pos + i], BWD ? gb[(size_t)c * S + pos + i] : 0.0f, p);
+            const float kf = DROP ? drop_factor1(ebase + (size_t)c * S + pos + i, k0, k1, drop.thr, drop.scale) : 1.0f;
+            const float o = one(xb[(size_t)c * S + pos + i], BWD ? gb[(size_t)c * S + pos + i] : 0.0f, p, kf);
             ob[(size_t)c * S + pos + i] = o;
             mx[i] = max(mx[i], __float_as_uint(fabsf(o)));
           }
@@ -354,6 +406,25 @@ static int pb_channel_groups(long position_blocks, int C) {
   return g;
 }
 
+// host side of the fused dropout: p in [0, 1) -> threshold on 16 random bits + the survivors' scale; p == 0 or no seed: off
+static bool make_drop(const void *drop_seed, float drop_p, Drop *d) {
+  if (drop_seed == nullptr || !(drop_p > 0.0f)) return false;
+  long t = lrintf(drop_p * 65536.0f);
+  d->key = static_cast<const unsigned long long *>(drop_seed);
+  d->thr = (uint32_t)(t < 0 ? 0 : t > 65536 ? 65536 : t);
+  d->scale = 1.0f / (1.0f - drop_p);
+  return true;
+}
+
+extern "C" int pvcnn_dropout_keep_mask(const void *drop_seed, float drop_p, long numel, unsigned char *keep, void *stream) {
+  PVCNN_REQUIRE(drop_seed && keep && numel >= 0 && drop_p >= 0.0f && drop_p < 1.0f, "bad argument");
+  if (numel == 0) return 0;
+  Drop d{static_cast<const unsigned long long *>(drop_seed), 0u, 1.0f};
+  make_drop(drop_seed, drop_p, &d);
+  hipLaunchKernelGGL(dropout_keep_mask_kernel, dim3((unsigned)((numel + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), d, numel, keep);
+  return check_launch("dropout_keep_mask");
+}
+
 extern "C" size_t pvcnn_bnact_workspace_bytes(int B, int C, int S) {
   if (B <= 0 || C <= 0 || S <= 0) return 16;
   return (size_t)C * B * ceil_div(S, kBnSlice) * sizeof(float2) + (size_t)C * sizeof(float) + 16;   // partials + per-channel shift
@@ -362,8 +433,12 @@ extern "C" size_t pvcnn_bnact_workspace_bytes(int B, int C, int S) {
 extern "C" int pvcnn_bnact_fwd(const float *x, const float *gamma, const float *beta, float *running_mean,
                                float *running_var, int B, int C, int S, float eps, float momentum, float slope, int training,
                                float *mean, float *rstd, float *y, void *y_amax, int amax_seg, int amax_zeroed, void *workspace,
-                               size_t workspace_bytes, void *stream) {
+                               size_t workspace_bytes, const void *drop_seed, float drop_p, void *stream) {
   PVCNN_REQUIRE(B > 0 && C > 0 && S > 0 && x && y && mean && rstd, "bad argument");
+  PVCNN_REQUIRE(drop_p >= 0.0f && drop_p < 1.0f, "drop_p must be in [0, 1)");
+  Drop drop{nullptr, 0u, 1.0f};
+  const bool dropping = make_drop(drop_seed, drop_p, &drop);
+  PVCNN_REQUIRE(!dropping || (y_amax && (size_t)B * C * S < ((size_t)1 << 33)), "fused dropout needs the amax-emitting pass (y_amax) and < 2^33 elements");
   PVCNN_REQUIRE(B <= 65535 && C <= 65535, "batch or channel count > 65535");
   PVCNN_REQUIRE(!y_amax || (amax_seg > 0 && amax_seg <= 256), "amax_seg must be in 1..256");
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -387,9 +462,14 @@ extern "C" int pvcnn_bnact_fwd(const float *x, const float *gamma, const float *
     const int vec = (S % 4 == 0) && (amax_seg % 4 == 0) && aligned16(x) && aligned16(y);
     uint32_t *am = static_cast<uint32_t *>(y_amax);
     const int groups = amax_zeroed ? pb_channel_groups((long)ceil_div(nseg, spb) * B, C) : 1;
-    hipLaunchKernelGGL(bnact_apply_pb_kernel<false>, dim3(ceil_div(nseg, spb), B, groups), dim3(256), 0, s, x, nullptr, 0L, mean, rstd, gamma,
-                       beta, nullptr, nullptr, slope, 0.0f, 0, C, S, amax_seg, nseg, vec, y, am, amax_zeroed ? 1 : 0, nullptr, nullptr,
-                       ceil_div(C, groups), groups > 1 ? 1 : 0);
+    if (dropping)
+      hipLaunchKernelGGL((bnact_apply_pb_kernel<false, true>), dim3(ceil_div(nseg, spb), B, groups), dim3(256), 0, s, x, nullptr, 0L, mean, rstd,
+                         gamma, beta, nullptr, nullptr, slope, 0.0f, 0, C, S, amax_seg, nseg, vec, y, am, amax_zeroed ? 1 : 0, nullptr, nullptr,
+                         ceil_div(C, groups), groups > 1 ? 1 : 0, drop);
+    else
+      hipLaunchKernelGGL(bnact_apply_pb_kernel<false>, dim3(ceil_div(nseg, spb), B, groups), dim3(256), 0, s, x, nullptr, 0L, mean, rstd, gamma,
+                         beta, nullptr, nullptr, slope, 0.0f, 0, C, S, amax_seg, nseg, vec, y, am, amax_zeroed ? 1 : 0, nullptr, nullptr,
+                         ceil_div(C, groups), groups > 1 ? 1 : 0);
     if (int e = check_launch("bnact_apply_pb")) return e;
     return amax_zeroed ? 0 : launch_amax_reduce(am, (long)B * nseg, s);
   }
@@ -429,7 +509,11 @@ extern "C" int pvcnn_bn_stats(const float *x, float *running_mean, float *runnin
 static int bnact_bwd_impl(const float *x, const float *grad_y, long gy_bstride, const float *gamma, const float *beta,
                           const float *mean, const float *rstd, int B, int C, int S, float slope, int training, float *grad_x,
                           float *grad_gamma, float *grad_beta, void *workspace, size_t workspace_bytes, void *stream,
-                          void *gx_amax = nullptr, int amax_seg = 0) {
+                          void *gx_amax = nullptr, int amax_seg = 0, const void *drop_seed = nullptr, float drop_p = 0.0f) {
+  PVCNN_REQUIRE(drop_p >= 0.0f && drop_p < 1.0f, "drop_p must be in [0, 1)");
+  Drop drop{nullptr, 0u, 1.0f};
+  const bool dropping = make_drop(drop_seed, drop_p, &drop);
+  PVCNN_REQUIRE(!dropping || (gx_amax && (size_t)B * C * S < ((size_t)1 << 33)), "fused dropout needs the amax-emitting pass (gx_amax) and < 2^33 elements");
   PVCNN_REQUIRE(B > 0 && C > 0 && S > 0 && x && grad_y && mean && rstd && grad_x && grad_gamma && grad_beta, "bad argument");
   PVCNN_REQUIRE(B <= 65535 && C <= 65535, "batch or channel count > 65535");
   PVCNN_REQUIRE(gy_bstride >= (long)C * S, "grad_y batch stride smaller than one sample");
@@ -439,8 +523,12 @@ static int bnact_bwd_impl(const float *x, const float *grad_y, long gy_bstride, 
   const int slices = ceil_div(S, kBnSlice);
   const dim3 grid(slices, B, C);
   float2 *part = static_cast<float2 *>(workspace);
-  hipLaunchKernelGGL(bnact_bwd_reduce_kernel, grid, dim3(kBnThreads), 0, s, x, grad_y, mean, rstd, gamma, beta, slope, C, S,
-                     slices, part, gy_bstride);
+  if (dropping)
+    hipLaunchKernelGGL(bnact_bwd_reduce_kernel<true>, grid, dim3(kBnThreads), 0, s, x, grad_y, mean, rstd, gamma, beta, slope, C, S, slices, part,
+                       gy_bstride, drop);
+  else
+    hipLaunchKernelGGL(bnact_bwd_reduce_kernel<false>, grid, dim3(kBnThreads), 0, s, x, grad_y, mean, rstd, gamma, beta, slope, C, S, slices, part,
+                       gy_bstride);
   if (int e = check_launch("bnact_bwd_reduce")) return e;
   hipLaunchKernelGGL(bnact_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, part, B * slices, grad_gamma, grad_beta,
                      static_cast<uint32_t *>(gx_amax), gx_amax ? 1 + (long)B * ceil_div(S, amax_seg) : 0L);
@@ -451,9 +539,14 @@ static int bnact_bwd_impl(const float *x, const float *grad_y, long gy_bstride, 
     const int vec = (S % 4 == 0) && (amax_seg % 4 == 0) && (gy_bstride % 4 == 0) && aligned16(x) && aligned16(grad_y) && aligned16(grad_x);
     uint32_t *am = static_cast<uint32_t *>(gx_amax);
     const int groups = pb_channel_groups((long)ceil_div(nseg, spb) * B, C);
-    hipLaunchKernelGGL(bnact_apply_pb_kernel<true>, dim3(ceil_div(nseg, spb), B, groups), dim3(256), 0, s, x, grad_y, gy_bstride, mean, rstd,
-                       gamma, beta, grad_gamma, grad_beta, slope, inv_count, training, C, S, amax_seg, nseg, vec, grad_x, am, 1, nullptr,
-                       nullptr, ceil_div(C, groups), groups > 1 ? 1 : 0);
+    if (dropping)
+      hipLaunchKernelGGL((bnact_apply_pb_kernel<true, true>), dim3(ceil_div(nseg, spb), B, groups), dim3(256), 0, s, x, grad_y, gy_bstride, mean,
+                         rstd, gamma, beta, grad_gamma, grad_beta, slope, inv_count, training, C, S, amax_seg, nseg, vec, grad_x, am, 1, nullptr,
+                         nullptr, ceil_div(C, groups), groups > 1 ? 1 : 0, drop);
+    else
+      hipLaunchKernelGGL(bnact_apply_pb_kernel<true>, dim3(ceil_div(nseg, spb), B, groups), dim3(256), 0, s, x, grad_y, gy_bstride, mean, rstd,
+                         gamma, beta, grad_gamma, grad_beta, slope, inv_count, training, C, S, amax_seg, nseg, vec, grad_x, am, 1, nullptr,
+                         nullptr, ceil_div(C, groups), groups > 1 ? 1 : 0);
     return check_launch("bnact_bwd_apply_pb");
   }
   hipLaunchKernelGGL(bnact_bwd_apply_kernel, grid, dim3(kBnThreads), 0, s, x, grad_y, mean, rstd, gamma, beta, grad_gamma,
@@ -473,9 +566,9 @@ extern "C" int pvcnn_bnact_bwd(const float *x, const float *grad_y, const float 
 extern "C" int pvcnn_bnact_bwd_strided(const float *x, const float *grad_y, long grad_y_batch_stride, const float *gamma,
                                        const float *beta, const float *mean, const float *rstd, int B, int C, int S, float slope,
                                        int training, float *grad_x, float *grad_gamma, float *grad_beta, void *gx_amax, int amax_seg,
-                                       void *workspace, size_t workspace_bytes, void *stream) {
+                                       void *workspace, size_t workspace_bytes, const void *drop_seed, float drop_p, void *stream) {
   return bnact_bwd_impl(x, grad_y, grad_y_batch_stride, gamma, beta, mean, rstd, B, C, S, slope, training, grad_x, grad_gamma,
-                        grad_beta, workspace, workspace_bytes, stream, gx_amax, amax_seg);
+                        grad_beta, workspace, workspace_bytes, stream, gx_amax, amax_seg, drop_seed, drop_p);
 }
 
 extern "C" int pvcnn_bnact_slices(int S) { return S > 0 ? ceil_div(S, kBnSlice) : 0; }
@@ -487,8 +580,8 @@ extern "C" int pvcnn_bnact_partial_sums(const float *x, const float *grad_y, lon
   PVCNN_REQUIRE(!grad_y || grad_y_batch_stride >= (long)C * S, "grad_y batch stride smaller than one sample");
   PVCNN_REQUIRE((reinterpret_cast<uintptr_t>(part) & 7) == 0, "part must be 8-byte aligned");
   const int slices = ceil_div(S, kBnSlice);
-  hipLaunchKernelGGL(bnact_bwd_reduce_kernel, dim3(slices, B, C), dim3(kBnThreads), 0, static_cast<hipStream_t>(stream), x, grad_y, mean, rstd,
-                     gamma, beta, slope, C, S, slices, reinterpret_cast<float2 *>(part), grad_y ? grad_y_batch_stride : (long)C * S);
+  hipLaunchKernelGGL(bnact_bwd_reduce_kernel<false>, dim3(slices, B, C), dim3(kBnThreads), 0, static_cast<hipStream_t>(stream), x, grad_y, mean,
+                     rstd, gamma, beta, slope, C, S, slices, reinterpret_cast<float2 *>(part), grad_y ? grad_y_batch_stride : (long)C * S);
   return check_launch("bnact_partial_sums");
 }
 

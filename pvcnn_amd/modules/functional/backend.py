@@ -732,14 +732,24 @@ class HipBackend:
 
     BNACT_AMAX_MAX_SEG = 256   # the apply passes emit amax buffers for segments up to this long
 
+    has_bnact_dropout = True
+
+    def dropout_keep_mask(self, seed, p, numel):
+        """keep(e), e = 0 .. numel - 1, of the dropout fused into bnact_forward / bnact_backward (drop=(seed, p)) -> bool tensor (tests)."""
+        keep = torch.empty((int(numel),), dtype=torch.uint8, device=seed.device)
+        with _Launch(seed) as s:
+            _lib.check(self.lib.pvcnn_dropout_keep_mask(_p(seed), float(p), int(numel), _p(keep), s), 'dropout_keep_mask')
+        return keep.bool()
+
     def bnact_forward(self, x, gamma, beta, running_mean, running_var, training, momentum, eps, slope, stats=None, amax_seg=0,
-                      y_amax=None):
+                      y_amax=None, drop=None):
         """x (B,C,S) -> (y, mean, rstd).  Training: batch statistics (running stats updated in place);
         eval: running statistics.  stats = (mean, rstd) already known (from a convolution epilogue +
         bn_finalize): only the normalise + activate pass runs.
         amax_seg > 0: -> (y, mean, rstd, y_amax), y's amax buffer with segments of amax_seg positions emitted by the apply pass.
         y_amax given: the buffer bn_finalize(..., zero_word=y_amax) already armed (all of it is zero: the pass then needs no
-        reduction launch behind it)."""
+        reduction launch behind it).
+        drop = (seed: one int64 on the device, p): the nn.Dropout(p) behind the pair, applied by the same pass (needs amax_seg > 0)."""
         _f32(x, 'x')
         b, c, s3 = x.shape
         dev = x.device
@@ -765,7 +775,8 @@ class HipBackend:
                                                 _p(running_var) if (training and running_var is not None) else nul,
                                                 b, c, s3, float(eps), float(momentum), float(slope), int(bool(training)),
                                                 _p(mean), _p(rstd), _p(y), _p(y_amax) if amax_seg > 0 else nul, amax_seg, int(armed),
-                                                _p(ws), ws.numel(), s), 'bnact_forward')
+                                                _p(ws), ws.numel(), _p(drop[0]) if drop else nul, float(drop[1]) if drop else 0.0, s),
+                       'bnact_forward')
         return (y, mean, rstd, y_amax) if amax_seg > 0 else (y, mean, rstd)
 
     has_devox_bnact = True
@@ -993,8 +1004,9 @@ class HipBackend:
                        'bnact_backward_apply')
         return gx, amax
 
-    def bnact_backward(self, x, grad_y, gamma, beta, mean, rstd, slope, training, amax_seg=0):
-        """-> (grad_x, grad_gamma, grad_beta [, grad_x's amax buffer with segments of amax_seg positions, emitted by the apply pass])."""
+    def bnact_backward(self, x, grad_y, gamma, beta, mean, rstd, slope, training, amax_seg=0, drop=None):
+        """-> (grad_x, grad_gamma, grad_beta [, grad_x's amax buffer with segments of amax_seg positions, emitted by the apply pass]).
+        drop = (seed, p) of the forward call: grad_y is then the gradient of the DROPPED output (needs amax_seg > 0)."""
         _f32(x, 'x')
         gy_bstride = _f32_rows(grad_y, 'grad_y')
         b, c, s3 = x.shape
@@ -1010,7 +1022,8 @@ class HipBackend:
             _lib.check(self.lib.pvcnn_bnact_bwd_strided(_p(x), _p(grad_y), gy_bstride, _p(gamma) if gamma is not None else nul,
                                                         _p(beta) if beta is not None else nul, _p(mean), _p(rstd), b, c, s3, float(slope),
                                                         int(bool(training)), _p(gx), _p(gg), _p(gb),
-                                                        _p(gx_amax) if amax_seg > 0 else nul, amax_seg, _p(ws), ws.numel(), s), 'bnact_backward')
+                                                        _p(gx_amax) if amax_seg > 0 else nul, amax_seg, _p(ws), ws.numel(),
+                                                        _p(drop[0]) if drop else nul, float(drop[1]) if drop else 0.0, s), 'bnact_backward')
         return (gx, gg, gb, gx_amax) if amax_seg > 0 else (gx, gg, gb)
 
 

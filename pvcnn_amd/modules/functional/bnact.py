@@ -55,27 +55,29 @@ def _amax_seg_for(shape, is_cuda):
     return 0
 
 
-def _bnact_backward(x3, g3, w, b, mean, rstd, slope, training, shape):
+def _bnact_backward(x3, g3, w, b, mean, rstd, slope, training, shape, drop=None):
     """native bnact_backward -> (grad_x viewed as `shape`, grad_gamma, grad_beta); the apply pass also leaves grad_x's amax buffer
     on the returned tensor (_cache.tag_amax) for the f16x2 backward products of the convolution in front of this BatchNorm."""
     be = native()
     seg = _amax_seg_for(shape, x3.is_cuda)
     if seg:
-        gx, gw, gb, amax = be.bnact_backward(x3, g3, w, b, mean, rstd, slope, training, amax_seg=seg)
+        gx, gw, gb, amax = be.bnact_backward(x3, g3, w, b, mean, rstd, slope, training, amax_seg=seg, **({'drop': drop} if drop else {}))
         return _cache.tag_amax(gx.view(shape), seg, amax), gw, gb
+    assert drop is None, 'the fused dropout rides on the amax-emitting passes'  
     gx, gw, gb = be.bnact_backward(x3, g3, w, b, mean, rstd, slope, training)
     return gx.view(shape), gw, gb
 
 
-__all__ = ['batch_norm_act', 'batch_norm_act_devoxelize', 'batch_norm_act_se_devoxelize', 'fusable_tail', 'run_layers']
+__all__ = ['batch_norm_act', 'batch_norm_act_devoxelize', 'batch_norm_act_se_devoxelize', 'fusable_tail', 'run_layers', 'fused_dropout_ok']
 
 
 class BatchNormAct(Function):
     @staticmethod
     @amp_fwd
     def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, slope, stats_part=None, stats_shift=None,
-                amax_seg=0, counter=None):
-        """-> y, or (y, y's amax buffer) when amax_seg > 0 (second output: not differentiable)."""
+                amax_seg=0, counter=None, drop_p=0.0, drop_seed=None):
+        """-> y, or (y, y's amax buffer) when amax_seg > 0 (second output: not differentiable).
+        drop_p > 0 (with amax_seg > 0): y = dropout(act(bn(x)), drop_p) with the keep decisions of csrc/bnact.hip under drop_seed."""
         shape = x.shape
         x3 = x.contiguous().view(shape[0], shape[1], -1)
         w = weight.contiguous() if weight is not None else None
@@ -90,9 +92,10 @@ class BatchNormAct(Function):
                 stats = native().bn_finalize(stats_part, x3.shape[0] * x3.shape[2], running_mean, running_var, momentum, eps, stats_shift,
                                              counter=counter)
         ctx.slope, ctx.training, ctx.shape = slope, training, shape
+        ctx.drop = (drop_seed, float(drop_p)) if (drop_p and drop_seed is not None) else None
         if amax_seg:
             y, mean, rstd, amax = native().bnact_forward(x3, w, b, running_mean, running_var, training, momentum, eps, slope, stats=stats,
-                                                         amax_seg=amax_seg, y_amax=armed)
+                                                         amax_seg=amax_seg, y_amax=armed, **({'drop': ctx.drop} if ctx.drop else {}))
             ctx.save_for_backward(x3, w, b, mean, rstd)
             ctx.mark_non_differentiable(amax)
             ctx.set_materialize_grads(False)
@@ -105,12 +108,12 @@ class BatchNormAct(Function):
     @amp_bwd
     def backward(ctx, grad_y, grad_amax=None):
         if grad_y is None:
-            return (None,) * 13
+            return (None,) * 15
         x3, w, b, mean, rstd = ctx.saved_tensors
         g3 = _rows(grad_y, ctx.shape)
-        gx, gw, gb = _bnact_backward(x3, g3, w, b, mean, rstd, ctx.slope, ctx.training, ctx.shape)
+        gx, gw, gb = _bnact_backward(x3, g3, w, b, mean, rstd, ctx.slope, ctx.training, ctx.shape, drop=ctx.drop)
         return (gx, gw if w is not None else None, gb if b is not None else None,
-                None, None, None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None, None, None, None)
 
 
 def _bn_mode(bn, finalize_counts=False):
@@ -142,16 +145,30 @@ def _split(stats):
     return part, (shift.detach().contiguous() if shift is not None else None)
 
 
-def batch_norm_act(x, bn, slope, stats_part=None):
+def fused_dropout_ok(x):
+    """Can an nn.Dropout in training mode behind a (BatchNorm, activation) pair over x ride on the pair's passes (batch_norm_act(...,
+    drop_p=p))?  Needs the amax-emitting passes (csrc/bnact.hip) -- i.e. the f16x2 arithmetic of the convolution next door -- and no
+    autocast."""
+    return (x.is_cuda and x.dtype == torch.float32 and getattr(native(), 'has_bnact_dropout', False) and not torch.is_autocast_enabled()
+            and _amax_seg_for(x.shape, True) > 0 and 0 < x.numel() < (1 << 33))
+
+
+def batch_norm_act(x, bn, slope, stats_part=None, drop_p=0.0):
     """Apply BatchNorm module `bn` followed by LeakyReLU(slope) (slope = 0: ReLU) to x (B, C, ...).
-    stats_part: (per-workgroup partial sums of x - shift written by the convolution that produced x, shift = its bias)."""
+    stats_part: (per-workgroup partial sums of x - shift written by the convolution that produced x, shift = its bias).
+    drop_p > 0 (only where fused_dropout_ok(x)): ... followed by a training-mode nn.Dropout(drop_p), in the same passes; the keep
+    decisions are a function of one int64 drawn here from torch's generator (so torch.manual_seed governs them, and a captured graph
+    draws a fresh one per replay) -- a different stream than torch.nn.functional.dropout's, the same distribution."""
     use_batch_stats, momentum, rm, rv, counter = _bn_mode(bn, finalize_counts=stats_part is not None and bn.training)
     part, shift = _split(stats_part)
     # the apply pass emits the f16x2 scale table of what it writes for the convolution that (usually) consumes it
     seg = _amax_seg_for(x.shape, x.is_cuda)
     if seg:
-        y, amax = BatchNormAct.apply(x, bn.weight, bn.bias, rm, rv, use_batch_stats, momentum, bn.eps, slope, part, shift, seg, counter)
+        seed = torch.randint(-(1 << 62), 1 << 62, (1,), dtype=torch.int64, device=x.device) if drop_p else None
+        y, amax = BatchNormAct.apply(x, bn.weight, bn.bias, rm, rv, use_batch_stats, momentum, bn.eps, slope, part, shift, seg, counter,
+                                     float(drop_p), seed)
         return _cache.tag_amax(y, seg, amax)
+    assert not drop_p, 'fused dropout: see fused_dropout_ok'
     return BatchNormAct.apply(x, bn.weight, bn.bias, rm, rv, use_batch_stats, momentum, bn.eps, slope, part, shift, 0, counter)
 
 
@@ -355,12 +372,14 @@ def _wants_batch_stats(m):
     return isinstance(m, nn.modules.batchnorm._BatchNorm) and (m.training or m.running_mean is None)
 
 
-def run_layers(layers, x, stop=None, tail_stats=False):
+def run_layers(layers, x, stop=None, tail_stats=False, tail_dropout=0.0):
     """nn.Sequential.forward with the GPU path's own kernels: 1x1 convolutions as channel-major MFMA GEMMs,
     (BatchNorm, ReLU|LeakyReLU) pairs fused, and the statistics of a BatchNorm that directly follows one of our
     convolutions taken from that convolution's epilogue instead of a pass over its output.
     `stop`: run only the first `stop` modules.  `tail_stats`: return (x, stats_part) where stats_part belongs
-    to the BatchNorm at position `stop` if the last module run was such a convolution (else None)."""
+    to the BatchNorm at position `stop` if the last module run was such a convolution (else None).
+    `tail_dropout` = p > 0: a training-mode nn.Dropout(p) follows the stack and its LAST two modules are a fusable (BatchNorm,
+    activation) pair: the pair's passes apply it (the caller has checked fused_dropout_ok and skips the Dropout module)."""
     all_mods = list(layers)
     mods = all_mods[:stop]
     # forward / backward hooks on a sub-module (FLOP counters, feature extractors, pruning) only fire through its
@@ -369,6 +388,7 @@ def run_layers(layers, x, stop=None, tail_stats=False):
     fuse = x.is_cuda and getattr(native(), 'has_bnact', False) and not hooked
     pw = x.is_cuda and getattr(native(), 'has_pwconv', False) and not hooked
     part = carried = None
+    dropped = False
     i = 0
     while i < len(mods):
         m = mods[i]
@@ -394,10 +414,14 @@ def run_layers(layers, x, stop=None, tail_stats=False):
             i += 1
         elif (fuse and isinstance(m, nn.modules.batchnorm._BatchNorm) and i + 1 < len(mods) and x.dim() >= 3
                 and _servable(x) and _slope(mods[i + 1]) is not None and x.numel() > 0):
-            x = batch_norm_act(x, m, _slope(mods[i + 1]), stats_part=carried)
+            drop_here = tail_dropout if (tail_dropout and i + 2 == len(mods) and fused_dropout_ok(x)) else 0.0
+            x = batch_norm_act(x, m, _slope(mods[i + 1]), stats_part=carried, drop_p=drop_here)
+            dropped = dropped or bool(drop_here)
             i += 2
         else:
             x = m(x)
             i += 1
         carried = part
+    if tail_dropout and not dropped:            # the last pair was not fusable after all: the Dropout the caller skipped, as torch runs it
+        x = torch.nn.functional.dropout(x, float(tail_dropout), True)
     return (x, part) if tail_stats else x

@@ -248,3 +248,87 @@ def test_se_excitation_kernels_match_the_torch_chain(hip, b, c, h, slices, affin
     assert rel(sq, sq_r) < 1e-6 and rel(hd, hd_r) < 1e-5 and rel(ex, ex_r) < 1e-5
     for name, x, y in zip(('g_w1', 'g_w2', 'g_mean', 'sum_beta', 'sum_gamma'), out, (g_w1, g_w2, g_mean, sb, sg)):
         assert rel(x, y) < 1e-5, (name, rel(x, y))
+
+
+@pytest.mark.parametrize('shape,p', [((16, 128, 4096), 0.3), ((3, 40, 1000), 0.5), ((2, 16, 260), 0.1), ((2, 8, 64, 32), 0.3)])
+def test_dropout_fused_into_the_bn_relu_passes(hip, shape, p):
+    """SharedMLP + nn.Dropout(p) of a classifier head (models/utils.py:15-36) as run_layers(..., tail_dropout=p): the Dropout rides on the
+    BatchNorm + ReLU passes (csrc/bnact.hip).  With the kernel's own keep mask (pvcnn_dropout_keep_mask under the same seed) the
+    forward output is bit-identical to dropout applied to the un-fused pair's output, every gradient agrees with autograd through
+    `pair(x) * keep / (1 - p)` in fp64 to 1e-5, the mask keeps 1 - p of the elements (4 sigma), differs from call to call and repeats
+    under the same torch seed."""
+    from pvcnn_amd.modules.functional import bnact as B
+    torch.manual_seed(3)
+    dim2 = len(shape) == 4
+    conv, norm = (nn.Conv2d, nn.BatchNorm2d) if dim2 else (nn.Conv1d, nn.BatchNorm1d)
+    cin = 24
+    net = nn.Sequential(conv(cin, shape[1], 1), norm(shape[1]), nn.ReLU(True)).to(DEV).train()
+    x = torch.randn(shape[0], cin, *shape[2:], device=DEV)
+    assert B.fused_dropout_ok(x)
+    seeds = []
+    real_randint = torch.randint
+
+    def spy(*a, **k):
+        t = real_randint(*a, **k)
+        seeds.append(t)
+        return t
+    xa = x.clone().requires_grad_()
+    torch.randint = spy
+    try:
+        torch.manual_seed(11)
+        ya = B.run_layers(net, xa, tail_dropout=p)
+        torch.manual_seed(11)
+        yb = B.run_layers(net, x, tail_dropout=p)
+        yc = B.run_layers(net, x, tail_dropout=p)
+    finally:
+        torch.randint = real_randint
+    assert len(seeds) == 3 and torch.equal(seeds[0], seeds[1]) and not torch.equal(seeds[1], seeds[2])
+    assert torch.equal(ya, yb) and not torch.equal(yb, yc)
+    keep = hip.dropout_keep_mask(seeds[0], p, ya.numel()).view(ya.shape)
+    n = keep.numel()
+    assert abs(keep.float().mean().item() - (1 - p)) < 4 * (p * (1 - p) / n) ** 0.5 + 1e-5
+    # per channel and per sample too (no stripes)
+    assert (keep.float().mean(dim=tuple(i for i in range(keep.dim()) if i != 1)) - (1 - p)).abs().max().item() < 6 * (p * (1 - p) / (n / shape[1])) ** 0.5 + 1e-5
+    with torch.no_grad():
+        plain = B.run_layers(net, x)                                  # the un-fused pair (statistics of the same batch)
+    want = torch.where(keep, plain * (1.0 / (1.0 - p)), torch.zeros_like(plain))
+    assert torch.equal(ya.detach(), want)
+    # gradients: autograd through the same function in fp64
+    ref = nn.Sequential(conv(cin, shape[1], 1), norm(shape[1]), nn.ReLU()).to(DEV).double().train()
+    ref.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in net.state_dict().items()})
+    xr = x.double().requires_grad_()
+    g = torch.randn_like(ya)
+    for q in net.parameters():
+        q.grad = None
+    ya.backward(g)
+    (ref(xr) * keep.double() / (1.0 - p)).backward(g.double())
+    assert _rel(xa.grad, xr.grad) < 2e-5
+    for (na, pa), (nb, pb) in zip(net.named_parameters(), ref.named_parameters()):
+        scale = max(pb.grad.abs().max().item(), dict(ref.named_parameters())[na.replace('.bias', '.weight')].grad.abs().max().item()
+                    if na.endswith('.bias') else 0.0, 1e-30)
+        assert (pa.grad.double() - pb.grad).abs().max().item() <= 3e-5 * scale, na
+
+
+def test_classifier_head_with_fused_dropout_trains_like_the_module_stack(hip):
+    """workload._classify (SharedMLP + Dropout pairs fused, last Conv1d on the package's GEMM) vs nn.Sequential.forward of the same
+    head: identical in eval mode and with p = 0; in training mode the two draw different masks, so the check is statistical -- the
+    mean and the second moment of the logits over 8 draws agree within their spread."""
+    from pvcnn_amd import workload
+    torch.manual_seed(5)
+    layers, _ = workload._head(96, [64, 0.3, 32, 0.3, 13], 1, pointwise=True, classify=True)
+    head = nn.Sequential(*layers).to(DEV)
+    x = torch.randn(4, 96, 2048, device=DEV)
+    head.eval()
+    with torch.no_grad():
+        assert (workload._classify(head, x) - head(x)).abs().max().item() < 1e-5 * head(x).abs().max().item()
+    head.train()
+    with torch.no_grad():
+        fused = torch.stack([workload._classify(head, x) for _ in range(8)])
+        plain = torch.stack([head(x) for _ in range(8)])
+    for stat in (lambda t: t.mean(), lambda t: t.pow(2).mean()):
+        a, b = stat(fused).item(), stat(plain).item()
+        spread = max(abs(stat(plain[i]).item() - b) for i in range(8)) + abs(b) * 0.02
+        assert abs(a - b) < 3 * spread, (a, b, spread)
+    xa = x.clone().requires_grad_()
+    workload._classify(head, xa).square().mean().backward()
+    assert xa.grad is not None and torch.isfinite(xa.grad).all() and all(q.grad is not None and torch.isfinite(q.grad).all() for q in head.parameters())
