@@ -48,3 +48,25 @@ def test_graphed_step_follows_the_eager_trajectory(hip):
     l_graph = step().item()
     l_eager = tf.cross_entropy(ref(x2), y2).item()             # same weights, same batch, eager forward
     assert abs(l_graph - l_eager) <= 1e-4 * abs(l_eager), (l_graph, l_eager)
+
+
+def test_fused_dropout_draws_a_fresh_mask_on_every_replay(hip):
+    """The dropout fused into the BatchNorm passes takes its key from torch.randint: captured in a hipGraph, torch's generator hands
+    every replay its own Philox offset, so each replayed step drops different elements (a frozen key would train on one fixed mask)."""
+    from pvcnn_amd import workload
+    torch.manual_seed(2)
+    layers, _ = workload._head(64, [64, 0.5, 13], 1, pointwise=True, classify=True)
+    head = torch.nn.Sequential(*layers).to(DEV).train()
+    x = torch.randn(2, 64, 1024, device=DEV)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side), torch.no_grad():
+        for _ in range(2):
+            workload._classify(head, x)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.no_grad(), torch.cuda.graph(g):
+        y = workload._classify(head, x)
+    g.replay(); a = y.clone()
+    g.replay(); b = y.clone()
+    assert torch.isfinite(a).all() and not torch.equal(a, b)
