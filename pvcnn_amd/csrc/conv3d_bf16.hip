@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256, (NS == 3 || TX * TY * TZ == 512 || TZ <= 16) ?
                                                                    float2 *__restrict__ stats_part,
                                                                    const uint32_t *__restrict__ x_absmax, const int *__restrict__ wexp,
                                                                    int amax_seg) {
-  static_assert(TX * TY * TZ == 128 || TX * TY * TZ == 256 || TX * TY * TZ == 512, "a workgroup tile is 4 waves x NBW x 32 voxels");
+  static_assert(TX * TY * TZ == 64 || TX * TY * TZ == 128 || TX * TY * TZ == 256 || TX * TY * TZ == 512, "a workgroup tile is 4 waves x NBW x 32 voxels");
   constexpr int HX = TX + 2, HY = TY + 2, HZ = TZ + 2, HS = HX * HY * HZ;
   // Wave arrangement inside the 64-channel x (TX*TY*TZ)-voxel workgroup tile.  Every lane fetches its own A (weight) fragments from
   // global memory, once per tap.  With the four waves side by side along the voxels (WM = 1) each wave pulls all 64 rows: 4 KiB per
@@ -260,8 +260,10 @@ __global__ __launch_bounds__(256, (NS == 3 || TX * TY * TZ == 512 || TZ <= 16) ?
   // 2 x 2: a wave owns 32 channels x half the voxels, the A traffic halves and the B fragments (LDS reads, which have headroom)
   // double.  Only the 128-voxel tile is arranged so: at 256 voxels the wider B ring spills (measured by the compiler: 136-424 bytes
   // of scratch), and the 512-voxel tile has 24 MFMAs per A fetch anyway.  Per output element the products and their order are the same.
-  constexpr int NB1 = TX * TY * TZ / 128;                       // 32-voxel column blocks per wave when the waves sit side by side
-  constexpr int WM = NB1 == 1 ? 2 : 1, MBW = 2 / WM, NBW = NB1 * WM;    // waves along the channels; row / column blocks per wave
+  // The 64-voxel tile (2 x 2 waves, ONE column block per wave) is for grids so small that larger tiles leave CUs idle (PVCNN++ at
+  // R = 8, B = 8, 128 channels: 64 workgroups of 128 voxels on 256 CUs -- 57 us for 9 us of matrix work).
+  constexpr int VOX = TX * TY * TZ;
+  constexpr int WM = VOX <= 128 ? 2 : 1, MBW = 2 / WM, NBW = VOX / (32 * (4 / WM));   // waves along the channels; row / column blocks per wave
   constexpr int WBLK = 3 * NS * kCoTileB * kKc;                 // bf16 elements of one (chunk, dxy, cotile) weight block
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
   uint32_t *xs = lds_u;                                         // [NS][HS][8] words (16 bf16 per voxel)
@@ -764,8 +766,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_f16_pipe_kernel(const flo
 struct SplitTile { int tx, ty, tz; bool vec; };
 static SplitTile split_tiles(int B, int Co, int R, int nsplit) {
   const bool vec = R % 4 == 0 && R <= 32;
-  if (R <= 8)    // tiny grids (PVCNN++ at R = 8, B = 8: 16 tiles of 256 voxels per 64 channels): halve the tile while the chip is not full
-    return (long)B * ceil_div(R, 4) * ceil_div(R, 8) * ceil_div(Co, kCoTileB) < kNumCU ? SplitTile{2, 8, 8, vec} : SplitTile{4, 8, 8, vec};
+  if (R <= 8) {  // tiny grids (PVCNN++ at R = 8, B = 8: 16 tiles of 256 voxels per 64 channels): halve the tile while the chip is not full
+    const long per = (long)B * ceil_div(R, 8) * ceil_div(Co, kCoTileB);
+    // (measured, f16x2 forward, (8,128,128,8): 38.5 -> 28.4 us; (8,256,256,8): 71.3 -> 61.6; PVCNN++ step 574.7 -> 581.0 clouds/s in one call)
+    if (per * ceil_div(R, 2) < kNumCU) return SplitTile{1, 8, 8, vec};
+    return per * ceil_div(R, 4) < kNumCU ? SplitTile{2, 8, 8, vec} : SplitTile{4, 8, 8, vec};
+  }
   if (!vec) return {4, 4, 16, false};
   if (R <= 16)   // too few 256-voxel tiles to give every SIMD two waves (R = 16, B = 16: 256 per 64 channels): halve them
     return (long)B * ceil_div(R, 4) * ceil_div(R, 4) * ceil_div(Co, kCoTileB) < 768 ? SplitTile{2, 4, 16, true} : SplitTile{4, 4, 16, true};
@@ -919,6 +925,7 @@ static int conv3d_fwd_split_impl(const float *x, const void *wts, const float *b
 #define PVCNN_IGEMM(NS, TX, TY, TZ, VEC) launch_igemm_bf16<NS, TX, TY, TZ, VEC>(x, w16, bias, y, B, Ci, Co, R, s, sp, am, wexp, amax_seg)
 #define PVCNN_IGEMM_NS(TX, TY, TZ, VEC) (nsplit == 3 ? PVCNN_IGEMM(3, TX, TY, TZ, VEC) : nsplit == 2 ? PVCNN_IGEMM(2, TX, TY, TZ, VEC) : PVCNN_IGEMM(1, TX, TY, TZ, VEC))
 #define PVCNN_IGEMM_BIG(TX, TY, TZ) (nsplit == 2 ? PVCNN_IGEMM(2, TX, TY, TZ, true) : PVCNN_IGEMM(1, TX, TY, TZ, true))
+  if (t.tz == 8 && t.tx == 1) return t.vec ? PVCNN_IGEMM_NS(1, 8, 8, true) : PVCNN_IGEMM_NS(1, 8, 8, false);
   if (t.tz == 8 && t.tx == 2) return t.vec ? PVCNN_IGEMM_NS(2, 8, 8, true) : PVCNN_IGEMM_NS(2, 8, 8, false);
   if (t.tz == 8) return t.vec ? PVCNN_IGEMM_NS(4, 8, 8, true) : PVCNN_IGEMM_NS(4, 8, 8, false);
   if (!t.vec) return PVCNN_IGEMM_NS(4, 4, 16, false);

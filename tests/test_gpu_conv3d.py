@@ -14,7 +14,11 @@ TOL = 1e-5
 CASES = [(2, 9, 64, 32), (1, 5, 7, 12), (2, 64, 64, 16), (1, 16, 130, 8), (1, 3, 4, 33), (1, 8, 8, 5), (3, 64, 128, 16),
          (1, 1, 1, 1), (1, 2, 3, 2),
          (2, 8, 32, 16),     # vector staging with a partial 64-wide output tile (Co % 4 == 0, Co < 64): PVCNN++ widths
-         (2, 16, 96, 8),     # R = 8: half tile (2,8,8), Co = 64 + 32
+         (2, 16, 96, 8),     # R = 8: the 64-voxel tile (1,8,8) of a nearly empty chip, Co = 64 + 32
+         (8, 128, 128, 8),   # ... PVCNN++'s own layer
+         (64, 16, 64, 8),    # R = 8: half tile (2,8,8)
+         (64, 16, 128, 8),   # R = 8: (4,8,8)
+         (3, 20, 64, 6),     # R = 6 (scalar staging) on the 64-voxel tile
          (20, 32, 64, 16),
          (2, 32, 40, 12),    # the pipelined 128-voxel f16x2 kernel (Ci % 16 == 0) on a Frustum grid: the fourth z quad of a row is padding
          (1, 16, 64, 16),    # ... with a single chunk
