@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void conv3d_weight_split_kernel(const float *_
 // f16x2 operand scale: amax_seg = 0 -> one scale for the whole tensor (x_absmax[0]); amax_seg = R -> x_absmax is an "amax buffer"
 // (include/pvcnn_hip.h) with one maximum per z row (b, gx, gy) behind the global one, and the workgroup scales ITS halo tile by the
 // largest row it stages: an outlier somewhere in the grid costs precision only in the tiles that contain it.
-template <int NS, int TX, int TY, int TZ, bool VEC>
+template <int NS, int TX, int TY, int TZ, bool VEC, bool CO32 = false>
 __global__ __launch_bounds__(256, (NS == 3 || TX * TY * TZ == 512 || TZ <= 16) ? 2 : 3) void conv3d_igemm_bf16_kernel(const float *__restrict__ x, const uint16_t *__restrict__ wts,
                                                                    const float *__restrict__ bias, float *__restrict__ y,
                                                                    int Ci, int Co, int R, int tiles_x, int tiles_y, int tiles_z,
@@ -262,8 +262,11 @@ __global__ __launch_bounds__(256, (NS == 3 || TX * TY * TZ == 512 || TZ <= 16) ?
   // of scratch), and the 512-voxel tile has 24 MFMAs per A fetch anyway.  Per output element the products and their order are the same.
   // The 64-voxel tile (2 x 2 waves, ONE column block per wave) is for grids so small that larger tiles leave CUs idle (PVCNN++ at
   // R = 8, B = 8, 128 channels: 64 workgroups of 128 voxels on 256 CUs -- 57 us for 9 us of matrix work).
+  // CO32 (Co <= 32: PVCNN++'s first stage, 32 channels at 32^3): only the first 32-row block of the 64-row weight tile exists -- the
+  // second one would be MFMAs on padding, half of the kernel's matrix work.  Side-by-side waves (WM = 1) only.
   constexpr int VOX = TX * TY * TZ;
-  constexpr int WM = VOX <= 128 ? 2 : 1, MBW = 2 / WM, NBW = VOX / (32 * (4 / WM));   // waves along the channels; row / column blocks per wave
+  constexpr int WM = VOX <= 128 ? 2 : 1, MBW = CO32 ? 1 : 2 / WM, NBW = VOX / (32 * (4 / WM));   // waves along the channels; row / column blocks per wave
+  static_assert(!CO32 || WM == 1, "the 32-channel variant is for the tiles whose waves sit side by side");
   constexpr int WBLK = 3 * NS * kCoTileB * kKc;                 // bf16 elements of one (chunk, dxy, cotile) weight block
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
   uint32_t *xs = lds_u;                                         // [NS][HS][8] words (16 bf16 per voxel)
@@ -790,14 +793,14 @@ static int launch_igemm_f16_pipe(const float *x, const uint16_t *wts, const floa
   return check_launch("conv3d_igemm_f16_pipe");
 }
 
-template <int NS, int TX, int TY, int TZ, bool VEC>
+template <int NS, int TX, int TY, int TZ, bool VEC, bool CO32 = false>
 static int launch_igemm_bf16(const float *x, const uint16_t *wts, const float *bias, float *y, int B, int Ci, int Co, int R,
                              hipStream_t s, float2 *stats_part, const uint32_t *x_absmax = nullptr, const int *wexp = nullptr,
                              int amax_seg = 0) {
   constexpr int HS = (TX + 2) * (TY + 2) * (TZ + 2);
   const size_t lds = std::max((size_t)NS * HS * 8 * sizeof(uint32_t), (size_t)4 * kCoTileB * sizeof(float2));
   const int tx = ceil_div(R, TX), ty = ceil_div(R, TY), tz = ceil_div(R, TZ);
-  auto k = conv3d_igemm_bf16_kernel<NS, TX, TY, TZ, VEC>;
+  auto k = conv3d_igemm_bf16_kernel<NS, TX, TY, TZ, VEC, CO32>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { set_error("conv3d(bf16): LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
@@ -932,6 +935,9 @@ static int conv3d_fwd_split_impl(const float *x, const void *wts, const float *b
   // the pipelined 128-voxel kernel (f16x2 only).  Round 3, 64 -> 64 at 16^3 x 16: see profiles/ab/r03u_convbench.jsonl
   if (t.tz == 16 && t.tx == 2 && nsplit == 2 && Ci % kKc == 0) return launch_igemm_f16_pipe<2, 4>(x, w16, bias, y, B, Ci, Co, R, s, sp, am, wexp, amax_seg);
   if (t.tz == 16) return t.tx == 2 ? PVCNN_IGEMM_NS(2, 4, 16, true) : PVCNN_IGEMM_NS(4, 4, 16, true);
+  if (Co <= 32 && nsplit == 2)     // a 32-row weight tile: no MFMAs on the padded half (f16x2, the default arithmetic, only)
+    return t.tx == 4 ? launch_igemm_bf16<2, 4, 4, 32, true, true>(x, w16, bias, y, B, Ci, Co, R, s, sp, am, wexp, amax_seg)
+                     : launch_igemm_bf16<2, 2, 4, 32, true, true>(x, w16, bias, y, B, Ci, Co, R, s, sp, am, wexp, amax_seg);
   return t.tx == 4 ? PVCNN_IGEMM_BIG(4, 4, 32) : PVCNN_IGEMM_NS(2, 4, 32, true);
 #undef PVCNN_IGEMM_BIG
 #undef PVCNN_IGEMM_NS

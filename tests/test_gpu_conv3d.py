@@ -19,6 +19,9 @@ CASES = [(2, 9, 64, 32), (1, 5, 7, 12), (2, 64, 64, 16), (1, 16, 130, 8), (1, 3,
          (64, 16, 64, 8),    # R = 8: half tile (2,8,8)
          (64, 16, 128, 8),   # R = 8: (4,8,8)
          (3, 20, 64, 6),     # R = 6 (scalar staging) on the 64-voxel tile
+         (2, 16, 32, 32),    # Co <= 32 at R = 32: the 32-row weight tile (256-voxel tile)
+         (8, 32, 32, 32),    # ... PVCNN++'s first stage (512-voxel tile)
+         (1, 9, 20, 32),     # ... ragged
          (20, 32, 64, 16),
          (2, 32, 40, 12),    # the pipelined 128-voxel f16x2 kernel (Ci % 16 == 0) on a Frustum grid: the fourth z quad of a row is padding
          (1, 16, 64, 16),    # ... with a single chunk
