@@ -388,6 +388,18 @@ PVCNN_API int pvcnn_bnact_bwd_strided(const float *x, const float *grad_y, long 
  *   g' = (grad_y * bc_mul[b][c] + bc_add[b][c]) * act'(z); bc_mul / bc_add (B,C) or NULL (1 / 0); sum_gamma / sum_beta (C) given by
  *   the caller; gx_amax / amax_seg as in pvcnn_bnact_bwd_strided. */
 PVCNN_API int pvcnn_bnact_slices(int S);
+/* Batched refresh of the f16x2 weight images (pvcnn_conv3d_weight_split_pair / pvcnn_pwconv_weight_split_pair of MANY weights in one
+ * launch each): a training step changes every weight once (the optimizer) and needs both images of every layer afterwards -- 13
+ * launches per PVCNN step, 56 per PVCNN++ step as per-layer calls.
+ * _entry: fills `entry` (HOST memory, 10 int64 words) for one weight and its two image buffers (sized by *_weight_split_bytes(.., 0 / 1,
+ *      2)) and returns the number of workgroups it takes (-1: bad argument).  The caller sets entry[9] to the running sum of the counts
+ *      of the entries before it, and copies the n x 10 words to device memory.
+ * _batch: table = those words on the device, total_rows = the sum of the counts.  Writes exactly what the per-weight calls write. */
+PVCNN_API long pvcnn_conv3d_weight_split_pair_entry(const float *w, int Co, int Ci, void *wts_fwd, void *wts_bwd, long long *entry);
+PVCNN_API int pvcnn_conv3d_weight_split_pair_batch(const void *table, int n, long total_rows, void *stream);
+PVCNN_API long pvcnn_pwconv_weight_split_pair_entry(const float *w, int Co, int Ci, void *wts_fwd, void *wts_bwd, long long *entry);
+PVCNN_API int pvcnn_pwconv_weight_split_pair_batch(const void *table, int n, long total_rows, void *stream);
+
 /* The max over the K neighbours of a centre (modules/pointnet.py:85: `mlp(grouper(...)).max(dim=-1).values` on (B, C, M, K)) and its
  * backward, one streaming pass each.  x: (rows, K) contiguous, 16-byte aligned, rows = B * C * M; K in {4, 8, 16, 32, 64}
  * (pvcnn_neighbor_max_supported; other K: the caller keeps torch's reduction).  out (rows) = the maxima, winners (rows) = their k

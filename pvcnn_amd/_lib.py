@@ -88,6 +88,10 @@ SIGNATURES = {
     'pvcnn_bn_stats': (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp, _sz, _vp]),
     'pvcnn_trilinear_devox_bnact_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     'pvcnn_bnact_slices': (_i, [_i]),
+    'pvcnn_conv3d_weight_split_pair_entry': (_l, [_vp, _i, _i, _vp, _vp, _vp]),
+    'pvcnn_conv3d_weight_split_pair_batch': (_i, [_vp, _i, _l, _vp]),
+    'pvcnn_pwconv_weight_split_pair_entry': (_l, [_vp, _i, _i, _vp, _vp, _vp]),
+    'pvcnn_pwconv_weight_split_pair_batch': (_i, [_vp, _i, _l, _vp]),
     'pvcnn_neighbor_max_supported': (_i, [_i]),
     'pvcnn_neighbor_max_fwd': (_i, [_vp, _l, _i, _vp, _vp, _vp]),
     'pvcnn_neighbor_max_bwd': (_i, [_vp, _vp, _l, _i, _vp, _vp]),

@@ -25,6 +25,19 @@ __host__ __device__ inline bool aligned16(const void *p) { return (reinterpret_c
 // out[0] = max over out[1 .. T] of an amax buffer whose table has just been written on stream s (conv3d_bf16.hip)
 int launch_amax_reduce(uint32_t *out, long T, hipStream_t s);
 
+// One weight of a batched image refresh (pvcnn_conv3d_weight_split_pair_batch / pvcnn_pwconv_weight_split_pair_batch): ten int64 words
+// in device memory, filled on the host by pvcnn_*_weight_split_pair_entry.  Workgroups [row_begin, row_begin + rows_f + rows_b) of the
+// launch write this weight's forward and backward-data images, one (padded) output row each.
+struct SplitEntry {
+  const float *w;
+  uint16_t *wts_f;
+  int *wexp_f;
+  uint16_t *wts_b;
+  int *wexp_b;
+  long long Co, Ci, rows_f, tm /* 1x1 only: TM_f | TM_b << 32 */, row_begin;
+};
+static_assert(sizeof(SplitEntry) == 80, "ten 8-byte words");
+
 #ifdef __HIPCC__
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding GLOBAL store of the
 // wave (s_waitcnt vmcnt(0): its release fence), which serialises "store a tile, barrier, load the next one" loops on the

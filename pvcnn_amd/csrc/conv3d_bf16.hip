@@ -32,6 +32,7 @@
 #include <algorithm>
 
 #include "common.h"
+#include <string.h>
 #include "split16.h"
 
 namespace pvcnn {
@@ -205,6 +206,18 @@ __global__ __launch_bounds__(256) void conv3d_weight_split_f16_pair_kernel(const
                                                                            uint16_t *__restrict__ wts_b, int *__restrict__ wexp_b) {
   if ((int)blockIdx.x < rows_fwd) conv3d_weight_split_f16_row(w, Co, Ci, 0, wts_f, wexp_f, blockIdx.x);
   else conv3d_weight_split_f16_row(w, Co, Ci, 1, wts_b, wexp_b, blockIdx.x - rows_fwd);
+}
+
+// ... of EVERY registered weight of a model in one launch (the weights change once per optimizer step: 7 launches of this kind per PVCNN
+// step, 25 per PVCNN++ step become one).  The entry of a workgroup: a scan of the row_begin column (uniform scalar loads).
+__global__ __launch_bounds__(256) void conv3d_weight_split_f16_batch_kernel(const SplitEntry *__restrict__ tab, int n) {
+  const long long blk = blockIdx.x;
+  int i = 0;
+  while (i + 1 < n && tab[i + 1].row_begin <= blk) ++i;
+  const SplitEntry e = tab[i];
+  const int row = (int)(blk - e.row_begin);
+  if (row < (int)e.rows_f) conv3d_weight_split_f16_row(e.w, (int)e.Co, (int)e.Ci, 0, e.wts_f, e.wexp_f, row);
+  else conv3d_weight_split_f16_row(e.w, (int)e.Co, (int)e.Ci, 1, e.wts_b, e.wexp_b, row - (int)e.rows_f);
 }
 
 // ---- weights: (Co, Ci, 27) fp32 -> [chunk][dxy][cotile][dz][plane][64 co][16 ci (halves swizzled)] bf16 ----
@@ -898,6 +911,31 @@ extern "C" int pvcnn_conv3d_weight_split_pair(const float *w, int Co, int Ci, vo
   hipLaunchKernelGGL(conv3d_weight_split_f16_pair_kernel, dim3(rows_f + rows_b), dim3(256), 0, static_cast<hipStream_t>(stream), w, Co, Ci,
                      rows_f, static_cast<uint16_t *>(wts_fwd), wexp_f, static_cast<uint16_t *>(wts_bwd), wexp_b);
   return check_launch("conv3d_weight_split_pair");
+}
+
+// batched form of pvcnn_conv3d_weight_split_pair: `entry` (host, 10 int64) describes one weight and its two image buffers and returns
+// the number of workgroups it takes; the caller sets word [9] (row_begin) to the running sum and copies the table to the device.
+extern "C" long pvcnn_conv3d_weight_split_pair_entry(const float *w, int Co, int Ci, void *wts_fwd, void *wts_bwd, long long *entry) {
+  if (!w || !wts_fwd || !wts_bwd || !entry || Co <= 0 || Ci <= 0 || !aligned16(wts_fwd) || !aligned16(wts_bwd)) return -1;
+  const int rows_f = ceil_div(Co, kCoTileB) * kCoTileB, rows_b = ceil_div(Ci, kCoTileB) * kCoTileB;
+  SplitEntry e;
+  e.w = w;
+  e.wts_f = static_cast<uint16_t *>(wts_fwd);
+  e.wexp_f = reinterpret_cast<int *>(static_cast<char *>(wts_fwd) + weight_image_bytes(Ci, Co, 2));
+  e.wts_b = static_cast<uint16_t *>(wts_bwd);
+  e.wexp_b = reinterpret_cast<int *>(static_cast<char *>(wts_bwd) + weight_image_bytes(Co, Ci, 2));
+  e.Co = Co; e.Ci = Ci; e.rows_f = rows_f; e.tm = 0; e.row_begin = 0;
+  memcpy(entry, &e, sizeof(e));
+  return rows_f + rows_b;
+}
+
+extern "C" int pvcnn_conv3d_weight_split_pair_batch(const void *table, int n, long total_rows, void *stream) {
+  PVCNN_REQUIRE(n >= 0 && total_rows >= 0 && total_rows <= 0x7fffffffL, "bad size");
+  if (n == 0 || total_rows == 0) return 0;
+  PVCNN_REQUIRE(table && (reinterpret_cast<uintptr_t>(table) & 7) == 0, "null or misaligned table");
+  hipLaunchKernelGGL(conv3d_weight_split_f16_batch_kernel, dim3((unsigned)total_rows), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const SplitEntry *>(table), n);
+  return check_launch("conv3d_weight_split_pair_batch");
 }
 
 extern "C" size_t pvcnn_conv3d_fwd_split_stats_parts(int B, int Co, int R, int nsplit) {

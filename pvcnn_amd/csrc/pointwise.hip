@@ -469,9 +469,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 // out[e] = sum over the P partial tiles: a workgroup owns 32 consecutive elements, its eight 32-lane groups take every eighth partial
 // (eight loads in flight each) and meet in LDS in a fixed order -- deterministic.  (First version: one thread per element walking all
 // P partials: 16 workgroups for a 64 x 64 weight and 512 partials, 14 us per launch, 8 launches per PVCNN step.)
-__global__ __launch_bounds__(256) void pw_reduce_kernel(const float *__restrict__ part, int n, int P, float *__restrict__ out) {
+// A second array (the bias gradient's partials: n2 elements, P2 partials) rides in the same launch: the workgroups behind the first
+// ceil(n / 32) take it -- one launch per backward-weight call instead of two (64 -> 32 launches per PVCNN++ step).
+__global__ __launch_bounds__(256) void pw_reduce_kernel(const float *__restrict__ part, int n, int P, float *__restrict__ out,
+                                                        const float *__restrict__ part2 = nullptr, int n2 = 0, int P2 = 0,
+                                                        float *__restrict__ out2 = nullptr) {
   __shared__ float red[8][32];
-  const int l = threadIdx.x & 31, g = threadIdx.x >> 5, e = blockIdx.x * 32 + l;
+  const int first = (n + 31) / 32;
+  int blk = blockIdx.x;
+  if (blk >= first) { blk -= first; part = part2; n = n2; P = P2; out = out2; }      // (uniform per workgroup)
+  const int l = threadIdx.x & 31, g = threadIdx.x >> 5, e = blk * 32 + l;
   float s = 0.0f;
   if (e < n) {
     int p = g;
@@ -609,11 +616,9 @@ extern "C" int pvcnn_pwconv_bwd_weight(const float *x, const float *grad_y, int 
   }
   if (int rc = check_launch("pwconv_wgrad")) return rc;
   const int n = M * K;
-  hipLaunchKernelGGL(pw_reduce_kernel, dim3(ceil_div(n, 32)), dim3(256), 0, s, part, n, PT, grad_w);
-  if (int rc = check_launch("pwconv_wgrad_reduce")) return rc;
-  if (grad_bias) {
-    hipLaunchKernelGGL(pw_reduce_kernel, dim3(ceil_div(M, 32)), dim3(256), 0, s, bias_part, M, P, grad_bias);
-    return check_launch("pwconv_bias_reduce");
-  }
-  return 0;
+  if (grad_bias)
+    hipLaunchKernelGGL(pw_reduce_kernel, dim3(ceil_div(n, 32) + ceil_div(M, 32)), dim3(256), 0, s, part, n, PT, grad_w, bias_part, M, P, grad_bias);
+  else
+    hipLaunchKernelGGL(pw_reduce_kernel, dim3(ceil_div(n, 32)), dim3(256), 0, s, part, n, PT, grad_w);
+  return check_launch("pwconv_wgrad_reduce");
 }

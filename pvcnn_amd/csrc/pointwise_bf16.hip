@@ -26,6 +26,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include <string.h>
 #include "split16.h"
 
 namespace pvcnn {
@@ -112,6 +113,17 @@ __global__ __launch_bounds__(256) void pw_weight_split_f16_pair_kernel(const flo
                                                                        uint16_t *__restrict__ wts_b, int *__restrict__ wexp_b) {
   if ((int)blockIdx.x < rows_fwd) pw_weight_split_f16_row(w, Co, Ci, 0, TM_f, wts_f, wexp_f, blockIdx.x);
   else pw_weight_split_f16_row(w, Co, Ci, 1, TM_b, wts_b, wexp_b, blockIdx.x - rows_fwd);
+}
+
+// ... of every registered 1x1 weight of a model in one launch (see conv3d_weight_split_f16_batch_kernel)
+__global__ __launch_bounds__(256) void pw_weight_split_f16_batch_kernel(const SplitEntry *__restrict__ tab, int n) {
+  const long long blk = blockIdx.x;
+  int i = 0;
+  while (i + 1 < n && tab[i + 1].row_begin <= blk) ++i;
+  const SplitEntry e = tab[i];
+  const int row = (int)(blk - e.row_begin);
+  if (row < (int)e.rows_f) pw_weight_split_f16_row(e.w, (int)e.Co, (int)e.Ci, 0, (int)(e.tm & 0xffffffffLL), e.wts_f, e.wexp_f, row);
+  else pw_weight_split_f16_row(e.w, (int)e.Co, (int)e.Ci, 1, (int)(e.tm >> 32), e.wts_b, e.wexp_b, row - (int)e.rows_f);
 }
 
 // ---- epilogue shared by the 1x1 GEMM kernels: D[i = m][j = point]; lanes = consecutive points (128-byte rows); bias; the optional
@@ -549,6 +561,31 @@ extern "C" int pvcnn_pwconv_weight_split_pair(const float *w, int Co, int Ci, vo
   hipLaunchKernelGGL(pw_weight_split_f16_pair_kernel, dim3(rows_f + rows_b), dim3(256), 0, static_cast<hipStream_t>(stream), w, Co, Ci, rows_f,
                      TM_f, TM_b, static_cast<uint16_t *>(wts_fwd), wexp_f, static_cast<uint16_t *>(wts_bwd), wexp_b);
   return check_launch("pwconv_weight_split_pair");
+}
+
+// batched form of pvcnn_pwconv_weight_split_pair (see pvcnn_conv3d_weight_split_pair_entry / _batch)
+extern "C" long pvcnn_pwconv_weight_split_pair_entry(const float *w, int Co, int Ci, void *wts_fwd, void *wts_bwd, long long *entry) {
+  if (!w || !wts_fwd || !wts_bwd || !entry || Co <= 0 || Ci <= 0 || !aligned16(wts_fwd) || !aligned16(wts_bwd)) return -1;
+  const int TM_f = 32 * pb_mb(Co), TM_b = 32 * pb_mb(Ci);
+  const int rows_f = ceil_div(Co, TM_f) * TM_f, rows_b = ceil_div(Ci, TM_b) * TM_b;
+  SplitEntry e;
+  e.w = w;
+  e.wts_f = static_cast<uint16_t *>(wts_fwd);
+  e.wexp_f = reinterpret_cast<int *>(static_cast<char *>(wts_fwd) + pb_image_bytes(Ci, Co, 2));
+  e.wts_b = static_cast<uint16_t *>(wts_bwd);
+  e.wexp_b = reinterpret_cast<int *>(static_cast<char *>(wts_bwd) + pb_image_bytes(Co, Ci, 2));
+  e.Co = Co; e.Ci = Ci; e.rows_f = rows_f; e.tm = (long long)TM_f | ((long long)TM_b << 32); e.row_begin = 0;
+  memcpy(entry, &e, sizeof(e));
+  return rows_f + rows_b;
+}
+
+extern "C" int pvcnn_pwconv_weight_split_pair_batch(const void *table, int n, long total_rows, void *stream) {
+  PVCNN_REQUIRE(n >= 0 && total_rows >= 0 && total_rows <= 0x7fffffffL, "bad size");
+  if (n == 0 || total_rows == 0) return 0;
+  PVCNN_REQUIRE(table && (reinterpret_cast<uintptr_t>(table) & 7) == 0, "null or misaligned table");
+  hipLaunchKernelGGL(pw_weight_split_f16_batch_kernel, dim3((unsigned)total_rows), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const SplitEntry *>(table), n);
+  return check_launch("pwconv_weight_split_pair_batch");
 }
 
 extern "C" size_t pvcnn_pwconv_fwd_split_stats_parts(int B, int N) {

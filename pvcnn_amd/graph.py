@@ -40,6 +40,12 @@ class GraphedTrainStep:
         elif self.capture and not all(g.get('capturable', False) for g in optimizer.param_groups):
             # a non-capturable optimizer keeps its step counter on the host: the captured update would replay step 1 forever
             raise ValueError('GraphedTrainStep captures optimizer.step(): build the optimizer with capturable=True')
+        # the f16x2 weight images of every layer from one launch per kind and step (backend.weight_bank_refresh) instead of one per layer
+        from .modules.functional._autograd import native
+        be = native() if torch.cuda.is_available() else None
+        self.bank = be if (be is not None and getattr(be, 'has_weight_bank', False) and next(model.parameters()).is_cuda) else None
+        if self.bank is not None:
+            self.bank.weight_bank_register(model)
         if not self.capture:
             return
         side = torch.cuda.Stream()
@@ -64,6 +70,8 @@ class GraphedTrainStep:
 
     def _forward_backward(self):
         self.reducer.zero_grad()
+        if self.bank is not None:
+            self.bank.weight_bank_refresh()
         with self.autocast():
             loss = self.loss_fn()
         loss.backward()

@@ -532,12 +532,35 @@ class HipBackend:
             _lib.check(self.lib.pvcnn_conv3d_weight_split(_p(weight), co, ci, int(for_bwd_data), int(nsplit), _p(wts), s), 'conv3d_weight_split')
         return wts
 
+    # ---- the f16x2 weight images of a whole model, refreshed by one launch per kind and step ---------------------------------
+    has_weight_bank = True
+
+    def weight_bank_register(self, model):
+        """Make the Conv3d / 1x1-convolution weights of `model` eligible for the batched refresh (weight_bank_refresh)."""
+        self._bank().register(model)
+
+    def weight_bank_refresh(self):
+        """Recompute, in ONE launch per kind, both f16x2 images of every registered weight a forward pass has asked for before, and arm
+        them: the next conv_weight_images / pw_weight_images call for such a weight takes its pair from the bank instead of launching.
+        Call right before the forward pass of a training step (after the optimizer step that changed the weights).  A weight that is
+        not armed -- not registered, first sighting, a second forward pass without a refresh, changed in place since (version
+        counter) -- is split by its own launch as before: never stale."""
+        self._bank().refresh()
+
+    def _bank(self):
+        if getattr(self, '_weight_bank', None) is None:
+            self._weight_bank = _WeightBank(self)
+        return self._weight_bank
+
     def conv_weight_images(self, weight, nsplit):
         """(forward image, backward-data image) of a Conv3d weight; f16x2: both from ONE launch (a training step needs both and the
         weights do not change between its forward and its backward)."""
         co, ci = weight.shape[0], weight.shape[1]
         if int(nsplit) != 2:
             return self._conv_wsplit(weight, False, nsplit), self._conv_wsplit(weight, True, nsplit)
+        hit = self._bank().take('conv', weight)
+        if hit is not None:
+            return hit
         wf = torch.empty((self.lib.pvcnn_conv3d_weight_split_bytes(co, ci, 0, 2),), dtype=torch.uint8, device=weight.device)
         wb = torch.empty((self.lib.pvcnn_conv3d_weight_split_bytes(co, ci, 1, 2),), dtype=torch.uint8, device=weight.device)
         with _Launch(weight) as s:
@@ -549,6 +572,9 @@ class HipBackend:
         co, ci = weight.shape
         if int(nsplit) != 2:
             return self._pw_wsplit(weight, False, nsplit), self._pw_wsplit(weight, True, nsplit)
+        hit = self._bank().take('pw', weight)
+        if hit is not None:
+            return hit
         wf = torch.empty((self.lib.pvcnn_pwconv_weight_split_bytes(co, ci, 0, 2),), dtype=torch.uint8, device=weight.device)
         wb = torch.empty((self.lib.pvcnn_pwconv_weight_split_bytes(co, ci, 1, 2),), dtype=torch.uint8, device=weight.device)
         with _Launch(weight) as s:
@@ -1025,6 +1051,108 @@ class HipBackend:
                                                         _p(gx_amax) if amax_seg > 0 else nul, amax_seg, _p(ws), ws.numel(),
                                                         _p(drop[0]) if drop else nul, float(drop[1]) if drop else 0.0, s), 'bnact_backward')
         return (gx, gg, gb, gx_amax) if amax_seg > 0 else (gx, gg, gb)
+
+
+class _WeightBank:
+    """Persistent f16x2 image pairs of registered weights (HipBackend.weight_bank_*).  An entry is keyed by (kind, data pointer,
+    (Co, Ci)); `wanted` = the keys a forward pass asked for (take() misses note them), so a refresh computes what is used and nothing
+    else; the device tables are rebuilt when that set changes (the warm-up steps), not in steady state."""
+
+    def __init__(self, be):
+        import weakref
+        self.be, self._weakref = be, weakref
+        self.params = []            # weakrefs of registered parameters
+        self.seen = set()           # id()s of registered parameters
+        self.wanted = set()
+        self.entries = {}           # key -> dict(param=weakref, wf, wb, armed, version)
+        self.tables = {}            # kind -> (device table, n, total rows, keys)
+        self.dirty = True
+
+    @staticmethod
+    def _kind_of(p):
+        if p.dim() == 5 and tuple(p.shape[2:]) == (3, 3, 3):
+            return 'conv'
+        if p.dim() in (3, 4) and all(k == 1 for k in p.shape[2:]):
+            return 'pw'
+        return None
+
+    def register(self, model):
+        import torch.nn as nn
+        for m in model.modules():
+            if isinstance(m, (nn.Conv1d, nn.Conv2d, nn.Conv3d)) and m.weight is not None and self._kind_of(m.weight) and id(m.weight) not in self.seen:
+                self.seen.add(id(m.weight))
+                self.params.append(self._weakref.ref(m.weight))
+                self.dirty = True
+
+    def take(self, kind, w):
+        key = (kind, w.data_ptr(), (int(w.shape[0]), int(w.shape[1])))
+        e = self.entries.get(key)
+        if e is not None and e['armed']:
+            e['armed'] = False
+            p = e['param']()
+            if p is not None and p._version == e['version'] and p.data_ptr() == key[1]:
+                return e['wf'], e['wb']
+        if key not in self.wanted:
+            self.wanted.add(key)
+            self.dirty = True
+        return None
+
+    def _rebuild(self):
+        lib = self.be.lib
+        live, by_kind = {}, {'conv': [], 'pw': []}
+        for ref in self.params:
+            p = ref()
+            if p is None or not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+                continue
+            kind = self._kind_of(p)
+            key = (kind, p.data_ptr(), (int(p.shape[0]), int(p.shape[1])))
+            if key not in self.wanted:
+                continue
+            e = self.entries.get(key)
+            if e is None or e['param']() is not p:
+                co, ci = key[2]
+                nbytes = lib.pvcnn_conv3d_weight_split_bytes if kind == 'conv' else lib.pvcnn_pwconv_weight_split_bytes
+                e = {'param': ref, 'armed': False, 'version': -1,
+                     'wf': torch.empty((nbytes(co, ci, 0, 2),), dtype=torch.uint8, device=p.device),
+                     'wb': torch.empty((nbytes(co, ci, 1, 2),), dtype=torch.uint8, device=p.device)}
+            live[key] = e
+            by_kind[kind].append((key, p, e))
+        self.entries, self.tables = live, {}
+        for kind, items in by_kind.items():
+            if not items:
+                continue
+            fill = lib.pvcnn_conv3d_weight_split_pair_entry if kind == 'conv' else lib.pvcnn_pwconv_weight_split_pair_entry
+            host = torch.zeros((len(items), 10), dtype=torch.int64)
+            rows = 0
+            for i, (key, p, e) in enumerate(items):
+                n = fill(_p(p), key[2][0], key[2][1], _p(e['wf']), _p(e['wb']), ctypes.c_void_p(host[i].data_ptr()))
+                if n < 0:
+                    raise RuntimeError('weight bank: bad entry')
+                host[i, 9] = rows
+                rows += n
+            dev = items[0][1].device
+            self.tables[kind] = (host.to(dev), len(items), rows, [k for k, _, _ in items], dev)
+        self.dirty = False
+
+    def refresh(self):
+        if self.dirty:
+            if torch.cuda.is_current_stream_capturing():        # no allocation / host-to-device copy inside a capture: this step's layers
+                for e in self.entries.values():                 # split their own weights (take() finds nothing armed)
+                    e['armed'] = False
+                return
+            self._rebuild()
+        for kind, (table, n, rows, keys, dev) in self.tables.items():
+            launch = self.be.lib.pvcnn_conv3d_weight_split_pair_batch if kind == 'conv' else self.be.lib.pvcnn_pwconv_weight_split_pair_batch
+            with _Launch(table) as s:
+                _lib.check(launch(_p(table), n, rows, s), 'weight_split_pair_batch')
+            for key in keys:
+                e = self.entries[key]
+                p = e['param']()
+                if p is not None and p.data_ptr() == key[1]:
+                    e['armed'], e['version'] = True, p._version
+                else:                                   # the parameter moved or died: rebuild before the next refresh
+                    e['armed'] = False
+                    self.dirty = True
 
 
 _backend = HipBackend()
