@@ -82,20 +82,29 @@ __global__ __launch_bounds__(256) void row_argmax_kernel(const float *__restrict
   if (row >= rows) return;                                // (wave-uniform)
   const float4 *r4 = reinterpret_cast<const float4 *>(x + row * K);
   const int quads = K >> 2;
+  // Rows are K * 4 bytes apart and every wave of the chip walks its row front to back at about the same pace: with all of them at
+  // the same offset modulo the row length only a fraction of the HBM channels is busy at any moment (N = 4096: 16 KiB rows, the
+  // un-rotated kernel -- and torch's reduction -- ran at 2.9 TB/s).  Row r therefore starts 1 KiB * r into the row and wraps around;
+  // the maximum does not care about the order, the tie rule is explicit in pool_better.
+  const int start = (int)((row * 64) % quads);
   float b = 0.0f;
   int k = -1;                                             // -1: nothing yet (loses against everything)
   for (int q0 = 0; q0 < quads; q0 += 64 * U) {
     float4 v[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) v[u] = r4[min(q0 + u * 64 + lane, quads - 1)];
+    int qq[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int q = q0 + u * 64 + lane;
-      if (q < quads) {
+      const int q = min(q0 + u * 64 + lane, quads - 1) + start;
+      qq[u] = q >= quads ? q - quads : q;
+      v[u] = r4[qq[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (q0 + u * 64 + lane < quads) {
         const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-          if (k < 0 || pool_better(e[i], 4 * q + i, b, k)) { b = e[i]; k = 4 * q + i; }
+          if (k < 0 || pool_better(e[i], 4 * qq[u] + i, b, k)) { b = e[i]; k = 4 * qq[u] + i; }
       }
     }
   }
