@@ -467,3 +467,31 @@ def test_pointwise_conv_routes_by_the_two_size_bars(monkeypatch):
         x2, w2, b2 = x.detach().clone().requires_grad_(), w.detach().clone().requires_grad_(), bias.detach().clone().requires_grad_()
         torch.nn.functional.conv1d(x2, w2, b2).backward(gy)
         assert torch.allclose(x.grad, x2.grad, atol=1e-5) and torch.allclose(w.grad, w2.grad, atol=1e-4) and torch.allclose(bias.grad, b2.grad, atol=1e-4)
+
+
+def test_classifier_head_and_pooling_fall_back_to_the_modules_on_cpu():
+    """workload._classify (fused Dropout, last Conv1d on the package's GEMM) and functional.pooling.neighbor_max (csrc/pool.hip) are
+    GPU paths: on CPU tensors they ARE nn.Sequential.forward / torch.max, bit for bit, in train and eval mode."""
+    import torch
+    import torch.nn as nn
+    from pvcnn_amd import workload
+    from pvcnn_amd.modules.functional.pooling import neighbor_max
+    torch.manual_seed(0)
+    layers, _ = workload._head(24, [16, 0.3, 8, 0.3, 5], 1, pointwise=True, classify=True)
+    head = nn.Sequential(*layers)
+    x = torch.randn(2, 24, 50)
+    head.eval()
+    assert torch.equal(workload._classify(head, x), head(x))
+    head.train()
+    torch.manual_seed(1); a = workload._classify(head, x)
+    head2 = nn.Sequential(*layers)            # same modules: running statistics moved once more, the outputs of the same draw agree
+    torch.manual_seed(1); b = head2(x)
+    assert torch.equal(a, b)
+    calls = []
+    head[0].register_forward_hook(lambda m, i, o: calls.append(1))      # a hooked module: the Sequential's own __call__ path
+    workload._classify(head, x)
+    assert calls
+    y = torch.relu(torch.randn(2, 3, 7, 32))
+    ya, yb = y.clone().requires_grad_(), y.clone().requires_grad_()
+    neighbor_max(ya).sum().backward(); yb.max(dim=-1).values.sum().backward()
+    assert torch.equal(neighbor_max(y), y.max(dim=-1).values) and torch.equal(ya.grad, yb.grad)
