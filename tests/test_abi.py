@@ -69,3 +69,25 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle', src, flags=re.M), f'{f} imports the oracle'
                 assert 'libpvcnn_oracle' not in src, f'{f} references the oracle library'
+
+
+def test_batched_weight_split_entries_are_filled_on_the_host():
+    """pvcnn_*_weight_split_pair_entry (host-only helpers of the batched image refresh): workgroup counts, the wexp pointers behind the
+    images, the packed tile heights -- and bad arguments are refused with -1 instead of a table entry."""
+    import torch
+    from pvcnn_amd import _lib
+    lib = _lib.load()
+    w, wf, wb = 0x100000, 0x200000, 0x300000                      # any non-null, 16-byte aligned addresses: nothing is dereferenced
+    e = torch.zeros(10, dtype=torch.int64)
+    vp = ctypes.c_void_p
+    rows = lib.pvcnn_conv3d_weight_split_pair_entry(vp(w), 70, 33, vp(wf), vp(wb), vp(e.data_ptr()))
+    assert rows == 128 + 64                                       # (padded) output rows of the forward + backward-data image
+    img_f = lib.pvcnn_conv3d_weight_split_bytes(70, 33, 0, 2) - 128 * 4
+    img_b = lib.pvcnn_conv3d_weight_split_bytes(70, 33, 1, 2) - 64 * 4
+    assert e.tolist() == [w, wf, wf + img_f, wb, wb + img_b, 70, 33, 128, 0, 0]
+    rows = lib.pvcnn_pwconv_weight_split_pair_entry(vp(w), 130, 70, vp(wf), vp(wb), vp(e.data_ptr()))
+    assert rows == 256 + 128 and e[5:8].tolist() == [130, 70, 256] and e[8].item() == (128 | (128 << 32))
+    assert e[2].item() == wf + lib.pvcnn_pwconv_weight_split_bytes(130, 70, 0, 2) - 256 * 4
+    assert lib.pvcnn_conv3d_weight_split_pair_entry(vp(w), 0, 33, vp(wf), vp(wb), vp(e.data_ptr())) == -1
+    assert lib.pvcnn_pwconv_weight_split_pair_entry(vp(w), 8, 8, vp(wf + 4), vp(wb), vp(e.data_ptr())) == -1     # misaligned image
+    assert lib.pvcnn_conv3d_weight_split_pair_batch(None, 0, 0, None) == 0                                          # empty table: no launch
