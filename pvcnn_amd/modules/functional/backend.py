@@ -1093,6 +1093,8 @@ class _WeightBank:
             if p is not None and p._version == e['version'] and p.data_ptr() == key[1]:
                 return e['wf'], e['wb']
         if key not in self.wanted:
+            if len(self.wanted) >= 4096:                # (keys of temporaries -- a weight that is copied to be made contiguous has a new
+                self.wanted.clear()                     # address per call -- must not pile up; registered weights are re-noted at once)
             self.wanted.add(key)
             self.dirty = True
         return None

@@ -495,3 +495,31 @@ def test_classifier_head_and_pooling_fall_back_to_the_modules_on_cpu():
     ya, yb = y.clone().requires_grad_(), y.clone().requires_grad_()
     neighbor_max(ya).sum().backward(); yb.max(dim=-1).values.sum().backward()
     assert torch.equal(neighbor_max(y), y.max(dim=-1).values) and torch.equal(ya.grad, yb.grad)
+
+
+def test_weight_bank_serves_an_armed_pair_once_and_never_a_changed_weight():
+    """backend._WeightBank.take (host logic of the batched weight-image refresh; the launches are GPU tests): a pair is served once per
+    arming, only while the parameter's version counter and address are what they were at the refresh; anything else is noted as
+    wanted (for the next table rebuild) and answered with None -- the caller then splits the weight itself."""
+    import weakref
+    import torch
+    from pvcnn_amd.modules.functional.backend import _WeightBank
+    bank = _WeightBank(be=None)
+    w = torch.nn.Parameter(torch.randn(8, 4, 1))
+    w2 = w.view(8, 4)
+    key = ('pw', w.data_ptr(), (8, 4))
+    assert bank.take('pw', w2) is None and key in bank.wanted and bank.dirty          # first sighting: noted
+    wf, wb = torch.zeros(1), torch.zeros(1)
+    bank.entries[key] = {'param': weakref.ref(w), 'wf': wf, 'wb': wb, 'armed': True, 'version': w._version}
+    bank.dirty = False
+    got = bank.take('pw', w2)
+    assert got is not None and got[0] is wf and got[1] is wb
+    assert bank.take('pw', w2) is None and not bank.dirty                              # served once per arming
+    bank.entries[key]['armed'] = True
+    with torch.no_grad():
+        w.mul_(2.0)                                                                     # in-place change since the refresh
+    assert bank.take('pw', w2) is None and not bank.entries[key]['armed']
+    assert bank.take('conv', w2) is None and ('conv', w.data_ptr(), (8, 4)) in bank.wanted    # the kind is part of the key
+    for i in range(5000):                                                               # temporaries do not pile up
+        bank.take('pw', torch.empty(2, 2))
+    assert len(bank.wanted) <= 4096
