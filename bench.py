@@ -280,6 +280,8 @@ def main():
     ap.add_argument('--eager', action='store_true',
                     help='time the eagerly issued step (one Python thread issues every launch: host-bound) instead of the hipGraph replay')
     ap.add_argument('--graph', action='store_true', help='(default since round 3; accepted for older command lines)')
+    ap.add_argument('--collectives-after-replay', action='store_true',
+                    help='N > 1: do not capture the RCCL all-reduces inside the graph; issue them (and Adam) after each replay')
     ap.add_argument('--torch-adam', action='store_true', help='torch.optim.Adam(fused=True) instead of pvcnn_amd.optim.FlatAdam')
     args = ap.parse_args()
 
@@ -380,7 +382,8 @@ def main():
     graphed, graph_error = None, None
     if not args.eager:
         try:
-            graphed = GraphedTrainStep(model, lambda: loss_of(model(x)), opt, reducer, autocast=autocast, warmup=3)
+            graphed = GraphedTrainStep(model, lambda: loss_of(model(x)), opt, reducer, autocast=autocast, warmup=3,
+                                       capture_collectives=False if args.collectives_after_replay else None)
         except Exception as exc:                                 # reported on the line; the eager step is timed instead
             import traceback
             frames = [f'{os.path.basename(f.filename)}:{f.lineno} {f.name}' for f in traceback.extract_tb(exc.__traceback__)]
@@ -416,6 +419,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     final_loss = float(loss.detach())
+
+    # ---- the step's collectives alone (all buckets, back to back, nothing to overlap with): what NOT overlapping them would cost ----
+    comm_us = None
+    if world > 1:
+        for _ in range(3):
+            for b in reducer.buckets:
+                dist.all_reduce(b.flat)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            for b in reducer.buckets:
+                dist.all_reduce(b.flat)
+        fence()
+        comm_us = round((time.perf_counter() - t0) / 20 * 1e6, 1)
 
     # ---- the same step issued launch by launch (host-bound on one Python thread): eager_value ----
     eager_steps = min(args.steps, 20)
@@ -487,10 +504,15 @@ def main():
             'config': {'workload': label, 'baseline_config': args.config,
                        'global_batch': global_batch, 'points': args.points, 'parallelism': f'dp{world}',
                        'gradient_bytes': reducer.gradient_bytes, 'final_loss': round(final_loss, 4),
-                       'step_issue': (timed + (' (1 GPU: zero_grad, forward, loss, backward, fused Adam in one graph launch)' if world == 1 else
-                                               ' of forward + backward; bucketed RCCL all-reduce + fused Adam issued after each replay')
-                                      if graphed is not None else 'eager: one Python thread issues every launch'),
-                       'rccl_ranks': world if world > 1 else 0, 'per_rank_ms_per_step': per_rank_ms},
+                       'step_issue': (timed + {'graph': ' (1 GPU: zero_grad, forward, loss, backward, fused Adam in one graph launch)',
+                                               'graph+collectives': ' of the whole step: the bucketed RCCL all-reduces are captured where the '
+                                                                    'reducer\'s hooks launch them, overlapped with the rest of backward; fused Adam inside',
+                                               'graph, collectives after replay': ' of forward + backward; bucketed RCCL all-reduce + fused Adam issued '
+                                                                                  'after each replay (not overlapped)'}[graphed.mode]
+                                      if graphed is not None else 'eager: one Python thread issues every launch; bucket all-reduces launched '
+                                                                  'from the autograd hooks (overlapped with backward)'),
+                       'rccl_ranks': world if world > 1 else 0, 'per_rank_ms_per_step': per_rank_ms,
+                       'gradient_buckets': len(reducer.buckets), 'allreduce_alone_us_per_step': comm_us},
             'timed_region': timed,
             'eager_value': None if eager_elapsed is None else round(global_batch * eager_steps / eager_elapsed, 2),
             'eager_ms_per_step': None if eager_elapsed is None else round(eager_elapsed / eager_steps * 1e3, 3),
@@ -509,6 +531,8 @@ def main():
         }
         if graph_error:
             line['graph_error'] = graph_error
+        if graphed is not None and graphed.capture_error:
+            line['collective_capture_error'] = graphed.capture_error
         if world == 1 and not args.no_cpu_baseline and args.config == 'cfg2':
             line['cpu_baseline'] = cpu_baseline(args, args.cpu_sample_batch or args.batch)
         print(json.dumps(line), flush=True)

@@ -47,7 +47,7 @@ extern "C" {
 #define PVCNN_API
 #endif
 
-#define PVCNN_ABI_VERSION 7
+#define PVCNN_ABI_VERSION 8
 #define PVCNN_OK 0
 #define PVCNN_ERR_INVALID_ARGUMENT (-1)
 
@@ -255,6 +255,10 @@ PVCNN_API int pvcnn_conv3d_weight_split(const float *w, int Co, int Ci, int for_
 /* both f16x2 images (for_bwd_data = 0 and 1) of one weight in ONE launch: a training step needs both, the weights do not change in between */
 PVCNN_API int pvcnn_conv3d_weight_split_pair(const float *w, int Co, int Ci, void *wts_fwd, void *wts_bwd, void *stream);
 PVCNN_API size_t pvcnn_conv3d_fwd_split_stats_parts(int B, int Co, int R, int nsplit);
+/* (ABI v8) which launch shape pvcnn_conv3d_fwd_split takes for this problem: (voxels per workgroup tile) << 8 | weight rows per
+ * tile (64, or 32 for the half-height tile of layers with Co <= 32 at R = 32).  Pure function of the sizes; for tests and tools
+ * that have to prove a given tile ran (tests/test_gpu_parity_as_benched.py). */
+PVCNN_API int pvcnn_conv3d_fwd_split_route(int B, int Ci, int Co, int R, int nsplit);
 PVCNN_API int pvcnn_absmax_bits(const float *x, size_t n, void *out, void *stream);
 PVCNN_API size_t pvcnn_absmax_tiles_count(int B, long L, int seg);      /* 1 + T words */
 PVCNN_API int pvcnn_absmax_tiles(const float *x, int B, int C, long L, int seg, void *out, void *stream);

@@ -16,7 +16,7 @@ import torch  # noqa: F401  (must be imported before the dlopen, see above)
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 LIB_PATH = os.path.join(_CSRC, 'libpvcnn_hip.so')
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _vp, _i, _f, _sz, _l = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_long
 
@@ -60,6 +60,7 @@ SIGNATURES = {
     'pvcnn_conv3d_weight_split': (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     'pvcnn_conv3d_weight_split_pair': (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     'pvcnn_conv3d_fwd_split_stats_parts': (_sz, [_i, _i, _i, _i]),
+    'pvcnn_conv3d_fwd_split_route': (_i, [_i, _i, _i, _i, _i]),
     'pvcnn_absmax_bits': (_i, [_vp, _sz, _vp, _vp]),
     'pvcnn_absmax_tiles_count': (_sz, [_i, ctypes.c_long, _i]),
     'pvcnn_absmax_tiles': (_i, [_vp, _i, _i, ctypes.c_long, _i, _vp, _vp]),

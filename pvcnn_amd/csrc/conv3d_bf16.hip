@@ -944,6 +944,16 @@ extern "C" size_t pvcnn_conv3d_fwd_split_stats_parts(int B, int Co, int R, int n
   return (size_t)B * ceil_div(R, t.tx) * ceil_div(R, t.ty) * ceil_div(R, t.tz);
 }
 
+// the launch shape conv3d_fwd_split_impl's dispatch below takes: (voxels per tile) << 8 | weight rows per tile
+extern "C" int pvcnn_conv3d_fwd_split_route(int B, int Ci, int Co, int R, int nsplit) {
+  if (B <= 0 || Ci <= 0 || Co <= 0 || R <= 0 || nsplit < 1 || nsplit > 3) return 0;
+  const SplitTile t = split_tiles(B, Co, R, nsplit);
+  int tx = t.tx, ty = t.ty, tz = t.tz, rows = kCoTileB;
+  if (t.tz == 16 && t.vec && t.tx == 2 && nsplit == 2 && Ci % kKc == 0) { tx = 2; ty = 4; tz = 16; }    // the pipelined kernel: same tile
+  if (t.vec && t.tz == 32 && Co <= 32 && nsplit == 2) rows = 32;
+  return ((tx * ty * tz) << 8) | rows;
+}
+
 // y = conv3d(x, w) + bias with the pre-split weights of pvcnn_conv3d_weight_split (forward layout: Ci, Co as given; backward-data:
 // call with x = grad_y, Ci = the forward Co, Co = the forward Ci, bias = NULL and the for_bwd_data = 1 weights).
 static int conv3d_fwd_split_impl(const float *x, const void *wts, const float *bias, int B, int Ci, int Co, int R, int nsplit,

@@ -6,9 +6,13 @@ host-bound.  The step has static shapes and no host synchronisation (the per-coo
 BatchNorm statistics all stay on the device), so it is captured once -- zero the gradient buckets, forward, loss, backward and,
 on one GPU, the fused Adam update -- and replayed with a single launch per step.
 
-Multi-GPU: only forward + backward are captured; the bucket all-reduces (RCCL) and the optimizer run eagerly after the replay
-(`GradBucketReducer.finish()` issues them in fixed bucket order).  PVCNN's gradients are a few MB, so nothing is lost by not
-overlapping them with backward, and no collective has to live inside a captured graph.
+Multi-GPU: the WHOLE step is captured as well, collectives included (`mode == 'graph+collectives'`): the reducer's autograd hooks
+launch each bucket's RCCL all-reduce while backward is being captured, so inside the graph the collective of a full bucket runs on
+RCCL's stream next to the rest of backward (the overlap of the eager path, `pvcnn_amd/dp.py`), `finish()` contributes the stream
+joins and the division by the world size, and the fused Adam update follows -- one graph launch per step on every rank, the same
+RCCL kernels in the same order everywhere.  If the collectives cannot be captured (an RCCL build without capture support), the
+fallback captures forward + backward only and issues the bucket all-reduces in fixed bucket order and the optimizer after each
+replay (`mode == 'graph, collectives after replay'`: not overlapped).
 
 New input data goes INTO the static tensors the step was captured with (`tensor.copy_(batch)`), as with any captured graph.
 """
@@ -26,18 +30,23 @@ class GraphedTrainStep:
 
     loss_fn() -> scalar loss tensor, reading the model's inputs / targets from static device tensors.
     optimizer: built with capturable=True when it is to be captured (single GPU).
-    capture=False (the default without a GPU): the same sequencing -- forward + backward with the reducer's collectives held back,
-    then finish() in fixed bucket order and the optimizer -- issued eagerly; this is what the world-size-2 gloo test drives.
+    capture=False (the default without a GPU): the same sequencing issued eagerly -- capture_collectives=True: the hooks launch each
+    full bucket's all-reduce during backward (the order the captured graph holds them in); otherwise the collectives are held back
+    and finish() issues them in fixed bucket order -- then the optimizer; this is what the world-size-2 gloo tests drive.
     """
 
-    def __init__(self, model, loss_fn, optimizer, reducer, autocast=contextlib.nullcontext, warmup=3, capture=None):
+    def __init__(self, model, loss_fn, optimizer, reducer, autocast=contextlib.nullcontext, warmup=3, capture=None,
+                 capture_collectives=None):
+        """capture_collectives (multi-rank / always_reduce only): None = try to capture the RCCL all-reduces inside the graph and
+        fall back to issuing them after each replay if that fails; True = capture them or raise; False = always after the replay."""
         self.model, self.loss_fn, self.optimizer, self.reducer, self.autocast = model, loss_fn, optimizer, reducer, autocast
         self.collective = bool(reducer.collective)
         self.capture = torch.cuda.is_available() if capture is None else bool(capture)
         self.graph = self.loss = None
-        if self.collective:
-            reducer.launch_from_hooks = False            # collectives are issued by finish(), outside the graph
-        elif self.capture and not all(g.get('capturable', False) for g in optimizer.param_groups):
+        self.whole_step = not self.collective            # does the graph hold finish() + optimizer.step() too?
+        self.capture_error = None
+        if self.capture and not all(g.get('capturable', False) for g in optimizer.param_groups) and (
+                not self.collective or capture_collectives is not False):
             # a non-capturable optimizer keeps its step counter on the host: the captured update would replay step 1 forever
             raise ValueError('GraphedTrainStep captures optimizer.step(): build the optimizer with capturable=True')
         # the f16x2 weight images of every layer from one launch per kind and step (backend.weight_bank_refresh) instead of one per layer
@@ -47,26 +56,56 @@ class GraphedTrainStep:
         if self.bank is not None:
             self.bank.weight_bank_register(model)
         if not self.capture:
+            if self.collective:
+                # the same sequencing as the captured modes, issued eagerly (tests/test_dp_gloo.py drives both on gloo): hooks launch
+                # each full bucket's all-reduce during backward (capture_collectives=True) or finish() issues them afterwards
+                reducer.launch_from_hooks = bool(capture_collectives)
+                self.whole_step = bool(capture_collectives)
             return
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):                    # warm up on the capture stream's side: lazy inits, allocator pools
-            for _ in range(max(1, warmup)):
+        with torch.cuda.stream(side):                    # warm up on the capture stream's side: lazy inits, allocator pools, and
+            for _ in range(max(1, warmup)):              # (multi-rank) the RCCL communicator, which must exist before a capture
                 self.eager_step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        if self.collective and capture_collectives is not False:
+            try:
+                self._capture(whole_step=True)
+            except Exception as exc:                     # noqa: BLE001 -- reported (mode / capture_error); the fallback still trains
+                if capture_collectives:
+                    raise
+                self.capture_error = f'{type(exc).__name__}: {str(exc)[:200]}'
+                self.graph = None
+                self.reducer.rearm()
+                torch.cuda.synchronize()
+        if self.graph is None:
+            if self.collective:
+                reducer.launch_from_hooks = False        # collectives are issued by finish(), after the replay, in fixed bucket order
+            self._capture(whole_step=not self.collective)
+
+    def _capture(self, whole_step):
         _cache.clear()                                   # the per-coords plans must be rebuilt INSIDE the graph
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.loss = self._forward_backward()
-            if not self.collective:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self.loss = self._forward_backward()         # (multi-rank, whole step: the hooks launch the bucket all-reduces in here)
+            if whole_step:
                 self.reducer.finish()
                 self.optimizer.step()
-        if self.collective:
+        self.graph, self.whole_step = graph, whole_step
+        if not whole_step:
             # the capture ran the reducer's hooks (pending -> 0, packed) but not finish(): re-arm the buckets so that an eager
             # backward after construction does not trip the "already all-reduced" guard
             self.reducer.rearm()
         _cache.clear()                                   # nothing outside may alias tensors of the graph's private pool
+
+    @property
+    def mode(self):
+        if self.graph is None:
+            return 'eager'
+        if not self.collective:
+            return 'graph'
+        return 'graph+collectives' if self.whole_step else 'graph, collectives after replay'
 
     def _forward_backward(self):
         self.reducer.zero_grad()
@@ -87,7 +126,7 @@ class GraphedTrainStep:
         if self.graph is None:
             return self.eager_step()
         self.graph.replay()
-        if self.collective:
+        if not self.whole_step:
             self.reducer.finish()
             self.optimizer.step()
         return self.loss

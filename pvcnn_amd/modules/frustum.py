@@ -60,6 +60,15 @@ class FrustumPointNetLoss(nn.Module):
                              torch.arange(0, 2 * math.pi, 2 * math.pi / self.num_heading_angle_bins))
 
     def forward(self, inputs, targets):
+        # fp32 under torch.autocast as well: the loss is a few hundred scalars -- the 3x3 rotations of the corner loss (torch.matmul)
+        # would otherwise run on bf16 operands, with a cast kernel per operand (BASELINE configs[4] asks for bf16 in the dense
+        # convolutions, not here)
+        up = lambda t: t.float() if t.dtype in (torch.bfloat16, torch.float16) else t
+        inputs = {k: up(v) for k, v in inputs.items()}
+        with torch.autocast(inputs['center'].device.type, enabled=False):
+            return self._forward(inputs, targets)
+
+    def _forward(self, inputs, targets):
         center = inputs['center']
         rows = torch.arange(center.size(0), device=center.device)
         h_id, s_id = targets['heading_bin_id'], targets['size_template_id']

@@ -352,7 +352,9 @@ class _FrustumSegmentation(nn.Module):
         per_point, coords = self.point_features((feats, feats[:, :3, :]))
         pooled, _ = self.cloud_features((per_point, coords)) if len(self.cloud_features) else (per_point, coords)
         pooled = pooled.max(dim=-1, keepdim=True).values.repeat([1, 1, npts])
-        return self.classifier(torch.cat([one_hot, per_point, pooled], dim=1))
+        # (the classifier head module by module on this package's kernels -- under torch.autocast the bare nn.Conv1d at its end would
+        # otherwise be a vendor bf16 GEMM with casts either side: _classify)
+        return _classify(self.classifier, torch.cat([one_hot, per_point, pooled], dim=1))
 
 
 class _CloudRegressor(nn.Module):
@@ -380,7 +382,12 @@ class _CloudRegressor(nn.Module):
         else:
             desc = self.features(coords)
         desc = desc.max(dim=-1, keepdim=False).values
-        return getattr(self, self._head_attr)(torch.cat([desc, inputs['one_hot_vectors']], dim=1))
+        # the dense head works on (B, C) numbers: it stays in fp32 under torch.autocast (BASELINE configs[4] asks for bf16 operands in
+        # the dense convolutions; three Linear layers on 32 rows gain nothing from them and would cost a cast kernel per operand)
+        up = lambda t: t.float() if t.dtype in (torch.bfloat16, torch.float16) else t
+        joined = torch.cat([up(desc), up(inputs['one_hot_vectors'])], dim=1)
+        with torch.autocast(joined.device.type, enabled=False):
+            return getattr(self, self._head_attr)(joined)
 
 
 class FrustumPVCNNE(nn.Module):

@@ -251,9 +251,10 @@ def test_gradients_are_packed_into_the_flat_buckets_and_unused_parameters_read_z
     assert torch.equal(used.weight.grad, twin.weight.grad)
 
 
-def _graphed_worker(rank, world, port, q):
-    """GraphedTrainStep's multi-rank branch on CPU (capture=False: same sequencing as the GPU path -- the reducer's hooks only
-    pack, finish() issues every collective in fixed bucket order after forward + backward, then the optimizer)."""
+def _graphed_worker(rank, world, port, q, overlapped):
+    """GraphedTrainStep's multi-rank branches on CPU (capture=False: same sequencing as the GPU path).  overlapped: the ordering the
+    'graph+collectives' mode captures -- the reducer's hooks launch each full bucket's all-reduce during backward; else the fallback
+    -- the hooks only pack, finish() issues every collective in fixed bucket order after forward + backward; then the optimizer."""
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
@@ -266,8 +267,9 @@ def _graphed_worker(rank, world, port, q):
         x = torch.randn(8, 6, 32, generator=g)
         y = torch.randint(0, 5, (8, 32), generator=g)
         sl = shard_batch(8, world, rank)
-        step = GraphedTrainStep(model, lambda: nn.functional.cross_entropy(model(x[sl]), y[sl]), opt, reducer, capture=False)
-        assert step.collective and reducer.launch_from_hooks is False
+        step = GraphedTrainStep(model, lambda: nn.functional.cross_entropy(model(x[sl]), y[sl]), opt, reducer, capture=False,
+                                capture_collectives=overlapped)
+        assert step.collective and reducer.launch_from_hooks is overlapped and step.mode == 'eager' 
         start = [p.detach().numpy().copy() for p in model.parameters()]
         losses = [float(step()) for _ in range(3)]
         # an eager backward after the graphed steps must still be accepted by the reducer (buckets re-armed)
@@ -277,11 +279,12 @@ def _graphed_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_graphed_step_multi_rank_branch_matches_big_batch_sgd():
+@pytest.mark.parametrize('overlapped', [False, True])
+def test_graphed_step_multi_rank_branch_matches_big_batch_sgd(overlapped):
     world, port = 2, _free_port()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_graphed_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_graphed_worker, args=(r, world, port, q, overlapped)) for r in range(world)]
     for p in procs:
         p.start()
     results = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])

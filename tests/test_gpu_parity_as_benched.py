@@ -1,0 +1,410 @@
+"""Train-step parity AT THE SIZES bench.py RUNS: BASELINE configs[2], [3], [4] at full width and at the per-GPU batch of their
+bench lines (configs[1] as benched: test_gpu_train_parity.py::test_full_width_cfg2_step_...), and the step composition the bench
+times (hipGraph + FlatAdam + weight bank + fused dropout).
+
+The reduced-width networks of test_gpu_train_parity.py never reach the launch shapes these sizes select: the 64-voxel Conv3d tile
+(R = 8 with few tiles), the 32-row weight tile (R = 32, Co <= 32), the f16x2 1x1 GEMMs above `pw_split_min_macs`, the fused SE
+excitation at 256-1024 channels, FPS at N = 8192, the neighbour max over 32-wide rows.  Call counters (and, for the Conv3d tiles,
+the library's own route query) prove those routes ran; the comparison is the one of the reduced-width tests: the HIP path, the
+fp32 oracle stack and an fp64 evaluation of the same network on the same weights and inputs (see test_gpu_train_parity.py).
+
+cfg5 (bf16 operands in the dense convolutions under torch.autocast) is compared with a MATCHED checker instead of stated bf16
+bounds: the CPU stacks evaluate every convolution the HIP path ran on bf16 operands on operands that carry THE SAME rounding
+errors -- the difference bf16(x) - x of each activation / gradient tensor is recorded on the GPU run and added to the CPU
+stack's own tensor at the same place (weights are the same fp32 numbers in all stacks: rounded directly) -- in fp32 (oracle
+stack) and in fp64 (truth).  What remains between the HIP path and that truth is fp32-class arithmetic, so the bar is the
+fp32 networks' bar, not 0.25 / 0.6.  (Recomputing the rounding on the CPU tensor instead would compare two different
+perturbations: an fp32 value within 1e-7 of a bf16 rounding boundary rounds the other way, a 2^-8 relative jump on that
+element, ~300x fp32 round-off in RMS over a tensor.)
+"""
+import contextlib
+
+import pytest
+import torch
+import torch.nn.functional as tf
+
+from test_gpu_train_parity import (DEV, NET_FACTOR, TOL_LOSS, PinMaxWinners, _grads, _no_dropout, _report, _run_three, cpu_stack)
+
+pytestmark = pytest.mark.gpu
+
+
+@contextlib.contextmanager
+def watch_native_calls(names, shapes_of=()):
+    """Count calls of the product backend's methods `names`; for those in `shapes_of` also record the first argument's shape and the
+    4th positional argument (the output channel count of the *_split launches)."""
+    from pvcnn_amd.modules.functional import backend as seam
+    be, counts, shapes = seam._backend, {n: 0 for n in names}, {n: [] for n in shapes_of}
+    for n in names:
+        orig = getattr(be, n)
+
+        def wrapped(*a, _o=orig, _n=n, **kw):
+            counts[_n] += 1
+            if _n in shapes:
+                shapes[_n].append((tuple(a[0].shape), int(a[3])))
+            return _o(*a, **kw)
+        setattr(be, n, wrapped)
+    try:
+        yield counts, shapes
+    finally:
+        for n in names:
+            delattr(be, n)
+
+
+def _assert_network(label, res, flip_allowance):
+    rows = _report(label, *res)
+    (lg, _), (lc, _), (lt, _) = res
+    assert abs(lg - lt) <= TOL_LOSS * max(abs(lt), 1.0) and abs(lg - lc) <= TOL_LOSS * max(abs(lc), 1.0), (lg, lc, lt)
+    worst_cpu = max(c for _, _, _, c in rows)
+    bound = max(NET_FACTOR * worst_cpu, flip_allowance)
+    bad = [(k, b) for k, _, b, _ in rows if b > bound]
+    assert not bad, f'{label}: beyond {bound:.1e} of the fp64 truth: {bad[:6]}'
+    errs = sorted(b for _, _, b, _ in rows)
+    print(f'[as benched] {label}: hip-vs-truth over {len(errs)} tensors: median {errs[len(errs) // 2]:.2e}, 90th percentile '
+          f'{errs[int(0.9 * len(errs))]:.2e}, worst {errs[-1]:.2e}; bound used {bound:.1e} (oracle stack\'s own worst {worst_cpu:.2e})')
+    return rows
+
+
+def test_full_width_cfg3_step_pvcnnpp(hip, oracle):
+    """BASELINE configs[2] AS BENCHED: PVCNN++ 1xC, B = 8, N = 8192 (dropout 0), one train step: 13 PVConvs with SE at R = 32 / 16 / 8,
+    four FPS + ball-query + grouping levels, four 3-NN interpolations."""
+    from pvcnn_amd import workload
+    x0, y0 = workload.make_s3dis_batch(8, 8192)
+
+    def make(dev, dtype):
+        x = x0.clone().to(dev, dtype).requires_grad_()
+        return x, x, y0.to(dev)
+
+    watched = ['conv3d_igemm_split', 'conv3d_backward_weight_f16', 'pwconv_gemm_split', 'pwconv_backward_weight_f16', 'se_excite_forward',
+               'se_excite_backward', 'neighbor_max_forward', 'neighbor_max_backward', 'furthest_point_sampling', 'ball_query', 'grouping_forward',
+               'three_nearest_neighbors_interpolate_forward', 'trilinear_devoxelize_bnact_forward', 'avg_voxelize_apply',
+               'trilinear_devoxelize_backward_apply']
+    with watch_native_calls(watched, shapes_of=('conv3d_igemm_split',)) as (calls, shapes):
+        res = _run_three(lambda: workload.PVCNN2(13, 6, width_multiplier=1), make, tf.cross_entropy, oracle, pin_winners=True)
+    print(f'[as benched] cfg3 native calls: {calls}')
+    # 13 PVConvs x 2 convolutions, forward + backward-data (the input leaf wants its gradient); every weight gradient in f16x2
+    assert calls['conv3d_igemm_split'] == 52 and calls['conv3d_backward_weight_f16'] == 26, calls
+    assert calls['se_excite_forward'] == 13 and calls['se_excite_backward'] == 13, calls
+    assert calls['trilinear_devoxelize_bnact_forward'] == 13 and calls['avg_voxelize_apply'] == 13 and calls['trilinear_devoxelize_backward_apply'] == 13, calls
+    assert calls['furthest_point_sampling'] == 4 and calls['ball_query'] == 4 and calls['three_nearest_neighbors_interpolate_forward'] == 4, calls
+    assert calls['neighbor_max_forward'] == 4 and calls['neighbor_max_backward'] == 4 and calls['grouping_forward'] == 8, calls
+    assert calls['pwconv_gemm_split'] >= 8, calls
+    # the launch shapes only this size selects, by the library's own dispatch (include/pvcnn_hip.h: pvcnn_conv3d_fwd_split_route)
+    routes = {}
+    for (xs, co) in shapes['conv3d_igemm_split']:
+        code = hip.lib.pvcnn_conv3d_fwd_split_route(xs[0], xs[1], co, xs[2], 2)
+        routes.setdefault((code >> 8, code & 255), set()).add((xs[1], co, xs[2]))
+    print(f'[as benched] cfg3 Conv3d routes (tile voxels, weight rows) -> (Ci, Co, R): {routes}')
+    assert any(vox == 64 for vox, _ in routes), routes                 # the 64-voxel tile of the R = 8 levels
+    assert any(rows == 32 for _, rows in routes), routes               # the 32-row weight tile of the 32-channel R = 32 layers
+    _assert_network('PVCNN++ 1xC B=8 N=8192 (cfg3 as benched) [max-pool winners pinned]', res, 1.0 / (8 * 16) ** 0.5)
+
+
+def test_full_width_cfg4_step_shapenet(hip, oracle):
+    """BASELINE configs[3] AS BENCHED per GPU: PVCNN ShapeNet 1xC, B = 8, N = 2048 (SE, normalize=False; dropout 0)."""
+    from pvcnn_amd import workload
+    x0, y0 = workload.make_shapenet_batch(8, 2048)
+
+    def make(dev, dtype):
+        x = x0.clone().to(dev, dtype).requires_grad_()
+        return x, x, y0.to(dev)
+
+    watched = ['conv3d_igemm_split', 'conv3d_backward_weight_f16', 'pwconv_gemm_split', 'pwconv_backward_weight_f16', 'se_excite_forward',
+               'se_excite_backward', 'trilinear_devoxelize_bnact_forward', 'avg_voxelize_apply', 'trilinear_devoxelize_backward_apply']
+    with watch_native_calls(watched) as (calls, _):
+        res = _run_three(lambda: workload.PVCNNShapeNet(50, 16, 3, width_multiplier=1), make, tf.cross_entropy, oracle, pin_winners=True)
+    print(f'[as benched] cfg4 native calls: {calls}')
+    assert calls['conv3d_igemm_split'] == 12 and calls['conv3d_backward_weight_f16'] == 6, calls
+    assert calls['se_excite_forward'] == 3 and calls['se_excite_backward'] == 3, calls
+    assert calls['trilinear_devoxelize_bnact_forward'] == 3 and calls['avg_voxelize_apply'] == 3 and calls['trilinear_devoxelize_backward_apply'] == 3, calls
+    assert calls['pwconv_gemm_split'] >= 8 and calls['pwconv_backward_weight_f16'] >= 2, calls
+    _assert_network('PVCNN ShapeNet 1xC B=8 N=2048 (cfg4 as benched) [max-pool winners pinned]', res, 1.0 / (8 * 2048) ** 0.5)
+
+
+# ---- cfg5: the matched bf16 checker ---------------------------------------------------------------------------------------------
+
+def _key(kind, direction, shape, co):
+    b, c = int(shape[0]), int(shape[1])
+    n = 1
+    for d in shape[2:]:
+        n *= int(d)
+    return (kind, direction, b, c, n, int(co))
+
+
+class Bf16RoundingRecorder:
+    """GPU side: wraps the two launches that take bf16 operands (nsplit == 1) and keeps, per call, bf16(x) - x of the activation /
+    gradient tensor they were handed, keyed by (kind, forward | backward, shape, output channels) in call order.  Layers of equal
+    shape sit on one dependency chain in these networks, so the order within a key is forced (forward: input to output; backward:
+    the reverse) and is the same in every stack."""
+
+    def __init__(self):
+        self.store = {}
+        self.calls = {'conv': 0, 'pw': 0}
+
+    @contextlib.contextmanager
+    def recording(self):
+        from pvcnn_amd.modules.functional import backend as seam
+        be = seam._backend
+        for name, kind in (('conv3d_igemm_split', 'conv'), ('pwconv_gemm_split', 'pw')):
+            orig = getattr(be, name)
+
+            def wrapped(x, wts, bias, co, nsplit, *a, _o=orig, _k=kind, **kw):
+                if int(nsplit) == 1:
+                    direction = 'bwd' if torch._C._current_graph_task_id() != -1 else 'fwd'
+                    delta = (x.detach().bfloat16().float() - x.detach()).cpu()
+                    self.store.setdefault(_key(_k, direction, x.shape, co), []).append(delta)
+                    self.calls[_k] += 1
+                return _o(x, wts, bias, co, nsplit, *a, **kw)
+            setattr(be, name, wrapped)
+        try:
+            yield self
+        finally:
+            for name in ('conv3d_igemm_split', 'pwconv_gemm_split'):
+                delattr(be, name)
+
+    def replay(self):
+        return {k: list(v) for k, v in self.store.items()}
+
+
+class _MatchedConv(torch.autograd.Function):
+    """conv(x + dx, bf16(w)) + b forward, conv_transpose(g + dg, bf16(w)) backward-data, EXACT backward-weight on (x, g): the HIP
+    path's arithmetic under torch.autocast(bfloat16) (functional/conv3d.py, functional/pwconv.py: forward / backward-data on bf16
+    operands, backward-weight in f16x2 = fp32-class on the unrounded tensors), in the dtype of the stack that calls it."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, nd, pad, pending, kind):
+        conv = {1: tf.conv1d, 2: tf.conv2d, 3: tf.conv3d}[nd]
+        wr = w.detach().float().bfloat16().to(w.dtype)
+        dx = pending[_key(kind, 'fwd', x.shape, w.shape[0])].pop(0).view(x.shape).to(x.dtype)
+        ctx.save_for_backward(x, w, wr)
+        ctx.nd, ctx.pad, ctx.pending, ctx.kind, ctx.has_bias = nd, pad, pending, kind, b is not None
+        return conv(x + dx, wr, b, padding=pad)
+
+    @staticmethod
+    def backward(ctx, g):
+        import torch.nn.grad as ng
+        x, w, wr = ctx.saved_tensors
+        inp = {1: ng.conv1d_input, 2: ng.conv2d_input, 3: ng.conv3d_input}[ctx.nd]
+        wgt = {1: ng.conv1d_weight, 2: ng.conv2d_weight, 3: ng.conv3d_weight}[ctx.nd]
+        gx = None
+        if ctx.needs_input_grad[0]:
+            dg = ctx.pending[_key(ctx.kind, 'bwd', g.shape, w.shape[1])].pop(0).view(g.shape).to(g.dtype)
+            gx = inp(x.shape, wr, g + dg, padding=ctx.pad)
+        gw = wgt(x, w.shape, g, padding=ctx.pad) if ctx.needs_input_grad[1] else None
+        gb = g.sum(dim=[0] + list(range(2, g.dim()))) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return gx, gw, gb, None, None, None, None
+
+
+class MatchedBf16Convs(torch.overrides.TorchFunctionMode):
+    """CPU side: every convolution call for which the GPU run recorded a bf16 launch (same kind / shape / channels pending) is
+    evaluated by _MatchedConv; all others as they are."""
+
+    def __init__(self, pending):
+        super().__init__()
+        self.pending = pending
+
+    def __torch_function__(self, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        nd = {torch.conv1d: 1, torch.conv2d: 2, torch.conv3d: 3}.get(func)
+        if nd is not None and not kwargs and len(args) >= 3 and not args[0].is_cuda:
+            x, w, b = args[0], args[1], args[2]
+            kind = 'conv' if nd == 3 else 'pw'
+            if self.pending.get(_key(kind, 'fwd', x.shape, w.shape[0])):
+                stride, pad, dil, groups = (list(args[3:7]) + [1, 0, 1, 1][len(args) - 3:])[:4] if len(args) > 3 else (1, 0, 1, 1)
+                one = lambda v: all(int(e) == 1 for e in (v if isinstance(v, (tuple, list)) else (v,)))
+                assert one(stride) and one(dil) and int(groups) == 1
+                pad = tuple(int(e) for e in pad) if isinstance(pad, (tuple, list)) else int(pad)
+                return _MatchedConv.apply(x, w, b, nd, pad, self.pending, kind)
+        return func(*args, **kwargs)
+
+
+def _logits_mask_with(coords, mask, picks, sampling):
+    nb, _, npts = coords.shape
+    n_fg = mask.sum(dim=-1, keepdim=True)
+    fg_coords = coords * mask.view(nb, 1, npts)
+    fg_mean = fg_coords.sum(dim=-1) / torch.max(n_fg, torch.ones_like(n_fg)).to(coords.dtype)
+    return sampling.gather(fg_coords - fg_mean.view(nb, -1, 1), picks), fg_mean, mask
+
+
+def _frustum_three_ways(build, in0, targets, loss_of, autocast):
+    """-> (res_gpu, res_oracle32, res_truth64, recorder) for one Frustum train step; max-pool winners, the foreground mask and the
+    sampled indices pinned to the GPU run's; under autocast the CPU stacks use the matched bf16 checker."""
+    from truth_backend import TruthBackend
+    from oracle.oracle_backend import OracleBackend
+    from pvcnn_amd.modules.functional import backend as seam
+    from pvcnn_amd.modules.functional import sampling
+    from pvcnn_amd.modules import functional as PF
+    oracle = OracleBackend()
+    torch.manual_seed(11)
+    cpu_net = _no_dropout(build()).train()
+    state = {k: v.clone() for k, v in cpu_net.state_dict().items()}
+    gpu_net = _no_dropout(build())
+    gpu_net.load_state_dict(state)
+    gpu_net = gpu_net.to(DEV).train()
+    f64_net = _no_dropout(build())
+    f64_net.load_state_dict(state)
+    f64_net = f64_net.double().train()
+
+    def make(dev, dtype):
+        feats = in0['features'].clone().to(dev, dtype).requires_grad_()
+        return {'features': feats, 'one_hot_vectors': in0['one_hot_vectors'].to(dev, dtype)}, feats
+
+    def tgt_on(dev, dtype):
+        return {k: (v.to(dev, dtype) if v.dtype.is_floating_point else v.to(dev)) for k, v in targets.items()}
+
+    # ---- GPU run: records winners, the foreground selection and (autocast) the bf16 rounding errors ----
+    picked = {}
+    orig_select = seam._backend.mask_select
+
+    def recording_select(mask, m, **kw):
+        out = orig_select(mask, m, **kw)
+        picked['mask'], picked['picks'] = mask.detach().cpu(), out.detach().cpu()
+        return out
+    seam._backend.mask_select = recording_select
+    winners, rounding = PinMaxWinners(), Bf16RoundingRecorder()
+    try:
+        with winners, rounding.recording():
+            inp, leaf = make(DEV, torch.float32)
+            with (torch.autocast('cuda', dtype=torch.bfloat16) if autocast else contextlib.nullcontext()):
+                loss_g = loss_of(gpu_net(inp), tgt_on(DEV, torch.float32), DEV, torch.float32)
+            loss_g.backward()
+            torch.cuda.synchronize()
+    finally:
+        del seam._backend.mask_select
+    res_g = (loss_g.item(), _grads(gpu_net, leaf))
+
+    # ---- CPU stacks: the same discrete decisions, the same bf16 rounding errors ----
+    def pinned_logits_mask(coords, logits, num_points_per_object, rng=None, choices=None):
+        return _logits_mask_with(coords, picked['mask'].to(coords.device), picked['picks'].to(coords.device), sampling)
+
+    def cpu_run(net, backend, dtype):
+        pending = rounding.replay()
+        prev = (sampling.logits_mask, PF.logits_mask)
+        sampling.logits_mask = PF.logits_mask = pinned_logits_mask
+        try:
+            with cpu_stack(backend), PinMaxWinners(winners.winners), MatchedBf16Convs(pending):
+                inp, leaf = make('cpu', dtype)
+                loss = loss_of(net(inp), tgt_on('cpu', dtype), 'cpu', dtype)
+                loss.backward()
+        finally:
+            sampling.logits_mask, PF.logits_mask = prev
+        left = {k: len(v) for k, v in pending.items() if v}
+        assert not left, f'bf16 launches of the GPU run without a counterpart in the CPU stack: {left}'
+        return loss.item(), _grads(net, leaf)
+
+    res_t = cpu_run(f64_net, TruthBackend(oracle), torch.float64)
+    res_c = cpu_run(cpu_net, oracle, torch.float32)
+    return res_g, res_c, res_t, rounding, picked
+
+
+def test_full_width_cfg5_step_frustum_under_bf16_autocast_against_the_matched_checker(hip, oracle):
+    """BASELINE configs[4] AS BENCHED: Frustum-PVCNN (efficient) 1xC, B = 32, N = 1024, torch.autocast(bfloat16), the multi-task
+    FrustumPointNetLoss, one train step -- segmentation net with every PVConv of the model (R = 16, 16, 12, 12), device-side
+    foreground sampling, centre regression and box estimation nets."""
+    from pvcnn_amd import workload
+    from pvcnn_amd.modules import FrustumPointNetLoss
+    templates = workload.frustum_size_templates()
+    in0, _ = workload.make_frustum_batch(32, 1024)
+    targets = workload.make_frustum_targets(32, 1024)
+
+    def build():
+        return workload.FrustumPVCNNE(3, 12, 8, 512, templates, 1, 1)
+
+    crit = {}
+
+    def loss_of(out, tgt, dev, dtype):
+        key = (str(dev), dtype)
+        if key not in crit:
+            crit[key] = FrustumPointNetLoss(12, 8, templates).to(dev, dtype)
+        out = {k: (v.to(dtype) if v.dtype.is_floating_point else v) for k, v in out.items()}
+        return crit[key](out, tgt)
+
+    res_g, res_c, res_t, rounding, picked = _frustum_three_ways(build, in0, targets, loss_of, autocast=True)
+    print(f'[as benched] cfg5 bf16 launches recorded: {rounding.calls}; foreground points per frustum: '
+          f'min {int(picked["mask"].sum(1).min())} max {int(picked["mask"].sum(1).max())}')
+    # 8 Conv3d layers forward + backward-data (the feature leaf wants its gradient) ran on bf16 operands, and the large 1x1 GEMMs
+    assert rounding.calls['conv'] == 16 and rounding.calls['pw'] >= 4, rounding.calls
+    rows = _report('Frustum-PVCNN 1xC B=32 N=1024 under autocast(bf16) vs the matched checker (cfg5 as benched)', res_g, res_c, res_t)
+    (lg, _), (lc, _), (lt, _) = res_g, res_c, res_t
+    assert abs(lg - lt) <= TOL_LOSS * max(abs(lt), 1.0) and abs(lg - lc) <= TOL_LOSS * max(abs(lc), 1.0), (lg, lc, lt)
+    worst_cpu = max(c for _, _, _, c in rows)
+    bound = max(NET_FACTOR * worst_cpu, 2e-3)
+    errs = sorted(b for _, _, b, _ in rows)
+    print(f'[as benched] cfg5 matched: hip-vs-matched-truth over {len(errs)} tensors: median {errs[len(errs) // 2]:.2e}, 90th percentile '
+          f'{errs[int(0.9 * len(errs))]:.2e}, worst {errs[-1]:.2e}; bound {bound:.1e} (matched fp32 stack\'s own worst {worst_cpu:.2e})')
+    bad = [(k, b) for k, _, b, _ in rows if b > bound]
+    assert not bad, f'beyond {bound:.1e} of the matched fp64 truth: {bad[:6]}'
+
+
+def test_full_width_cfg5_step_frustum_fp32(hip, oracle):
+    """The same network and step without autocast (every product fp32-class): the ordinary three-way comparison."""
+    from pvcnn_amd import workload
+    from pvcnn_amd.modules import FrustumPointNetLoss
+    templates = workload.frustum_size_templates()
+    in0, _ = workload.make_frustum_batch(32, 1024)
+    targets = workload.make_frustum_targets(32, 1024)
+    crit = {}
+
+    def loss_of(out, tgt, dev, dtype):
+        key = (str(dev), dtype)
+        if key not in crit:
+            crit[key] = FrustumPointNetLoss(12, 8, templates).to(dev, dtype)
+        return crit[key](out, tgt)
+
+    res_g, res_c, res_t, rounding, _ = _frustum_three_ways(lambda: workload.FrustumPVCNNE(3, 12, 8, 512, templates, 1, 1), in0, targets,
+                                                           loss_of, autocast=False)
+    assert rounding.calls == {'conv': 0, 'pw': 0}
+    _assert_network('Frustum-PVCNN 1xC B=32 N=1024 fp32 (cfg5\'s network)', (res_g, res_c, res_t), 1.0 / (32 * 512) ** 0.5)
+
+
+# ---- the step composition bench.py times -------------------------------------------------------------------------------------------
+
+def test_graph_replay_of_the_benched_composition_follows_the_eager_steps(hip):
+    """bench.py's timed region: hipGraph replay of zero_grad + weight-bank refresh + forward (fused dropout, p > 0) + loss + backward +
+    bucket packing + FlatAdam, PVCNN 1xC at B = 16, N = 4096.  Replayed steps against the same steps issued eagerly on a twin, both
+    drawing their dropout keys from the device generator re-seeded at the same points: the losses follow each other."""
+    import copy
+    from pvcnn_amd import workload
+    from pvcnn_amd.dp import GradBucketReducer
+    from pvcnn_amd.graph import GraphedTrainStep
+    from pvcnn_amd.optim import FlatAdam
+    torch.manual_seed(0)
+    model = workload.PVCNN(13, 6, width_multiplier=1).to(DEV).train()
+    assert any(isinstance(m, torch.nn.Dropout) and m.p > 0 for m in model.modules())
+    x, y = workload.make_s3dis_batch(16, 4096, device=DEV, seed=3)
+    twin = copy.deepcopy(model)
+
+    def build(mod):
+        red = GradBucketReducer(mod, bucket_mb=8.0)
+        return red, FlatAdam(red, lr=1e-3, weight_decay=1e-5)
+    red, opt = build(model)
+
+    def eager():
+        red.zero_grad()
+        loss = tf.cross_entropy(model(x), y)
+        loss.backward()
+        red.finish()
+        opt.step()
+        return loss
+    torch.cuda.manual_seed(100)
+    want = [eager().item() for _ in range(3)]
+    torch.cuda.manual_seed(101)
+    want += [eager().item() for _ in range(3)]
+
+    red2, opt2 = build(twin)
+    torch.cuda.manual_seed(100)
+    with watch_native_calls(['weight_bank_refresh']) as (calls, _):
+        step = GraphedTrainStep(twin, lambda: tf.cross_entropy(twin(x), y), opt2, red2, warmup=3)   # eager steps 0..2 happen in here
+    assert step.graph is not None and step.bank is not None and calls['weight_bank_refresh'] >= 4       # 3 warm-up steps + the capture
+    torch.cuda.manual_seed(101)
+    got = [step().item() for _ in range(3)]
+    print(f'[as benched] graph vs eager losses: eager {want[3:]}, replayed {got}')
+    assert want[3] < want[0]
+    # the same dropout keys: the trajectories agree to round-off amplified by Adam's normalised updates (a different mask moves the
+    # loss by ~1e-2 already on the first step)
+    for a, b, tol in zip(want[3:], got, (2e-4, 2e-3, 1e-2)):
+        assert abs(a - b) <= tol * abs(a), (want, got)
+    # the parameters the replay updates are the twin's own (FlatAdam writes through the flat buckets the modules alias)
+    before = [p.detach().clone() for p in twin.parameters()]
+    step()
+    torch.cuda.synchronize()
+    assert all(not torch.equal(p, q) for p, q in zip(twin.parameters(), before))

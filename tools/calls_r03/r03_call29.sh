@@ -1,2 +1,2 @@
 #!/bin/bash
-cd ${GRAFT_REPO_ROOT:-$PWD}; python tools/zero_test.py 2>&1 | tail -16
+cd ${GRAFT_REPO_ROOT:-$PWD}; python tools/mfma_fill_probe.py 2>&1 | tail -16
