@@ -453,9 +453,11 @@ PVCNN_API int pvcnn_concat_points(const float *const *srcs, const long *bstrides
  * replaces torch.optim.Adam's per-tensor update of train.py:96-119 (optimizer.step()) when the parameters share the flat layout of
  * the gradient buckets (pvcnn_amd/dp.py): p, m (exp_avg), v (exp_avg_sq) updated in place, g read; arithmetic of torch.optim.Adam
  * (no amsgrad; weight_decay added to the gradient), fp32.  `step`: one float in device memory = updates done so far (nothing is
- * read back: graph-capturable); inc_step != 0 increments it behind this update (the last buffer of an optimizer step). */
-PVCNN_API int pvcnn_adam_step(float *p, const float *g, float *m, float *v, size_t n, float *step, float lr, float beta1, float beta2,
-                    float eps, float weight_decay, int inc_step, void *stream);
+ * read back: graph-capturable); inc_step != 0 increments it behind this update (the last buffer of an optimizer step).
+ * (ABI v8) `hyper`: five floats in DEVICE memory -- lr, beta1, beta2, eps, weight_decay -- read by the kernel, so that a learning-rate
+ * schedule (train.py:121-122: scheduler.step()) reaches launches that were captured into a hipGraph. */
+PVCNN_API int pvcnn_adam_step(float *p, const float *g, float *m, float *v, size_t n, float *step, const float *hyper, int inc_step,
+                    void *stream);
 
 #ifdef __cplusplus
 }

@@ -104,7 +104,7 @@ SIGNATURES = {
     'pvcnn_bnact_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     'pvcnn_bnact_bwd_strided': (_i, [_vp, _vp, ctypes.c_long, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp, _f, _vp]),
     'pvcnn_concat_points': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
-    'pvcnn_adam_step': (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _f, _f, _f, _f, _f, _i, _vp]),
+    'pvcnn_adam_step': (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _vp, _i, _vp]),
     'pvcnn_trilinear_devox_bwd_strided': (_i, [_vp, ctypes.c_long, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
 }
 

@@ -10,6 +10,8 @@
 //     m   = m + (g - m) * (1 - b1)                  (torch: exp_avg.lerp_)
 //     v   = b2 * v + (1 - b2) * g * g
 //     p  -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps),        t = *step + 1
+// The hyper-parameters (lr, beta1, beta2, eps, weight_decay) are read from DEVICE memory too: a learning-rate schedule changes five
+// floats there, and a hipGraph that captured this launch follows it (a scalar kernel argument would be frozen at capture time).
 #include <algorithm>
 
 #include "common.h"
@@ -17,8 +19,9 @@
 namespace pvcnn {
 
 __global__ __launch_bounds__(256) void adam_flat_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
-                                                        float *__restrict__ v, size_t n, const float *__restrict__ step, float lr,
-                                                        float b1, float b2, float eps, float wd) {
+                                                        float *__restrict__ v, size_t n, const float *__restrict__ step,
+                                                        const float *__restrict__ hyper) {
+  const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4];
   const float t = *step + 1.0f;
   const float bc1 = 1.0f - powf(b1, t), bc2_sqrt = sqrtf(1.0f - powf(b2, t));
   const float step_size = lr / bc1;
@@ -50,16 +53,16 @@ using namespace pvcnn;
 
 // One Adam update of n contiguous fp32 parameters (p, m = exp_avg, v = exp_avg_sq updated in place; g read).  `step` = one float in
 // device memory, the number of updates done so far; inc_step != 0 increments it behind the update (pass it with the LAST buffer of an
-// optimizer step when the parameters live in several buffers).
-extern "C" int pvcnn_adam_step(float *p, const float *g, float *m, float *v, size_t n, float *step, float lr, float beta1, float beta2,
-                               float eps, float weight_decay, int inc_step, void *stream) {
-  PVCNN_REQUIRE(step, "null step counter");
+// optimizer step when the parameters live in several buffers).  hyper: five floats in device memory (lr, beta1, beta2, eps, weight_decay).
+extern "C" int pvcnn_adam_step(float *p, const float *g, float *m, float *v, size_t n, float *step, const float *hyper, int inc_step,
+                               void *stream) {
+  PVCNN_REQUIRE(step && hyper, "null step counter / hyper-parameter block");
   PVCNN_REQUIRE(n == 0 || (p && g && m && v), "null pointer");
   PVCNN_REQUIRE(n == 0 || (aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v)), "buffers must be 16-byte aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (n > 0) {
     const unsigned grid = (unsigned)std::min<size_t>(2048, (n / 4 + 255) / 256 + 1);
-    hipLaunchKernelGGL(adam_flat_kernel, dim3(grid), dim3(256), 0, s, p, g, m, v, n, step, lr, beta1, beta2, eps, weight_decay);
+    hipLaunchKernelGGL(adam_flat_kernel, dim3(grid), dim3(256), 0, s, p, g, m, v, n, step, hyper);
     if (int rc = check_launch("adam_flat")) return rc;
   }
   if (inc_step) {

@@ -44,6 +44,7 @@ class GraphedTrainStep:
         self.capture = torch.cuda.is_available() if capture is None else bool(capture)
         self.graph = self.loss = None
         self.whole_step = not self.collective            # does the graph hold finish() + optimizer.step() too?
+        self._sync_hyper = getattr(optimizer, 'sync_hyperparameters', None)      # pvcnn_amd.optim.FlatAdam
         self.capture_error = None
         if self.capture and not all(g.get('capturable', False) for g in optimizer.param_groups) and (
                 not self.collective or capture_collectives is not False):
@@ -125,6 +126,8 @@ class GraphedTrainStep:
     def __call__(self):
         if self.graph is None:
             return self.eager_step()
+        if self._sync_hyper is not None:
+            self._sync_hyper()                           # a scheduler moved the learning rate: the captured update reads it from the device
         self.graph.replay()
         if not self.whole_step:
             self.reducer.finish()

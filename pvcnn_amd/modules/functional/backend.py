@@ -547,6 +547,13 @@ class HipBackend:
         counter) -- is split by its own launch as before: never stale."""
         self._bank().refresh()
 
+    def weight_bank_invalidate(self):
+        """Every armed image pair is stale from now on: call after the parameters were written behind torch's back (raw device pointers
+        -- pvcnn_amd.optim.FlatAdam; in-place torch updates are caught by the tensors' version counters already)."""
+        bank = getattr(self, '_weight_bank', None)
+        if bank is not None:
+            bank.epoch += 1
+
     def _bank(self):
         if getattr(self, '_weight_bank', None) is None:
             self._weight_bank = _WeightBank(self)
@@ -1067,6 +1074,8 @@ class _WeightBank:
         self.entries = {}           # key -> dict(param=weakref, wf, wb, armed, version)
         self.tables = {}            # kind -> (device table, n, total rows, keys)
         self.dirty = True
+        self.epoch = 0              # bumped by weight_bank_invalidate(): pairs armed in an earlier epoch are never served
+        self.pinned = []            # buffers a stream capture saw (a replayed graph reads and writes them by raw pointer): never freed
 
     @staticmethod
     def _kind_of(p):
@@ -1090,7 +1099,9 @@ class _WeightBank:
         if e is not None and e['armed']:
             e['armed'] = False
             p = e['param']()
-            if p is not None and p._version == e['version'] and p.data_ptr() == key[1]:
+            if p is not None and p._version == e['version'] and p.data_ptr() == key[1] and e['epoch'] == self.epoch:
+                if e['wf'].is_cuda and torch.cuda.is_current_stream_capturing():
+                    self._pin(e)
                 return e['wf'], e['wb']
         if key not in self.wanted:
             if len(self.wanted) >= 4096:                # (keys of temporaries -- a weight that is copied to be made contiguous has a new
@@ -1098,6 +1109,11 @@ class _WeightBank:
             self.wanted.add(key)
             self.dirty = True
         return None
+
+    def _pin(self, e):
+        if not e.get('pinned'):
+            e['pinned'] = True
+            self.pinned.append((e['wf'], e['wb']))
 
     def _rebuild(self):
         lib = self.be.lib
@@ -1114,7 +1130,7 @@ class _WeightBank:
             if e is None or e['param']() is not p:
                 co, ci = key[2]
                 nbytes = lib.pvcnn_conv3d_weight_split_bytes if kind == 'conv' else lib.pvcnn_pwconv_weight_split_bytes
-                e = {'param': ref, 'armed': False, 'version': -1,
+                e = {'param': ref, 'armed': False, 'version': -1, 'epoch': -1,
                      'wf': torch.empty((nbytes(co, ci, 0, 2),), dtype=torch.uint8, device=p.device),
                      'wb': torch.empty((nbytes(co, ci, 1, 2),), dtype=torch.uint8, device=p.device)}
             live[key] = e
@@ -1143,15 +1159,20 @@ class _WeightBank:
                     e['armed'] = False
                 return
             self._rebuild()
+        capturing = torch.cuda.is_current_stream_capturing()
         for kind, (table, n, rows, keys, dev) in self.tables.items():
             launch = self.be.lib.pvcnn_conv3d_weight_split_pair_batch if kind == 'conv' else self.be.lib.pvcnn_pwconv_weight_split_pair_batch
             with _Launch(table) as s:
                 _lib.check(launch(_p(table), n, rows, s), 'weight_split_pair_batch')
+            if capturing:                               # the captured launch walks this table and writes every entry's buffers on replay
+                self.pinned.append(table)
             for key in keys:
                 e = self.entries[key]
+                if capturing:
+                    self._pin(e)
                 p = e['param']()
                 if p is not None and p.data_ptr() == key[1]:
-                    e['armed'], e['version'] = True, p._version
+                    e['armed'], e['version'], e['epoch'] = True, p._version, self.epoch
                 else:                                   # the parameter moved or died: rebuild before the next refresh
                     e['armed'] = False
                     self.dirty = True

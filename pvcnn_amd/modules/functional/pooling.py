@@ -10,11 +10,18 @@ from ._autograd import native, amp_fwd, amp_bwd
 __all__ = ['neighbor_max']
 
 
+def _aligned(t):
+    """contiguous AND on a 16-byte boundary (the kernels read rows with 16-byte loads): a contiguous view at an odd storage offset is
+    copied to a fresh allocation instead of being refused by the library."""
+    t = t.contiguous()
+    return t if t.data_ptr() % 16 == 0 else t.clone()
+
+
 class NeighborMax(Function):
     @staticmethod
     @amp_fwd
     def forward(ctx, x):
-        x = x.contiguous()
+        x = _aligned(x)
         out, winners = native().neighbor_max_forward(x)
         ctx.save_for_backward(winners)
         ctx.k = x.shape[-1]
@@ -24,7 +31,7 @@ class NeighborMax(Function):
     @amp_bwd
     def backward(ctx, grad_out):
         winners, = ctx.saved_tensors
-        return native().neighbor_max_backward(grad_out.contiguous(), winners, ctx.k)
+        return native().neighbor_max_backward(_aligned(grad_out), winners, ctx.k)
 
 
 def neighbor_max(x):

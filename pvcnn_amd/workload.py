@@ -50,10 +50,15 @@ class _TapAndPool(torch.autograd.Function):
             return None, None
         if g_tap is None:
             g = torch.zeros(g_pool.shape + (int(ctx.npoints),), dtype=g_pool.dtype, device=g_pool.device)
-        else:
-            # g_tap is this node's own slice of the concatenation's gradient (torch.cat's backward hands every input a disjoint
-            # view): adding in place keeps it a batch-strided view for the consumer (no copy) and touches B*C elements
+        elif getattr(g_tap, '_pvcnn_private_slice', False) and not torch.is_grad_enabled():
+            # g_tap is this node's own slice of the concatenation's gradient, handed over by _ConcatPoints.backward (every input gets
+            # a disjoint view, nobody else holds it): adding in place keeps it a batch-strided view for the consumer (no copy) and
+            # touches B*C elements
             g = g_tap
+        else:
+            # any other producer (torch.cat's own backward, a hook, an expanded / overlapping tensor, double backward): autograd does
+            # not allow modifying a grad_output it may hand to someone else as well
+            g = g_tap.clone(memory_format=torch.contiguous_format)
         if g_pool is not None:
             g.scatter_add_(2, winners.unsqueeze(-1), g_pool.unsqueeze(-1).to(g.dtype))
         return g, None
@@ -81,7 +86,9 @@ class _ConcatPoints(torch.autograd.Function):
             return (None,) * len(ctx.splits)
         grads, off = [], 0
         for c in ctx.splits:
-            grads.append(grad.narrow(1, off, c))        # a broadcast source: expand's own backward sums its slice over the points
+            piece = grad.narrow(1, off, c)              # a broadcast source: expand's own backward sums its slice over the points
+            piece._pvcnn_private_slice = True           # (disjoint views of a buffer only this node holds: _TapAndPool may add in place)
+            grads.append(piece)
             off += c
         return tuple(grads)
 
@@ -112,7 +119,7 @@ def tap_and_pool(x):
     from .modules.functional._autograd import native
     be = native() if x.is_cuda else None
     if (be is not None and getattr(be, 'has_neighbor_max', False) and x.dtype == torch.float32 and x.is_contiguous()
-            and x.shape[-1] % 4 == 0 and x.numel() > 0):
+            and x.data_ptr() % 16 == 0 and x.shape[-1] % 4 == 0 and x.numel() > 0):
         winners = be.row_argmax(x.detach())              # csrc/pool.hip: one read of x at the streaming rate (same winners)
     else:
         winners = x.max(dim=-1).indices

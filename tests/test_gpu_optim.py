@@ -73,3 +73,119 @@ def test_flat_adam_trains_a_graphed_step(hip):
     assert want[4] < want[0]
     assert abs(got[0] - same[3]) <= 1e-3 * abs(same[3]) and abs(got[1] - same[4]) <= 1e-3 * abs(same[4]), (same, got)
     assert abs(got[0] - want[3]) <= 2e-3 * abs(want[3]) and abs(got[1] - want[4]) <= 1e-2 * abs(want[4]), (want, got)
+
+
+def _toy():
+    torch.manual_seed(0)
+    return nn.Sequential(nn.Conv1d(7, 33, 1), nn.BatchNorm1d(33), nn.ReLU(), nn.Conv1d(33, 5, 1), nn.Conv3d(3, 4, 3)).to(DEV)
+
+
+def _fake_grads(nets, gen):
+    for ps in zip(*[n.parameters() for n in nets]):
+        grad = torch.randn(ps[0].shape, device=DEV, generator=gen)
+        for p in ps:
+            p.grad = grad.clone()
+
+
+def test_flat_adam_is_a_torch_optimizer_with_adams_checkpoint_layout(hip):
+    """FlatAdam subclasses torch.optim.Optimizer; its state_dict loads into torch.optim.Adam and vice versa (the
+    reference's train.py:186-199 / 249-255 checkpoint the optimizer), and the continued trajectories agree."""
+    from pvcnn_amd.dp import GradBucketReducer
+    from pvcnn_amd.optim import FlatAdam
+    a, b = _toy(), _toy()
+    b.load_state_dict(a.state_dict())
+    ref = torch.optim.Adam(a.parameters(), lr=1e-2, weight_decay=1e-3)
+    gen = torch.Generator(device=DEV).manual_seed(1)
+    for _ in range(3):
+        _fake_grads([a], gen)
+        ref.step()
+    b.load_state_dict(a.state_dict())
+    red = GradBucketReducer(b, bucket_mb=0.001)
+    flat = FlatAdam(red, lr=5e-1)                                  # wrong hyper-parameters on purpose: the checkpoint's must win
+    assert isinstance(flat, torch.optim.Optimizer) and len(red.buckets) > 1
+    flat.load_state_dict(ref.state_dict())
+    assert flat.param_groups[0]['lr'] == 1e-2 and flat.param_groups[0]['weight_decay'] == 1e-3 and flat.step_count.item() == 3
+    for _ in range(3):
+        _fake_grads([a, b], gen)
+        ref.step()
+        red.finish()
+        flat.step()
+    for p, q in zip(a.parameters(), b.parameters()):
+        assert torch.allclose(p, q, rtol=1e-5, atol=1e-7)
+    # ... and back: FlatAdam's state_dict into a fresh torch.optim.Adam on a third copy
+    c = _toy()
+    c.load_state_dict(b.state_dict())
+    back = torch.optim.Adam(c.parameters(), lr=1.0)
+    back.load_state_dict(flat.state_dict())
+    assert back.param_groups[0]['lr'] == 1e-2
+    for _ in range(2):
+        _fake_grads([b, c], gen)
+        red.finish()
+        flat.step()
+        back.step()
+    for p, q in zip(b.parameters(), c.parameters()):
+        assert torch.allclose(p, q, rtol=1e-5, atol=1e-7)
+
+
+def test_lr_scheduler_reaches_a_captured_flat_adam_update(hip):
+    """The learning rate lives in device memory: a torch.optim.lr_scheduler changes param_groups['lr'] on the host, GraphedTrainStep
+    copies it to the device block before the next replay, and the CAPTURED update follows (a scalar kernel argument would have been
+    frozen at capture time).  lr -> 0 must freeze the parameters; lr back up must move them again."""
+    import torch.nn.functional as tf
+    from pvcnn_amd.dp import GradBucketReducer
+    from pvcnn_amd.graph import GraphedTrainStep
+    from pvcnn_amd.optim import FlatAdam
+    net = _toy()[:4]
+    x = torch.randn(4, 7, 64, device=DEV)
+    y = torch.randint(0, 5, (4, 64), device=DEV)
+    red = GradBucketReducer(net)
+    opt = FlatAdam(red, lr=1e-2)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda epoch: (1.0, 0.0, 0.5)[min(epoch, 2)])     # constructing it is the point
+    step = GraphedTrainStep(net, lambda: tf.cross_entropy(net(x), y), opt, red, warmup=2)
+    assert step.graph is not None
+    snap = lambda: [p.detach().clone() for p in net.parameters()]
+    p0 = snap(); step(); torch.cuda.synchronize(); p1 = snap()
+    assert all(not torch.equal(a, b) for a, b in zip(p0, p1))
+    sched.step()                                                   # lr = 0
+    assert opt.param_groups[0]['lr'] == 0.0
+    step(); torch.cuda.synchronize(); p2 = snap()
+    assert all(torch.equal(a, b) for a, b in zip(p1, p2))
+    sched.step()                                                   # lr = 5e-3
+    step(); torch.cuda.synchronize(); p3 = snap()
+    assert all(not torch.equal(a, b) for a, b in zip(p2, p3))
+
+
+def test_flat_adam_refuses_parameters_that_left_their_bucket(hip):
+    from pvcnn_amd.dp import GradBucketReducer
+    from pvcnn_amd.optim import FlatAdam
+    net = _toy()
+    red = GradBucketReducer(net)
+    opt = FlatAdam(red)
+    net.double().float()                                           # re-allocates every parameter
+    _fake_grads([net], torch.Generator(device=DEV).manual_seed(2))
+    red.finish()
+    with pytest.raises(RuntimeError, match='flat bucket'):
+        opt.step()
+
+
+def test_a_flat_adam_step_invalidates_armed_weight_images(hip):
+    """a pair armed by weight_bank_refresh() but not consumed must not survive an optimizer step that writes the weights
+    through raw pointers (no version counter moves)."""
+    from pvcnn_amd.dp import GradBucketReducer
+    from pvcnn_amd.optim import FlatAdam
+    from pvcnn_amd.modules.functional import backend as seam
+    be = seam._backend
+    net = nn.Sequential(nn.Conv3d(16, 64, 3, padding=1)).to(DEV)
+    red = GradBucketReducer(net)
+    opt = FlatAdam(red, lr=1e-1)
+    w = net[0].weight
+    be.weight_bank_register(net)
+    be.conv_weight_images(w, 2)                                    # first sighting: noted as wanted
+    be.weight_bank_refresh()                                       # armed, NOT consumed
+    _fake_grads([net], torch.Generator(device=DEV).manual_seed(3))
+    red.finish()
+    opt.step()
+    got = be.conv_weight_images(w, 2)                              # must be images of the UPDATED weight
+    again = be.conv_weight_images(w, 2)                            # (nothing armed any more: the layer's own launch)
+    torch.cuda.synchronize()
+    assert torch.equal(got[0], again[0]) and torch.equal(got[1], again[1])

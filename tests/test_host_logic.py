@@ -510,11 +510,17 @@ def test_weight_bank_serves_an_armed_pair_once_and_never_a_changed_weight():
     key = ('pw', w.data_ptr(), (8, 4))
     assert bank.take('pw', w2) is None and key in bank.wanted and bank.dirty          # first sighting: noted
     wf, wb = torch.zeros(1), torch.zeros(1)
-    bank.entries[key] = {'param': weakref.ref(w), 'wf': wf, 'wb': wb, 'armed': True, 'version': w._version}
+    bank.entries[key] = {'param': weakref.ref(w), 'wf': wf, 'wb': wb, 'armed': True, 'version': w._version, 'epoch': bank.epoch}
     bank.dirty = False
     got = bank.take('pw', w2)
     assert got is not None and got[0] is wf and got[1] is wb
     assert bank.take('pw', w2) is None and not bank.dirty                              # served once per arming
+    # a raw-pointer write of the parameters (FlatAdam's kernel: no version counter moves) is announced by an epoch bump:
+    # a pair that was armed before it and not consumed is never served afterwards
+    bank.entries[key]['armed'] = True
+    bank.epoch += 1                                                                     # = HipBackend.weight_bank_invalidate()
+    assert bank.take('pw', w2) is None and not bank.entries[key]['armed']
+    bank.entries[key]['epoch'] = bank.epoch
     bank.entries[key]['armed'] = True
     with torch.no_grad():
         w.mul_(2.0)                                                                     # in-place change since the refresh
