@@ -266,12 +266,15 @@ PVCNN_API int pvcnn_conv3d_fwd_split(const float *x, const void *wts, const floa
                            const void *x_absmax, int amax_seg /* 0 | R */, float *y, float *stats_part, void *stream);
 
 /* Backward-weight in the same f16x2 arithmetic (csrc/conv3d_wgrad_f16.hip), R = 8, 12, 16 or 32 (workspace_bytes returns 0 for
- * any other R: use pvcnn_conv3d_bwd_weight).  x_absmax / gy_absmax: pvcnn_absmax_bits of x and grad_y.  Deterministic
- * (split-K partials summed in a fixed order), <= 1e-5 vs fp64 like pvcnn_conv3d_bwd_weight. */
+ * any other R: use pvcnn_conv3d_bwd_weight).  x_absmax / gy_absmax: pvcnn_absmax_bits of x and grad_y (word [0] of an amax
+ * buffer).  (ABI v8) x_amax_seg = R says x_absmax IS an amax buffer with one maximum per z row (pvcnn_absmax_tiles(x, ..., seg = R),
+ * or what pvcnn_bnact_fwd emitted): output rows whose nine neighbouring x rows are all zero -- the empty part of a voxelised
+ * cloud -- skip their matrix work (exact: they would add zeros); x_amax_seg = 0: a 1-word buffer, nothing is skipped.
+ * Deterministic (split-K partials summed in a fixed order), <= 1e-5 vs fp64 like pvcnn_conv3d_bwd_weight. */
 PVCNN_API size_t pvcnn_conv3d_bwd_weight_f16_workspace_bytes(int B, int Ci, int Co, int R);
-PVCNN_API int pvcnn_conv3d_bwd_weight_f16(const float *x, const float *grad_y, const void *x_absmax, const void *gy_absmax, int B, int Ci,
-                                int Co, int R, float *grad_w, float *grad_bias, void *workspace, size_t workspace_bytes,
-                                void *stream);
+PVCNN_API int pvcnn_conv3d_bwd_weight_f16(const float *x, const float *grad_y, const void *x_absmax, int x_amax_seg, const void *gy_absmax,
+                                int B, int Ci, int Co, int R, float *grad_w, float *grad_bias, void *workspace,
+                                size_t workspace_bytes, void *stream);
 
 /* ---- 1x1 convolutions of SharedMLP (point branch, classifier) ------------------------------------
  * replaces the nn.Conv1d / nn.Conv2d (kernel 1) calls of modules/shared_mlp.py:9-25 (cuDNN / cuBLAS in the

@@ -65,7 +65,7 @@ SIGNATURES = {
     'pvcnn_absmax_tiles_count': (_sz, [_i, ctypes.c_long, _i]),
     'pvcnn_absmax_tiles': (_i, [_vp, _i, _i, ctypes.c_long, _i, _vp, _vp]),
     'pvcnn_conv3d_bwd_weight_f16_workspace_bytes': (_sz, [_i, _i, _i, _i]),
-    'pvcnn_conv3d_bwd_weight_f16': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    'pvcnn_conv3d_bwd_weight_f16': (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     'pvcnn_conv3d_fwd_split': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
     'pvcnn_pwconv_transpose': (_i, [_vp, _i, _i, _vp, _vp]),
     'pvcnn_pwconv_fwd': (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp]),

@@ -47,12 +47,18 @@ template <int R, bool PACK = false>
 __global__ __launch_bounds__(512, 2) void conv3d_wgrad_f16_kernel(const float *__restrict__ x, const float *__restrict__ gy,
                                                                   const uint32_t *__restrict__ x_absmax,
                                                                   const uint32_t *__restrict__ gy_absmax, int B, int Ci, int Co, int P,
-                                                                  int citiles, float *__restrict__ part, float *__restrict__ gb_part) {
+                                                                  int citiles, float *__restrict__ part, float *__restrict__ gb_part,
+                                                                  int x_seg) {
   using L = WgradLds<R>;
   constexpr int QZ = R / 4, KS = L::RP / 16, ROWB = L::ROWB;
   constexpr int XITEMS = 3 * kWgCi * QZ, GITEMS = kWgCo * QZ;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned char *xl = lds, *gl = lds + 2 * L::XPL;
+  // ZERO ROWS of x (round 4; x_seg == R: x_absmax is an amax buffer with one maximum per z row behind the global one).  The input of a
+  // PVConv's first convolution is a voxelised cloud -- exact zeros outside the ~14 % of the grid the block occupies -- and an output
+  // row (b, x, y) whose nine neighbouring x rows (x - 1 .. x + 1, y - 1 .. y + 1) are all zero adds zeros to every tap: its MFMAs are
+  // skipped (its grad_y row is still staged: grad_bias sums every row).  rowmax[dx][1 + y]: the strip's three x planes, zero halo.
+  uint32_t *rowmax = reinterpret_cast<uint32_t *>(lds + L::BYTES);
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, kh = lane >> 5;
   int bid = blockIdx.x;
@@ -95,10 +101,22 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_f16_kernel(const float *_
     *reinterpret_cast<uint2 *>(plane0 + plane_bytes + off) = make_uint2(w0[1], w1[1]);   // lo
   };
 
+  // strips of partition p: pass i takes strip i * P + (p + i * kRot) % P -- rotated from pass to pass, because P is usually a multiple
+  // of R, and `strip = p + i * P` then gives a partition the SAME x plane of every cloud: on a voxelised cloud (x planes ~9 .. 22 of
+  // 32 occupied) a third of the partitions would own all the live planes and the rest none (measured: 78 % of the rows skipped, 15 %
+  // of the time).  Any assignment that covers every strip once is the same sum; this one mixes the planes.
+  constexpr int kRot = R / 4 + 1;
   const int nstrips = B * R;
-  for (int strip = p; strip < nstrips; strip += P) {
+  for (int i0 = 0; i0 * P < nstrips; ++i0) {
+    const int strip = i0 * P + (p + i0 * kRot) % P;
+    if (strip >= nstrips) continue;
     const int b = strip / R, xo = strip - b * R;
     const float *xb = x + (size_t)b * Ci * S, *gb_ = gy + (size_t)b * Co * S;
+    if (tid < 3 * (R + 2)) {                                    // (read from t = 0 on: two barriers behind this store)
+      const int dx = tid / (R + 2), yy = tid - dx * (R + 2) - 1, gx = xo + dx - 1;
+      const bool in = (unsigned)gx < (unsigned)R && (unsigned)yy < (unsigned)R;
+      rowmax[tid] = x_seg > 0 ? (in ? x_absmax[1 + ((size_t)b * R + gx) * R + yy] : 0u) : 1u;
+    }
     for (int t = -2; t < R; ++t) {
       // ---- loads for the rows that enter the window: x rows y = t + 2 (three x planes), grad_y row y = t + 1 ----
       const int y2 = t + 2, y1 = t + 1;
@@ -114,17 +132,22 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_f16_kernel(const float *_
       if (y1 >= 0 && y1 < R && has_g && co0 + gco < Co)
         vg = *reinterpret_cast<const float4 *>(gb_ + (size_t)(co0 + gco) * S + (size_t)xo * RR + (size_t)y1 * R + 4 * gq);
 
-      // ---- multiply output row y = t ----
+      // ---- multiply output row y = t (unless every x row it reads is zero) ----
+      uint32_t live = 0;
       if (t >= 0) {
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy) live |= rowmax[dx * (R + 2) + t + dy];
+        live = __builtin_amdgcn_readfirstlane(live);
+      }
+      if (live != 0) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           const int z8 = ks * 16 + kh * 8;
-          uint4 a[2][2];                                         // [mb][hi, lo]
-#pragma unroll
-          for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl)
-              a[mb][pl] = *reinterpret_cast<const uint4 *>(gl + pl * L::GPL + (((t & 1) * kWgCo + mb * 32 + j) * ROWB) + (z8 + 8) * 2);
+          // (the A fragments are read per unit, not once for both 32-row blocks: 16 registers fewer across the unit loop -- the
+          // kernel sat at its 256-register cap with 1-3 spilled -- for two more 16-byte LDS reads per k-step and wave)
+          const unsigned char *arow = gl + (((t & 1) * kWgCo + j) * ROWB) + (z8 + 8) * 2;
 #pragma unroll
           for (int u = 0; u < 3; ++u) {
             if (u < nunits) {
@@ -144,7 +167,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_f16_kernel(const float *_
                 bw[pl][2] = make_uint4(__builtin_amdgcn_alignbit(m.y, m.x, 16), __builtin_amdgcn_alignbit(m.z, m.y, 16),
                                        __builtin_amdgcn_alignbit(m.w, m.z, 16), __builtin_amdgcn_alignbit(d5, m.w, 16));    // x[z + 1]
               }
-              const uint4 ah = mb ? a[1][0] : a[0][0], al = mb ? a[1][1] : a[0][1];
+              const uint4 ah = *reinterpret_cast<const uint4 *>(arow + mb * 32 * ROWB), al = *reinterpret_cast<const uint4 *>(arow + L::GPL + mb * 32 * ROWB);
 #pragma unroll
               for (int dz = 0; dz < 3; ++dz) acc[u][dz] = mfma16<2>(al, bw[0][dz], acc[u][dz]);     // lo x hi
 #pragma unroll
@@ -273,16 +296,16 @@ static WgradPlan wgrad_f16_plan(int B, int Ci, int Co, int R) {
 
 template <int R>
 static int launch_wgrad_f16(const float *x, const float *gy, const uint32_t *xa, const uint32_t *ga, int B, int Ci, int Co, float *gw,
-                            float *gb, float *ws, hipStream_t s) {
+                            float *gb, float *ws, hipStream_t s, int x_seg) {
   const WgradPlan w = wgrad_f16_plan(B, Ci, Co, R);
   float *part = ws, *gb_part = ws + w.part_floats;
   const bool pack = 3 * Ci <= kWgCi && (R == 32 || R == 16);     // (instantiated for the grids a network's first layer has)
   auto k = pack ? conv3d_wgrad_f16_kernel<R, (R == 32 || R == 16)> : conv3d_wgrad_f16_kernel<R, false>;
-  const int lds = WgradLds<R>::BYTES;
+  const int lds = WgradLds<R>::BYTES + (3 * (R + 2) * 4 + 15) / 16 * 16;     // + the strip's row maxima
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e != hipSuccess) { set_error("conv3d_wgrad_f16: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
   hipLaunchKernelGGL(k, dim3((unsigned)(w.P * w.citiles * w.cotiles)), dim3(512), lds, s, x, gy, xa, ga, B, Ci, Co, w.P, w.citiles, part,
-                     gb ? gb_part : nullptr);
+                     gb ? gb_part : nullptr, x_seg);
   if (int rc = check_launch("conv3d_wgrad_f16")) return rc;
   const int CoP = w.cotiles * kWgCo, CiP = w.citiles * kWgCi;
   hipLaunchKernelGGL(conv3d_wgrad_f16_reduce_kernel, dim3((unsigned)(CoP * w.citiles)), dim3(1024), 0, s, part, gb_part, xa, ga, w.P, CoP, CiP,
@@ -303,10 +326,11 @@ extern "C" size_t pvcnn_conv3d_bwd_weight_f16_workspace_bytes(int B, int Ci, int
   return (w.part_floats + w.gb_floats) * sizeof(float);
 }
 
-extern "C" int pvcnn_conv3d_bwd_weight_f16(const float *x, const float *grad_y, const void *x_absmax, const void *gy_absmax, int B, int Ci,
-                                           int Co, int R, float *grad_w, float *grad_bias, void *workspace, size_t workspace_bytes,
-                                           void *stream) {
+extern "C" int pvcnn_conv3d_bwd_weight_f16(const float *x, const float *grad_y, const void *x_absmax, int x_amax_seg, const void *gy_absmax,
+                                           int B, int Ci, int Co, int R, float *grad_w, float *grad_bias, void *workspace,
+                                           size_t workspace_bytes, void *stream) {
   PVCNN_REQUIRE(B > 0 && Ci > 0 && Co > 0 && wgrad_f16_serves(R), "bad size (R must be 8, 12, 16 or 32)");
+  PVCNN_REQUIRE(x_amax_seg == 0 || x_amax_seg == R, "x_amax_seg must be 0 (1-word buffer) or R (amax buffer with one maximum per z row)");
   PVCNN_REQUIRE(x && grad_y && grad_w && x_absmax && gy_absmax, "null pointer");
   PVCNN_REQUIRE(aligned16(x) && aligned16(grad_y), "x and grad_y must be 16-byte aligned");
   PVCNN_REQUIRE(workspace && aligned16(workspace) && workspace_bytes >= pvcnn_conv3d_bwd_weight_f16_workspace_bytes(B, Ci, Co, R),
@@ -315,9 +339,9 @@ extern "C" int pvcnn_conv3d_bwd_weight_f16(const float *x, const float *grad_y, 
   const uint32_t *xa = static_cast<const uint32_t *>(x_absmax), *ga = static_cast<const uint32_t *>(gy_absmax);
   float *ws = static_cast<float *>(workspace);
   switch (R) {
-    case 32: return launch_wgrad_f16<32>(x, grad_y, xa, ga, B, Ci, Co, grad_w, grad_bias, ws, s);
-    case 16: return launch_wgrad_f16<16>(x, grad_y, xa, ga, B, Ci, Co, grad_w, grad_bias, ws, s);
-    case 12: return launch_wgrad_f16<12>(x, grad_y, xa, ga, B, Ci, Co, grad_w, grad_bias, ws, s);
-    default: return launch_wgrad_f16<8>(x, grad_y, xa, ga, B, Ci, Co, grad_w, grad_bias, ws, s);
+    case 32: return launch_wgrad_f16<32>(x, grad_y, xa, ga, B, Ci, Co, grad_w, grad_bias, ws, s, x_amax_seg);
+    case 16: return launch_wgrad_f16<16>(x, grad_y, xa, ga, B, Ci, Co, grad_w, grad_bias, ws, s, x_amax_seg);
+    case 12: return launch_wgrad_f16<12>(x, grad_y, xa, ga, B, Ci, Co, grad_w, grad_bias, ws, s, x_amax_seg);
+    default: return launch_wgrad_f16<8>(x, grad_y, xa, ga, B, Ci, Co, grad_w, grad_bias, ws, s, x_amax_seg);
   }
 }

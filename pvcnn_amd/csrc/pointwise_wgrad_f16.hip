@@ -213,6 +213,7 @@ __global__ __launch_bounds__(512) void pw_wgrad_f16_wide_kernel(const float *__r
   constexpr int GI = T::GI, NI = T::NI;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];          // 2 * T::BUF
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, kh = lane >> 5;
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);     // (for the epilogue: survives the chunk loop in a scalar register)
   const int wm = wave / WC, wk = wave % WC;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, tiles = mtiles * ktiles;
   const int grp = slot / tiles, tile = slot - grp * tiles, p = xcd + 8 * grp;
@@ -342,6 +343,11 @@ __global__ __launch_bounds__(512) void pw_wgrad_f16_wide_kernel(const float *__r
   }
 
   // ---- epilogue: part[p][m][k] over the padded (MP x KP) grid, lanes along k ----
+  // (the epilogue's lane-dependent offsets are derived from a laundered thread index: the compiler otherwise computes them in front of
+  // the chunk loop and -- at the 256-register cap of this kernel -- spills them across it: 5 dwords of scratch per lane in round 3)
+  int tid_e = wave_s * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));   // wave index (scalar register) + lane
+  asm volatile("" : "+v"(tid_e));
+  const int lane_e = tid_e & 63, j_e = lane_e & 31, kh_e = lane_e >> 5, wave_e = tid_e >> 6, wm_e = wave_e / WC, wk_e = wave_e % WC;
   const int MP = mtiles * T::TM, KP = ktiles * T::TK;
   float *pp = part + (size_t)p * MP * KP;
 #pragma unroll
@@ -350,20 +356,21 @@ __global__ __launch_bounds__(512) void pw_wgrad_f16_wide_kernel(const float *__r
     for (int nb = 0; nb < WNB; ++nb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = m0 + (wm * WMB + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        pp[(size_t)m * KP + k0 + (wk * WNB + nb) * 32 + j] = acc[mb][nb][r];
+        const int m = m0 + (wm_e * WMB + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh_e;
+        pp[(size_t)m * KP + k0 + (wk_e * WNB + nb) * 32 + j_e] = acc[mb][nb][r];
       }
   if (gb_part != nullptr && kt == 0) {                          // grad_bias partial: the 8 quads of a row, fixed order
     __syncthreads();
     float *red = reinterpret_cast<float *>(lds);                // [TM rows][8 quads]
+    const int q_e = tid_e & 7, r0_e = tid_e >> 3;
 #pragma unroll
-    for (int u = 0; u < GI; ++u) red[(r0 + 64 * u) * 8 + q] = gsum[u];
+    for (int u = 0; u < GI; ++u) red[(r0_e + 64 * u) * 8 + q_e] = gsum[u];
     __syncthreads();
-    if (tid < T::TM) {
+    if (tid_e < T::TM) {
       float s = 0.0f;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) s += red[tid * 8 + i];
-      gb_part[(size_t)p * MP + m0 + tid] = s;
+      for (int i = 0; i < 8; ++i) s += red[tid_e * 8 + i];
+      gb_part[(size_t)p * MP + m0 + tid_e] = s;
     }
   }
 }

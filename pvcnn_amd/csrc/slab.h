@@ -468,27 +468,38 @@ __global__ __launch_bounds__(1024) void gather_lds_pipe_kernel(P p, XF xf, const
   // (row base, u * 16 KiB) is scalar; the hardware bounds check returns zeros past the row (no clamp)
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   const int voff = (int)threadIdx.x * 16;
-  auto issue = [&](int c) {
+  // STRAIGHT-LINE on purpose: every vector-memory operation of the slab loop is issued unconditionally -- a slab that does not exist
+  // / a null addend / a thread past J is a buffer descriptor of ZERO bytes (the bounds check answers zeros and drops the store) --
+  // because the compiler can only count outstanding loads along one path: with a branch around any of them it waits with vmcnt(0)
+  // in front of every committed quad, i.e. for the load it has just issued (seen in the ISA of the first rolling version).
+  auto row_descriptor = [&](const float *base, size_t off, int bytes) {
     // (the row base is wave-uniform; readfirstlane says so to the compiler, which otherwise wraps every load in a waterfall loop)
-    const uintptr_t rowp = reinterpret_cast<uintptr_t>(src + ((size_t)b * C + c) * L);
+    const uintptr_t rowp = reinterpret_cast<uintptr_t>(base + off);
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)rowp), hi = __builtin_amdgcn_readfirstlane((uint32_t)(rowp >> 32));
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        reinterpret_cast<void *>(((uintptr_t)hi << 32) | lo), /*stride*/ 0, /*bytes*/ L * 4, 0x00020000);
-#pragma unroll
-    for (int u = 0; u < kB; ++u) {
-      const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, u * THREADS * 16, 0);
-      v[u] = make_float4(__uint_as_float(raw.x), __uint_as_float(raw.y), __uint_as_float(raw.z), __uint_as_float(raw.w));
-    }
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((uintptr_t)hi << 32) | lo), /*stride*/ 0,
+                                             /*bytes*/ __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
   };
+  auto load = [&](const __amdgpu_buffer_rsrc_t &rsrc, int u) {
+    const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, u * THREADS * 16, 0);
+    v[u] = make_float4(__uint_as_float(raw.x), __uint_as_float(raw.y), __uint_as_float(raw.z), __uint_as_float(raw.w));
+  };
+  const int first = blockIdx.x * SEQ;
   // the row transform's raw parameters are fetched one slab ahead, BEFORE the row's own loads (so that waiting for them
   // never waits for the row), and combined into (scale, shift) when the row is committed
-  float scale = 1.0f, shift = 0.0f;
   [[maybe_unused]] float raw[XF::kRaw];
-  auto commit = [&]() {
-    if constexpr (!XF::kIdentity) xfb.combine(raw, scale, shift);
+  // ROLLING commit (round 4): load u of the NEXT grid is issued into the registers load u of this grid has just left for the LDS,
+  // so the HBM stream never pauses while a grid is written to the LDS (32 ds_write_b32 per thread: ~1 us per grid, during which
+  // the round-3 kernel had nothing in flight -- the next grid's loads went out only after the commit and the barrier behind it)
+  auto commit = [&](bool refill, int cnext) {
+    float scale = 1.0f, shift = 0.0f;
+    [[maybe_unused]] float m = 1.0f;
+    if constexpr (!XF::kIdentity) { xfb.combine(raw, scale, shift); m = raw[XF::kRaw - 1]; }
     auto f = [&](float x) {
-      if constexpr (XF::kIdentity) return x; else return xfb.apply(x, scale, shift, raw[4]);
+      if constexpr (XF::kIdentity) return x; else return xfb.apply(x, scale, shift, m);
     };
+    const int cn = refill ? cnext : first;                  // (a valid channel for the parameter fetch; its grid loads are 0 bytes)
+    const __amdgpu_buffer_rsrc_t next = row_descriptor(src, ((size_t)b * C + cn) * L, refill ? L * 4 : 0);
+    if constexpr (!XF::kIdentity) xfb.fetch(cn, raw);
 #pragma unroll
     for (int u = 0; u < kB; ++u) {
       const int q = (int)threadIdx.x + u * THREADS;
@@ -497,49 +508,53 @@ __global__ __launch_bounds__(1024) void gather_lds_pipe_kernel(P p, XF xf, const
         float *d = lds + i + (i >> pshift);
         d[0] = f(v[u].x); d[1] = f(v[u].y); d[2] = f(v[u].z); d[3] = f(v[u].w);
       }
+      load(next, u);
+      __builtin_amdgcn_sched_barrier(0);                    // one load per committed quad, in this order
     }
   };
-  const int first = blockIdx.x * SEQ;
-  if (first < C) {                                          // the first grid's loads go out BEFORE the taps are derived: the
-    if constexpr (!XF::kIdentity) xfb.fetch(first, raw);    // coordinate loads and the tap arithmetic run under them
-    issue(first);
+  {                                                         // the first grid's loads go out BEFORE the taps are derived: the
+    const bool any = first < C;                             // coordinate loads and the tap arithmetic run under them
+    if constexpr (!XF::kIdentity) xfb.fetch(any ? first : 0, raw);
+    const __amdgpu_buffer_rsrc_t rsrc = row_descriptor(src, ((size_t)b * C + (any ? first : 0)) * L, any ? L * 4 : 0);
+#pragma unroll
+    for (int u = 0; u < kB; ++u) load(rsrc, u);
   }
-  typename P::Packed pk[4];
+  typename P::Packed pk[4] = {};
   if (has) p.pack4(b, jf, pk);
   for (int sq = 0; sq < SEQ; ++sq) {
     const int c = first + sq;
     if (c >= C) break;
-    if (sq > 0) lds_barrier();                              // every wave is done reading the previous slab
-    commit();                                               // waits for this slab's loads only
-    lds_barrier();                                          // slab visible (LDS-only: the previous outputs keep draining)
-    // this slab's addend quad is requested BEFORE the next grid: loads return in order -- behind the eight grid loads it made the
-    // first store of the slab wait for the whole next grid (vmcnt(0))
+    // this slab's addend quad is requested BEFORE the next grid's loads: loads return in order -- behind a grid's loads the
+    // slab's store would wait for that whole grid
     const size_t rowoff = ((size_t)b * C + c) * J;
-    float4 add = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (addend) add = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(addend + rowoff) + (uint32_t)min(jf, max(J - 4, 0)) * 4u);
-    if (sq + 1 < SEQ && c + 1 < C) {
-      if constexpr (!XF::kIdentity) xfb.fetch(c + 1, raw);
-      issue(c + 1);
-    }
-    __builtin_amdgcn_sched_barrier(0);                      // keep the loads HERE: the scheduler sinks them to their first use
-    if (has) {
-      float r[4];
+    const __amdgpu_buffer_rsrc_t arsrc = row_descriptor(addend ? addend : dst, rowoff, addend ? J * 4 : 0);
+    const u32x4 add = __builtin_amdgcn_raw_buffer_load_b128(arsrc, voff, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (sq > 0) lds_barrier();                              // every wave is done reading the previous slab
+    commit(sq + 1 < SEQ && c + 1 < C, c + 1);               // waits for this slab's loads only; refills the registers as it goes
+    lds_barrier();                                          // slab visible (LDS-only: the previous outputs keep draining)
+    float r[4];
 #pragma unroll
-      for (int h = 0; h < 4; ++h) {
-        // the taps are re-expanded per slab ON PURPOSE (4 registers per point instead of 16 held across the loop): hide the
-        // loop invariance from the optimiser, or it hoists the expansion out of the slab loop and spills it
-        if constexpr (sizeof(typename P::Packed) == 16) {
-          uint4 &raw = reinterpret_cast<uint4 &>(pk[h]);
-          asm volatile("" : "+v"(raw.x), "+v"(raw.y), "+v"(raw.z), "+v"(raw.w));
-        }
-        Taps<NC> t;
-        p.unpack(pk[h], t);
-        r[h] = combine<NC, P::kMaySkip, true>(t, lds, pshift);
+    for (int h = 0; h < 4; ++h) {
+      // the taps are re-expanded per slab ON PURPOSE (4 registers per point instead of 16 held across the loop): hide the
+      // loop invariance from the optimiser, or it hoists the expansion out of the slab loop and spills it
+      if constexpr (sizeof(typename P::Packed) == 16) {
+        uint4 &raw4 = reinterpret_cast<uint4 &>(pk[h]);
+        asm volatile("" : "+v"(raw4.x), "+v"(raw4.y), "+v"(raw4.z), "+v"(raw4.w));
       }
-      // uniform row base + the thread's 32-bit byte offset (jf * 4): no 64-bit per-lane addresses live across the loop
-      if (addend) { r[0] = r[0] + add.x; r[1] = r[1] + add.y; r[2] = r[2] + add.z; r[3] = r[3] + add.w; }
-      *reinterpret_cast<float4 *>(reinterpret_cast<char *>(dst + rowoff) + (uint32_t)jf * 4u) = make_float4(r[0], r[1], r[2], r[3]);
+      Taps<NC> t;
+      p.unpack(pk[h], t);
+      r[h] = combine<NC, P::kMaySkip, true>(t, lds, pshift);
     }
+    if (addend) {                                           // (no memory operation in here)
+      r[0] = r[0] + __uint_as_float(add.x); r[1] = r[1] + __uint_as_float(add.y);
+      r[2] = r[2] + __uint_as_float(add.z); r[3] = r[3] + __uint_as_float(add.w);
+    }
+    // uniform row descriptor + the thread's 32-bit byte offset: threads past J are dropped by the bounds check
+    const __amdgpu_buffer_rsrc_t drsrc = row_descriptor(dst, rowoff, J * 4);
+    u32x4 o;
+    o.x = __float_as_uint(r[0]); o.y = __float_as_uint(r[1]); o.z = __float_as_uint(r[2]); o.w = __float_as_uint(r[3]);
+    __builtin_amdgcn_raw_buffer_store_b128(o, drsrc, voff, 0, 0);
   }
   // side outputs (devoxelize: inds / wgts) once per cloud -- last: four expanded tap sets (64 registers) have no room while a grid's
   // loads are in flight
@@ -571,18 +586,19 @@ __global__ __launch_bounds__(1024) void gather_lds_pipe_rows_kernel(P p, XF xf, 
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   const int voff = (int)threadIdx.x * 16;
   float4 v[G];
-  auto issue = [&](int c0) {
-    const int rows = min(G, C - c0);
+  auto issue_sized = [&](int c0, int bytes) {
     const uintptr_t rowp = reinterpret_cast<uintptr_t>(src + ((size_t)b * C + c0) * L);
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)rowp), hi = __builtin_amdgcn_readfirstlane((uint32_t)(rowp >> 32));
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        reinterpret_cast<void *>(((uintptr_t)hi << 32) | lo), /*stride*/ 0, /*bytes*/ rows * L * 4, 0x00020000);
+        reinterpret_cast<void *>(((uintptr_t)hi << 32) | lo), /*stride*/ 0, /*bytes*/ __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 #pragma unroll
     for (int u = 0; u < G; ++u) {                           // rows past C: the bounds check returns zeros
       const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, u * THREADS * 16, 0);
       v[u] = make_float4(__uint_as_float(raw.x), __uint_as_float(raw.y), __uint_as_float(raw.z), __uint_as_float(raw.w));
     }
   };
+  auto issue = [&](int c0) { issue_sized(c0, min(G, C - c0) * L * 4); };
+  auto issue_none = [&]() { issue_sized(0, 0); };           // the same G loads, zero bytes: the loop's memory operations never branch
   [[maybe_unused]] float raw[G][XF::kRaw];
 #pragma unroll
   for (int u = 0; u < G; ++u)
@@ -609,48 +625,65 @@ __global__ __launch_bounds__(1024) void gather_lds_pipe_rows_kernel(P p, XF xf, 
     }
   };
   const int first = blockIdx.x * SEQ * G;
-  if (first < C) {                                          // the grid rows first: they are in flight while the taps are derived
-    fetch(first);
-    issue(first);
+  // straight-line slab loop, as in gather_lds_pipe_kernel: loads and stores through wave-uniform buffer descriptors whose SIZE says
+  // what exists (rows past C, a null addend, threads past J: zero bytes) -- no branch around a memory operation, no 64-bit per-lane
+  // address, and (round 4) no scratch: the round-3 form of this loop spilled 10 registers at the 128-register cap of a 1024-thread
+  // workgroup, 44 bytes of scratch per lane stored and reloaded per launch (1.44x the algorithmic HBM traffic by the counters)
+  auto row_descriptor = [&](const float *base, size_t off, int bytes) {
+    const uintptr_t rowp = reinterpret_cast<uintptr_t>(base + off);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)rowp), hi = __builtin_amdgcn_readfirstlane((uint32_t)(rowp >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((uintptr_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+  };
+  {                                                         // the grid rows first: they are in flight while the taps are derived
+    fetch(min(first, max(C - 1, 0)));
+    if (first < C) issue(first); else issue_none();
   }
-  typename P::Packed pk[4];
+  typename P::Packed pk[4] = {};
   if (has) p.pack4(b, jf, pk);
   for (int sq = 0; sq < SEQ; ++sq) {
     const int c0 = first + sq * G;
     if (c0 >= C) break;
+    const int rows = min(G, C - c0);
+    const size_t rowoff = ((size_t)b * C + c0) * J;
+    // the slab's addend quads (one per row) BEFORE the next slab's grid loads: loads return in order
+    const __amdgpu_buffer_rsrc_t arsrc = row_descriptor(addend ? addend : dst, rowoff, addend ? rows * J * 4 : 0);
+    u32x4 add[G];
+#pragma unroll
+    for (int u = 0; u < G; ++u) add[u] = __builtin_amdgcn_raw_buffer_load_b128(arsrc, voff, u * J * 4, 0);
+    __builtin_amdgcn_sched_barrier(0);
     if (sq > 0) lds_barrier();                              // every wave is done reading the previous slab
     commit();                                               // waits for this slab's loads only
     lds_barrier();
-    if (sq + 1 < SEQ && c0 + G < C) {
-      fetch(c0 + G);
-      issue(c0 + G);
+    {
+      const bool more = sq + 1 < SEQ && c0 + G < C;
+      fetch(more ? c0 + G : c0);
+      if (more) issue(c0 + G); else issue_none();
     }
     __builtin_amdgcn_sched_barrier(0);                      // keep the loads HERE
-    if (has) {
-      float r[G][4];
+    float r[G][4];
 #pragma unroll
-      for (int h = 0; h < 4; ++h) {
-        if constexpr (sizeof(typename P::Packed) == 16) {   // (see gather_lds_pipe_kernel: keep the expansion inside the slab loop)
-          uint4 &rw = reinterpret_cast<uint4 &>(pk[h]);
-          asm volatile("" : "+v"(rw.x), "+v"(rw.y), "+v"(rw.z), "+v"(rw.w));
-        }
-        Taps<NC> t;
-        p.unpack(pk[h], t);
-#pragma unroll
-        for (int u = 0; u < G; ++u) r[u][h] = combine<NC, P::kMaySkip, true>(t, lds + u * Lp, pshift);
+    for (int h = 0; h < 4; ++h) {
+      if constexpr (sizeof(typename P::Packed) == 16) {     // (see gather_lds_pipe_kernel: keep the expansion inside the slab loop)
+        uint4 &rw = reinterpret_cast<uint4 &>(pk[h]);
+        asm volatile("" : "+v"(rw.x), "+v"(rw.y), "+v"(rw.z), "+v"(rw.w));
       }
+      Taps<NC> t;
+      p.unpack(pk[h], t);
 #pragma unroll
-      for (int u = 0; u < G; ++u) {
-        if (c0 + u < C) {
-          const size_t rowoff = ((size_t)b * C + c0 + u) * J;
-          float4 o = make_float4(r[u][0], r[u][1], r[u][2], r[u][3]);
-          if (addend) {
-            const float4 a = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(addend + rowoff) + (uint32_t)jf * 4u);
-            o.x = o.x + a.x; o.y = o.y + a.y; o.z = o.z + a.z; o.w = o.w + a.w;
-          }
-          *reinterpret_cast<float4 *>(reinterpret_cast<char *>(dst + rowoff) + (uint32_t)jf * 4u) = o;
-        }
+      for (int u = 0; u < G; ++u) r[u][h] = combine<NC, P::kMaySkip, true>(t, lds + u * Lp, pshift);
+    }
+    const __amdgpu_buffer_rsrc_t drsrc = row_descriptor(dst, rowoff, rows * J * 4);   // rows past C / threads past J: dropped
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      if (addend) {                                         // (no memory operation in here)
+        r[u][0] = r[u][0] + __uint_as_float(add[u].x); r[u][1] = r[u][1] + __uint_as_float(add[u].y);
+        r[u][2] = r[u][2] + __uint_as_float(add[u].z); r[u][3] = r[u][3] + __uint_as_float(add[u].w);
       }
+      u32x4 o;
+      o.x = __float_as_uint(r[u][0]); o.y = __float_as_uint(r[u][1]); o.z = __float_as_uint(r[u][2]); o.w = __float_as_uint(r[u][3]);
+      // (row u of the slab starts u * J floats behind row 0; a thread past J must not land in the next row: its offset is pushed
+      // past the descriptor's end instead)
+      __builtin_amdgcn_raw_buffer_store_b128(o, drsrc, has ? voff : 0x7ffffff0, u * J * 4, 0);
     }
   }
   // side outputs (devoxelize: inds / wgts) once per cloud -- LAST: four expanded tap sets are 64 registers, which the loop above

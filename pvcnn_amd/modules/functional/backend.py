@@ -639,7 +639,7 @@ class HipBackend:
         gb = torch.empty((co,), dtype=torch.float32, device=x.device) if with_bias else None
         ws = self._scratch(self.lib.pvcnn_conv3d_bwd_weight_f16_workspace_bytes(b, ci, co, r), x.device)
         with _Launch(x) as s:
-            _lib.check(self.lib.pvcnn_conv3d_bwd_weight_f16(_p(x), _p(grad_y), _p(x_amax), _p(gy_amax), b, ci, co, r, _p(gw),
+            _lib.check(self.lib.pvcnn_conv3d_bwd_weight_f16(_p(x), _p(grad_y), _p(x_amax), self._amax_seg(x_amax, b * r * r, r), _p(gy_amax), b, ci, co, r, _p(gw),
                                                             _p(gb) if with_bias else None, _p(ws), ws.numel(), s), 'conv3d_backward_weight_f16')
         return (gw, gb) if with_bias else gw
 

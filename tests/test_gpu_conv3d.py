@@ -216,3 +216,47 @@ def test_voxel_conv_autograd_in_f16x2_matches_fp64(hip):
     ya.square().sum().backward(); yb.square().sum().backward()
     assert _rel(ya, yb.detach()) < TOL and _rel(xa.grad, xb.grad) < TOL
     assert _rel(mine.weight.grad, theirs.weight.grad) < TOL and _rel(mine.bias.grad, theirs.bias.grad) < TOL
+
+
+def _voxelised_like(b, ci, r, g, frac=0.4):
+    """A grid like the input of a PVConv's first convolution: exact zeros outside a box (the block of the room inside the unit ball)."""
+    x = torch.zeros(b, ci, r, r, r)
+    lo, hi = int(r * (0.5 - frac / 2)), max(int(r * (0.5 + frac / 2)), int(r * (0.5 - frac / 2)) + 1)
+    box = torch.randn(b, ci, hi - lo, hi - lo, r, generator=g)
+    box = box * (torch.rand(b, 1, hi - lo, hi - lo, r, generator=g) < 0.5)       # sparse inside the box as well
+    x[:, :, lo:hi, lo:hi, :] = box
+    return x, lo, hi
+
+
+@pytest.mark.parametrize('b,ci,co,r', [(2, 9, 64, 32), (2, 64, 64, 32), (3, 64, 64, 16), (2, 64, 128, 16), (2, 32, 32, 32), (4, 16, 32, 12),
+                                       (8, 64, 64, 8), (2, 5, 7, 16)])
+def test_zero_input_tiles_take_the_bias_shortcut_exactly(hip, b, ci, co, r):
+    """Round 4: an f16x2 workgroup whose halo tile is all zero (the amax buffer says so) writes bias and zero BatchNorm partial sums
+    without multiplying.  Against fp64 the whole output meets the usual bar; the rows whose 3 x 3 neighbourhood of z rows is empty
+    are EXACTLY bias; the statistics are those of the output; and the backward-weight kernel, which skips output rows whose nine x
+    rows are zero, returns the very bits it returns without the row table (the skipped rows add +0)."""
+    g = torch.Generator().manual_seed(r * 100 + ci)
+    x, lo, hi = _voxelised_like(b, ci, r, g)
+    x = x.to(DEV)
+    w = (torch.randn(co, ci, 3, 3, 3, generator=g) * 0.1).to(DEV)
+    bias = torch.randn(co, generator=g).to(DEV)
+    gy = torch.randn(b, co, r, r, r, generator=g).to(DEV)
+    ref = F.conv3d(x.double(), w.double(), bias.double(), padding=1)
+    amax = hip.conv_amax(x)
+    assert (amax[1:].view(b, r, r)[:, :max(lo - 1, 0)] == 0).all()
+    y, part = hip.conv3d_forward_split(x, w, bias, 2, want_stats=True, amax=amax)
+    assert _rel(y, ref) < TOL
+    far = torch.ones(r, r, dtype=torch.bool)
+    far[max(lo - 1, 0):hi + 1, max(lo - 1, 0):hi + 1] = False          # (x, y) rows whose neighbourhood holds no input at all
+    want = bias.view(1, co, 1, 1).expand(b, co, int(far.sum()), r)
+    assert torch.equal(y[:, :, far.to(DEV)], want)
+    centred = (y.double() - bias.double().view(1, -1, 1, 1, 1)).transpose(0, 1).reshape(co, -1)
+    sums = part.double().sum(dim=1)
+    assert _rel(sums[:, 0], centred.sum(dim=1)) < 1e-5 and _rel(sums[:, 1], (centred * centred).sum(dim=1)) < 1e-5
+    if hip.conv3d_backward_weight_f16_serves(x):
+        gref = torch.nn.grad.conv3d_weight(x.double(), w.shape, gy.double(), padding=1)
+        g_amax = hip.conv_amax(gy)
+        gw_rows, gb_rows = hip.conv3d_backward_weight_f16(x, gy, amax, g_amax, with_bias=True)          # row table: zero rows skipped
+        gw_flat, gb_flat = hip.conv3d_backward_weight_f16(x, gy, amax[:1].clone(), g_amax, with_bias=True)   # 1-word buffer: nothing skipped
+        assert _rel(gw_rows, gref) < TOL and _rel(gb_rows, gy.double().sum(dim=(0, 2, 3, 4))) < TOL
+        assert torch.equal(gw_rows, gw_flat) and torch.equal(gb_rows, gb_flat)
