@@ -99,3 +99,45 @@ def test_weight_bank_images_are_the_per_layer_images(hip):
     assert fresh[0] is not bank.entries[('conv', convs[1].data_ptr(), (40, 64))]['wf']
     hip.weight_bank_refresh()
     assert torch.equal(hip.conv_weight_images(convs[1], 2)[0], fresh[0])
+
+
+def test_the_training_loop_of_integration_md_section_c(hip, tmp_path):
+    """INTEGRATION.md, section C, end to end on synthetic batches: static input tensors refilled per batch (DevicePrefetcher), the
+    captured step (FlatAdam inside), a torch lr_scheduler on top, and a checkpoint that torch.optim.Adam loads."""
+    from pvcnn_amd import workload
+    from pvcnn_amd.dp import GradBucketReducer
+    from pvcnn_amd.graph import GraphedTrainStep
+    from pvcnn_amd.optim import FlatAdam
+    from pvcnn_amd.pipeline import DevicePrefetcher, synthetic_stream
+    torch.manual_seed(1)
+    model = workload.PVCNN(13, 6, width_multiplier=0.25).to(DEV).train()
+    reducer = GradBucketReducer(model)
+    optimizer = FlatAdam(reducer, lr=2e-3, weight_decay=1e-5)
+    scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, T_max=3)
+
+    def host_batch(i):
+        feats, labels = workload.make_s3dis_batch(2, 1024, seed=100 + i)
+        return {'features': feats, 'targets': labels}
+    first = host_batch(0)
+    x, y = first['features'].to(DEV).clone(), first['targets'].to(DEV).clone()
+    step = GraphedTrainStep(model, lambda: tf.cross_entropy(model(x), y), optimizer, reducer)
+    assert step.mode == 'graph'
+    losses, lrs = [], []
+    for epoch in range(3):
+        for batch in DevicePrefetcher(synthetic_stream(lambda i: host_batch(epoch * 2 + i), 2), DEV):
+            x.copy_(batch['features'], non_blocking=True)
+            y.copy_(batch['targets'], non_blocking=True)
+            losses.append(step())
+        scheduler.step()
+        lrs.append(optimizer.param_groups[0]['lr'])
+    torch.cuda.synchronize()
+    vals = [float(losses[-1].detach()), float(losses[0].detach())]
+    assert all(torch.isfinite(torch.tensor(vals)))
+    assert lrs[0] < 2e-3 and lrs[-1] < lrs[0] and abs(optimizer.hyper[0].item() - lrs[-2]) < 1e-9     # the device block follows the schedule (synced before a replay)
+    path = tmp_path / 'ckpt.pt'
+    torch.save({'model': model.state_dict(), 'optimizer': optimizer.state_dict()}, path)
+    twin = workload.PVCNN(13, 6, width_multiplier=0.25).to(DEV)
+    twin.load_state_dict(torch.load(path)['model'])
+    adam = torch.optim.Adam(twin.parameters(), lr=1.0)
+    adam.load_state_dict(torch.load(path)['optimizer'])
+    assert adam.param_groups[0]['lr'] == lrs[-1] and float(adam.state[next(twin.parameters())]['step']) == 9.0      # 3 warm-up steps of the capture + 6 replays
