@@ -10,8 +10,9 @@ on one synthetic batch already resident in HBM.
 How the step is issued.  A PVCNN step is ~320 kernel launches of 4-250 us; one Python thread issues them slower (~25 us each)
 than the GPU retires them, so an eagerly issued step measures the host, not the GPU.  The timed region therefore REPLAYS the
 step from a hipGraph captured once (pvcnn_amd/graph.py: the same kernels on the same stream in the same order; 1 GPU: the
-whole step incl. the fused Adam update; N GPUs: forward + backward captured, the bucketed RCCL all-reduce and Adam issued
-after each replay).  `value` / `ms_per_step` are that region; `eager_value` is the same step issued launch by launch from
+whole step incl. the fused Adam update; N GPUs: the whole step as well -- the bucketed RCCL all-reduces are captured where the
+reducer's autograd hooks launch them, overlapped with the rest of backward -- or, if RCCL refuses the capture, forward + backward
+captured and the all-reduces + Adam issued after each replay; `config.step_issue` says which).  `value` / `ms_per_step` are that region; `eager_value` is the same step issued launch by launch from
 Python (timed separately, after the timed region).  `--eager` times the eager step instead.
 
 Extra objects on the JSON line:
@@ -558,9 +559,10 @@ def main():
                 'unit': 'TFLOP/s', 'frac': round(mfma['frac_of_peak'] * mfma_price, 4), 'avg_us': mfma['avg_us'], 'algorithmic_GFLOP': mfma['GFLOP'],
                 'effective_fp32_TFLOPs': mfma['effective_TFLOPs'], 'x_fp32_mfma_peak_157TF': mfma['x_fp32_mfma_peak'],
                 'note': 'achieved = MFMA flops actually executed (f16x2: 3 fp16 partial products per fp32 product; bf16x3: 6) / launch time; '
-                        'effective = algorithmic 2*B*R^3*27*Ci*Co / launch time; the dense MFMA kernels run at the rate the matrix cores '
-                        'sustain inside the power budget (~1400 TFLOP/s executed on random data; zeros run 18-30 % faster: '
-                        'profiles/ab/r03v_mfma_power_limit.md)'},
+                        'effective = algorithmic 2*B*R^3*27*Ci*Co / launch time; frac is priced on the slower of live events and the '
+                        'committed in-graph rocprofv3 average (in_graph_us).  By the counters (profiles/r04_pmc_mfma_bench_table.md, '
+                        'r04_pmc_mfma_fill_probe.jsonl) the matrix pipes are busy in 0.46-0.57 of the shader cycles and the chip clocks '
+                        '2.0-2.2 GHz under these kernels on real operands (2.4 GHz on constant ones): frac = busy x clock / 2.4'},
             'kernels': kernels,
         }
         if graph_error:

@@ -98,8 +98,8 @@ def concat_points(taps):
     from .modules.functional import _cache
     from .modules.functional._autograd import native
     be = native()
-    ok = (getattr(be, 'has_concat_points', False) and len(taps) <= 8 and all(t.is_cuda and t.dtype == torch.float32 and t.dim() == 3 for t in taps)
-          and not torch.is_autocast_enabled())
+    # (fp32 taps only -- also under torch.autocast, where every tensor between this package's modules is fp32)
+    ok = getattr(be, 'has_concat_points', False) and len(taps) <= 8 and all(t.is_cuda and t.dtype == torch.float32 and t.dim() == 3 for t in taps)
     if not ok:
         return torch.cat(taps, dim=1)
     ok = all((t.shape[2] > 1 and t.stride(2) == 0 and (t.stride(1) == 1 or t.shape[1] == 1)) or
@@ -355,13 +355,15 @@ class _FrustumSegmentation(nn.Module):
     def forward(self, inputs):
         feats = inputs['features']
         npts = feats.size(-1)
-        one_hot = inputs['one_hot_vectors'].unsqueeze(-1).repeat([1, 1, npts])
+        # (expand, not repeat: the concatenation reads the broadcast views -- the repeated (B, 3, N) / (B, 1024, N) tensors are never
+        # written on their own; reference: .repeat([1, 1, npts]), models/kitti/frustum/segmentation/pointnet.py:52-57, same values)
+        one_hot = inputs['one_hot_vectors'].unsqueeze(-1).expand(-1, -1, npts)
         per_point, coords = self.point_features((feats, feats[:, :3, :]))
         pooled, _ = self.cloud_features((per_point, coords)) if len(self.cloud_features) else (per_point, coords)
-        pooled = pooled.max(dim=-1, keepdim=True).values.repeat([1, 1, npts])
+        pooled = pooled.max(dim=-1, keepdim=True).values.expand(-1, -1, npts)
         # (the classifier head module by module on this package's kernels -- under torch.autocast the bare nn.Conv1d at its end would
-        # otherwise be a vendor bf16 GEMM with casts either side: _classify)
-        return _classify(self.classifier, torch.cat([one_hot, per_point, pooled], dim=1))
+        # otherwise be a vendor bf16 GEMM with casts either side: _classify; its input from concat_points: one pass, amax table included)
+        return _classify(self.classifier, concat_points([one_hot, per_point, pooled]))
 
 
 class _CloudRegressor(nn.Module):
