@@ -455,7 +455,10 @@ def main():
     eager_steps = min(args.steps, 20)
     eager_elapsed = None
     if graphed is not None:
-        for _ in range(3):
+        # (the eager steps allocate from the default stream's pool, which is empty after a capture: the caching allocator needs a few
+        # steps of its own before a step stops calling hipMalloc -- with 3 warm-up steps this figure read 1 100 ... 2 150 clouds/s from
+        # process to process on the same code)
+        for _ in range(10):
             eager_step()
         fence()
         t0 = time.perf_counter()
