@@ -321,6 +321,9 @@ def main():
     dev = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        # whole-step graph capture with collectives inside (pvcnn_amd/graph.py): torch's documented set-up for captured NCCL work is to
+        # switch the process group's asynchronous error handling off -- its watchdog thread otherwise polls events while a capture runs
+        os.environ.setdefault('TORCH_NCCL_ASYNC_ERROR_HANDLING', '0')
         dist.init_process_group('nccl', device_id=dev)       # backend "nccl" IS RCCL on ROCm
 
     from pvcnn_amd import workload

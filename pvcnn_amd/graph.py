@@ -88,7 +88,18 @@ class GraphedTrainStep:
     def _capture(self, whole_step):
         _cache.clear()                                   # the per-coords plans must be rebuilt INSIDE the graph
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        mode = 'global'
+        if self.collective:
+            # A process group runs a watchdog thread that polls the events of collectives issued so far (the warm-up steps').  In the
+            # default 'global' capture mode ANY thread's hipEventQuery while this thread captures is an error -- seen as a process
+            # abort in the middle of a capture, once in ~4 runs (gpurun_out/r04/gpu_tests.log).  'thread_local' restricts the check to
+            # the capturing thread (the watchdog's polls have nothing to do with this capture); and the device is drained first, with
+            # a pause of a few watchdog periods, so that it has nothing left to poll.
+            import time
+            mode = 'thread_local'
+            torch.cuda.synchronize()
+            time.sleep(0.5)
+        with torch.cuda.graph(graph, capture_error_mode=mode):
             self.loss = self._forward_backward()         # (multi-rank, whole step: the hooks launch the bucket all-reduces in here)
             if whole_step:
                 self.reducer.finish()

@@ -11,9 +11,9 @@ rm -rf /tmp/kt; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv
 grep "^{\"metric\"" $O/bench_under_rocprof.log | tail -1 > $O/bench_under_rocprof.json
 f=$(find /tmp/kt -name "*kernel_stats.csv" | head -1); head -90 $f > $O/bench_kernel_stats.csv
 t=$(find /tmp/kt -name "*kernel_trace.csv" | head -1)
-python $R/tools/trace_steady.py $t 100 90 43 --by-grid conv3d_igemm --json $O/kernel_durations.json > $O/bench_steady_state.txt 2>&1
-python $R/tools/trace_steady.py $t 100 0 43 --by-grid gather_lds > $O/bench_gather_by_launch.txt 2>&1
-python $R/tools/trace_steady.py $t 100 0 43 --by-grid bnact > $O/bench_bnact_by_launch.txt 2>&1
+python $R/tools/trace_steady.py $t 100 90 50 --by-grid conv3d_igemm --json $O/kernel_durations.json > $O/bench_steady_state.txt 2>&1
+python $R/tools/trace_steady.py $t 100 0 50 --by-grid gather_lds > $O/bench_gather_by_launch.txt 2>&1
+python $R/tools/trace_steady.py $t 100 0 50 --by-grid bnact > $O/bench_bnact_by_launch.txt 2>&1
 cp $O/kernel_durations.json $R/profiles/kernel_durations.json
 # 2. the bench line under the DRIVER's command, and with the default flags (100 steps, 30 warm-ups); cpu_baseline at the full batch
 (cd $R && timeout 600 $BENCH --gpus 1 --steps 20 --warmup 5 2>$O/bench_20_5.err | tail -1 > $O/bench_20_5.json)
@@ -70,7 +70,7 @@ done
  timeout 120 python tools/step_profile.py --rows 70 > $O/step_profile.txt 2>/dev/null)
 for c in cfg3 cfg4 cfg5; do
   rm -rf /tmp/kt_$c; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$c -- $BENCH --config $c --no-cpu-baseline --steps 40 --warmup 10 > $O/${c}_under_rocprof.log 2>&1
-  t=$(find /tmp/kt_$c -name "*kernel_trace.csv" | head -1); python $R/tools/trace_steady.py $t 40 50 43 > $O/${c}_steady_state.txt 2>&1
+  t=$(find /tmp/kt_$c -name "*kernel_trace.csv" | head -1); python $R/tools/trace_steady.py $t 40 50 50 > $O/${c}_steady_state.txt 2>&1
   (cd $R && timeout 300 python bench.py --config $c --no-cpu-baseline --steps 40 --warmup 10 2>/dev/null | tail -1 > $O/bench_$c.json)
 done
 rm -f $O/*_under_rocprof.log
