@@ -70,7 +70,8 @@ done
  timeout 120 python tools/step_profile.py --rows 70 > $O/step_profile.txt 2>/dev/null)
 for c in cfg3 cfg4 cfg5; do
   rm -rf /tmp/kt_$c; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$c -- $BENCH --config $c --no-cpu-baseline --steps 40 --warmup 10 > $O/${c}_under_rocprof.log 2>&1
-  t=$(find /tmp/kt_$c -name "*kernel_trace.csv" | head -1); python $R/tools/trace_steady.py $t 40 50 50 > $O/${c}_steady_state.txt 2>&1
+  t=$(find /tmp/kt_$c -name "*kernel_trace.csv" | head -1); python $R/tools/trace_steady.py $t 40 50 50 --json $O/kernel_durations_$c.json > $O/${c}_steady_state.txt 2>&1
+  cp $O/kernel_durations_$c.json $R/profiles/kernel_durations_$c.json
   (cd $R && timeout 300 python bench.py --config $c --no-cpu-baseline --steps 40 --warmup 10 2>/dev/null | tail -1 > $O/bench_$c.json)
 done
 rm -f $O/*_under_rocprof.log
