@@ -17,11 +17,13 @@ Python (timed separately, after the timed region).  `--eager` times the eager st
 
 Extra objects on the JSON line:
   roofline     : the hot path's headline kernel (trilinear_devoxelize fwd at the R=32 stage,
-                 16x64x4096 points from a 16x64x32^3 grid), timed LIVE in this process with HIP events on the
+                 16x64x4096 points from a 16x64x32^3 grid), timed twice: LIVE in this process with HIP events on the
                  launch stream around every launch of it in instrumented eager steps AFTER the timed region (a replayed
-                 graph cannot carry per-kernel events); achieved = SURVEY 8(d) algorithmic bytes / (mean event-pair time -
-                 the calibrated time of an empty event pair on a busy stream).
-  roofline_mfma: the step's largest MFMA-bound launch (Conv3d forward, 64->64 at 32^3), same live timing,
+                 graph cannot carry per-kernel events; mean event-pair time - the calibrated time of an empty event pair
+                 on a busy stream), and from the committed rocprofv3 trace of this command, the average of the SAME launch
+                 inside the replayed graph (profiles/kernel_durations.json).  achieved = SURVEY 8(d) algorithmic bytes /
+                 the SLOWER of the two; both are on the line.
+  roofline_mfma: the step's largest MFMA-bound launch (Conv3d forward, 64->64 at 32^3), same two timings, same pricing,
                  against the dense fp16 MFMA peak (f16x2 executes 3 fp16 products per fp32 product).
   kernels      : the same for every watched kernel family that ran in the step.
   cpu_baseline : the same network on the host cores with the CPU oracle as native backend
@@ -300,6 +302,10 @@ def main():
     ap.add_argument('--graph', action='store_true', help='(default since round 3; accepted for older command lines)')
     ap.add_argument('--collectives-after-replay', action='store_true',
                     help='N > 1: do not capture the RCCL all-reduces inside the graph; issue them (and Adam) after each replay')
+    ap.add_argument('--single-rank-collectives', action='store_true',
+                    help='self-test of the multi-GPU step on ONE GPU: a 1-rank RCCL process group, the reducer forced to issue its bucket '
+                         'all-reduces (the identity over one rank) -- the timed region is then the N > 1 code path (graph + captured '
+                         'collectives) with everything but a second rank')
     ap.add_argument('--torch-adam', action='store_true', help='torch.optim.Adam(fused=True) instead of pvcnn_amd.optim.FlatAdam')
     args = ap.parse_args()
 
@@ -320,7 +326,15 @@ def main():
         raise SystemExit('bench.py needs a GPU: the PVConv hot path has no CPU fallback')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    multi = world > 1 or args.single_rank_collectives           # the code path with a process group and collectives
+    if multi and world == 1:
+        import socket
+        with socket.socket() as sock:
+            sock.bind(('127.0.0.1', 0))
+            os.environ.setdefault('MASTER_PORT', str(sock.getsockname()[1]))
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
+    if multi:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         # whole-step graph capture with collectives inside (pvcnn_amd/graph.py): torch's documented set-up for captured NCCL work is to
         # switch the process group's asynchronous error handling off -- its watchdog thread otherwise polls events while a capture runs
@@ -372,7 +386,7 @@ def main():
                  'Conv3d on bf16 MFMA operands, fp32 accumulate; device-side logits_mask')
         metric = 'frustums/sec fwd+bwd, Frustum-PVCNN KITTI N=1024'
     model = model.to(dev).train()
-    reducer = GradBucketReducer(model, bucket_mb=args.bucket_mb)
+    reducer = GradBucketReducer(model, bucket_mb=args.bucket_mb, always_reduce=args.single_rank_collectives)
     # Adam (lr 1e-3, weight decay 1e-5: configs/s3dis/__init__.py) on the reducer's flat buckets: one elementwise launch per bucket,
     # step counter on the device (pvcnn_amd/optim.py; same arithmetic as torch.optim.Adam -- tests/test_gpu_optim.py).
     # --torch-adam: torch's fused multi-tensor Adam over the ~100 parameter tensors instead (2 x 72 us per PVCNN step).
@@ -386,7 +400,7 @@ def main():
     clock.install()
 
     def fence():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -443,7 +457,7 @@ def main():
 
     # ---- the step's collectives alone (all buckets, back to back, nothing to overlap with): what NOT overlapping them would cost ----
     comm_us = None
-    if world > 1:
+    if multi:
         for _ in range(3):
             for b in reducer.buckets:
                 dist.all_reduce(b.flat)
@@ -556,7 +570,7 @@ def main():
                                                                                   'after each replay (not overlapped)'}[graphed.mode]
                                       if graphed is not None else 'eager: one Python thread issues every launch; bucket all-reduces launched '
                                                                   'from the autograd hooks (overlapped with backward)'),
-                       'rccl_ranks': world if world > 1 else 0, 'per_rank_ms_per_step': per_rank_ms,
+                       'rccl_ranks': world if multi else 0, 'per_rank_ms_per_step': per_rank_ms,
                        'gradient_buckets': len(reducer.buckets), 'allreduce_alone_us_per_step': comm_us},
             'timed_region': timed,
             'eager_value': None if eager_elapsed is None else round(global_batch * eager_steps / eager_elapsed, 2),
@@ -583,10 +597,18 @@ def main():
             line['collective_capture_error'] = graphed.capture_error
         if world == 1 and not args.no_cpu_baseline and args.config == 'cfg2':
             line['cpu_baseline'] = cpu_baseline(args, args.cpu_sample_batch or args.batch)
-        print(json.dumps(line), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line must be the LAST line of stdout: RCCL writes a start-up banner ("RCCL version : ...", five lines) through C stdio,
+        # which -- into a pipe -- stays in libc's buffer until the process exits, i.e. behind anything Python has printed.  Flush it first.
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == '__main__':
