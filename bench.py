@@ -597,18 +597,22 @@ def main():
             line['collective_capture_error'] = graphed.capture_error
         if world == 1 and not args.no_cpu_baseline and args.config == 'cfg2':
             line['cpu_baseline'] = cpu_baseline(args, args.cpu_sample_batch or args.batch)
+    # the JSON line must be the LAST line of the job's stdout: RCCL writes a start-up banner ("RCCL version : ...", five lines per rank)
+    # through C stdio, which -- into a pipe -- stays in libc's buffer until the process exits, i.e. behind anything Python has printed.
+    # Every rank flushes it, the ranks meet, THEN rank 0 prints.
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    sys.stdout.flush()
+    if multi:
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps(line), flush=True)
     if multi:
         dist.barrier()
         dist.destroy_process_group()
-    if rank == 0:
-        # the JSON line must be the LAST line of stdout: RCCL writes a start-up banner ("RCCL version : ...", five lines) through C stdio,
-        # which -- into a pipe -- stays in libc's buffer until the process exits, i.e. behind anything Python has printed.  Flush it first.
-        import ctypes
-        try:
-            ctypes.CDLL(None).fflush(None)
-        except OSError:
-            pass
-        print(json.dumps(line), flush=True)
 
 
 if __name__ == '__main__':
