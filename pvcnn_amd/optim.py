@@ -55,6 +55,12 @@ class FlatAdam(torch.optim.Optimizer):
         self._lib = _lib.load()
         self.sync_hyperparameters()
 
+    def add_param_group(self, param_group):
+        if getattr(self, 'reducer', None) is not None and self.param_groups:
+            raise NotImplementedError('FlatAdam updates the ONE parameter group its reducer laid out (the reference trains with one: '
+                                      'train.py:163); build a second reducer / optimizer pair for other parameters')
+        super().add_param_group(param_group)
+
     def _group_hyper(self):
         g = self.param_groups[0]
         return (float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']), float(g['weight_decay']))
