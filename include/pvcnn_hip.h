@@ -47,7 +47,7 @@ extern "C" {
 #define PVCNN_API
 #endif
 
-#define PVCNN_ABI_VERSION 8
+#define PVCNN_ABI_VERSION 9
 #define PVCNN_OK 0
 #define PVCNN_ERR_INVALID_ARGUMENT (-1)
 
@@ -419,6 +419,19 @@ PVCNN_API int pvcnn_neighbor_max_bwd(const float *grad_out, const unsigned char 
  * (B, C, N)).  x: (rows, K) contiguous, 16-byte aligned, K % 4 == 0; winners (rows) int64 = the first index of the row maximum (a NaN
  * wins against numbers), values (rows) = the maxima or NULL. */
 PVCNN_API int pvcnn_row_argmax(const float *x, long rows, int K, long long *winners, float *values, void *stream);
+
+/* (ABI v9) The same arg-max WITHOUT a read of its own: the BatchNorm + activation pass that writes the tensor the max-pool reduces
+ * (the last SharedMLP of models/s3dis/pvcnn.py:37-43) emits, per (sample, channel) row, a 64-bit key
+ *     (orderable bits of the maximum << 32) | ~(first position of that maximum)
+ * into row_keys[b * C + c] by atomic maxima, and pvcnn_row_keys_decode turns the keys into int64 winners (the indices torch.max
+ * returns: first index on ties, -0 == +0, a NaN wins) and, unless NULL, the values (read back from y: bit-identical elements).
+ * pvcnn_bnact_apply_rowmax is the apply pass of pvcnn_bnact_fwd alone: mean / rstd from pvcnn_bn_finalize, whose zero_words
+ * argument must have zeroed BOTH y_amax (pvcnn_absmax_tiles_count(B, S, amax_seg) words) and row_keys (B * C uint64, 8-byte aligned)
+ * -- e.g. one buffer holding the two.  S % 256 == 0, amax_seg a multiple of 4 in 4..256, x / y 16-byte aligned. */
+PVCNN_API int pvcnn_bnact_apply_rowmax(const float *x, const float *gamma, const float *beta, const float *mean, const float *rstd, int B,
+                                       int C, int S, float slope, float *y, void *y_amax, int amax_seg, void *row_keys, void *stream);
+PVCNN_API int pvcnn_row_keys_decode(const void *row_keys, const float *y, long rows, int S, long long *winners, float *values,
+                                    void *stream);
 
 /* The excitation of SE3d (modules/se.py:6-17: Linear(C, H, bias=False) + ReLU + Linear(H, C, bias=False) + Sigmoid on the squeezed
  * (B, C) descriptor) between the two reduction passes of PVConv's fused squeeze-and-excitation tail, and its backward.

@@ -812,6 +812,33 @@ class HipBackend:
                        'bnact_forward')
         return (y, mean, rstd, y_amax) if amax_seg > 0 else (y, mean, rstd)
 
+    has_bnact_rowmax = True
+
+    def amax_and_row_keys(self, b, c, n, seg, device):
+        """One uninitialised int32 buffer holding the amax buffer of a (b, c, n) tensor AND its b * c 64-bit row keys (8-byte aligned)
+        -> (whole buffer: hand it to bn_finalize(zero_word=...), amax view, keys view)."""
+        words = self.lib.pvcnn_absmax_tiles_count(int(b), int(n), int(seg))
+        off = (words + 1) // 2 * 2
+        whole = torch.empty((off + 2 * int(b) * int(c),), dtype=torch.int32, device=device)
+        return whole, whole[:words], whole[off:]
+
+    def bnact_apply_rowmax(self, x, gamma, beta, mean, rstd, slope, amax_seg, y_amax, row_keys):
+        """The apply pass of bnact_forward on known statistics, also emitting the row maxima of y: x (B,C,S) -> (y, winners (B,C) int64,
+        values (B,C)) == (y, *y.max(dim=-1)[::-1]).  y_amax / row_keys: the views of amax_and_row_keys, ZEROED (bn_finalize)."""
+        _f32(x, 'x')
+        b, c, s3 = x.shape
+        _shape(s3 % 256 == 0 and amax_seg % 4 == 0 and 0 < amax_seg <= 256, 'bnact_apply_rowmax: S % 256 == 0 and amax_seg % 4 == 0 expected')
+        y = torch.empty_like(x)
+        winners = torch.empty((b, c), dtype=torch.int64, device=x.device)
+        values = torch.empty((b, c), dtype=torch.float32, device=x.device)
+        nul = ctypes.c_void_p(None)
+        with _Launch(x) as s:
+            _lib.check(self.lib.pvcnn_bnact_apply_rowmax(_p(x), _p(gamma) if gamma is not None else nul, _p(beta) if beta is not None else nul,
+                                                         _p(mean), _p(rstd), b, c, s3, float(slope), _p(y), _p(y_amax), int(amax_seg),
+                                                         _p(row_keys), s), 'bnact_apply_rowmax')
+            _lib.check(self.lib.pvcnn_row_keys_decode(_p(row_keys), _p(y), b * c, s3, _p(winners), _p(values), s), 'row_keys_decode')
+        return y, winners, values
+
     has_devox_bnact = True
 
     def amax_buffer(self, b, n, seg, device):

@@ -6,6 +6,9 @@ running_var (unbiased variance, `momentum`; cumulative average when momentum is 
 num_batches_tracked exactly like torch.nn.BatchNorm; eval mode uses the running statistics.
 `run_layers` walks an nn.Sequential and fuses every (BatchNorm, activation) pair it meets on a GPU
 tensor -- parameters, buffers and state_dict keys stay those of the plain modules."""
+import contextlib
+import threading
+
 import torch
 import torch.nn as nn
 from torch.autograd import Function
@@ -75,15 +78,27 @@ class BatchNormAct(Function):
     @staticmethod
     @amp_fwd
     def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, slope, stats_part=None, stats_shift=None,
-                amax_seg=0, counter=None, drop_p=0.0, drop_seed=None):
+                amax_seg=0, counter=None, drop_p=0.0, drop_seed=None, row_max=False):
         """-> y, or (y, y's amax buffer) when amax_seg > 0 (second output: not differentiable).
-        drop_p > 0 (with amax_seg > 0): y = dropout(act(bn(x)), drop_p) with the keep decisions of csrc/bnact.hip under drop_seed."""
+        drop_p > 0 (with amax_seg > 0): y = dropout(act(bn(x)), drop_p) with the keep decisions of csrc/bnact.hip under drop_seed.
+        row_max (amax_seg > 0, statistics from an epilogue, no dropout): -> (y, amax, winners, values), the last two == y.max(dim=-1)'s
+        indices and values, emitted by the apply pass (emit_row_max)."""
         shape = x.shape
         x3 = x.contiguous().view(shape[0], shape[1], -1)
         w = weight.contiguous() if weight is not None else None
         b = bias.contiguous() if bias is not None else None
         stats = armed = None
         if training and stats_part is not None:   # partial sums from the producing convolution's epilogue
+            if amax_seg and row_max:              # ... and zeroes the row keys of the max-pool that follows, in the same buffer
+                whole, armed, keys = native().amax_and_row_keys(x3.shape[0], x3.shape[1], x3.shape[2], amax_seg, x3.device)
+                stats = native().bn_finalize(stats_part, x3.shape[0] * x3.shape[2], running_mean, running_var, momentum, eps, stats_shift,
+                                             zero_word=whole, counter=counter)
+                ctx.slope, ctx.training, ctx.shape, ctx.drop = slope, training, shape, None
+                y, winners, values = native().bnact_apply_rowmax(x3, w, b, stats[0], stats[1], slope, amax_seg, armed, keys)
+                ctx.save_for_backward(x3, w, b, stats[0], stats[1])
+                ctx.mark_non_differentiable(armed, winners, values)
+                ctx.set_materialize_grads(False)
+                return y.view(shape), armed, winners, values
             if amax_seg:                          # the finalize launch also arms word [0] of the amax buffer the apply pass fills
                 armed = native().amax_buffer(x3.shape[0], x3.shape[2], amax_seg, x3.device)
                 stats = native().bn_finalize(stats_part, x3.shape[0] * x3.shape[2], running_mean, running_var, momentum, eps, stats_shift,
@@ -106,14 +121,32 @@ class BatchNormAct(Function):
 
     @staticmethod
     @amp_bwd
-    def backward(ctx, grad_y, grad_amax=None):
+    def backward(ctx, grad_y, grad_amax=None, grad_winners=None, grad_values=None):
         if grad_y is None:
-            return (None,) * 15
+            return (None,) * 16
         x3, w, b, mean, rstd = ctx.saved_tensors
         g3 = _rows(grad_y, ctx.shape)
         gx, gw, gb = _bnact_backward(x3, g3, w, b, mean, rstd, ctx.slope, ctx.training, ctx.shape, drop=ctx.drop)
         return (gx, gw if w is not None else None, gb if b is not None else None,
-                None, None, None, None, None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None, None, None, None, None)
+
+
+# ---- the max-pool over the points behind a (BatchNorm, activation) pair, emitted by the pair's apply pass ----------------------------
+_ROW_MAX = threading.local()
+
+
+@contextlib.contextmanager
+def emit_row_max(bn):
+    """with emit_row_max(bn): inside, the fused (BatchNorm `bn`, activation) pass ALSO emits the row maxima of the (B, C, N) tensor it
+    writes; the tensor then carries them as `_pvcnn_row_max` = (winners (B,C) int64, values (B,C)) == y.max(dim=-1)'s (indices, values)
+    -- what the global max-pool of models/s3dis/pvcnn.py:41-43 needs, without a read of the tensor.  Only the training path whose
+    statistics come from the producing convolution's epilogue takes it; elsewhere nothing is attached and the caller reduces itself."""
+    prev = getattr(_ROW_MAX, 'bn', None)
+    _ROW_MAX.bn = bn
+    try:
+        yield
+    finally:
+        _ROW_MAX.bn = prev
 
 
 def _bn_mode(bn, finalize_counts=False):
@@ -163,6 +196,13 @@ def batch_norm_act(x, bn, slope, stats_part=None, drop_p=0.0):
     part, shift = _split(stats_part)
     # the apply pass emits the f16x2 scale table of what it writes for the convolution that (usually) consumes it
     seg = _amax_seg_for(x.shape, x.is_cuda)
+    if (seg and bn is getattr(_ROW_MAX, 'bn', None) and not drop_p and use_batch_stats and part is not None and x.dim() == 3
+            and x.shape[2] % 256 == 0 and seg % 4 == 0 and x.dtype == torch.float32 and x.data_ptr() % 16 == 0 and x.is_contiguous()
+            and getattr(native(), 'has_bnact_rowmax', False)):
+        y, amax, winners, values = BatchNormAct.apply(x, bn.weight, bn.bias, rm, rv, use_batch_stats, momentum, bn.eps, slope, part, shift,
+                                                      seg, counter, 0.0, None, True)
+        y._pvcnn_row_max = (winners, values)
+        return _cache.tag_amax(y, seg, amax)
     if seg:
         seed = torch.randint(-(1 << 62), 1 << 62, (1,), dtype=torch.int64, device=x.device) if drop_p else None
         y, amax = BatchNormAct.apply(x, bn.weight, bn.bias, rm, rv, use_batch_stats, momentum, bn.eps, slope, part, shift, seg, counter,

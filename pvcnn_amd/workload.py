@@ -14,11 +14,13 @@ Synthetic inputs follow SURVEY.md 8(d): seed 1588147245 (configs/__init__.py:3),
 layout of datasets/s3dis.py:90 (block-local xyz in metres, rgb, room-normalised xyz), ~5 % exact
 duplicate points (the loader samples with replacement when a window holds < N points).
 """
+import contextlib
+
 import torch
 import torch.nn as nn
 
 from .modules import PVConv, PointNetAModule, PointNetFPModule, PointNetSAModule, SharedMLP
-from .modules.functional.bnact import run_layers
+from .modules.functional.bnact import emit_row_max, run_layers
 
 SEED = 1588147245
 
@@ -38,16 +40,17 @@ class _TapAndPool(torch.autograd.Function):
     at the winner positions -- the very sum the reference's graph forms, one addition per winner, same rounding."""
 
     @staticmethod
-    def forward(ctx, x, winners):
+    def forward(ctx, x, winners, values=None):
         ctx.save_for_backward(winners)
         ctx.npoints = x.shape[-1]
-        return x.view_as(x), x.gather(2, winners.unsqueeze(-1)).squeeze(-1)
+        # values: x[..., winners] already known (the pass that wrote x emitted both: functional/bnact.py: emit_row_max)
+        return x.view_as(x), (values.view_as(values) if values is not None else x.gather(2, winners.unsqueeze(-1)).squeeze(-1))
 
     @staticmethod
     def backward(ctx, g_tap, g_pool):
         (winners,) = ctx.saved_tensors
         if g_tap is None and g_pool is None:
-            return None, None
+            return None, None, None
         if g_tap is None:
             g = torch.zeros(g_pool.shape + (int(ctx.npoints),), dtype=g_pool.dtype, device=g_pool.device)
         elif getattr(g_tap, '_pvcnn_private_slice', False) and not torch.is_grad_enabled():
@@ -61,7 +64,7 @@ class _TapAndPool(torch.autograd.Function):
             g = g_tap.clone(memory_format=torch.contiguous_format)
         if g_pool is not None:
             g.scatter_add_(2, winners.unsqueeze(-1), g_pool.unsqueeze(-1).to(g.dtype))
-        return g, None
+        return g, None, None
 
 
 class _ConcatPoints(torch.autograd.Function):
@@ -112,10 +115,21 @@ def concat_points(taps):
     return out
 
 
+def _last_norm(stage):
+    """The BatchNorm of a SharedMLP's last (conv, BatchNorm, ReLU) triple, or None."""
+    layers = getattr(stage, 'layers', None)
+    if isinstance(layers, nn.Sequential) and len(layers) >= 2 and isinstance(layers[-2], nn.modules.batchnorm._BatchNorm):
+        return layers[-2]
+    return None
+
+
 def tap_and_pool(x):
     """-> (x as a tap, max over the points (B,C)).  The winners come from `x.max(dim=-1)` itself (ties: torch's rule)."""
     if not (x.requires_grad and torch.is_grad_enabled()):
         return x, x.max(dim=-1).values
+    emitted = getattr(x, '_pvcnn_row_max', None)          # (winners, values) from the BatchNorm + ReLU pass that wrote x
+    if emitted is not None:
+        return _TapAndPool.apply(x, emitted[0], emitted[1])
     from .modules.functional._autograd import native
     be = native() if x.is_cuda else None
     if (be is not None and getattr(be, 'has_neighbor_max', False) and x.dtype == torch.float32 and x.is_contiguous()
@@ -215,8 +229,11 @@ class PVCNN(nn.Module):
             inputs = inputs['features']
         coords = inputs[:, :3, :]
         feats, taps = inputs, []
-        for stage in self.point_features:
-            feats, _ = stage((feats, coords))
+        last = len(self.point_features) - 1
+        for i, stage in enumerate(self.point_features):
+            # (the last stage's BatchNorm + ReLU pass also emits the row maxima the global max-pool needs: no read of the 268 MB tensor)
+            with (emit_row_max(_last_norm(stage)) if i == last else contextlib.nullcontext()):
+                feats, _ = stage((feats, coords))
             taps.append(feats)
         taps[-1], pooled = tap_and_pool(feats)             # the last stage's features: a tap AND the global max pool
         cloud = self.cloud_features(pooled)
@@ -326,8 +343,11 @@ class PVCNNShapeNet(nn.Module):
         feats = inputs[:, :self.in_channels, :]
         taps = [inputs[:, -self.num_shapes:, :]]
         coords = feats[:, :3, :]
-        for stage in self.point_features:
-            feats, _ = stage((feats, coords))
+        last = len(self.point_features) - 1
+        for i, stage in enumerate(self.point_features):
+            # (the last stage's BatchNorm + ReLU pass also emits the row maxima the global max-pool needs: no read of the 268 MB tensor)
+            with (emit_row_max(_last_norm(stage)) if i == last else contextlib.nullcontext()):
+                feats, _ = stage((feats, coords))
             taps.append(feats)
         taps[-1], pooled = tap_and_pool(feats)             # the last stage's features: a tap AND the global max pool
         taps.append(pooled.unsqueeze(-1).expand(-1, -1, coords.size(-1)))

@@ -332,3 +332,54 @@ def test_classifier_head_with_fused_dropout_trains_like_the_module_stack(hip):
     xa = x.clone().requires_grad_()
     workload._classify(head, xa).square().mean().backward()
     assert xa.grad is not None and torch.isfinite(xa.grad).all() and all(q.grad is not None and torch.isfinite(q.grad).all() for q in head.parameters())
+
+
+@pytest.mark.parametrize('b,c,n', [(16, 1024, 4096), (2, 40, 256), (3, 64, 2048), (1, 8, 512)])
+def test_apply_pass_emits_the_row_maxima_torch_max_returns(hip, b, c, n):
+    """csrc/bnact.hip bnact_apply_pb_kernel<.., ROWMAX> + row_keys_decode (the global max-pool over the points behind the last
+    SharedMLP, models/s3dis/pvcnn.py:37-43, riding on the BatchNorm + ReLU pass that writes the tensor): y and its amax buffer
+    bit-identical to the plain pass, winners / values == y.max(dim=-1) on ReLU outputs -- rows that are all zero (a mix of -0 and
+    +0: the first index), repeated maxima, and a NaN wins."""
+    gen = torch.Generator().manual_seed(b * 1000 + c)
+    x = torch.randn(b, c, n, generator=gen).mul(2).round().div(2).to(DEV)           # coarse values: plenty of exact ties
+    x[0, 0] = -x[0, 0].abs() - 1.0                                                    # a row ReLU turns into -0 everywhere
+    x[-1, -1, 7] = float('nan')
+    gamma, beta = torch.rand(c, device=DEV) + 0.5, torch.randn(c, device=DEV) * 0.1
+    gamma[0], beta[0] = 1.0, 0.0
+    mean, rstd = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+    seg = 256
+    plain, _, _, amax_plain = hip.bnact_forward(x, gamma, beta, None, None, False, 0.1, 1e-5, 0.0, stats=(mean, rstd), amax_seg=seg)
+    whole, amax, keys = hip.amax_and_row_keys(b, c, n, seg, x.device)
+    whole.zero_()
+    y, winners, values = hip.bnact_apply_rowmax(x, gamma, beta, mean, rstd, 0.0, seg, amax, keys)
+    assert torch.equal(y.view(torch.int32), plain.view(torch.int32))
+    assert torch.equal(amax, amax_plain)
+    ref = y.max(dim=-1)
+    nan_row = torch.isnan(ref.values)
+    assert nan_row[-1, -1] and winners[-1, -1].item() == 7 and torch.isnan(values[-1, -1])
+    assert torch.equal(winners[~nan_row], ref.indices[~nan_row])
+    assert torch.equal(values[~nan_row].view(torch.int32), ref.values[~nan_row].view(torch.int32))
+    assert winners[0, 0].item() == 0 and values[0, 0].item() == 0.0
+
+
+def test_last_point_stage_hands_its_row_maxima_to_the_max_pool(hip):
+    """workload.PVCNN's last SharedMLP under emit_row_max: tap_and_pool takes (winners, values) from the tensor instead of reading it
+    (counted), and the pooled features and every gradient equal the path that reduces the tensor itself."""
+    from pvcnn_amd import workload
+    from pvcnn_amd.modules import SharedMLP
+    from pvcnn_amd.modules.functional.bnact import emit_row_max
+    torch.manual_seed(3)
+    mlp = SharedMLP(32, 96).to(DEV).train()
+    x = torch.randn(4, 32, 1024, device=DEV)
+    outs = []
+    for fused in (True, False):
+        xa = x.clone().requires_grad_()
+        mlp.zero_grad()
+        with (emit_row_max(workload._last_norm(mlp)) if fused else __import__('contextlib').nullcontext()):
+            y = mlp(xa)
+        assert (getattr(y, '_pvcnn_row_max', None) is not None) == fused
+        tap, pooled = workload.tap_and_pool(y)
+        (tap.square().mean() + pooled.square().sum()).backward()
+        outs.append((pooled.detach().clone(), xa.grad.clone(), [p.grad.clone() for p in mlp.parameters()]))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert all(torch.equal(a, b) for a, b in zip(outs[0][2], outs[1][2]))
