@@ -231,7 +231,7 @@ class PVCNN(nn.Module):
         feats, taps = inputs, []
         last = len(self.point_features) - 1
         for i, stage in enumerate(self.point_features):
-            # (the last stage's BatchNorm + ReLU pass also emits the row maxima the global max-pool needs: no read of the 268 MB tensor)
+            # (the last stage's BatchNorm + ReLU pass also emits the row maxima the global max-pool needs: no read of that tensor)
             with (emit_row_max(_last_norm(stage)) if i == last else contextlib.nullcontext()):
                 feats, _ = stage((feats, coords))
             taps.append(feats)
@@ -345,7 +345,7 @@ class PVCNNShapeNet(nn.Module):
         coords = feats[:, :3, :]
         last = len(self.point_features) - 1
         for i, stage in enumerate(self.point_features):
-            # (the last stage's BatchNorm + ReLU pass also emits the row maxima the global max-pool needs: no read of the 268 MB tensor)
+            # (the last stage's BatchNorm + ReLU pass also emits the row maxima the global max-pool needs: no read of that tensor)
             with (emit_row_max(_last_norm(stage)) if i == last else contextlib.nullcontext()):
                 feats, _ = stage((feats, coords))
             taps.append(feats)
