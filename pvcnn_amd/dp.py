@@ -103,6 +103,15 @@ class GradBucketReducer:
         if chunk:
             self._seal(chunk)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        self._slots = []
+        self._register_slots()
+
+    def _register_slots(self):
+        """Tell this package's backward kernels where each parameter's gradient lives in the buckets (functional/_gradslots.py): they
+        write it there, and `_Bucket.pack` has nothing left to copy for those parameters."""
+        from .modules.functional import _gradslots
+        _gradslots.unregister(self._slots)
+        self._slots = [_gradslots.register(p, v) for b in self.buckets for p, v in zip(b.params, b.views)]
 
     def _seal(self, chunk):
         flat = torch.zeros(sum(p.numel() for p in chunk), dtype=chunk[0].dtype, device=chunk[0].device)
@@ -171,6 +180,8 @@ class GradBucketReducer:
         for b in self.buckets:
             for p in b.params:
                 p.grad = None
+        for ent in self._slots:
+            ent[2] = False                                     # (functional/_gradslots.py: every slot may be handed out once per step)
 
     def flatten_parameters(self):
         """Lay the PARAMETERS out like their gradients: one flat buffer per bucket, `p.data` becoming views of it (values kept).  An
@@ -187,6 +198,7 @@ class GradBucketReducer:
                     view.copy_(p.data)
                     p.data = view
                     off += p.numel()
+        self._register_slots()                                 # (keyed by the parameters' addresses, which have just changed)
         return self
 
     @property
@@ -194,5 +206,8 @@ class GradBucketReducer:
         return sum(b.flat.numel() * b.flat.element_size() for b in self.buckets)
 
     def remove(self):
+        from .modules.functional import _gradslots
+        _gradslots.unregister(self._slots)
+        self._slots = []
         for h in self._hooks:
             h.remove()

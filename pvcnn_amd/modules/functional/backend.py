@@ -460,13 +460,25 @@ class HipBackend:
             _lib.check(self.lib.pvcnn_conv3d_fwd(_p(grad_y), _p(wt), None, b, co, ci, r, _p(gx), s), 'conv3d_backward_data')
         return gx
 
-    def conv3d_backward_weight(self, x, grad_y, with_bias=False):
+    # the backward-weight / BatchNorm-backward entries take `out_w` / `out_b`: where to write the two parameter gradients (contiguous
+    # fp32 tensors of the right shape, e.g. the parameter's slot in a flat gradient bucket: functional/_gradslots.py) instead of fresh ones
+    has_grad_out = True
+
+    @staticmethod
+    def _grad_out(dst, shape, device):
+        if dst is None:
+            return torch.empty(shape, dtype=torch.float32, device=device)
+        _shape(tuple(dst.shape) == tuple(shape) and dst.dtype == torch.float32 and dst.is_contiguous() and dst.device == device,
+               'gradient destination: contiguous float32 tensor of the gradient\'s shape expected')
+        return dst
+
+    def conv3d_backward_weight(self, x, grad_y, with_bias=False, out_w=None, out_b=None):
         """-> grad_weight, or (grad_weight, grad_bias) when with_bias (the bias sum rides on the same pass)."""
         _f32(x, 'x'); _f32(grad_y, 'grad_y')
         b, ci, r = x.shape[0], x.shape[1], x.shape[2]
         co = grad_y.shape[1]
-        gw = torch.empty((co, ci, 3, 3, 3), dtype=torch.float32, device=x.device)
-        gb = torch.empty((co,), dtype=torch.float32, device=x.device) if with_bias else None
+        gw = self._grad_out(out_w, (co, ci, 3, 3, 3), x.device)
+        gb = self._grad_out(out_b, (co,), x.device) if with_bias else None
         ws = self._scratch(self.lib.pvcnn_conv3d_bwd_weight_workspace_bytes(b, ci, co, r), x.device)
         with _Launch(x) as s:
             _lib.check(self.lib.pvcnn_conv3d_bwd_weight(_p(x), _p(grad_y), b, ci, co, r, _p(gw), _p(gb) if with_bias else None,
@@ -626,7 +638,7 @@ class HipBackend:
     def conv3d_backward_weight_f16_serves(self, x):
         return x.dim() == 5 and x.shape[2] in (8, 12, 16, 32)
 
-    def conv3d_backward_weight_f16(self, x, grad_y, x_amax=None, gy_amax=None, with_bias=False):
+    def conv3d_backward_weight_f16(self, x, grad_y, x_amax=None, gy_amax=None, with_bias=False, out_w=None, out_b=None):
         """grad_w (Co,Ci,3,3,3) [, grad_bias]: x (B,Ci,R,R,R), grad_y (B,Co,R,R,R); *_amax = amax buffers of the two tensors (word [0],
         the global maximum, is what this kernel scales by)."""
         _f32(x, 'x'); _f32(grad_y, 'grad_y')
@@ -635,8 +647,8 @@ class HipBackend:
         _shape(self.conv3d_backward_weight_f16_serves(x) and tuple(grad_y.shape) == (b, co, r, r, r), 'conv3d_backward_weight_f16: R must be 8, 12, 16 or 32')
         x_amax = x_amax if x_amax is not None else self.absmax_bits(x)
         gy_amax = gy_amax if gy_amax is not None else self.absmax_bits(grad_y)
-        gw = torch.empty((co, ci, 3, 3, 3), dtype=torch.float32, device=x.device)
-        gb = torch.empty((co,), dtype=torch.float32, device=x.device) if with_bias else None
+        gw = self._grad_out(out_w, (co, ci, 3, 3, 3), x.device)
+        gb = self._grad_out(out_b, (co,), x.device) if with_bias else None
         ws = self._scratch(self.lib.pvcnn_conv3d_bwd_weight_f16_workspace_bytes(b, ci, co, r), x.device)
         with _Launch(x) as s:
             _lib.check(self.lib.pvcnn_conv3d_bwd_weight_f16(_p(x), _p(grad_y), _p(x_amax), self._amax_seg(x_amax, b * r * r, r), _p(gy_amax), b, ci, co, r, _p(gw),
@@ -728,13 +740,13 @@ class HipBackend:
         _f32(grad_y, 'grad_y'); _f32(weight, 'weight')
         return self.pwconv_gemm_split(grad_y, self._pw_wsplit(weight, True, nsplit), None, weight.shape[1], nsplit, False, amax)
 
-    def pwconv_backward_weight(self, x, grad_y, with_bias=False):
+    def pwconv_backward_weight(self, x, grad_y, with_bias=False, out_w=None, out_b=None):
         """-> grad_weight (Co,Ci), or (grad_weight, grad_bias) when with_bias."""
         _f32(x, 'x'); _f32(grad_y, 'grad_y')
         b, ci, n = x.shape
         co = grad_y.shape[1]
-        gw = torch.empty((co, ci), dtype=torch.float32, device=x.device)
-        gb = torch.empty((co,), dtype=torch.float32, device=x.device) if with_bias else None
+        gw = self._grad_out(out_w, (co, ci), x.device)
+        gb = self._grad_out(out_b, (co,), x.device) if with_bias else None
         ws = self._scratch(self.lib.pvcnn_pwconv_bwd_weight_workspace_bytes(b, ci, co, n), x.device)
         with _Launch(x) as s:
             _lib.check(self.lib.pvcnn_pwconv_bwd_weight(_p(x), _p(grad_y), b, ci, co, n, _p(gw), _p(gb) if with_bias else None,
@@ -744,7 +756,7 @@ class HipBackend:
     def pwconv_backward_weight_f16_serves(self, x):
         return x.dim() == 3 and x.shape[2] % 4 == 0
 
-    def pwconv_backward_weight_f16(self, x, grad_y, x_amax=None, gy_amax=None, with_bias=False):
+    def pwconv_backward_weight_f16(self, x, grad_y, x_amax=None, gy_amax=None, with_bias=False, out_w=None, out_b=None):
         """f16x2 on the fp16 matrix cores (csrc/pointwise_wgrad_f16.hip): -> grad_weight (Co,Ci) [, grad_bias]."""
         _f32(x, 'x'); _f32(grad_y, 'grad_y')
         b, ci, n = x.shape
@@ -752,8 +764,8 @@ class HipBackend:
         _shape(self.pwconv_backward_weight_f16_serves(x) and tuple(grad_y.shape) == (b, co, n), 'pwconv_backward_weight_f16: N must be a multiple of 4')
         x_amax = x_amax if x_amax is not None else self.absmax_bits(x)
         gy_amax = gy_amax if gy_amax is not None else self.absmax_bits(grad_y)
-        gw = torch.empty((co, ci), dtype=torch.float32, device=x.device)
-        gb = torch.empty((co,), dtype=torch.float32, device=x.device) if with_bias else None
+        gw = self._grad_out(out_w, (co, ci), x.device)
+        gb = self._grad_out(out_b, (co,), x.device) if with_bias else None
         ws = self._scratch(self.lib.pvcnn_pwconv_bwd_weight_f16_workspace_bytes(b, ci, co, n), x.device)
         with _Launch(x) as s:
             _lib.check(self.lib.pvcnn_pwconv_bwd_weight_f16(_p(x), _p(grad_y), _p(x_amax), _p(gy_amax), b, ci, co, n, _p(gw),
@@ -1064,7 +1076,7 @@ class HipBackend:
                        'bnact_backward_apply')
         return gx, amax
 
-    def bnact_backward(self, x, grad_y, gamma, beta, mean, rstd, slope, training, amax_seg=0, drop=None):
+    def bnact_backward(self, x, grad_y, gamma, beta, mean, rstd, slope, training, amax_seg=0, drop=None, out_w=None, out_b=None):
         """-> (grad_x, grad_gamma, grad_beta [, grad_x's amax buffer with segments of amax_seg positions, emitted by the apply pass]).
         drop = (seed, p) of the forward call: grad_y is then the gradient of the DROPPED output (needs amax_seg > 0)."""
         _f32(x, 'x')
@@ -1072,8 +1084,8 @@ class HipBackend:
         b, c, s3 = x.shape
         dev = x.device
         gx = torch.empty_like(x)
-        gg = torch.empty((c,), dtype=torch.float32, device=dev)
-        gb = torch.empty((c,), dtype=torch.float32, device=dev)
+        gg = self._grad_out(out_w, (c,), dev)
+        gb = self._grad_out(out_b, (c,), dev)
         ws = self._scratch(self.lib.pvcnn_bnact_workspace_bytes(b, c, s3), dev)
         nul = ctypes.c_void_p(None)
         amax_seg = int(amax_seg)

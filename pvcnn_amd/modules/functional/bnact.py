@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 from torch.autograd import Function
 
-from . import _cache
+from . import _cache, _gradslots
 from ._autograd import native, amp_fwd, amp_bwd
 from .devoxelization import CornerTaps
 
@@ -63,11 +63,12 @@ def _bnact_backward(x3, g3, w, b, mean, rstd, slope, training, shape, drop=None)
     on the returned tensor (_cache.tag_amax) for the f16x2 backward products of the convolution in front of this BatchNorm."""
     be = native()
     seg = _amax_seg_for(shape, x3.is_cuda)
+    dst = _gradslots.destinations(be, w, b)       # gamma's / beta's slots in a flat gradient bucket, where there is one
     if seg:
-        gx, gw, gb, amax = be.bnact_backward(x3, g3, w, b, mean, rstd, slope, training, amax_seg=seg, **({'drop': drop} if drop else {}))
+        gx, gw, gb, amax = be.bnact_backward(x3, g3, w, b, mean, rstd, slope, training, amax_seg=seg, **({'drop': drop} if drop else {}), **dst)
         return _cache.tag_amax(gx.view(shape), seg, amax), gw, gb
     assert drop is None, 'the fused dropout rides on the amax-emitting passes'  
-    gx, gw, gb = be.bnact_backward(x3, g3, w, b, mean, rstd, slope, training)
+    gx, gw, gb = be.bnact_backward(x3, g3, w, b, mean, rstd, slope, training, **dst)
     return gx.view(shape), gw, gb
 
 

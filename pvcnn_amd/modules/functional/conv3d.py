@@ -8,7 +8,7 @@ backward-weight kernel does not serve.  The bias gradient rides on the backward-
 import torch
 from torch.autograd import Function
 
-from . import _cache
+from . import _cache, _gradslots
 from ._autograd import native, amp_fwd, amp_bwd
 
 __all__ = ['voxel_conv3d', 'conv_nsplit']
@@ -35,6 +35,7 @@ class VoxelConv3d(Function):
         weight = weight.contiguous()
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        ctx.bias_param = bias                     # (only asked where its gradient should be written: _gradslots.claim)
         ctx.nsplit = int(nsplit)
         b = bias.contiguous() if bias is not None else None
         be = native()
@@ -92,8 +93,9 @@ class VoxelConv3d(Function):
         gw = gb = None
         if ctx.needs_input_grad[1]:
             # the bias gradient is accumulated by the same kernel from the grad_y tiles it stages anyway
-            res = (be.conv3d_backward_weight_f16(x, grad_y, ctx.x_amax, g_amax, with_bias=want_bias) if wgrad_f16
-                   else be.conv3d_backward_weight(x, grad_y, with_bias=want_bias))
+            dst = _gradslots.destinations(be, weight, ctx.bias_param if want_bias else None)   # the parameters' slots in a flat gradient bucket
+            res = (be.conv3d_backward_weight_f16(x, grad_y, ctx.x_amax, g_amax, with_bias=want_bias, **dst) if wgrad_f16
+                   else be.conv3d_backward_weight(x, grad_y, with_bias=want_bias, **dst))
             gw, gb = res if want_bias else (res, None)
         elif want_bias:
             gb = grad_y.sum(dim=(0, 2, 3, 4))

@@ -8,7 +8,7 @@ cores (csrc/pointwise_bf16.hip, pointwise_wgrad_f16.hip: fp32 tensors, operands 
 import torch
 from torch.autograd import Function
 
-from . import _cache
+from . import _cache, _gradslots
 from ._autograd import native, amp_fwd, amp_bwd
 
 __all__ = ['pointwise_conv', 'pw_nsplit']
@@ -39,6 +39,7 @@ class PointwiseConv(Function):
         w2 = weight.contiguous().view(weight.shape[0], weight.shape[1])
         ctx.save_for_backward(x3, w2)
         ctx.has_bias, ctx.x_shape, ctx.w_shape = bias is not None, shape, weight.shape
+        ctx.bias_param = bias                     # (only asked where its gradient should be written: _gradslots.claim)
         b = bias.contiguous() if bias is not None else None
         be = native()
         # the split products on the 16-bit matrix cores (csrc/pointwise_bf16.hip): 2 = f16x2, 3 = bf16x3, 1 = bf16, 0 = fp32 MFMA
@@ -95,8 +96,9 @@ class PointwiseConv(Function):
         gw = gb = None
         if ctx.needs_input_grad[1]:
             # (x_amax / g_amax None -- the bf16 mode measured neither: backward-weight takes the global maxima in one read each)
-            res = (be.pwconv_backward_weight_f16(x3, g3, ctx.x_amax, g_amax, with_bias=want_bias) if wgrad_f16
-                   else be.pwconv_backward_weight(x3, g3, with_bias=want_bias))
+            dst = _gradslots.destinations(be, w2, ctx.bias_param if want_bias else None)   # the parameters' slots in a flat gradient bucket
+            res = (be.pwconv_backward_weight_f16(x3, g3, ctx.x_amax, g_amax, with_bias=want_bias, **dst) if wgrad_f16
+                   else be.pwconv_backward_weight(x3, g3, with_bias=want_bias, **dst))
             gw, gb = res if want_bias else (res, None)
             gw = gw.view(ctx.w_shape)
         elif want_bias:

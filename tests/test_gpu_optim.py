@@ -189,3 +189,42 @@ def test_a_flat_adam_step_invalidates_armed_weight_images(hip):
     again = be.conv_weight_images(w, 2)                            # (nothing armed any more: the layer's own launch)
     torch.cuda.synchronize()
     assert torch.equal(got[0], again[0]) and torch.equal(got[1], again[1])
+
+
+def test_backward_kernels_write_parameter_gradients_into_the_buckets(hip):
+    """functional/_gradslots.py on the GPU path: with a GradBucketReducer the Conv3d / 1x1-convolution / BatchNorm backward kernels
+    write their parameter gradients into the flat buckets themselves -- `_Bucket.pack` has nothing to copy for a PVConv -- and every
+    gradient is bit-identical to the step whose gradients were gathered by the multi-tensor copy."""
+    from pvcnn_amd.dp import GradBucketReducer
+    from pvcnn_amd.modules import PVConv
+    from pvcnn_amd.modules.functional import _gradslots
+    torch.manual_seed(11)
+    net = PVConv(16, 32, 3, 8).to(DEV).train()
+    feats = torch.randn(2, 16, 512, device=DEV)
+    coords = torch.rand(2, 3, 512, device=DEV)
+    red = GradBucketReducer(net)
+
+    def step():
+        red.zero_grad()
+        out, _ = net((feats, coords))
+        out.square().mean().backward()
+        red.finish()
+        return [p.grad.clone() for p in net.parameters()]
+
+    copied = []
+    orig = torch._foreach_copy_
+    torch._foreach_copy_ = lambda d, s: (copied.append(len(d)), orig(d, s))[1]
+    try:
+        in_place = step()
+        assert copied == [], copied
+        saved, _gradslots._by_ptr = _gradslots._by_ptr, {}           # no slots: the gathering path
+        try:
+            gathered = step()
+        finally:
+            _gradslots._by_ptr = saved
+        assert sum(copied) == len(in_place)
+    finally:
+        torch._foreach_copy_ = orig
+    for a, b in zip(in_place, gathered):
+        assert torch.equal(a, b)
+    red.remove()

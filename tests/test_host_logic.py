@@ -529,3 +529,74 @@ def test_weight_bank_serves_an_armed_pair_once_and_never_a_changed_weight():
     for i in range(5000):                                                               # temporaries do not pile up
         bank.take('pw', torch.empty(2, 2))
     assert len(bank.wanted) <= 4096
+
+
+def test_gradient_slots_are_handed_out_once_per_step_and_only_for_a_first_gradient():
+    """functional/_gradslots.py (the backward kernels write parameter gradients straight into the reducer's flat buckets): the rules of
+    claim(), and that autograd installs the returned alias as `p.grad` without a copy -- `_Bucket.pack` has nothing left to gather."""
+    import torch.nn as nn
+    from pvcnn_amd.dp import GradBucketReducer
+    from pvcnn_amd.modules.functional import _gradslots
+
+    class Lin(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w, b):
+            ctx.save_for_backward(x, w)
+            ctx.b = b
+            return x @ w.t() + b
+
+        @staticmethod
+        def backward(ctx, g):
+            x, w = ctx.saved_tensors
+            gw, gb = _gradslots.claim(w), _gradslots.claim(ctx.b)
+            if gw is None:                                   # (the rules said no: a tensor of its own, as before)
+                return g @ w, g.t() @ x, g.sum(0)
+            torch.mm(g.t(), x, out=gw)
+            gb.copy_(g.sum(0))
+            return g @ w, gw, gb
+
+    torch.manual_seed(0)
+    m = nn.Linear(4, 3)
+    ref = nn.Linear(4, 3)
+    ref.load_state_dict(m.state_dict())
+    red = GradBucketReducer(m)
+    x = torch.randn(5, 4)
+    copied = []
+    orig = torch._foreach_copy_
+    torch._foreach_copy_ = lambda d, s: (copied.append(len(d)), orig(d, s))[1]
+    try:
+        red.zero_grad()
+        Lin.apply(x, m.weight, m.bias).square().sum().backward()
+        red.finish()
+        assert copied == []                                  # both gradients were written in place and taken over as they were
+        ref(x).square().sum().backward()
+        assert torch.allclose(m.weight.grad, ref.weight.grad) and torch.allclose(m.bias.grad, ref.bias.grad)
+        view = next(v for p, v in zip(red.buckets[0].params, red.buckets[0].views) if p is m.weight)
+        assert m.weight.grad.data_ptr() == view.data_ptr()
+        # a second backward WITHOUT zero_grad accumulates: p.grad exists, so no slot -- autograd adds the node's own tensor
+        Lin.apply(x, m.weight, m.bias).square().sum().backward()
+        red.finish()
+        assert torch.allclose(m.weight.grad, 2 * ref.weight.grad)
+        # a parameter used twice in one graph: the slot goes to the first use only, the sum is still right
+        red.zero_grad()
+        (Lin.apply(x, m.weight, m.bias) + Lin.apply(2 * x, m.weight, m.bias)).square().sum().backward()
+        red.finish()
+        ref.zero_grad()
+        (ref(x) + ref(2 * x)).square().sum().backward()
+        assert torch.allclose(m.weight.grad, ref.weight.grad, rtol=1e-5, atol=1e-6)
+    finally:
+        torch._foreach_copy_ = orig
+    red.zero_grad()
+    with torch.no_grad():
+        a = _gradslots.claim(m.weight)
+        assert a is not None and a is not view and a.data_ptr() == view.data_ptr() and a.shape == m.weight.shape
+        assert _gradslots.claim(m.weight) is None            # once per step
+        assert _gradslots.claim(m.weight.view(12)) is None   # (still the same slot)
+    red.zero_grad()
+    assert _gradslots.claim(m.weight) is None                # grad mode on (create_graph): the node's result must be differentiable
+    with torch.no_grad():
+        assert _gradslots.claim(torch.zeros(3, 4)) is None   # not a registered parameter
+        assert _gradslots.claim(m.weight.view(12)).shape == (12,)     # a contiguous view of the whole parameter gets the slot, shaped like it
+    red.remove()
+    with torch.no_grad():
+        assert _gradslots.claim(m.bias) is None              # the reducer is gone
