@@ -1,5 +1,5 @@
 #!/bin/bash
-# Evidence set of a round, one gpurun call (~6 GPU-minutes):  [ROUND=r04] tools/collect_evidence.sh
+# Evidence set of a round, one gpurun call (~6 GPU-minutes):  [ROUND=r04] [QUICK=1] tools/collect_evidence.sh
 # Outputs -> gpurun_out/$ROUND/; copy what is judged to profiles/ as ${ROUND}_*  (tools/publish_evidence.sh does that).
 R=${GRAFT_REPO_ROOT:-$PWD}; RD=${ROUND:-r04}; O=$R/gpurun_out/$RD; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
@@ -20,6 +20,7 @@ cp $O/kernel_durations.json $R/profiles/kernel_durations.json
 (cd $R && timeout 600 $BENCH --no-cpu-baseline 2>$O/bench.err | tail -1 > $O/bench.json)
 (cd $R && timeout 300 $BENCH --no-cpu-baseline --eager --steps 30 --warmup 10 2>/dev/null | tail -1 > $O/bench_eager.json)
 (cd $R && timeout 300 $BENCH --no-cpu-baseline --eager --torch-adam --steps 30 --warmup 10 2>/dev/null | tail -1 > $O/bench_eager_torch_adam.json)
+if [ -z "$QUICK" ]; then     # QUICK=1: the bench lines, the traces and the other configs only (the counters of steps 3-5 belong to kernels that did not change)
 # 3. HBM traffic counters, separate passes, ON THE BENCH COMMAND ITSELF, per (kernel, launch grid)
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c; timeout 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -- $BENCH --steps 10 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
@@ -68,6 +69,7 @@ done
  python tools/sparse_probe.py 2>/dev/null | grep "B=" > $O/sparse_probe.txt
  PVCNN_CONV_MATH=fp32 PVCNN_PW_MATH=fp32 timeout 300 python bench.py --no-cpu-baseline --steps 40 --warmup 10 2>/dev/null | tail -1 > $O/bench_fp32_mfma.json
  timeout 120 python tools/step_profile.py --rows 70 > $O/step_profile.txt 2>/dev/null)
+fi
 for c in cfg3 cfg4 cfg5; do
   rm -rf /tmp/kt_$c; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$c -- $BENCH --config $c --no-cpu-baseline --steps 40 --warmup 10 > $O/${c}_under_rocprof.log 2>&1
   t=$(find /tmp/kt_$c -name "*kernel_trace.csv" | head -1); python $R/tools/trace_steady.py $t 40 50 50 --json $O/kernel_durations_$c.json > $O/${c}_steady_state.txt 2>&1
