@@ -172,6 +172,9 @@ class GradBucketReducer:
         """Forget the per-step bucket state (gradients pending, in-flight work, packed flag): the state after finish()."""
         for b in self.buckets:
             b.pending, b.work, b.packed = len(b.params), None, False
+        for ent in self._slots:
+            ent[2] = False                                     # (a step is over: functional/_gradslots.py may hand every slot out again --
+                                                               #  it does so only to a parameter whose `grad` is None by then)
 
     def zero_grad(self):
         """Forget last step's gradients: `p.grad = None`, so autograd hands every new gradient over as it is (no memset of the
