@@ -47,7 +47,7 @@ extern "C" {
 #define PVCNN_API
 #endif
 
-#define PVCNN_ABI_VERSION 9
+#define PVCNN_ABI_VERSION 10
 #define PVCNN_OK 0
 #define PVCNN_ERR_INVALID_ARGUMENT (-1)
 
@@ -432,6 +432,27 @@ PVCNN_API int pvcnn_bnact_apply_rowmax(const float *x, const float *gamma, const
                                        int C, int S, float slope, float *y, void *y_amax, int amax_seg, void *row_keys, void *stream);
 PVCNN_API int pvcnn_row_keys_decode(const void *row_keys, const float *y, long rows, int S, long long *winners, float *values,
                                     void *stream);
+
+/* (ABI v10) The box part of Frustum-PointNet's multi-task loss (modules/frustum.py:43-124: FrustumPointNetLoss without the
+ * foreground-mask cross entropy) AND its gradient, one launch:
+ *   box = huber(|c_t - c|, 2) + huber(|c_t - c_reg|, 1) + CE(heading_scores, h) + CE(size_scores, s)
+ *       + w_heading_residual * huber(hrn[h] - h_res_t / heading_bin_width, 1) + w_size_residual * huber(|s_res_t / T[s] - srn[s]|, 1)
+ *       + w_corners * huber(min(|corners - corners_t|, |corners - corners_t turned by pi|), 1),   every term a mean over the batch.
+ * Inputs (fp32, contiguous): center, center_reg, center_t (B,3); heading_scores, heading_residuals_normalized, heading_residuals
+ * (B,NH); size_scores (B,NS); size_residuals_normalized, size_residuals (B,NS,3); heading_bin_id, size_template_id (B) int64;
+ * heading_residual_t (B); size_residual_t (B,3); size_templates (NS,3); heading_bin_centers (NH); heading_bin_width = pi / NH in
+ * the reference.  Outputs: loss[0] = box; grads (pvcnn_frustum_box_loss_grad_floats(B, NH, NS) floats) = d box / d of the eight network
+ * outputs, concatenated: [center 3B | center_reg 3B | heading_scores B*NH | size_scores B*NS | heading_residuals_normalized B*NH |
+ * size_residuals_normalized B*NS*3 | heading_residuals B*NH | size_residuals B*NS*3], every element written.  Sub-gradients as
+ * autograd takes them (0 at |x| = 0 and at a zero-length vector; an exact tie of the two corner distances splits evenly). */
+PVCNN_API size_t pvcnn_frustum_box_loss_grad_floats(int B, int NH, int NS);
+PVCNN_API int pvcnn_frustum_box_loss(const float *center, const float *center_reg, const float *heading_scores, const float *size_scores,
+                                     const float *heading_residuals_normalized, const float *size_residuals_normalized,
+                                     const float *heading_residuals, const float *size_residuals, const long long *heading_bin_id,
+                                     const long long *size_template_id, const float *heading_residual_t, const float *size_residual_t,
+                                     const float *center_t, const float *size_templates, const float *heading_bin_centers, int B, int NH,
+                                     int NS, float heading_bin_width, float w_heading_residual, float w_size_residual, float w_corners,
+                                     float *loss, float *grads, void *stream);
 
 /* The excitation of SE3d (modules/se.py:6-17: Linear(C, H, bias=False) + ReLU + Linear(H, C, bias=False) + Sigmoid on the squeezed
  * (B, C) descriptor) between the two reduction passes of PVConv's fused squeeze-and-excitation tail, and its backward.

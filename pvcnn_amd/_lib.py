@@ -16,7 +16,7 @@ import torch  # noqa: F401  (must be imported before the dlopen, see above)
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 LIB_PATH = os.path.join(_CSRC, 'libpvcnn_hip.so')
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _vp, _i, _f, _sz, _l = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_long
 
@@ -99,6 +99,8 @@ SIGNATURES = {
     'pvcnn_row_argmax': (_i, [_vp, _l, _i, _vp, _vp, _vp]),
     'pvcnn_bnact_apply_rowmax': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _i, _vp, _vp]),
     'pvcnn_row_keys_decode': (_i, [_vp, _vp, _l, _i, _vp, _vp, _vp]),
+    'pvcnn_frustum_box_loss_grad_floats': (_sz, [_i, _i, _i]),
+    'pvcnn_frustum_box_loss': (_i, [_vp] * 15 + [_i, _i, _i, _f, _f, _f, _f, _vp, _vp, _vp]),
     'pvcnn_se_excite_fwd': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     'pvcnn_se_excite_bwd': (_i, [_vp, _i] + [_vp] * 9 + [_i, _i, _i, _f] + [_vp] * 7),
     'pvcnn_bnact_partial_sums': (_i, [_vp, _vp, ctypes.c_long, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp]),

@@ -1,7 +1,9 @@
 """Frustum-PointNet multi-task loss and box-corner helper (reference: modules/frustum.py:11-124).
-Pure torch on (B, <=8x3) tensors -- not on the hot path; provided so `modules.frustum` resolves
-for the reference's KITTI configs and meters."""
+(B, <= 8 x 3) tensors: ~260 torch launches per step when written as the reference writes it -- a third of a Frustum-PVCNN step's
+launches.  On the GPU path the box part of the loss and its gradient are ONE launch (csrc/frustum.hip: `_BoxLoss` below); the torch
+formulation stays as the definition (CPU, other dtypes, double backward) and as the checker of tests/test_gpu_frustum_loss.py."""
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -10,6 +12,37 @@ import torch.nn.functional as tf
 from . import functional as PF
 
 __all__ = ['FrustumPointNetLoss', 'get_box_corners_3d']
+
+_GRAD_ORDER = ('center', 'center_reg', 'heading_scores', 'size_scores', 'heading_residuals_normalized', 'size_residuals_normalized',
+               'heading_residuals', 'size_residuals')
+
+
+class _BoxLoss(torch.autograd.Function):
+    """(the eight network outputs of _GRAD_ORDER, targets, constants) -> box loss (0-dim); the kernel that evaluates it also writes
+    its gradient, backward scales that by the incoming gradient (one elementwise launch)."""
+
+    @staticmethod
+    def forward(ctx, *args):
+        outs, rest = args[:8], args[8:]
+        from .functional._autograd import native
+        loss, grads = native().frustum_box_loss(*[t.contiguous() for t in outs], *rest)
+        ctx.save_for_backward(grads)
+        ctx.shapes = [tuple(t.shape) for t in outs]
+        return loss
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        (grads,) = ctx.saved_tensors
+        scaled = grads * g
+        res, off = [], 0
+        for shape in ctx.shapes:
+            n = 1
+            for d in shape:
+                n *= d
+            res.append(scaled[off:off + n].view(shape))
+            off += n
+        return (*res, *([None] * 11))
 
 # corner sign pattern (l, h, w) of the 8 box corners, counter-clockwise, top face first
 _SX = (1, 1, -1, -1, 1, 1, -1, -1)
@@ -68,7 +101,28 @@ class FrustumPointNetLoss(nn.Module):
         with torch.autocast(inputs['center'].device.type, enabled=False):
             return self._forward(inputs, targets)
 
+    def _fused_ok(self, inputs, targets):
+        if not inputs['center'].is_cuda or os.environ.get('PVCNN_FUSED_FRUSTUM_LOSS', '1') == '0':      # (0: debug / A-B, the torch formulation)
+            return False
+        from .functional._autograd import native
+        if not getattr(native(), 'has_frustum_loss', False):
+            return False
+        f32 = all(inputs[k].dtype == torch.float32 and inputs[k].is_cuda for k in _GRAD_ORDER)
+        tg = all(targets[k].dtype == torch.float32 and targets[k].is_cuda for k in ('heading_residual', 'size_residual', 'center'))
+        ids = all(targets[k].dtype == torch.int64 and targets[k].is_cuda and targets[k].dim() == 1 for k in ('heading_bin_id', 'size_template_id'))
+        return f32 and tg and ids and self.size_templates.dtype == torch.float32 and self.size_templates.is_cuda
+
     def _forward(self, inputs, targets):
+        if self._fused_ok(inputs, targets):
+            # csrc/frustum.hip: every term below except the mask's cross entropy, and its gradient, in one launch
+            box = _BoxLoss.apply(*[inputs[k] for k in _GRAD_ORDER], targets['heading_bin_id'].contiguous(), targets['size_template_id'].contiguous(),
+                                 targets['heading_residual'].contiguous(), targets['size_residual'].contiguous(), targets['center'].contiguous(),
+                                 self.size_templates, self.heading_angle_bin_centers, math.pi / self.num_heading_angle_bins,
+                                 self.heading_residual_loss_weight, self.size_residual_loss_weight, self.corners_loss_weight)
+            return tf.cross_entropy(inputs['mask_logits'], targets['mask_logits']) + self.box_loss_weight * box
+        return self._forward_torch(inputs, targets)
+
+    def _forward_torch(self, inputs, targets):
         center = inputs['center']
         rows = torch.arange(center.size(0), device=center.device)
         h_id, s_id = targets['heading_bin_id'], targets['size_template_id']

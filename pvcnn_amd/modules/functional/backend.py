@@ -996,6 +996,33 @@ class HipBackend:
             _lib.check(self.lib.pvcnn_row_argmax(_p(x), x.numel() // k, k, _p(winners), _p(values), s), 'row_argmax')
         return (winners, values) if with_values else winners
 
+    has_frustum_loss = True
+
+    def frustum_box_loss(self, center, center_reg, heading_scores, size_scores, hrn, srn, hr, sr, heading_bin_id, size_template_id,
+                         heading_residual, size_residual, center_t, templates, bin_centers, bin_width, w_heading, w_size, w_corners):
+        """csrc/frustum.hip: the box part of FrustumPointNetLoss (modules/frustum.py:43-124) and its gradient in one launch ->
+        (loss, 0-dim; grads, flat: the gradients with respect to the first eight arguments, concatenated in that order)."""
+        outs = (center, center_reg, heading_scores, size_scores, hrn, srn, hr, sr)
+        for t in outs + (heading_residual, size_residual, center_t, templates, bin_centers):
+            _f32(t, 'frustum_box_loss input')
+        b, nh, ns = center.shape[0], heading_scores.shape[1], size_scores.shape[1]
+        _shape(tuple(center.shape) == (b, 3) and tuple(center_reg.shape) == (b, 3) and tuple(center_t.shape) == (b, 3)
+               and tuple(heading_scores.shape) == (b, nh) and tuple(hrn.shape) == (b, nh) and tuple(hr.shape) == (b, nh)
+               and tuple(size_scores.shape) == (b, ns) and tuple(srn.shape) == (b, ns, 3) and tuple(sr.shape) == (b, ns, 3)
+               and tuple(heading_residual.shape) == (b,) and tuple(size_residual.shape) == (b, 3) and tuple(templates.shape) == (ns, 3)
+               and tuple(bin_centers.shape) == (nh,) and tuple(heading_bin_id.shape) == (b,) and tuple(size_template_id.shape) == (b,)
+               and heading_bin_id.dtype == torch.int64 and size_template_id.dtype == torch.int64
+               and heading_bin_id.is_contiguous() and size_template_id.is_contiguous(), 'frustum_box_loss: shapes of modules/frustum.py:57-75 expected')
+        loss = torch.empty((), dtype=torch.float32, device=center.device)
+        grads = torch.empty((self.lib.pvcnn_frustum_box_loss_grad_floats(b, nh, ns),), dtype=torch.float32, device=center.device)
+        with _Launch(center) as s:
+            _lib.check(self.lib.pvcnn_frustum_box_loss(_p(center), _p(center_reg), _p(heading_scores), _p(size_scores), _p(hrn), _p(srn), _p(hr),
+                                                       _p(sr), _p(heading_bin_id), _p(size_template_id), _p(heading_residual),
+                                                       _p(size_residual), _p(center_t), _p(templates), _p(bin_centers), b, nh, ns,
+                                                       float(bin_width), float(w_heading), float(w_size), float(w_corners), _p(loss),
+                                                       _p(grads), s), 'frustum_box_loss')
+        return loss, grads
+
     has_se_excite = True
 
     def se_excite_forward(self, part, gamma, beta, w1, w2, s3):
