@@ -406,6 +406,12 @@ PVCNN_API long pvcnn_conv3d_weight_split_pair_entry(const float *w, int Co, int 
 PVCNN_API int pvcnn_conv3d_weight_split_pair_batch(const void *table, int n, long total_rows, void *stream);
 PVCNN_API long pvcnn_pwconv_weight_split_pair_entry(const float *w, int Co, int Ci, void *wts_fwd, void *wts_bwd, long long *entry);
 PVCNN_API int pvcnn_pwconv_weight_split_pair_batch(const void *table, int n, long total_rows, void *stream);
+/* (ABI v10) The same for the plain-bf16 images (nsplit = 1: torch.autocast; buffers sized by *_weight_split_bytes(.., 0 / 1, 1)): a
+ * Frustum-PVCNN step issued 41 per-layer launches for them. */
+PVCNN_API long pvcnn_conv3d_weight_split_pair_entry_bf16(const float *w, int Co, int Ci, void *wts_fwd, void *wts_bwd, long long *entry);
+PVCNN_API int pvcnn_conv3d_weight_split_pair_batch_bf16(const void *table, int n, long total_rows, void *stream);
+PVCNN_API long pvcnn_pwconv_weight_split_pair_entry_bf16(const float *w, int Co, int Ci, void *wts_fwd, void *wts_bwd, long long *entry);
+PVCNN_API int pvcnn_pwconv_weight_split_pair_batch_bf16(const void *table, int n, long total_rows, void *stream);
 
 /* The max over the K neighbours of a centre (modules/pointnet.py:85: `mlp(grouper(...)).max(dim=-1).values` on (B, C, M, K)) and its
  * backward, one streaming pass each.  x: (rows, K) contiguous, 16-byte aligned, rows = B * C * M; K in {4, 8, 16, 32, 64}

@@ -93,6 +93,10 @@ SIGNATURES = {
     'pvcnn_conv3d_weight_split_pair_batch': (_i, [_vp, _i, _l, _vp]),
     'pvcnn_pwconv_weight_split_pair_entry': (_l, [_vp, _i, _i, _vp, _vp, _vp]),
     'pvcnn_pwconv_weight_split_pair_batch': (_i, [_vp, _i, _l, _vp]),
+    'pvcnn_conv3d_weight_split_pair_entry_bf16': (_l, [_vp, _i, _i, _vp, _vp, _vp]),
+    'pvcnn_conv3d_weight_split_pair_batch_bf16': (_i, [_vp, _i, _l, _vp]),
+    'pvcnn_pwconv_weight_split_pair_entry_bf16': (_l, [_vp, _i, _i, _vp, _vp, _vp]),
+    'pvcnn_pwconv_weight_split_pair_batch_bf16': (_i, [_vp, _i, _l, _vp]),
     'pvcnn_neighbor_max_supported': (_i, [_i]),
     'pvcnn_neighbor_max_fwd': (_i, [_vp, _l, _i, _vp, _vp, _vp]),
     'pvcnn_neighbor_max_bwd': (_i, [_vp, _vp, _l, _i, _vp, _vp]),

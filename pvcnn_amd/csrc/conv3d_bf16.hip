@@ -223,12 +223,11 @@ __global__ __launch_bounds__(256) void conv3d_weight_split_f16_batch_kernel(cons
 // ---- weights: (Co, Ci, 27) fp32 -> [chunk][dxy][cotile][dz][plane][64 co][16 ci (halves swizzled)] bf16 ----
 // for_bwd_data: the convolution computed is grad_x = conv(grad_y, w') with Ci' = Co, Co' = Ci, w'[ci][co][tap] = w[co][ci][26 - tap]
 template <int NS>
-__global__ __launch_bounds__(256) void conv3d_weight_split_kernel(const float *__restrict__ w, int Co, int Ci, int for_bwd_data,
-                                                                  uint16_t *__restrict__ wts) {
+__device__ __forceinline__ void conv3d_weight_split_elem(const float *__restrict__ w, int Co, int Ci, int for_bwd_data,
+                                                         uint16_t *__restrict__ wts, long e) {
   const int CiE = for_bwd_data ? Co : Ci, CoE = for_bwd_data ? Ci : Co;       // effective (reduction, output) channel counts
   const int chunks = ceil_div(CiE, kKc), cotiles = ceil_div(CoE, kCoTileB);
   const long total = (long)chunks * 9 * cotiles * 3 * kCoTileB * kKc;          // one thread per (.., dz, co, ci): writes NS planes
-  const long e = (long)blockIdx.x * 256 + threadIdx.x;
   if (e >= total) return;
   const int ci_l = (int)(e % kKc), co_l = (int)((e / kKc) % kCoTileB), dz = (int)((e / (kKc * kCoTileB)) % 3);
   long rest = e / (kKc * kCoTileB * 3);
@@ -245,6 +244,25 @@ __global__ __launch_bounds__(256) void conv3d_weight_split_kernel(const float *_
   const size_t blk = (((size_t)chunk * 9 + dxy) * cotiles + cot) * (3 * NS * kCoTileB * kKc);
 #pragma unroll
   for (int s = 0; s < NS; ++s) wts[blk + ((size_t)(dz * NS + s) * kCoTileB + co_l) * kKc + pos] = (uint16_t)p[s];
+}
+
+template <int NS>
+__global__ __launch_bounds__(256) void conv3d_weight_split_kernel(const float *__restrict__ w, int Co, int Ci, int for_bwd_data,
+                                                                  uint16_t *__restrict__ wts) {
+  conv3d_weight_split_elem<NS>(w, Co, Ci, for_bwd_data, wts, (long)blockIdx.x * 256 + threadIdx.x);
+}
+
+// the plain-bf16 (torch.autocast) images of EVERY registered weight in one launch, forward and backward-data: the batched form of
+// conv3d_weight_split_kernel<1> (the Frustum-PVCNN step issued 15 of those).  An entry's rows are 256-element blocks here: rows_f of
+// the forward image first, then the backward-data image; wexp_* are unused (no per-row scale in this arithmetic).
+__global__ __launch_bounds__(256) void conv3d_weight_split_bf16_batch_kernel(const SplitEntry *__restrict__ tab, int n) {
+  const long long blk = blockIdx.x;
+  int i = 0;
+  while (i + 1 < n && tab[i + 1].row_begin <= blk) ++i;
+  const SplitEntry e = tab[i];
+  const long local = (long)(blk - e.row_begin);
+  if (local < (long)e.rows_f) conv3d_weight_split_elem<1>(e.w, (int)e.Co, (int)e.Ci, 0, e.wts_f, local * 256 + threadIdx.x);
+  else conv3d_weight_split_elem<1>(e.w, (int)e.Co, (int)e.Ci, 1, e.wts_b, (local - (long)e.rows_f) * 256 + threadIdx.x);
 }
 
 // Variants measured on (16,64,64,32^3), bf16x3 (fp32 kernel: 0.87 ms; 6x the MFMAs at 16x the rate = 0.28 ms at 2.4 GHz):
@@ -987,6 +1005,31 @@ extern "C" int pvcnn_conv3d_weight_split_pair_batch(const void *table, int n, lo
   hipLaunchKernelGGL(conv3d_weight_split_f16_batch_kernel, dim3((unsigned)total_rows), dim3(256), 0, static_cast<hipStream_t>(stream),
                      static_cast<const SplitEntry *>(table), n);
   return check_launch("conv3d_weight_split_pair_batch");
+}
+
+// ... and of the plain-bf16 images (nsplit = 1; buffers sized by pvcnn_conv3d_weight_split_bytes(.., 0 / 1, 1))
+static long conv_bf16_image_blocks(int CiE, int CoE) {
+  return ((long)ceil_div(CiE, kKc) * 9 * ceil_div(CoE, kCoTileB) * 3 * kCoTileB * kKc + 255) / 256;
+}
+
+extern "C" long pvcnn_conv3d_weight_split_pair_entry_bf16(const float *w, int Co, int Ci, void *wts_fwd, void *wts_bwd, long long *entry) {
+  if (!w || !wts_fwd || !wts_bwd || !entry || Co <= 0 || Ci <= 0 || !aligned16(wts_fwd) || !aligned16(wts_bwd)) return -1;
+  SplitEntry e;
+  e.w = w;
+  e.wts_f = static_cast<uint16_t *>(wts_fwd); e.wexp_f = nullptr;
+  e.wts_b = static_cast<uint16_t *>(wts_bwd); e.wexp_b = nullptr;
+  e.Co = Co; e.Ci = Ci; e.rows_f = conv_bf16_image_blocks(Ci, Co); e.tm = 0; e.row_begin = 0;
+  memcpy(entry, &e, sizeof(e));
+  return (long)e.rows_f + conv_bf16_image_blocks(Co, Ci);
+}
+
+extern "C" int pvcnn_conv3d_weight_split_pair_batch_bf16(const void *table, int n, long total_rows, void *stream) {
+  PVCNN_REQUIRE(n >= 0 && total_rows >= 0 && total_rows <= 0x7fffffffL, "bad size");
+  if (n == 0 || total_rows == 0) return 0;
+  PVCNN_REQUIRE(table && (reinterpret_cast<uintptr_t>(table) & 7) == 0, "null or misaligned table");
+  hipLaunchKernelGGL(conv3d_weight_split_bf16_batch_kernel, dim3((unsigned)total_rows), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const SplitEntry *>(table), n);
+  return check_launch("conv3d_weight_split_pair_batch_bf16");
 }
 
 extern "C" size_t pvcnn_conv3d_fwd_split_stats_parts(int B, int Co, int R, int nsplit) {

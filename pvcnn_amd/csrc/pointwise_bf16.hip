@@ -50,12 +50,11 @@ __device__ __forceinline__ void pb_split(float v, uint32_t (&p)[NS]) {
 // W (Mo, Ko) fp32 [forward: Mo = Co, Ko = Ci;  for_bwd_data: the GEMM's output channels are Ci and it reduces over Co, W'[ci][co] =
 // W[co][ci]] -> image [chunk][mtile][plane][TM rows][16 k (halves swizzled by bit 3 of the row)] bf16, TM = 32 * MB
 template <int NS>
-__global__ __launch_bounds__(256) void pw_weight_split_kernel(const float *__restrict__ w, int Co, int Ci, int for_bwd_data, int TM,
-                                                              uint16_t *__restrict__ wts) {
+__device__ __forceinline__ void pw_weight_split_elem(const float *__restrict__ w, int Co, int Ci, int for_bwd_data, int TM,
+                                                     uint16_t *__restrict__ wts, long e) {
   const int KE = for_bwd_data ? Co : Ci, ME = for_bwd_data ? Ci : Co;
   const int chunks = ceil_div(KE, kPbK), mtiles = ceil_div(ME, TM);
   const long total = (long)chunks * mtiles * TM * kPbK;
-  const long e = (long)blockIdx.x * 256 + threadIdx.x;
   if (e >= total) return;
   const int k_l = (int)(e % kPbK), row = (int)((e / kPbK) % TM);
   const long rest = e / ((long)kPbK * TM);
@@ -69,6 +68,24 @@ __global__ __launch_bounds__(256) void pw_weight_split_kernel(const float *__res
   const size_t blk = ((size_t)chunk * mtiles + mt) * ((size_t)NS * TM * kPbK);
 #pragma unroll
   for (int s = 0; s < NS; ++s) wts[blk + ((size_t)s * TM + row) * kPbK + pos] = (uint16_t)p[s];
+}
+
+template <int NS>
+__global__ __launch_bounds__(256) void pw_weight_split_kernel(const float *__restrict__ w, int Co, int Ci, int for_bwd_data, int TM,
+                                                              uint16_t *__restrict__ wts) {
+  pw_weight_split_elem<NS>(w, Co, Ci, for_bwd_data, TM, wts, (long)blockIdx.x * 256 + threadIdx.x);
+}
+
+// plain-bf16 (torch.autocast) images of every registered 1x1 weight in one launch (see conv3d_weight_split_bf16_batch_kernel): an
+// entry's rows are 256-element blocks, the forward image's first
+__global__ __launch_bounds__(256) void pw_weight_split_bf16_batch_kernel(const SplitEntry *__restrict__ tab, int n) {
+  const long long blk = blockIdx.x;
+  int i = 0;
+  while (i + 1 < n && tab[i + 1].row_begin <= blk) ++i;
+  const SplitEntry e = tab[i];
+  const long local = (long)(blk - e.row_begin);
+  if (local < (long)e.rows_f) pw_weight_split_elem<1>(e.w, (int)e.Co, (int)e.Ci, 0, (int)(e.tm & 0xffffffffLL), e.wts_f, local * 256 + threadIdx.x);
+  else pw_weight_split_elem<1>(e.w, (int)e.Co, (int)e.Ci, 1, (int)(e.tm >> 32), e.wts_b, (local - (long)e.rows_f) * 256 + threadIdx.x);
 }
 
 // f16x2 image: one workgroup per (padded) output row finds the row's max |w|, scales by the power of two of scale_shift and writes the
@@ -586,6 +603,30 @@ extern "C" int pvcnn_pwconv_weight_split_pair_batch(const void *table, int n, lo
   hipLaunchKernelGGL(pw_weight_split_f16_batch_kernel, dim3((unsigned)total_rows), dim3(256), 0, static_cast<hipStream_t>(stream),
                      static_cast<const SplitEntry *>(table), n);
   return check_launch("pwconv_weight_split_pair_batch");
+}
+
+// ... and of the plain-bf16 images (nsplit = 1; buffers sized by pvcnn_pwconv_weight_split_bytes(.., 0 / 1, 1))
+extern "C" long pvcnn_pwconv_weight_split_pair_entry_bf16(const float *w, int Co, int Ci, void *wts_fwd, void *wts_bwd, long long *entry) {
+  if (!w || !wts_fwd || !wts_bwd || !entry || Co <= 0 || Ci <= 0 || !aligned16(wts_fwd) || !aligned16(wts_bwd)) return -1;
+  const int TM_f = 32 * pb_mb(Co), TM_b = 32 * pb_mb(Ci);
+  const long blocks_f = ((long)ceil_div(Ci, kPbK) * ceil_div(Co, TM_f) * TM_f * kPbK + 255) / 256;
+  const long blocks_b = ((long)ceil_div(Co, kPbK) * ceil_div(Ci, TM_b) * TM_b * kPbK + 255) / 256;
+  SplitEntry e;
+  e.w = w;
+  e.wts_f = static_cast<uint16_t *>(wts_fwd); e.wexp_f = nullptr;
+  e.wts_b = static_cast<uint16_t *>(wts_bwd); e.wexp_b = nullptr;
+  e.Co = Co; e.Ci = Ci; e.rows_f = blocks_f; e.tm = (long long)TM_f | ((long long)TM_b << 32); e.row_begin = 0;
+  memcpy(entry, &e, sizeof(e));
+  return blocks_f + blocks_b;
+}
+
+extern "C" int pvcnn_pwconv_weight_split_pair_batch_bf16(const void *table, int n, long total_rows, void *stream) {
+  PVCNN_REQUIRE(n >= 0 && total_rows >= 0 && total_rows <= 0x7fffffffL, "bad size");
+  if (n == 0 || total_rows == 0) return 0;
+  PVCNN_REQUIRE(table && (reinterpret_cast<uintptr_t>(table) & 7) == 0, "null or misaligned table");
+  hipLaunchKernelGGL(pw_weight_split_bf16_batch_kernel, dim3((unsigned)total_rows), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const SplitEntry *>(table), n);
+  return check_launch("pwconv_weight_split_pair_batch_bf16");
 }
 
 extern "C" size_t pvcnn_pwconv_fwd_split_stats_parts(int B, int N) {

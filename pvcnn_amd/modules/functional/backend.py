@@ -576,6 +576,9 @@ class HipBackend:
         weights do not change between its forward and its backward)."""
         co, ci = weight.shape[0], weight.shape[1]
         if int(nsplit) != 2:
+            hit = self._bank().take('conv', weight, 1) if int(nsplit) == 1 else None      # plain bf16 (autocast): batched as well
+            if hit is not None:
+                return hit
             return self._conv_wsplit(weight, False, nsplit), self._conv_wsplit(weight, True, nsplit)
         hit = self._bank().take('conv', weight)
         if hit is not None:
@@ -590,6 +593,9 @@ class HipBackend:
         """(forward image, backward-data image) of a 1x1 convolution weight (Co, Ci); f16x2: one launch."""
         co, ci = weight.shape
         if int(nsplit) != 2:
+            hit = self._bank().take('pw', weight, 1) if int(nsplit) == 1 else None
+            if hit is not None:
+                return hit
             return self._pw_wsplit(weight, False, nsplit), self._pw_wsplit(weight, True, nsplit)
         hit = self._bank().take('pw', weight)
         if hit is not None:
@@ -1159,8 +1165,8 @@ class _WeightBank:
                 self.params.append(self._weakref.ref(m.weight))
                 self.dirty = True
 
-    def take(self, kind, w):
-        key = (kind, w.data_ptr(), (int(w.shape[0]), int(w.shape[1])))
+    def take(self, kind, w, nsplit=2):
+        key = (kind, w.data_ptr(), (int(w.shape[0]), int(w.shape[1])), int(nsplit))
         e = self.entries.get(key)
         if e is not None and e['armed']:
             e['armed'] = False
@@ -1183,29 +1189,32 @@ class _WeightBank:
 
     def _rebuild(self):
         lib = self.be.lib
-        live, by_kind = {}, {'conv': [], 'pw': []}
+        # (kind, nsplit): nsplit 2 = the f16x2 pairs, 1 = the plain-bf16 pairs of the autocast mode
+        live, by_kind = {}, {('conv', 2): [], ('pw', 2): [], ('conv', 1): [], ('pw', 1): []}
         for ref in self.params:
             p = ref()
             if p is None or not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
                 continue
             kind = self._kind_of(p)
-            key = (kind, p.data_ptr(), (int(p.shape[0]), int(p.shape[1])))
-            if key not in self.wanted:
-                continue
-            e = self.entries.get(key)
-            if e is None or e['param']() is not p:
-                co, ci = key[2]
-                nbytes = lib.pvcnn_conv3d_weight_split_bytes if kind == 'conv' else lib.pvcnn_pwconv_weight_split_bytes
-                e = {'param': ref, 'armed': False, 'version': -1, 'epoch': -1,
-                     'wf': torch.empty((nbytes(co, ci, 0, 2),), dtype=torch.uint8, device=p.device),
-                     'wb': torch.empty((nbytes(co, ci, 1, 2),), dtype=torch.uint8, device=p.device)}
-            live[key] = e
-            by_kind[kind].append((key, p, e))
+            for nsplit in (2, 1):
+                key = (kind, p.data_ptr(), (int(p.shape[0]), int(p.shape[1])), nsplit)
+                if key not in self.wanted:
+                    continue
+                e = self.entries.get(key)
+                if e is None or e['param']() is not p:
+                    co, ci = key[2]
+                    nbytes = lib.pvcnn_conv3d_weight_split_bytes if kind == 'conv' else lib.pvcnn_pwconv_weight_split_bytes
+                    e = {'param': ref, 'armed': False, 'version': -1, 'epoch': -1,
+                         'wf': torch.empty((nbytes(co, ci, 0, nsplit),), dtype=torch.uint8, device=p.device),
+                         'wb': torch.empty((nbytes(co, ci, 1, nsplit),), dtype=torch.uint8, device=p.device)}
+                live[key] = e
+                by_kind[(kind, nsplit)].append((key, p, e))
         self.entries, self.tables = live, {}
-        for kind, items in by_kind.items():
+        for (kind, nsplit), items in by_kind.items():
             if not items:
                 continue
-            fill = lib.pvcnn_conv3d_weight_split_pair_entry if kind == 'conv' else lib.pvcnn_pwconv_weight_split_pair_entry
+            fill = {('conv', 2): lib.pvcnn_conv3d_weight_split_pair_entry, ('pw', 2): lib.pvcnn_pwconv_weight_split_pair_entry,
+                    ('conv', 1): lib.pvcnn_conv3d_weight_split_pair_entry_bf16, ('pw', 1): lib.pvcnn_pwconv_weight_split_pair_entry_bf16}[(kind, nsplit)]
             host = torch.zeros((len(items), 10), dtype=torch.int64)
             rows = 0
             for i, (key, p, e) in enumerate(items):
@@ -1215,7 +1224,7 @@ class _WeightBank:
                 host[i, 9] = rows
                 rows += n
             dev = items[0][1].device
-            self.tables[kind] = (host.to(dev), len(items), rows, [k for k, _, _ in items], dev)
+            self.tables[(kind, nsplit)] = (host.to(dev), len(items), rows, [k for k, _, _ in items], dev)
         self.dirty = False
 
     def refresh(self):
@@ -1226,8 +1235,11 @@ class _WeightBank:
                 return
             self._rebuild()
         capturing = torch.cuda.is_current_stream_capturing()
+        lib = self.be.lib
+        launches = {('conv', 2): lib.pvcnn_conv3d_weight_split_pair_batch, ('pw', 2): lib.pvcnn_pwconv_weight_split_pair_batch,
+                    ('conv', 1): lib.pvcnn_conv3d_weight_split_pair_batch_bf16, ('pw', 1): lib.pvcnn_pwconv_weight_split_pair_batch_bf16}
         for kind, (table, n, rows, keys, dev) in self.tables.items():
-            launch = self.be.lib.pvcnn_conv3d_weight_split_pair_batch if kind == 'conv' else self.be.lib.pvcnn_pwconv_weight_split_pair_batch
+            launch = launches[kind]
             with _Launch(table) as s:
                 _lib.check(launch(_p(table), n, rows, s), 'weight_split_pair_batch')
             if capturing:                               # the captured launch walks this table and writes every entry's buffers on replay

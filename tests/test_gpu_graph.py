@@ -72,9 +72,11 @@ def test_fused_dropout_draws_a_fresh_mask_on_every_replay(hip):
     assert torch.isfinite(a).all() and not torch.equal(a, b)
 
 
-def test_weight_bank_images_are_the_per_layer_images(hip):
-    """backend.weight_bank_refresh (one launch per kind for every registered weight) writes byte for byte what the per-layer
-    pvcnn_*_weight_split_pair calls write, arms each pair for exactly one take, and never serves a weight changed in place since."""
+@pytest.mark.parametrize('nsplit', [2, 1])
+def test_weight_bank_images_are_the_per_layer_images(hip, nsplit):
+    """backend.weight_bank_refresh (one launch per kind for every registered weight; nsplit 2 = the f16x2 pairs, 1 = the plain-bf16
+    pairs of the autocast mode) writes byte for byte what the per-layer launches write, arms each pair for exactly one take, and
+    never serves a weight changed in place since."""
     import torch.nn as nn
     torch.manual_seed(4)
     net = nn.Sequential(nn.Conv3d(9, 64, 3, padding=1), nn.Conv3d(64, 40, 3, padding=1), nn.Conv1d(70, 130, 1), nn.Conv2d(33, 64, 1),
@@ -83,22 +85,23 @@ def test_weight_bank_images_are_the_per_layer_images(hip):
     hip.weight_bank_register(net)
     convs = [net[0].weight, net[1].weight]
     pws = [net[2].weight.view(130, 70), net[3].weight.view(64, 33)]
-    lazy = [hip.conv_weight_images(w, 2) for w in convs] + [hip.pw_weight_images(w, 2) for w in pws]     # first sighting: own launches
+    images = lambda: [hip.conv_weight_images(w, nsplit) for w in convs] + [hip.pw_weight_images(w, nsplit) for w in pws]
+    lazy = images()                                                # first sighting: the layers' own launches
     hip.weight_bank_refresh()
-    got = [hip.conv_weight_images(w, 2) for w in convs] + [hip.pw_weight_images(w, 2) for w in pws]
+    got = images()
     for (af, ab), (bf, bb), w in zip(lazy, got, convs + pws):
         assert torch.equal(af, bf) and torch.equal(ab, bb)
-        key = ('conv' if w.dim() == 5 else 'pw', w.data_ptr(), (w.shape[0], w.shape[1]))
+        key = ('conv' if w.dim() == 5 else 'pw', w.data_ptr(), (w.shape[0], w.shape[1]), nsplit)
         assert bank.entries[key]['wf'] is bf                       # served from the bank ...
-    again = hip.conv_weight_images(convs[0], 2)
+    again = hip.conv_weight_images(convs[0], nsplit)
     assert again[0] is not got[0][0] and torch.equal(again[0], got[0][0])     # ... once per refresh
     hip.weight_bank_refresh()
     with torch.no_grad():
         net[1].weight.mul_(2.0)                                    # changed in place after the refresh: the armed pair is stale
-    fresh = hip.conv_weight_images(convs[1], 2)
-    assert fresh[0] is not bank.entries[('conv', convs[1].data_ptr(), (40, 64))]['wf']
+    fresh = hip.conv_weight_images(convs[1], nsplit)
+    assert fresh[0] is not bank.entries[('conv', convs[1].data_ptr(), (40, 64), nsplit)]['wf']
     hip.weight_bank_refresh()
-    assert torch.equal(hip.conv_weight_images(convs[1], 2)[0], fresh[0])
+    assert torch.equal(hip.conv_weight_images(convs[1], nsplit)[0], fresh[0])
 
 
 def test_the_training_loop_of_integration_md_section_c(hip, tmp_path):

@@ -507,7 +507,7 @@ def test_weight_bank_serves_an_armed_pair_once_and_never_a_changed_weight():
     bank = _WeightBank(be=None)
     w = torch.nn.Parameter(torch.randn(8, 4, 1))
     w2 = w.view(8, 4)
-    key = ('pw', w.data_ptr(), (8, 4))
+    key = ('pw', w.data_ptr(), (8, 4), 2)                                              # (kind, address, (Co, Ci), nsplit: 2 = f16x2, 1 = plain bf16)
     assert bank.take('pw', w2) is None and key in bank.wanted and bank.dirty          # first sighting: noted
     wf, wb = torch.zeros(1), torch.zeros(1)
     bank.entries[key] = {'param': weakref.ref(w), 'wf': wf, 'wb': wb, 'armed': True, 'version': w._version, 'epoch': bank.epoch}
@@ -525,7 +525,8 @@ def test_weight_bank_serves_an_armed_pair_once_and_never_a_changed_weight():
     with torch.no_grad():
         w.mul_(2.0)                                                                     # in-place change since the refresh
     assert bank.take('pw', w2) is None and not bank.entries[key]['armed']
-    assert bank.take('conv', w2) is None and ('conv', w.data_ptr(), (8, 4)) in bank.wanted    # the kind is part of the key
+    assert bank.take('conv', w2) is None and ('conv', w.data_ptr(), (8, 4), 2) in bank.wanted    # the kind is part of the key
+    assert bank.take('pw', w2, 1) is None and ('pw', w.data_ptr(), (8, 4), 1) in bank.wanted      # ... and so is the arithmetic (bf16 pairs)
     for i in range(5000):                                                               # temporaries do not pile up
         bank.take('pw', torch.empty(2, 2))
     assert len(bank.wanted) <= 4096
