@@ -229,21 +229,50 @@ def pmc_traffic(kernel, shape):
     return {'traffic': None}
 
 
-def in_graph_us(needles, nth=None, config='cfg2'):
-    """Average duration of one launch of a kernel INSIDE the replayed step graph, from the committed rocprofv3 kernel trace of this very
-    command (profiles/kernel_durations.json -- kernel_durations_cfgN.json for the other configs --, written by tools/trace_steady.py
-    --json; one entry per launch of a step: kernel name, grid, position among the equal launches).  -> (avg_us, kernel name) of the
-    SLOWEST matching launch, or (None, None): no file, or no launch whose name holds all `needles`."""
+def trace_table(config='cfg2'):
+    """The committed per-launch table of this command's rocprofv3 trace + whether it was taken on the kernel sources this run executes."""
     path = os.path.join(ROOT, 'profiles', 'kernel_durations.json' if config == 'cfg2' else f'kernel_durations_{config}.json')
     try:
         table = json.load(open(path))
     except (OSError, ValueError):
+        return None, {'file': os.path.relpath(path, ROOT), 'present': False}
+    from pvcnn_amd._lib import sources_digest
+    now = sources_digest()
+    return table, {'file': os.path.relpath(path, ROOT), 'present': True, 'trace_commit': table.get('trace_commit'),
+                   'trace_sources_digest': table.get('sources_digest'), 'running_sources_digest': now,
+                   'matches_running_sources': table.get('sources_digest') == now}
+
+
+def in_graph_us(needles, nth=None, config='cfg2'):
+    """Average duration of one launch of a kernel INSIDE the replayed step graph, from the committed rocprofv3 kernel trace of this very
+    command (profiles/kernel_durations.json -- kernel_durations_cfgN.json for the other configs --, written by tools/trace_steady.py
+    --json; one entry per launch of a step: kernel name, grid, position among the equal launches).  -> (avg_us, kernel name) of the
+    SLOWEST matching launch, or (None, None): no file, a file taken on OTHER kernel sources than the ones running (digest mismatch: a
+    stale trace must not price this run), or no launch whose name holds all `needles`."""
+    table, info = trace_table(config)
+    if table is None or not info['matches_running_sources']:
         return None, None
     hits = [r for r in table.get('launches', []) if all(n in r['kernel'] for n in needles) and (nth is None or r['nth_in_step'] == nth)]
     if not hits:
         return None, None
     hits.sort(key=lambda r: -r['avg_us'])
     return hits[0]['avg_us'], hits[0]['kernel'][:110]
+
+
+def run_variant(config, extra_args=(), env=None, steps=20, warmup=5, timeout=300):
+    """The same bench command in a process of its own (the arithmetic switches are read once per process; a second model in this
+    process would share the weight bank and the allocator pools with the first): -> its JSON line, or {'error': ...}."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--config', config, '--steps', str(steps), '--warmup', str(warmup),
+           '--no-cpu-baseline', '--no-variants', *extra_args]
+    try:
+        out = subprocess.run(cmd, env={**os.environ, **(env or {})}, capture_output=True, text=True, timeout=timeout)
+        lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
+        if out.returncode != 0 or not lines:
+            return {'error': f'rc={out.returncode}: {out.stderr.strip()[-300:]}'}
+        return json.loads(lines[-1])
+    except Exception as exc:                                   # noqa: BLE001 -- reported on the line
+        return {'error': f'{type(exc).__name__}: {str(exc)[:200]}'}
 
 
 def cpu_baseline(args, sample_batch):
@@ -307,6 +336,16 @@ def main():
                          'all-reduces (the identity over one rank) -- the timed region is then the N > 1 code path (graph + captured '
                          'collectives) with everything but a second rank')
     ap.add_argument('--torch-adam', action='store_true', help='torch.optim.Adam(fused=True) instead of pvcnn_amd.optim.FlatAdam')
+    ap.add_argument('--reference-composition', action='store_true',
+                    help='time the network composed EXACTLY as the reference\'s models/ compose it (tests/reference_composition.py: plain '
+                         '.max / .repeat / torch.cat, nn.Sequential heads with nn.Dropout and nn.Conv1d as modules) on pvcnn_amd.modules -- '
+                         'what a user gets who swaps the `modules` package and nothing else -- instead of pvcnn_amd.workload\'s composition')
+    ap.add_argument('--no-variants', action='store_true',
+                    help='do not add reference_composition_value / fp32_mfma_value to the line (each is this command again in a process of its own, 20 steps)')
+    ap.add_argument('--dry-collectives', action='store_true',
+                    help='no GPU needed: run the N-rank step SEQUENCING (both orderings of pvcnn_amd/graph.py\'s multi-rank branch, issued eagerly) '
+                         'on a reduced-width network over gloo / CPU tensors with the CPU oracle as native backend and check it against the '
+                         'single-process step on the concatenated batch; prints one JSON line (not a performance figure)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -355,6 +394,13 @@ def main():
     args.batch = args.batch or defaults[0]
     args.points = args.points or defaults[1]
     autocast = contextlib.nullcontext
+    composed = None
+    if args.reference_composition:
+        if args.config == 'cfg5':
+            raise SystemExit('--reference-composition: cfg2 / cfg3 / cfg4 (tests/reference_composition.py)')
+        sys.path.insert(0, os.path.join(ROOT, 'tests'))
+        import reference_composition                              # bench / test infrastructure: the reference's forward() on pvcnn_amd.modules
+        composed = reference_composition.BY_CONFIG[args.config]
     if args.config == 'cfg2':      # BASELINE configs[1]: the headline
         model = workload.PVCNN(13, 6, width_multiplier=args.width)
         x, y = workload.make_s3dis_batch(args.batch, args.points, device=dev, seed=workload.SEED + rank)
@@ -385,6 +431,10 @@ def main():
         label = (f'Frustum-PVCNN ({args.width:g}xC) KITTI fwd+bwd+Adam, B={args.batch}/GPU N={args.points} R=16/12, torch.autocast(bf16): '
                  'Conv3d on bf16 MFMA operands, fp32 accumulate; device-side logits_mask')
         metric = 'frustums/sec fwd+bwd, Frustum-PVCNN KITTI N=1024'
+    if composed is not None:       # same constructor (same parameters, same state_dict), the reference's own forward()
+        torch.manual_seed(workload.SEED)
+        model = composed[0](*composed[1], width_multiplier=args.width)
+        label += ' -- composed as the reference\'s models/ (plain .max / .repeat / torch.cat, nn.Sequential heads with nn.Dropout, nn.Conv1d)'
     model = model.to(dev).train()
     reducer = GradBucketReducer(model, bucket_mb=args.bucket_mb, always_reduce=args.single_rank_collectives)
     # Adam (lr 1e-3, weight decay 1e-5: configs/s3dis/__init__.py) on the reducer's flat buckets: one elementwise launch per bucket,
@@ -515,12 +565,12 @@ def main():
             # the two timings -- in the graph the gather starts right behind the convolution that wrote its grid
             # (other configs: the slowest devoxelize gather of the step IS the one at the largest resolution -- there the live figure is
             # an event pair on a host-bound stream around a 15-25 us launch and over-reads; the in-graph average is the kernel)
-            if args.config == 'cfg2':
-                graph_us, graph_kernel = (in_graph_us(('gather_lds_pipe_kernel', 'TrilinearFromCoords', 'XfBnAct'))
-                                          if (pipe and fused and (b_, c_, n_, r_) == (16, 64, 4096, 32)) else (None, None))
-            else:
-                graph_us, graph_kernel = in_graph_us(('gather_lds', 'TrilinearFromCoords'), config=args.config)
-            priced_us = max(head['avg_us'], graph_us or 0.0) if args.config == 'cfg2' else (graph_us or head['avg_us'])
+            # (the step's slowest devoxelize gather IS the one at the largest resolution; nothing about the shape is hard-coded)
+            needles = ('gather_lds_pipe_kernel', 'TrilinearFromCoords', 'XfBnAct') if (pipe and fused and args.config == 'cfg2') else ('gather_lds', 'TrilinearFromCoords')
+            graph_us, graph_kernel = in_graph_us(needles, config=args.config)
+            # ALWAYS the slower of the two: the live figure of this run, and the in-graph average only while the committed
+            # trace was taken on the kernel sources this run executes (sources digest) -- a stale trace never prices a run
+            priced_us = max(head['avg_us'], graph_us or 0.0)
             roofline = {'bound': 'hbm',
                         'kernel': ('pvcnn::gather_lds_pipe_kernel<TrilinearFromCoords, XfBnAct>' if pipe else 'pvcnn::gather_lds_kernel<TrilinearFromCoords>')
                                   + ' = trilinear_devoxelize fwd' + (' with PVConv\'s last BatchNorm+LeakyReLU applied in its LDS staging and the point branch added in its store' if fused else ''),
@@ -530,7 +580,7 @@ def main():
                         'priced_on_us': round(priced_us, 2),
                         'priced_on': ('rocprofv3 in-graph average (profiles/kernel_durations*.json)' if graph_us and priced_us == graph_us
                                       else 'live HIP events of this run'),
-                        'in_graph_us': graph_us, 'in_graph_kernel': graph_kernel,
+                        'in_graph_us': graph_us, 'in_graph_kernel': graph_kernel, 'in_graph_trace': trace_table(args.config)[1],
                         'live_frac': round(survey_bytes / (head['avg_us'] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                         'algorithmic_MB': round(survey_bytes / 1e6, 3),
                         'algorithmic_bytes_formula': 'SURVEY 8(d): 4B(3N + C*min(S,8N) + C*N) + 64BN',
@@ -561,6 +611,8 @@ def main():
             'dtype': ('bf16 Conv3d operands (fp32 accumulate), fp32 elsewhere' if args.config == 'cfg5' else dtype_label(seam._backend)),
             'data': 'synthetic',
             'config': {'workload': label, 'baseline_config': args.config,
+                       'composition': ('reference: tests/reference_composition.py' if composed is not None else
+                                       'pvcnn_amd.workload (caller-side fusions around the operator API; see reference_composition_value)'),
                        'global_batch': global_batch, 'points': args.points, 'parallelism': f'dp{world}',
                        'gradient_bytes': reducer.gradient_bytes, 'final_loss': round(final_loss, 4),
                        'step_issue': (timed + {'graph': ' (1 GPU: zero_grad, forward, loss, backward, fused Adam in one graph launch)',
@@ -595,6 +647,24 @@ def main():
             line['graph_error'] = graph_error
         if graphed is not None and graphed.capture_error:
             line['collective_capture_error'] = graphed.capture_error
+        if world == 1 and not args.no_variants and not args.reference_composition and not args.eager and args.config in ('cfg2', 'cfg3', 'cfg4'):
+            # the same command twice more, each in a process of its own (20 timed steps): what a user of the reference gets who swaps
+            # the `modules` package and keeps their models/ unchanged, and (cfg2) the single-rounding fp32-MFMA arithmetic
+            passthrough = ['--batch', str(args.batch), '--points', str(args.points), '--width', str(args.width)]
+            v = run_variant(args.config, ['--reference-composition', *passthrough])
+            line['reference_composition_value'] = v.get('value')
+            line['reference_composition'] = ({'value': v.get('value'), 'ms_per_step': v.get('ms_per_step'), 'timed_region': v.get('timed_region'),
+                                              'eager_value': v.get('eager_value'), 'eager_ms_per_step': v.get('eager_ms_per_step'),
+                                              'steps': v.get('steps'), 'what': 'this command with --reference-composition: the network composed as '
+                                              'models/s3dis/pvcnn.py:34-46 + models/utils.py:15-46 compose it (tests/reference_composition.py), on pvcnn_amd.modules only'}
+                                             if 'error' not in v else v)
+            if args.config == 'cfg2':
+                v = run_variant(args.config, passthrough, env={'PVCNN_CONV_MATH': 'fp32', 'PVCNN_PW_MATH': 'fp32'})
+                line['fp32_mfma_value'] = v.get('value')
+                line['fp32_mfma'] = ({'value': v.get('value'), 'ms_per_step': v.get('ms_per_step'), 'steps': v.get('steps'), 'dtype': v.get('dtype'),
+                                      'what': 'this command under PVCNN_CONV_MATH=fp32 PVCNN_PW_MATH=fp32: every Conv3d / 1x1 product on '
+                                              'v_mfma_f32_32x32x2_f32 (single-rounding fp32 MFMA) instead of the f16x2 split'}
+                                     if 'error' not in v else v)
         if world == 1 and not args.no_cpu_baseline and args.config == 'cfg2':
             line['cpu_baseline'] = cpu_baseline(args, args.cpu_sample_batch or args.batch)
     # the JSON line must be the LAST line of the job's stdout: RCCL writes a start-up banner ("RCCL version : ...", five lines per rank)

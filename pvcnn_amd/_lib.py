@@ -148,6 +148,22 @@ def load():
     return lib
 
 
+def sources_digest():
+    """sha1 over the kernel sources the library is built from (csrc/*.hip, csrc/*.h, include/pvcnn_hip.h), 12 hex digits.  Evidence
+    files that describe kernels (profiles/kernel_durations*.json, pmc_traffic.json) carry the digest they were taken at; bench.py only
+    prices on them while it equals the digest of the sources it runs (the GPU box has no .git to ask for a commit)."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    names = sorted(glob.glob(os.path.join(_CSRC, '*.hip')) + glob.glob(os.path.join(_CSRC, '*.h')))
+    names.append(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include', 'pvcnn_hip.h'))
+    for name in names:
+        h.update(os.path.basename(name).encode())
+        with open(name, 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:12]
+
+
 def check(rc, what):
     """Turn a non-zero ABI return code into an exception carrying the library's message."""
     if rc != 0:

@@ -61,14 +61,14 @@ def check_modules(dev, atol):
     x = g['x'].to(dev)
     with torch.no_grad():
         y, _ = layer((x, x[:, :3, :]))
-    assert torch.allclose(y.cpu(), g['y'], atol=atol, rtol=atol)
+    assert torch.allclose(y.cpu(), g['y'], atol=atol, rtol=atol), ((y.cpu() - g['y']).abs() / (1 + g['y'].abs())).max().item()
     g = load('pvcnn_c0p125_eval')
     net = workload.PVCNN(13, 6, width_multiplier=0.125)
     net.load_state_dict(g['state'])            # the reference's checkpoint keys load unchanged
     net = net.to(dev).eval()
     with torch.no_grad():
         logits = net(g['x'].to(dev))
-    assert torch.allclose(logits.cpu(), g['logits'], atol=atol, rtol=atol)
+    assert torch.allclose(logits.cpu(), g['logits'], atol=atol, rtol=atol), ((logits.cpu() - g['logits']).abs() / (1 + g['logits'].abs())).max().item()
 
 
 def test_oracle_reproduces_reference_vectors(oracle):
@@ -86,7 +86,8 @@ def test_hip_reproduces_reference_vectors(hip):
 
 @pytest.mark.gpu
 def test_modules_reproduce_reference_vectors_gpu(hip):
-    # Conv3d / BatchNorm run in MIOpen here vs torch-CPU in the reference run: fp32 tolerance.  A point
-    # whose normalised coordinate lands within an ulp of a .5 voxel boundary may round differently
-    # (torch reductions differ CPU vs GPU) -- none does for this seeded input.
-    check_modules('cuda:0', atol=2e-4)
+    # Conv3d / BatchNorm / 1x1 GEMMs run on this package's MFMA kernels here vs torch-CPU in the reference run (another summation
+    # order): every element within 2e-6 * (1 + |reference|) -- the bar of test_gpu_models.py (rounds 1-4 allowed 2e-4 here).  A point
+    # whose normalised coordinate lands within an ulp of a .5 voxel boundary may round differently (torch reductions differ CPU vs
+    # GPU) -- none does for this seeded input.
+    check_modules('cuda:0', atol=2e-6)

@@ -1,0 +1,80 @@
+"""The reference's own model composition (tests/reference_composition.py: plain .max / .repeat / torch.cat / nn.Sequential heads with
+nn.Dropout and nn.Conv1d -- models/s3dis/pvcnn.py:34-46, pvcnnpp.py:44-59, shapenet/pvcnn.py:30-42, models/utils.py:15-46) on the GPU,
+at the sizes bench.py runs, against the `pvcnn_amd.workload` classes the headline is timed on: same state_dict, same batch, train mode,
+dropout p = 0 (the fused dropout draws another stream), forward + backward.
+
+What may differ between the two compositions, and only by fp32 rounding:
+  * the classifier's last Conv1d: the vendor library's GEMM (nn.Conv1d as a module) vs this package's kernel (workload._classify) --
+    the logits themselves and its three gradients;
+  * the backward of `.repeat` (a reshaped sum) vs of `.expand` (sum_to_size) over the N points: two summation orders of 4096 terms;
+everything else (the pooled values and winners, the concatenated tensor, the SharedMLP stages) is the same arithmetic on the same bits.
+No discrete decision differs: the activations in front of the last Conv1d are bit-identical, so no ReLU and no max-pool winner can
+flip -- the bars are fp32 round-off bars, not the whole-network bars of test_gpu_train_parity.py.
+"""
+import pytest
+import torch
+import torch.nn.functional as tf
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+TOL_FWD = 2e-6          # logits, relative to the largest |logit|
+TOL_GRAD = 2e-5         # every gradient tensor, relative to its largest entry (measured values are printed; see the module docstring)
+TOL_GRAD_MEDIAN = 2e-6  # ... and the median over the tensors
+
+
+def _no_dropout(net):
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    return net
+
+
+def _step(net, x, y):
+    x = x.clone().requires_grad_()
+    out = net(x)
+    loss = tf.cross_entropy(out, y)
+    loss.backward()
+    torch.cuda.synchronize()
+    grads = {'<input>': x.grad.detach().double()}
+    grads.update({k: p.grad.detach().double() for k, p in net.named_parameters() if p.grad is not None})
+    grads.update({'buffer ' + k: b.detach().double() for k, b in net.named_buffers() if b.dtype.is_floating_point})
+    return out.detach().double(), loss.item(), grads
+
+
+CASES = {
+    'cfg2': ('PVCNN', 'ReferencePVCNN', (13, 6), lambda wl: wl.make_s3dis_batch(16, 4096, device=DEV)),
+    'cfg3': ('PVCNN2', 'ReferencePVCNN2', (13, 6), lambda wl: wl.make_s3dis_batch(8, 8192, device=DEV)),
+    'cfg4': ('PVCNNShapeNet', 'ReferencePVCNNShapeNet', (50, 16, 3), lambda wl: wl.make_shapenet_batch(8, 2048, device=DEV)),
+}
+
+
+@pytest.mark.parametrize('cfg', list(CASES))
+def test_reference_composition_equals_the_benched_composition(hip, cfg):
+    import reference_composition as rc
+    from pvcnn_amd import workload
+    mine_name, ref_name, ctor, batch = CASES[cfg]
+    torch.manual_seed(7)
+    benched = _no_dropout(getattr(workload, mine_name)(*ctor, width_multiplier=1)).to(DEV).train()
+    composed = _no_dropout(getattr(rc, ref_name)(*ctor, width_multiplier=1)).to(DEV).train()
+    assert list(benched.state_dict().keys()) == list(composed.state_dict().keys())
+    composed.load_state_dict(benched.state_dict())
+    x, y = batch(workload)
+    out_b, loss_b, g_b = _step(benched, x, y)
+    out_c, loss_c, g_c = _step(composed, x, y)
+    fwd = ((out_b - out_c).abs().max() / out_b.abs().max()).item()
+    assert g_b.keys() == g_c.keys()
+    rows = sorted(((((g_b[k] - g_c[k]).abs().max() / g_b[k].abs().max().clamp_min(1e-30)).item(), k) for k in g_b), reverse=True)
+    errs = sorted(e for e, _ in rows)
+    exact = sum(1 for e in errs if e == 0.0)
+    print(f'[reference composition] {cfg}: loss benched {loss_b:.7f} composed {loss_c:.7f}; logits differ by {fwd:.2e} of the largest; '
+          f'{len(rows)} tensors: {exact} bit-equal, median {errs[len(errs) // 2]:.2e}, worst {rows[0][0]:.2e} ({rows[0][1]}); '
+          f'next: {[(f"{e:.1e}", k) for e, k in rows[1:4]]}')
+    assert fwd <= TOL_FWD, fwd
+    assert abs(loss_b - loss_c) <= 1e-6 * max(abs(loss_b), 1.0)
+    # the running statistics are forward-only quantities in front of the last Conv1d: the same bits
+    for k in g_b:
+        if k.startswith('buffer '):
+            assert torch.equal(g_b[k], g_c[k]), k
+    bad = [(k, e) for e, k in rows if e > TOL_GRAD]
+    assert not bad, bad[:6]
+    assert errs[len(errs) // 2] <= TOL_GRAD_MEDIAN

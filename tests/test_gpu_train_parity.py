@@ -198,7 +198,84 @@ def test_pvconv_train_gradients_match_the_oracle_stack(hip, oracle, cin, cout, r
     assert not bad, f'{label}: {bad[:6]}'
 
 
-def _check_network(label, build, make, loss_fn, oracle, flip_allowance):
+FLOOR_T = 1e-4         # per-tensor floor of the strict bar (max-norm, relative to the tensor's largest entry)
+FLOOR_FWD = 1e-5       # ... for forward-only quantities (BatchNorm running statistics): no discrete decision is amplified into them
+SPARSE_Q = 0.9         # flip allowance: this share of a tensor's ELEMENTS must still meet the strict bar
+
+
+def _kth(e, q):
+    n = e.numel()
+    return e.kthvalue(min(n, max(1, int(-(-q * n // 1))))).values.item()
+
+
+def per_tensor_rows(res_g, res_c, res_t):
+    """One dict per tensor: element count, max-norm errors of the HIP path and of the fp32 oracle stack against the fp64 truth (relative
+    to the tensor's largest entry, _scale), and the SPARSE_Q quantiles of the same element-wise errors."""
+    (_, gg), (_, gc), (_, gt) = res_g, res_c, res_t
+    assert gg.keys() == gc.keys() == gt.keys()
+    rows = []
+    for k in gt:
+        sc = _scale(gt, k)
+        eh = ((gg[k] - gt[k]).abs() / sc).flatten()
+        ec = ((gc[k] - gt[k]).abs() / sc).flatten()
+        rows.append({'name': k, 'n': eh.numel(), 'hip': eh.max().item(), 'cpu': ec.max().item(),
+                     'hip_q': _kth(eh, SPARSE_Q), 'cpu_q': _kth(ec, SPARSE_Q), 'forward_only': k.startswith('buffer ')})
+    return rows
+
+
+def judge_per_tensor(label, res, flip_cap, dense_cap=None, max_flip_share=0.5):
+    """PER TENSOR t (round 5; the round-4 bar was one number per network, set by its worst tensor):
+
+        strict           |hip - truth|_t <= max(NET_FACTOR x |oracle stack - truth|_t, floor_t),   floor_t = 1e-4, 1e-5 for forward-only
+                         quantities (running statistics) -- every tensor is first held to ITS OWN bar;
+        flip allowance   a GRADIENT tensor beyond its strict bar passes only if the excess is SPARSE: SPARSE_Q of its elements are still
+                         within the strict bar and none is beyond `flip_cap` (~ 1/sqrt(elements per channel): what ONE ReLU / max decision
+                         taken the other way on a value within round-off of its threshold moves a per-channel sum by, see _check_network).
+                         A wrong scale, a missing term, a 10 % error of a whole tensor is DENSE and fails here whatever the worst tensor
+                         of the network does.  Forward-only quantities never get it;
+        dense allowance  only for networks with a level of <= 128 elements per channel (`dense_cap` given: PVCNN++, whose coarsest level
+                         has 16 centres per cloud): there one flipped decision moves a BatchNorm's batch means by 1/128 of an element and
+                         with them EVERY element of every gradient upstream -- in the fp32 oracle stack just as well, on different
+                         decisions.  Such a tensor must stay within `dense_cap`, and the share of tensors that needed it is asserted.
+
+    The counts of tensors per class are printed; the strict class is asserted to hold the majority."""
+    rows = per_tensor_rows(*res)
+    strict, flip, dense, bad = [], [], [], []
+    for r in rows:
+        floor = FLOOR_FWD if r['forward_only'] else FLOOR_T
+        bar = max(NET_FACTOR * r['cpu'], floor)
+        r['bar'] = bar
+        if r['hip'] <= bar:
+            strict.append(r)
+        elif not r['forward_only'] and r['hip_q'] <= bar and r['hip'] <= flip_cap:
+            flip.append(r)
+        elif not r['forward_only'] and dense_cap is not None and r['hip'] <= dense_cap:
+            dense.append(r)
+        else:
+            bad.append(r)
+    errs = sorted(r['hip'] for r in rows)
+    print(f'[per tensor] {label}: {len(rows)} tensors: {len(strict)} within their own bar max({NET_FACTOR:g} x oracle-vs-truth_t, floor_t), '
+          f'{len(flip)} on the flip allowance (sparse excess, cap {flip_cap:.1e}), {len(dense)} on the dense allowance'
+          + (f' (cap {dense_cap:.1e})' if dense_cap is not None else ' (not granted for this network)')
+          + f', {len(bad)} FAILED; hip-vs-truth median {errs[len(errs) // 2]:.2e}, 90th percentile {errs[int(0.9 * len(errs))]:.2e}, worst {errs[-1]:.2e}')
+    for cls, members in (('flip', flip), ('dense', dense), ('FAILED', bad)):
+        for r in sorted(members, key=lambda r: -r['hip'])[:12]:
+            print(f"    {cls:6s} hip {r['hip']:.2e} (q{int(SPARSE_Q * 100)} {r['hip_q']:.2e})  oracle {r['cpu']:.2e} (q{int(SPARSE_Q * 100)} {r['cpu_q']:.2e})  "
+                  f"bar {r['bar']:.1e}  n={r['n']}  {r['name']}")
+    dump = os.environ.get('PVCNN_PARITY_DUMP')
+    if dump:
+        import json
+        os.makedirs(dump, exist_ok=True)
+        with open(os.path.join(dump, ''.join(c if c.isalnum() else '_' for c in label)[:80] + '.json'), 'w') as fh:
+            json.dump({'label': label, 'flip_cap': flip_cap, 'dense_cap': dense_cap, 'rows': rows}, fh)
+    assert not bad, f'{label}: beyond the per-tensor bars: ' + ', '.join(f"{r['name']} {r['hip']:.2e} > {r['bar']:.1e}" for r in bad[:6])
+    assert len(flip) <= max_flip_share * len(rows), f'{label}: {len(flip)} of {len(rows)} tensors needed the flip allowance'
+    if dense_cap is not None:
+        assert len(dense) <= 0.25 * len(rows), f'{label}: {len(dense)} of {len(rows)} tensors needed the dense allowance'
+    return rows
+
+
+def _check_network(label, build, make, loss_fn, oracle, flip_allowance, dense_cap=None):
     """Whole networks, 10-40 train-mode BatchNorms deep, compared with an fp64 evaluation of the same network
     (tests/truth_backend.py) next to the fp32 oracle stack.
 
@@ -210,20 +287,14 @@ def _check_network(label, build, make, loss_fn, oracle, flip_allowance):
     channel's bias gradient by ~1/sqrt(B*N) ~ 1e-2 relative, and everything upstream of it by ~1e-3.  (Same for a
     max-pool winner; those are pinned to the fp64 run's here, see PinMaxWinners.  ReLU decisions live inside the fused
     kernels and cannot be pinned.)  Per-layer, where no such flip occurs, the HIP path is within 2e-6 of both
-    (test_pvconv_train_gradients_match_the_oracle_stack).  Hence, per tensor:
-        |hip - truth| <= max(NET_FACTOR x the fp32 oracle stack's worst distance from the truth, flip_allowance),
-    flip_allowance ~ 1/sqrt(elements per channel) of the smallest level; the loss agrees to 1e-5; and as the networks
-    really run (winners not pinned) nothing is beyond NET_CAP."""
+    (test_pvconv_train_gradients_match_the_oracle_stack).  Hence the PER-TENSOR criteria of judge_per_tensor (strict bar of the
+    tensor's own; sparse excess up to flip_allowance ~ 1/sqrt(elements per channel) of the smallest level); the loss agrees to 1e-5;
+    and as the networks really run (winners not pinned) nothing is beyond NET_CAP."""
     res = _run_three(build, make, loss_fn, oracle, pin_winners=True)
-    rows = _report(label + ' [max-pool winners pinned]', *res)
+    _report(label + ' [max-pool winners pinned]', *res)
     (lg, _), (lc, _), (lt, _) = res
     assert abs(lg - lt) <= TOL_LOSS * max(abs(lt), 1.0) and abs(lg - lc) <= TOL_LOSS * max(abs(lc), 1.0), (lg, lc, lt)
-    worst_cpu = max(c for _, _, _, c in rows)
-    bound = max(NET_FACTOR * worst_cpu, flip_allowance)
-    bad = [(k, b) for k, _, b, _ in rows if b > bound]
-    assert not bad, f'{label}: beyond {bound:.1e} of the fp64 truth: {bad[:6]}'
-    med = sorted(b for _, _, b, _ in rows)[len(rows) // 2]
-    print(f'[train parity] {label}: median over tensors of hip-vs-truth {med:.2e}; bound used {bound:.1e}')
+    judge_per_tensor(label + ' [max-pool winners pinned]', res, flip_allowance, dense_cap)
 
     res = _run_three(build, make, loss_fn, oracle, pin_winners=False)
     rows = _report(label + ' [as is]', *res)
@@ -242,6 +313,8 @@ NETS = {
 
 # 1/sqrt(elements per channel at the smallest level): 8192 points (PVCNN), 4096 (ShapeNet), 4 x 16 centres (PVCNN++)
 FLIP = {'PVCNN': 1e-2, 'PVCNNShapeNet': 2e-2, 'PVCNN2': 0.25}
+# PVCNN++ only: its coarsest level has 4 x 16 = 64 elements per channel (judge_per_tensor: dense allowance)
+DENSE = {'PVCNN2': 0.25}
 
 
 @pytest.mark.parametrize('name', list(NETS))
@@ -254,7 +327,7 @@ def test_network_train_gradients_match_the_oracle_stack(hip, oracle, name):
         x = x0.clone().to(dev, dtype).requires_grad_()
         return x, x, y0.to(dev)
 
-    _check_network(name, lambda: build(workload), make, tf.cross_entropy, oracle, FLIP[name])
+    _check_network(name, lambda: build(workload), make, tf.cross_entropy, oracle, FLIP[name], dense_cap=DENSE.get(name))
 
 
 def test_frustum_segmentation_train_gradients_match_the_oracle_stack(hip, oracle):
@@ -296,7 +369,7 @@ def test_full_width_cfg2_step_runs_the_default_arithmetic_and_matches_the_oracle
     size -- the SharedMLP GEMMs cross `pw_split_min_macs` and take the f16x2 kernels (forward, backward-data, backward-weight) through
     autograd, with the absmax hand-over (`x_amax` saved in ctx, the gradient's tagged maximum); the call counter proves those
     routes ran.  Same criteria as the reduced-width networks: loss to 1e-5 against the fp32 oracle stack and the fp64 truth; every
-    gradient within max(4 x the oracle stack's own distance from the truth, 1/sqrt(B*N)) of the truth."""
+    tensor judged against ITS OWN bar (judge_per_tensor)."""
     from pvcnn_amd import workload
     x0, y0 = workload.make_s3dis_batch(16, 4096)
 
@@ -313,15 +386,12 @@ def test_full_width_cfg2_step_runs_the_default_arithmetic_and_matches_the_oracle
     assert calls['pwconv_gemm_split'] >= 4 and calls['pwconv_backward_weight_f16'] >= 2, calls
     assert calls['conv3d_igemm_split'] >= 15 and calls['conv3d_backward_weight_f16'] == 8, calls
     assert calls['trilinear_devoxelize_bnact_forward'] == 4 and calls['avg_voxelize_apply'] == 4 and calls['trilinear_devoxelize_backward_apply'] == 4, calls
-    rows = _report('PVCNN 1xC B=16 N=4096 (cfg2 as benched) [max-pool winners pinned]', *res)
+    _report('PVCNN 1xC B=16 N=4096 (cfg2 as benched) [max-pool winners pinned]', *res)
     (lg, _), (lc, _), (lt, _) = res
     assert abs(lg - lt) <= TOL_LOSS * max(abs(lt), 1.0) and abs(lg - lc) <= TOL_LOSS * max(abs(lc), 1.0), (lg, lc, lt)
-    worst_cpu = max(c for _, _, _, c in rows)
-    bound = max(NET_FACTOR * worst_cpu, 1.0 / (16 * 4096) ** 0.5)
-    bad = [(k, b) for k, _, b, _ in rows if b > bound]
-    assert not bad, f'beyond {bound:.1e} of the fp64 truth: {bad[:6]}'
-    med = sorted(b for _, _, b, _ in rows)[len(rows) // 2]
-    print(f'[train parity] full-width cfg2: median over tensors of hip-vs-truth {med:.2e}; bound used {bound:.1e}')
+    # per tensor: its own bar; sparse excess up to 3e-2 (one flipped ReLU moves a channel sum over B*N = 65536 random-signed terms by
+    # 1/256 = 4e-3; in `<input>` it changes ONE POINT's gradient by O(1) of that point's, measured 1e-2 of the tensor's largest entry)
+    judge_per_tensor('PVCNN 1xC B=16 N=4096 (cfg2 as benched)', res, flip_cap=3e-2)
 
 
 # bf16 operands keep 8 bits: 2^-9 = 2e-3 relative per rounded operand of the eight 3x3x3 convolutions (everything else on the path

@@ -182,3 +182,51 @@ def test_baseline_config0_cpu_plumbing(oracle_seam):
         logits = net(x)
     assert logits.shape == (1, 13, 4096) and torch.isfinite(logits).all()
     assert [m.resolution for m in net.point_features[:4]] == [32, 16, 16, 16]
+
+
+@pytest.mark.parametrize('name,ref_name,n', [('ReferencePVCNN', 'PVCNN', 512), ('ReferencePVCNN2', 'PVCNN2', 1024)])
+def test_reference_composition_is_the_reference_forward(ref, name, ref_name, n):
+    """tests/reference_composition.py claims to compose this package's modules exactly as the reference's forward() methods do
+    (models/s3dis/pvcnn.py:34-46, pvcnnpp.py:44-59).  Pinned here against the reference's own classes on the CPU oracle stack, TRAIN
+    mode (dropout p = 0: the two models would otherwise draw different masks from one generator), forward and every gradient: bit-equal."""
+    import reference_composition as rc
+    from pvcnn_amd import workload
+    torch.manual_seed(3)
+    theirs = getattr(ref.models, ref_name)(13, 6, width_multiplier=0.125)
+    mine = getattr(rc, name)(13, 6, width_multiplier=0.125)
+    _same_state(theirs, mine)
+    mine.load_state_dict(theirs.state_dict())
+    for net in (theirs, mine):
+        net.train()
+        for m in net.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+    x, y = workload.make_s3dis_batch(2, n)
+    xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+    la = torch.nn.functional.cross_entropy(theirs(xa), y)
+    lb = torch.nn.functional.cross_entropy(mine(xb), y)
+    assert torch.equal(la, lb)
+    la.backward(); lb.backward()
+    assert torch.equal(xa.grad, xb.grad)
+    for (n1, p1), (n2, p2) in zip(theirs.named_parameters(), mine.named_parameters()):
+        assert n1 == n2 and torch.equal(p1.grad, p2.grad), n1
+    for (n1, b1), (n2, b2) in zip(theirs.named_buffers(), mine.named_buffers()):
+        assert n1 == n2 and torch.equal(b1, b2), n1
+
+
+def test_reference_composition_shapenet_is_the_reference_forward(ref):
+    import reference_composition as rc
+    from pvcnn_amd import workload
+    sys.path.insert(0, REF)
+    try:
+        shapenet = importlib.import_module('models.shapenet')
+    finally:
+        sys.path.remove(REF)
+    torch.manual_seed(4)
+    theirs, mine = shapenet.PVCNN(50, 16, 3, 0.125), rc.ReferencePVCNNShapeNet(50, 16, 3, 0.125)
+    _same_state(theirs, mine)
+    mine.load_state_dict(theirs.state_dict())
+    theirs.eval(); mine.eval()
+    x, _ = workload.make_shapenet_batch(2, 512)
+    with torch.no_grad():
+        assert torch.equal(theirs(x), mine(x))

@@ -68,7 +68,15 @@ if by_grid:
             print('%8.3f ms/step  steps=%4d avg=%8.1f us  grid=%s #%d  %s' % (ns / 1e6 / steps, calls, ns / 1e3 / calls, grid, nth, name[:70]))
 if json_out:
     import json
-    out = {'source': 'rocprofv3 --kernel-trace of the bench command, steady-state steps inside the replayed graph (tools/trace_steady.py)',
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    try:
+        from pvcnn_amd._lib import sources_digest
+        digest = sources_digest()
+    except Exception:                                   # noqa: BLE001
+        digest = None
+    out = {'sources_digest': digest, 'trace_commit': os.environ.get('PVCNN_TRACE_COMMIT'),
+           'source': 'rocprofv3 --kernel-trace of the bench command, steady-state steps inside the replayed graph (tools/trace_steady.py)',
            'steps': steps, 'wall_ms_per_step': round(span / steps, 4), 'kernel_ms_per_step': round(busy / steps, 4),
            'launches': [{'kernel': name, 'grid': list(grid), 'nth_in_step': nth, 'steps': calls, 'avg_us': round(ns / 1e3 / calls, 3)}
                         for (name, grid, nth), (calls, ns) in sorted(per_launch.items(), key=lambda kv: -kv[1][1]) if 'pvcnn::' in name]}
