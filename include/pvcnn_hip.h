@@ -433,7 +433,8 @@ PVCNN_API int pvcnn_row_argmax(const float *x, long rows, int K, long long *winn
  * returns: first index on ties, -0 == +0, a NaN wins) and, unless NULL, the values (read back from y: bit-identical elements).
  * pvcnn_bnact_apply_rowmax is the apply pass of pvcnn_bnact_fwd alone: mean / rstd from pvcnn_bn_finalize, whose zero_words
  * argument must have zeroed BOTH y_amax (pvcnn_absmax_tiles_count(B, S, amax_seg) words) and row_keys (B * C uint64, 8-byte aligned)
- * -- e.g. one buffer holding the two.  S % 256 == 0, amax_seg a multiple of 4 in 4..256, x / y 16-byte aligned. */
+ * -- e.g. one buffer holding the two.  S % 256 == 0, amax_seg a multiple of 4 that DIVIDES 256 (4, 8, 16, 32, 64, 128, 256: every lane
+ * of a workgroup's 256 positions takes part in the row butterfly), x / y 16-byte aligned. */
 PVCNN_API int pvcnn_bnact_apply_rowmax(const float *x, const float *gamma, const float *beta, const float *mean, const float *rstd, int B,
                                        int C, int S, float slope, float *y, void *y_amax, int amax_seg, void *row_keys, void *stream);
 PVCNN_API int pvcnn_row_keys_decode(const void *row_keys, const float *y, long rows, int S, long long *winners, float *values,

@@ -528,12 +528,15 @@ extern "C" int pvcnn_bnact_fwd(const float *x, const float *gamma, const float *
 }
 
 // The apply pass alone (statistics known: pvcnn_bn_finalize, which also ZEROED y_amax and row_keys -- its zero_words argument), with the
-// row maxima of y: row_keys[b * C + c] (uint64, see the kernel) for pvcnn_row_keys_decode.  S % 256 == 0, amax_seg % 4 == 0.
+// row maxima of y: row_keys[b * C + c] (uint64, see the kernel) for pvcnn_row_keys_decode.  S % 256 == 0, amax_seg % 4 == 0, 256 % amax_seg == 0.
 extern "C" int pvcnn_bnact_apply_rowmax(const float *x, const float *gamma, const float *beta, const float *mean, const float *rstd, int B,
                                         int C, int S, float slope, float *y, void *y_amax, int amax_seg, void *row_keys, void *stream) {
   PVCNN_REQUIRE(B > 0 && C > 0 && S > 0 && x && y && mean && rstd && y_amax && row_keys, "bad argument");
   PVCNN_REQUIRE(B <= 65535 && C <= 65535, "batch or channel count > 65535");
-  PVCNN_REQUIRE(amax_seg > 0 && amax_seg <= 256 && amax_seg % 4 == 0 && S % 256 == 0, "needs S % 256 == 0 and amax_seg in 4..256, a multiple of 4");
+  // (256 % amax_seg == 0: the row-maximum butterfly assumes every lane of the workgroup's 256 positions is active -- a segment length
+  //  that does not divide 256, e.g. 12 -> span 252, would leave lanes out of the __shfl_xor / __ballot: undefined winners)
+  PVCNN_REQUIRE(amax_seg >= 4 && amax_seg <= 256 && amax_seg % 4 == 0 && 256 % amax_seg == 0 && S % 256 == 0,
+                "needs S % 256 == 0 and amax_seg a multiple of 4 that divides 256");
   PVCNN_REQUIRE(aligned16(x) && aligned16(y) && ((uintptr_t)row_keys & 7) == 0, "x / y must be 16-byte aligned, row_keys 8-byte aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int nseg = ceil_div(S, amax_seg), spb = amax_seg >= 256 ? 1 : 256 / amax_seg;

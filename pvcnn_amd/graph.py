@@ -63,6 +63,10 @@ class GraphedTrainStep:
                 reducer.launch_from_hooks = bool(capture_collectives)
                 self.whole_step = bool(capture_collectives)
             return
+        self._warm_up(warmup)
+        self._capture_agreed(capture_collectives)
+
+    def _warm_up(self, warmup):
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                    # warm up on the capture stream's side: lazy inits, allocator pools, and
@@ -70,20 +74,69 @@ class GraphedTrainStep:
                 self.eager_step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+
+    @staticmethod
+    def _sync():
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+
+    def _capture_agreed(self, capture_collectives):
+        """Capture the step in the best mode EVERY rank can take (tests/test_dp_gloo.py drives this with a capture that fails on one
+        rank only)."""
+        reducer = self.reducer
         if self.collective and capture_collectives is not False:
+            failure = None
             try:
                 self._capture(whole_step=True)
             except Exception as exc:                     # noqa: BLE001 -- reported (mode / capture_error); the fallback still trains
-                if capture_collectives:
-                    raise
-                self.capture_error = f'{type(exc).__name__}: {str(exc)[:200]}'
+                failure = exc
                 self.graph = None
                 self.reducer.rearm()
-                torch.cuda.synchronize()
+                self._sync()
+            # THE RANKS DECIDE TOGETHER (ADVICE r04): a rank that replays a graph with the collectives inside and a rank that issues
+            # them after its replay post different RCCL sequences and hang.  The outcome is agreed outside any capture -- a MIN
+            # all-reduce of the success flag over the reducer's group -- and EVERY rank falls back if any rank failed (an aborted
+            # capture has executed nothing: its all-reduces were recorded, never launched, so the communicator is where the warm-up
+            # steps left it).
+            if not self._all_ranks(failure is None):
+                if capture_collectives:                  # "capture them or raise": raise on every rank, not only on the one that failed
+                    raise (failure or RuntimeError('GraphedTrainStep: the capture of the collectives failed on another rank'))
+                self.capture_error = (f'{type(failure).__name__}: {str(failure)[:200]}' if failure is not None
+                                      else 'the capture of the collectives failed on another rank')
+                if self.graph is not None:               # this rank's capture worked: drop it, take the agreed mode
+                    self.graph = None
+                    self.reducer.rearm()
+                    self._sync()
         if self.graph is None:
             if self.collective:
                 reducer.launch_from_hooks = False        # collectives are issued by finish(), after the replay, in fixed bucket order
-            self._capture(whole_step=not self.collective)
+            try:
+                self._capture(whole_step=not self.collective)
+            except Exception:
+                self._all_ranks(False)                   # the others learn it here instead of hanging in their first collective
+                raise
+        if self.collective and not self._all_ranks(True):
+            raise RuntimeError('GraphedTrainStep: another rank failed to capture the step')
+
+    def _all_ranks(self, ok):
+        """True iff `ok` on every rank of the reducer's group (one MIN all-reduce, outside any capture; 1 rank / no group: `ok`)."""
+        import torch.distributed as dist
+        if not (self.collective and dist.is_initialized() and self.reducer.world > 1):
+            return bool(ok)
+        dev = next(self.model.parameters()).device
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.reducer.group)
+        return bool(flag.item())
+
+    def _quiesce(self):
+        """Drain everything the process group's watchdog could still be polling before a capture starts: the device, then every
+        outstanding collective of the warm-up steps (the reducer's own Work handles are waited on in finish(); a barrier's completion
+        on every rank orders this rank behind the others' warm-up collectives too)."""
+        import torch.distributed as dist
+        torch.cuda.synchronize()
+        if dist.is_initialized() and self.reducer.world > 1:
+            dist.barrier(group=self.reducer.group)
+            torch.cuda.synchronize()
 
     def _capture(self, whole_step):
         _cache.clear()                                   # the per-coords plans must be rebuilt INSIDE the graph
@@ -93,12 +146,10 @@ class GraphedTrainStep:
             # A process group runs a watchdog thread that polls the events of collectives issued so far (the warm-up steps').  In the
             # default 'global' capture mode ANY thread's hipEventQuery while this thread captures is an error -- seen as a process
             # abort in the middle of a capture, once in ~4 runs (gpurun_out/r04/gpu_tests.log).  'thread_local' restricts the check to
-            # the capturing thread (the watchdog's polls have nothing to do with this capture); and the device is drained first, with
-            # a pause of a few watchdog periods, so that it has nothing left to poll.
-            import time
+            # the capturing thread (the watchdog's polls have nothing to do with this capture) -- THAT is what makes the capture safe;
+            # the device and the group are drained first (_quiesce: deterministic, no sleep) so that the watchdog has nothing new to poll.
             mode = 'thread_local'
-            torch.cuda.synchronize()
-            time.sleep(0.5)
+            self._quiesce()
         with torch.cuda.graph(graph, capture_error_mode=mode):
             self.loss = self._forward_backward()         # (multi-rank, whole step: the hooks launch the bucket all-reduces in here)
             if whole_step:

@@ -845,7 +845,8 @@ class HipBackend:
         values (B,C)) == (y, *y.max(dim=-1)[::-1]).  y_amax / row_keys: the views of amax_and_row_keys, ZEROED (bn_finalize)."""
         _f32(x, 'x')
         b, c, s3 = x.shape
-        _shape(s3 % 256 == 0 and amax_seg % 4 == 0 and 0 < amax_seg <= 256, 'bnact_apply_rowmax: S % 256 == 0 and amax_seg % 4 == 0 expected')
+        _shape(s3 % 256 == 0 and amax_seg % 4 == 0 and 0 < amax_seg <= 256 and 256 % amax_seg == 0,
+               'bnact_apply_rowmax: S % 256 == 0 and an amax_seg that is a multiple of 4 and divides 256 expected')
         y = torch.empty_like(x)
         winners = torch.empty((b, c), dtype=torch.int64, device=x.device)
         values = torch.empty((b, c), dtype=torch.float32, device=x.device)

@@ -202,7 +202,7 @@ def batch_norm_act(x, bn, slope, stats_part=None, drop_p=0.0):
             and getattr(native(), 'has_bnact_rowmax', False)):
         y, amax, winners, values = BatchNormAct.apply(x, bn.weight, bn.bias, rm, rv, use_batch_stats, momentum, bn.eps, slope, part, shift,
                                                       seg, counter, 0.0, None, True)
-        y._pvcnn_row_max = (winners, values)
+        y._pvcnn_row_max = (winners, values, y._version)     # (keyed by the in-place version: workload.tap_and_pool re-checks it)
         return _cache.tag_amax(y, seg, amax)
     if seg:
         seed = torch.randint(-(1 << 62), 1 << 62, (1,), dtype=torch.int64, device=x.device) if drop_p else None

@@ -130,10 +130,29 @@ class FlatAdam(torch.optim.Optimizer):
         tensor) -- and therefore FlatAdam's own.  The moments are copied INTO the flat buffers (the kernel's addresses never change: a
         captured graph stays valid); a parameter without saved state (never stepped) keeps zero moments."""
         groups = state_dict['param_groups']
+        # validate BEFORE any state is touched.  FlatAdam has ONE set of hyper-parameters (one elementwise pass per bucket): a checkpoint
+        # with several param groups -- e.g. a no-decay group for BatchNorm / biases -- loads only if they all agree (ADVICE r04: it used to
+        # load silently with groups[0]'s values)
+        keys = ('lr', 'betas', 'eps', 'weight_decay')
+        for g in groups:
+            if g.get('amsgrad') or g.get('maximize'):
+                raise ValueError('FlatAdam implements neither amsgrad nor maximize')
+            for key in keys:
+                a, b = g.get(key), groups[0].get(key)
+                if (tuple(a) if key == 'betas' and a is not None else a) != (tuple(b) if key == 'betas' and b is not None else b):
+                    raise ValueError(f'FlatAdam keeps one set of hyper-parameters; the checkpoint\'s {len(groups)} param groups differ in {key!r}: '
+                                     f'{[gg.get(key) for gg in groups]}')
         ids = [i for g in groups for i in g['params']]
         params = self.param_groups[0]['params']
         if len(ids) != len(params):
             raise ValueError(f'optimizer state for {len(ids)} parameters, this model has {len(params)}')
+        for i, p in zip(ids, params):
+            st = state_dict['state'].get(i)
+            if st is not None and tuple(st['exp_avg'].shape) != tuple(p.shape):
+                raise ValueError(f'optimizer state {i}: shape {tuple(st["exp_avg"].shape)} vs parameter {tuple(p.shape)}')
+        found = {float(st['step']) for st in (state_dict['state'].get(i) for i in ids) if st is not None}
+        if len(found) > 1:
+            raise ValueError(f'FlatAdam keeps ONE step counter; the checkpoint has parameters at steps {sorted(found)}')
         steps = set()
         for i, p in zip(ids, params):
             st = state_dict['state'].get(i)
@@ -154,6 +173,4 @@ class FlatAdam(torch.optim.Optimizer):
         for key in ('lr', 'betas', 'eps', 'weight_decay', 'initial_lr'):
             if key in g:
                 self.param_groups[0][key] = tuple(g[key]) if key == 'betas' else g[key]
-        if g.get('amsgrad') or g.get('maximize'):
-            raise ValueError('FlatAdam implements neither amsgrad nor maximize')
         self.sync_hyperparameters()

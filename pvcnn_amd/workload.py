@@ -127,9 +127,9 @@ def tap_and_pool(x):
     """-> (x as a tap, max over the points (B,C)).  The winners come from `x.max(dim=-1)` itself (ties: torch's rule)."""
     if not (x.requires_grad and torch.is_grad_enabled()):
         return x, x.max(dim=-1).values
-    emitted = getattr(x, '_pvcnn_row_max', None)          # (winners, values) from the BatchNorm + ReLU pass that wrote x
-    if emitted is not None:
-        return _TapAndPool.apply(x, emitted[0], emitted[1])
+    emitted = getattr(x, '_pvcnn_row_max', None)          # (winners, values, version) from the BatchNorm + ReLU pass that wrote x
+    if emitted is not None and emitted[2] == x._version:  # (an in-place op on x since then -- a residual add_, an in-place activation --
+        return _TapAndPool.apply(x, emitted[0], emitted[1])   # makes them stale: fall through to a pass over x as it is now)
     from .modules.functional._autograd import native
     be = native() if x.is_cuda else None
     if (be is not None and getattr(be, 'has_neighbor_max', False) and x.dtype == torch.float32 and x.is_contiguous()

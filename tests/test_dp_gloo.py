@@ -279,9 +279,9 @@ def _graphed_worker(rank, world, port, q, overlapped):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('overlapped', [False, True])
-def test_graphed_step_multi_rank_branch_matches_big_batch_sgd(overlapped):
-    world, port = 2, _free_port()
+@pytest.mark.parametrize('overlapped,world', [(False, 2), (True, 2), (False, 4), (True, 4)])
+def test_graphed_step_multi_rank_branch_matches_big_batch_sgd(overlapped, world):
+    port = _free_port()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     procs = [ctx.Process(target=_graphed_worker, args=(r, world, port, q, overlapped)) for r in range(world)]
@@ -291,10 +291,11 @@ def test_graphed_step_multi_rank_branch_matches_big_batch_sgd(overlapped):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (_, start0, end0, _, nb0), (_, start1, end1, _, nb1) = results
-    assert nb0 == nb1 and nb0 > 1
-    for a, b in zip(end0, end1):
-        assert (a == b).all()                         # the ranks stay in lock-step
+    (_, start0, end0, _, nb0) = results[0]
+    for (_, _, end_r, _, nb_r) in results[1:]:
+        assert nb0 == nb_r and nb0 > 1
+        for a, b in zip(end0, end_r):
+            assert (a == b).all()                     # the ranks stay in lock-step
     # single-process reference: 4 SGD steps on the whole batch
     model = _net()
     with torch.no_grad():
@@ -310,6 +311,84 @@ def test_graphed_step_multi_rank_branch_matches_big_batch_sgd(overlapped):
         opt.step()
     for p, got in zip(model.parameters(), end0):
         assert torch.allclose(torch.from_numpy(got), p.detach(), atol=1e-5, rtol=1e-4)
+
+
+def _mixed_capture_worker(rank, world, port, q, failing_rank, demand):
+    """GraphedTrainStep._capture_agreed with a capture of the collectives that FAILS ON ONE RANK ONLY (each rank used to
+    decide on its own, so the ranks ended up in different modes, posted different collective sequences and hung).  The capture itself
+    is stood in for by an object whose replay() issues the same sequencing eagerly -- what is under test is the agreement."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from pvcnn_amd.graph import GraphedTrainStep
+
+        class Stub(GraphedTrainStep):
+            def _warm_up(self, warmup):
+                self.eager_step()
+
+            def _capture(self, whole_step):
+                if whole_step and self.collective and rank == failing_rank:
+                    raise RuntimeError('stand-in: this rank cannot capture the collectives')
+                outer = self
+
+                class Replay:
+                    def replay(self):
+                        outer.loss = outer._forward_backward()
+                        if whole_step:
+                            outer.reducer.finish()
+                            outer.optimizer.step()
+                self.graph, self.whole_step = Replay(), whole_step
+                if not whole_step:
+                    self.reducer.rearm()
+
+        torch.manual_seed(100 + rank)
+        model = _net()
+        reducer = GradBucketReducer(model, bucket_mb=0.0005)
+        opt = torch.optim.SGD(model.parameters(), lr=0.1)
+        g = torch.Generator().manual_seed(7)
+        x = torch.randn(8, 6, 32, generator=g)
+        y = torch.randint(0, 5, (8, 32), generator=g)
+        sl = shard_batch(8, world, rank)
+        step = Stub.__new__(Stub)
+        # (the constructor's CUDA-only prologue is skipped: the fields it sets, then the part under test)
+        step.model, step.loss_fn, step.optimizer, step.reducer = model, (lambda: nn.functional.cross_entropy(model(x[sl]), y[sl])), opt, reducer
+        import contextlib
+        step.autocast, step.collective, step.capture, step.graph, step.loss = contextlib.nullcontext, True, True, None, None
+        step.whole_step, step._sync_hyper, step.capture_error, step.bank = False, None, None, None
+        step._warm_up(1)
+        try:
+            step._capture_agreed(True if demand else None)
+            outcome = step.mode
+        except RuntimeError as exc:
+            outcome = 'raised: ' + str(exc)[:60]
+            q.put((rank, outcome, None, None))
+            return
+        losses = [float(step()) for _ in range(3)]
+        q.put((rank, outcome, step.capture_error, [p.detach().numpy().copy() for p in model.parameters()]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('failing_rank,demand', [(1, False), (0, False), (1, True)])
+def test_a_capture_that_fails_on_one_rank_moves_every_rank_to_the_same_mode(failing_rank, demand):
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_mixed_capture_worker, args=(r, world, port, q, failing_rank, demand)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])       # (a hang would time out here)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    modes = [r[1] for r in results]
+    if demand:                                         # capture_collectives=True: "capture them or raise" -- on EVERY rank
+        assert all(m.startswith('raised') for m in modes), modes
+        return
+    assert modes == ['graph, collectives after replay'] * world, modes
+    assert results[failing_rank][2].startswith('RuntimeError') and 'another rank' in results[1 - failing_rank][2]
+    for a, b in zip(results[0][3], results[1][3]):
+        assert (a == b).all()                          # ... and they trained in lock-step
 
 
 def test_graphed_step_wants_a_capturable_optimizer_when_it_captures_the_update():

@@ -383,3 +383,23 @@ def test_last_point_stage_hands_its_row_maxima_to_the_max_pool(hip):
         outs.append((pooled.detach().clone(), xa.grad.clone(), [p.grad.clone() for p in mlp.parameters()]))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert all(torch.equal(a, b) for a, b in zip(outs[0][2], outs[1][2]))
+
+
+def test_row_maxima_handed_over_by_the_batchnorm_pass_die_with_an_in_place_update(hip):
+    """ADVICE r04: the (winners, values) a BatchNorm + ReLU pass attaches to its output are keyed by the tensor's in-place version;
+    after `y.add_(...)` tap_and_pool reduces the tensor as it is now instead of trusting them."""
+    from pvcnn_amd import workload
+    from pvcnn_amd.modules import SharedMLP
+    from pvcnn_amd.modules.functional.bnact import emit_row_max
+    torch.manual_seed(4)
+    mlp = SharedMLP(16, 64).to(DEV).train()
+    x = torch.randn(2, 16, 512, device=DEV).requires_grad_()
+    with emit_row_max(workload._last_norm(mlp)):
+        y = mlp(x)
+    assert y._pvcnn_row_max is not None
+    bump = torch.zeros_like(y)
+    bump[:, :, 7] = 1e3                                   # position 7 becomes every row's maximum
+    with torch.no_grad():
+        y.add_(bump)
+    _, pooled = workload.tap_and_pool(y)
+    assert torch.equal(pooled, y.max(dim=-1).values) and (pooled > 999).all()

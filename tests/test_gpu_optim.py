@@ -87,6 +87,37 @@ def _fake_grads(nets, gen):
             p.grad = grad.clone()
 
 
+def test_flat_adam_refuses_a_checkpoint_whose_param_groups_disagree_and_touches_nothing(hip):
+    """a torch.optim.Adam checkpoint with several param groups (a no-decay group for biases, say) used to load with the
+    FIRST group's hyper-parameters for everything.  Groups that differ are refused BEFORE any moment or counter is written; groups that
+    agree load."""
+    from pvcnn_amd.dp import GradBucketReducer
+    from pvcnn_amd.optim import FlatAdam
+    a, b = _toy(), _toy()
+    b.load_state_dict(a.state_dict())
+    params = list(a.parameters())
+    first, rest = params[:3], params[3:]               # two groups IN PARAMETER ORDER: the checkpoint's state ids line up with the model's
+    gen = torch.Generator(device=DEV).manual_seed(2)
+    for wd_rest, ok in ((0.0, False), (1e-3, True)):
+        ref = torch.optim.Adam([{'params': first, 'weight_decay': 1e-3}, {'params': rest, 'weight_decay': wd_rest}], lr=1e-2)
+        _fake_grads([a], gen)
+        ref.step()
+        red = GradBucketReducer(b, bucket_mb=0.001)
+        flat = FlatAdam(red, lr=5e-1)
+        before = (flat.step_count.item(), [m.clone() for m in flat.exp_avg])
+        if not ok:
+            with pytest.raises(ValueError, match='weight_decay'):
+                flat.load_state_dict(ref.state_dict())
+            assert flat.step_count.item() == before[0] and all(torch.equal(x, y) for x, y in zip(flat.exp_avg, before[1]))
+            assert flat.param_groups[0]['lr'] == 5e-1
+        else:
+            flat.load_state_dict(ref.state_dict())
+            assert flat.param_groups[0]['weight_decay'] == 1e-3 and flat.param_groups[0]['lr'] == 1e-2 and flat.step_count.item() == 1
+            for p, q in zip(a.parameters(), b.parameters()):
+                assert torch.equal(flat.state[q]['exp_avg'], ref.state[p]['exp_avg'])
+        red.remove()
+
+
 def test_flat_adam_is_a_torch_optimizer_with_adams_checkpoint_layout(hip):
     """FlatAdam subclasses torch.optim.Optimizer; its state_dict loads into torch.optim.Adam and vice versa (the
     reference's train.py:186-199 / 249-255 checkpoint the optimizer), and the continued trajectories agree."""

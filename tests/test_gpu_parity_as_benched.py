@@ -51,13 +51,13 @@ def watch_native_calls(names, shapes_of=()):
             delattr(be, n)
 
 
-def _assert_network(label, res, flip_allowance, dense_cap=None):
-    """Loss to 1e-5 three ways; every tensor against ITS OWN bar (test_gpu_train_parity.judge_per_tensor: strict / sparse flip
-    allowance / -- PVCNN++ only -- dense allowance, counts printed)."""
+def _assert_network(label, res, flip_allowance):
+    """Loss to 1e-5 three ways; every tensor against ITS OWN bar (test_gpu_train_parity.judge_per_tensor: strict / flip site / flip
+    shadow, counts printed)."""
     _report(label, *res)
     (lg, _), (lc, _), (lt, _) = res
     assert abs(lg - lt) <= TOL_LOSS * max(abs(lt), 1.0) and abs(lg - lc) <= TOL_LOSS * max(abs(lc), 1.0), (lg, lc, lt)
-    return judge_per_tensor('[as benched] ' + label, res, flip_allowance, dense_cap)
+    return judge_per_tensor('[as benched] ' + label, res, flip_allowance)
 
 
 def test_full_width_cfg3_step_pvcnnpp(hip, oracle):
@@ -92,9 +92,9 @@ def test_full_width_cfg3_step_pvcnnpp(hip, oracle):
     print(f'[as benched] cfg3 Conv3d routes (tile voxels, weight rows) -> (Ci, Co, R): {routes}')
     assert any(vox == 64 for vox, _ in routes), routes                 # the 64-voxel tile of the R = 8 levels
     assert any(rows == 32 for _, rows in routes), routes               # the 32-row weight tile of the 32-channel R = 32 layers
-    # coarsest level: 8 clouds x 16 centres = 128 elements per channel -> one flipped decision there is 1/sqrt(128) = 9e-2 of a channel sum
-    # and moves every element upstream (dense allowance, counted)
-    _assert_network('PVCNN++ 1xC B=8 N=8192 (cfg3 as benched) [max-pool winners pinned]', res, 1.0 / (8 * 16) ** 0.5, dense_cap=0.25)
+    # coarsest level: 8 clouds x 16 centres = 128 elements per channel -> one flipped decision there is 1/sqrt(128) = 9e-2 of a channel
+    # sum; cap = two of them (measured: one tensor at 1.24e-1, sparse -- its 90th-percentile element is at 4e-3, the oracle stack's too)
+    _assert_network('PVCNN++ 1xC B=8 N=8192 (cfg3 as benched) [max-pool winners pinned]', res, 2.0 / (8 * 16) ** 0.5)
 
 
 def test_full_width_cfg4_step_shapenet(hip, oracle):
@@ -324,9 +324,12 @@ def test_full_width_cfg5_step_frustum_under_bf16_autocast_against_the_matched_ch
     _report('Frustum-PVCNN 1xC B=32 N=1024 under autocast(bf16) vs the matched checker (cfg5 as benched)', res_g, res_c, res_t)
     (lg, _), (lc, _), (lt, _) = res_g, res_c, res_t
     assert abs(lg - lt) <= TOL_LOSS * max(abs(lt), 1.0) and abs(lg - lc) <= TOL_LOSS * max(abs(lc), 1.0), (lg, lc, lt)
-    # per tensor, against the matched fp64 truth: its own bar (4 x the matched fp32 stack's distance on THAT tensor, floor 1e-4); sparse
-    # excess up to 2e-2 (32 frustums x 512 foreground points per channel at the box nets: 1/sqrt(16384) = 8e-3)
-    judge_per_tensor('[as benched] cfg5 under autocast(bf16) vs the matched checker', (res_g, res_c, res_t), flip_cap=2e-2)
+    # per tensor, against the matched fp64 truth: its own bar (4 x the matched fp32 stack's distance on THAT tensor, floor 1e-4); flip
+    # sites and their shadows up to 1/sqrt(32 frustums x 512 foreground points) = 7.8e-3 (measured, round 5: ONE flipped ReLU in
+    # box_est_net.features.2 -- its BatchNorm bias gradient is off in one channel by 3.7e-3, 90 % of its elements by < 1e-6 -- and every
+    # tensor in front of it in backward order, the centre-regression net included, moves densely by 2e-4 ... 3e-3; everything behind
+    # it, and the whole segmentation net, is at 1e-6)
+    judge_per_tensor('[as benched] cfg5 under autocast(bf16) vs the matched checker', (res_g, res_c, res_t), flip_cap=1.0 / (32 * 512) ** 0.5)
 
 
 def test_full_width_cfg5_step_frustum_fp32(hip, oracle):

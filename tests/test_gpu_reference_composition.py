@@ -29,6 +29,15 @@ def _no_dropout(net):
     return net
 
 
+def _scale(ref, name):
+    """Magnitude an error in tensor `name` is judged against: its own largest entry, or -- for a bias, whose exact gradient is ZERO in
+    front of a train-mode BatchNorm (pure round-off in any evaluation) -- its layer's weight gradient (test_gpu_train_parity._scale)."""
+    m = ref[name].abs().max().item()
+    if name.endswith('.bias') and name[:-len('bias')] + 'weight' in ref:
+        m = max(m, ref[name[:-len('bias')] + 'weight'].abs().max().item())
+    return max(m, 1e-30)
+
+
 def _step(net, x, y):
     x = x.clone().requires_grad_()
     out = net(x)
@@ -63,12 +72,17 @@ def test_reference_composition_equals_the_benched_composition(hip, cfg):
     out_c, loss_c, g_c = _step(composed, x, y)
     fwd = ((out_b - out_c).abs().max() / out_b.abs().max()).item()
     assert g_b.keys() == g_c.keys()
-    rows = sorted(((((g_b[k] - g_c[k]).abs().max() / g_b[k].abs().max().clamp_min(1e-30)).item(), k) for k in g_b), reverse=True)
+    rows = sorted((((g_b[k] - g_c[k]).abs().max().item() / _scale(g_b, k), k) for k in g_b), reverse=True)
     errs = sorted(e for e, _ in rows)
     exact = sum(1 for e in errs if e == 0.0)
     print(f'[reference composition] {cfg}: loss benched {loss_b:.7f} composed {loss_c:.7f}; logits differ by {fwd:.2e} of the largest; '
           f'{len(rows)} tensors: {exact} bit-equal, median {errs[len(errs) // 2]:.2e}, worst {rows[0][0]:.2e} ({rows[0][1]}); '
           f'next: {[(f"{e:.1e}", k) for e, k in rows[1:4]]}')
+    import json
+    import os
+    if os.environ.get('PVCNN_PARITY_DUMP'):
+        os.makedirs(os.environ['PVCNN_PARITY_DUMP'], exist_ok=True)
+        json.dump({'cfg': cfg, 'fwd': fwd, 'rows': rows}, open(os.path.join(os.environ['PVCNN_PARITY_DUMP'], f'reference_composition_{cfg}.json'), 'w'))
     assert fwd <= TOL_FWD, fwd
     assert abs(loss_b - loss_c) <= 1e-6 * max(abs(loss_b), 1.0)
     # the running statistics are forward-only quantities in front of the last Conv1d: the same bits

@@ -223,42 +223,47 @@ def per_tensor_rows(res_g, res_c, res_t):
     return rows
 
 
-def judge_per_tensor(label, res, flip_cap, dense_cap=None, max_flip_share=0.5):
-    """PER TENSOR t (round 5; the round-4 bar was one number per network, set by its worst tensor):
+def judge_per_tensor(label, res, flip_cap, max_allowance_share=0.25):
+    """PER TENSOR t (round 5; the round-4 bar was one number per network, set by its worst tensor).  Errors are max-norms relative to
+    the tensor's largest entry (_scale); `bar_t` = max(NET_FACTOR x |oracle stack - truth|_t, floor_t), floor_t = 1e-4 (1e-5 for
+    forward-only quantities: BatchNorm running statistics).  Every tensor is first held to ITS OWN bar; what is beyond it must fit one
+    of two NAMED patterns of a discrete decision (a ReLU, LeakyReLU or max taken the other way on a value within fp32 round-off of
+    its threshold -- measured between two CPU evaluations without any GPU, tools/parity_probe.py), and is counted and printed:
 
-        strict           |hip - truth|_t <= max(NET_FACTOR x |oracle stack - truth|_t, floor_t),   floor_t = 1e-4, 1e-5 for forward-only
-                         quantities (running statistics) -- every tensor is first held to ITS OWN bar;
-        flip allowance   a GRADIENT tensor beyond its strict bar passes only if the excess is SPARSE: SPARSE_Q of its elements are still
-                         within the strict bar and none is beyond `flip_cap` (~ 1/sqrt(elements per channel): what ONE ReLU / max decision
-                         taken the other way on a value within round-off of its threshold moves a per-channel sum by, see _check_network).
-                         A wrong scale, a missing term, a 10 % error of a whole tensor is DENSE and fails here whatever the worst tensor
-                         of the network does.  Forward-only quantities never get it;
-        dense allowance  only for networks with a level of <= 128 elements per channel (`dense_cap` given: PVCNN++, whose coarsest level
-                         has 16 centres per cloud): there one flipped decision moves a BatchNorm's batch means by 1/128 of an element and
-                         with them EVERY element of every gradient upstream -- in the fp32 oracle stack just as well, on different
-                         decisions.  Such a tensor must stay within `dense_cap`, and the share of tensors that needed it is asserted.
+        strict       |hip - truth|_t <= bar_t;
+        flip site    a GRADIENT tensor whose excess is SPARSE: SPARSE_Q of its elements within bar_t, none beyond `flip_cap`
+                     (~ 1/sqrt(elements per channel): what one element moves a random-signed per-channel sum by) -- the layer where a
+                     decision flipped: one element of its bias gradient, one row of its weight gradient, one point of `<input>`;
+        flip shadow  a gradient tensor with a DENSE excess is admitted only if a flip site exists LATER in forward order (= earlier in
+                     backward: the flipped element's gradient passes through every layer in front of it and enters EVERY channel's
+                     per-channel sum there as one more term -- all elements of those small tensors move a little), and only within
+                     `flip_cap` with SPARSE_Q of its elements within flip_cap / 4.  Seen where layers have few elements per channel:
+                     Frustum-PVCNN's box nets (32 x 512 points), PVCNN++'s coarse levels (8 x 16 centres).
 
-    The counts of tensors per class are printed; the strict class is asserted to hold the majority."""
+    A wrong scale, a missing term, a 10 % error of a whole tensor is dense, has no flip site behind it or exceeds the caps, and FAILS
+    whatever the worst tensor of the network does (tests/test_host_logic.py::test_the_per_tensor_judge_...).  Forward-only quantities
+    never get an allowance.  Strict must hold for >= 1 - max_allowance_share of the tensors."""
     rows = per_tensor_rows(*res)
-    strict, flip, dense, bad = [], [], [], []
+    for i, r in enumerate(rows):                       # _grads order: <input>, parameters in registration (= forward) order, buffers
+        r['bar'] = max(NET_FACTOR * r['cpu'], FLOOR_FWD if r['forward_only'] else FLOOR_T)
+        r['order'] = i
+    sites = [r for r in rows if not r['forward_only'] and r['hip'] > r['bar'] and r['hip_q'] <= r['bar'] and r['hip'] <= flip_cap]
+    last_site = max((r['order'] for r in sites), default=-1)
+    strict, shadow, bad = [], [], []
     for r in rows:
-        floor = FLOOR_FWD if r['forward_only'] else FLOOR_T
-        bar = max(NET_FACTOR * r['cpu'], floor)
-        r['bar'] = bar
-        if r['hip'] <= bar:
+        if r['hip'] <= r['bar']:
             strict.append(r)
-        elif not r['forward_only'] and r['hip_q'] <= bar and r['hip'] <= flip_cap:
-            flip.append(r)
-        elif not r['forward_only'] and dense_cap is not None and r['hip'] <= dense_cap:
-            dense.append(r)
+        elif r in sites:
+            continue
+        elif not r['forward_only'] and r['order'] < last_site and r['hip'] <= flip_cap and r['hip_q'] <= flip_cap / 4:
+            shadow.append(r)
         else:
             bad.append(r)
     errs = sorted(r['hip'] for r in rows)
     print(f'[per tensor] {label}: {len(rows)} tensors: {len(strict)} within their own bar max({NET_FACTOR:g} x oracle-vs-truth_t, floor_t), '
-          f'{len(flip)} on the flip allowance (sparse excess, cap {flip_cap:.1e}), {len(dense)} on the dense allowance'
-          + (f' (cap {dense_cap:.1e})' if dense_cap is not None else ' (not granted for this network)')
-          + f', {len(bad)} FAILED; hip-vs-truth median {errs[len(errs) // 2]:.2e}, 90th percentile {errs[int(0.9 * len(errs))]:.2e}, worst {errs[-1]:.2e}')
-    for cls, members in (('flip', flip), ('dense', dense), ('FAILED', bad)):
+          f'{len(sites)} flip sites (sparse excess), {len(shadow)} in the shadow of a flip site (dense excess), cap {flip_cap:.1e}; '
+          f'{len(bad)} FAILED; hip-vs-truth median {errs[len(errs) // 2]:.2e}, 90th percentile {errs[int(0.9 * len(errs))]:.2e}, worst {errs[-1]:.2e}')
+    for cls, members in (('site', sites), ('shadow', shadow), ('FAILED', bad)):
         for r in sorted(members, key=lambda r: -r['hip'])[:12]:
             print(f"    {cls:6s} hip {r['hip']:.2e} (q{int(SPARSE_Q * 100)} {r['hip_q']:.2e})  oracle {r['cpu']:.2e} (q{int(SPARSE_Q * 100)} {r['cpu_q']:.2e})  "
                   f"bar {r['bar']:.1e}  n={r['n']}  {r['name']}")
@@ -267,15 +272,14 @@ def judge_per_tensor(label, res, flip_cap, dense_cap=None, max_flip_share=0.5):
         import json
         os.makedirs(dump, exist_ok=True)
         with open(os.path.join(dump, ''.join(c if c.isalnum() else '_' for c in label)[:80] + '.json'), 'w') as fh:
-            json.dump({'label': label, 'flip_cap': flip_cap, 'dense_cap': dense_cap, 'rows': rows}, fh)
+            json.dump({'label': label, 'flip_cap': flip_cap, 'rows': rows}, fh)
     assert not bad, f'{label}: beyond the per-tensor bars: ' + ', '.join(f"{r['name']} {r['hip']:.2e} > {r['bar']:.1e}" for r in bad[:6])
-    assert len(flip) <= max_flip_share * len(rows), f'{label}: {len(flip)} of {len(rows)} tensors needed the flip allowance'
-    if dense_cap is not None:
-        assert len(dense) <= 0.25 * len(rows), f'{label}: {len(dense)} of {len(rows)} tensors needed the dense allowance'
+    assert len(sites) + len(shadow) <= max_allowance_share * len(rows), \
+        f'{label}: {len(sites)} + {len(shadow)} of {len(rows)} tensors needed a flip allowance'
     return rows
 
 
-def _check_network(label, build, make, loss_fn, oracle, flip_allowance, dense_cap=None):
+def _check_network(label, build, make, loss_fn, oracle, flip_allowance):
     """Whole networks, 10-40 train-mode BatchNorms deep, compared with an fp64 evaluation of the same network
     (tests/truth_backend.py) next to the fp32 oracle stack.
 
@@ -288,13 +292,14 @@ def _check_network(label, build, make, loss_fn, oracle, flip_allowance, dense_ca
     max-pool winner; those are pinned to the fp64 run's here, see PinMaxWinners.  ReLU decisions live inside the fused
     kernels and cannot be pinned.)  Per-layer, where no such flip occurs, the HIP path is within 2e-6 of both
     (test_pvconv_train_gradients_match_the_oracle_stack).  Hence the PER-TENSOR criteria of judge_per_tensor (strict bar of the
-    tensor's own; sparse excess up to flip_allowance ~ 1/sqrt(elements per channel) of the smallest level); the loss agrees to 1e-5;
+    tensor's own; flip sites and their shadows up to flip_allowance ~ 1/sqrt(elements per channel) of the smallest level, counted);
+    the loss agrees to 1e-5;
     and as the networks really run (winners not pinned) nothing is beyond NET_CAP."""
     res = _run_three(build, make, loss_fn, oracle, pin_winners=True)
     _report(label + ' [max-pool winners pinned]', *res)
     (lg, _), (lc, _), (lt, _) = res
     assert abs(lg - lt) <= TOL_LOSS * max(abs(lt), 1.0) and abs(lg - lc) <= TOL_LOSS * max(abs(lc), 1.0), (lg, lc, lt)
-    judge_per_tensor(label + ' [max-pool winners pinned]', res, flip_allowance, dense_cap)
+    judge_per_tensor(label + ' [max-pool winners pinned]', res, flip_allowance)
 
     res = _run_three(build, make, loss_fn, oracle, pin_winners=False)
     rows = _report(label + ' [as is]', *res)
@@ -313,8 +318,6 @@ NETS = {
 
 # 1/sqrt(elements per channel at the smallest level): 8192 points (PVCNN), 4096 (ShapeNet), 4 x 16 centres (PVCNN++)
 FLIP = {'PVCNN': 1e-2, 'PVCNNShapeNet': 2e-2, 'PVCNN2': 0.25}
-# PVCNN++ only: its coarsest level has 4 x 16 = 64 elements per channel (judge_per_tensor: dense allowance)
-DENSE = {'PVCNN2': 0.25}
 
 
 @pytest.mark.parametrize('name', list(NETS))
@@ -327,7 +330,7 @@ def test_network_train_gradients_match_the_oracle_stack(hip, oracle, name):
         x = x0.clone().to(dev, dtype).requires_grad_()
         return x, x, y0.to(dev)
 
-    _check_network(name, lambda: build(workload), make, tf.cross_entropy, oracle, FLIP[name], dense_cap=DENSE.get(name))
+    _check_network(name, lambda: build(workload), make, tf.cross_entropy, oracle, FLIP[name])
 
 
 def test_frustum_segmentation_train_gradients_match_the_oracle_stack(hip, oracle):

@@ -606,17 +606,22 @@ def test_gradient_slots_are_handed_out_once_per_step_and_only_for_a_first_gradie
 def test_the_per_tensor_judge_fails_a_dense_error_and_passes_a_sparse_flip():
     """tests/test_gpu_train_parity.judge_per_tensor (the whole-network bar since round 5), on synthetic gradients: a 10 % error of ONE
     whole tensor fails although another tensor of the network is far worse in the oracle stack (the round-4 bar, one number per
-    network set by the worst tensor, let it pass); one flipped element passes on the counted flip allowance; a forward-only quantity
-    (a running statistic) never gets the allowance."""
+    network set by the worst tensor, let it pass); one flipped element passes as a counted flip site; a small dense excess passes only
+    in FRONT of a flip site (its shadow) and never behind one or without one; a forward-only quantity (a running statistic) never gets
+    an allowance."""
     import test_gpu_train_parity as tp
     g = torch.Generator().manual_seed(0)
     truth = {'<input>': torch.randn(4, 9, 64, generator=g).double(), 'a.weight': torch.randn(32, 16, generator=g).double(),
-             'b.weight': torch.randn(64, 32, generator=g).double(), 'buffer bn.running_mean': torch.randn(32, generator=g).double()}
+             'b.weight': torch.randn(64, 32, generator=g).double(), 'c.weight': torch.randn(64, 32, generator=g).double(),
+             'd.weight': torch.randn(8, 8, generator=g).double(), 'e.weight': torch.randn(8, 8, generator=g).double(),
+             'f.weight': torch.randn(8, 8, generator=g).double(), 'g.weight': torch.randn(8, 8, generator=g).double(),
+             'buffer bn.running_mean': torch.randn(32, generator=g).double()}
     noise = lambda t, rel: t + rel * t.abs().max() * torch.randn(t.shape, generator=g).double().clamp(-1, 1)
     cpu = {k: noise(v, 1e-6) for k, v in truth.items()}
-    cpu['b.weight'] = noise(truth['b.weight'], 5e-2)                   # the network's ill-conditioned tensor: the oracle stack is 5e-2 off
+    cpu['c.weight'] = noise(truth['c.weight'], 5e-2)                   # the network's ill-conditioned tensor: the oracle stack is 5e-2 off
     hip = {k: noise(v, 1e-6) for k, v in truth.items()}
-    ok = tp.judge_per_tensor('synthetic: all within', ((0.0, hip), (0.0, cpu), (0.0, truth)), flip_cap=1e-2)
+    judge = lambda label, h, cap=1e-2: tp.judge_per_tensor(label, ((0.0, h), (0.0, cpu), (0.0, truth)), flip_cap=cap)
+    ok = judge('synthetic: all within', hip)
     assert all(r['hip'] <= r['bar'] for r in ok)
 
     dense = dict(hip)
@@ -624,18 +629,31 @@ def test_the_per_tensor_judge_fails_a_dense_error_and_passes_a_sparse_flip():
     worst_cpu = max(r['cpu'] for r in ok)
     assert (dense['a.weight'] - truth['a.weight']).abs().max() / truth['a.weight'].abs().max() < 4 * worst_cpu   # the old bar passes it
     with pytest.raises(AssertionError, match='a.weight'):
-        tp.judge_per_tensor('synthetic: dense 10 %', ((0.0, dense), (0.0, cpu), (0.0, truth)), flip_cap=1e-2)
+        judge('synthetic: dense 10 %', dense)
 
     flip = dict(hip)
-    flip['<input>'] = hip['<input>'].clone()
-    flip['<input>'][1, 2, 3] += 5e-3 * truth['<input>'].abs().max()  # one element: a flipped decision
-    rows = tp.judge_per_tensor('synthetic: one flip', ((0.0, flip), (0.0, cpu), (0.0, truth)), flip_cap=1e-2)
-    assert [r['name'] for r in rows if r['hip'] > r['bar']] == ['<input>']
-    with pytest.raises(AssertionError, match='input'):                 # ... but not beyond the cap
-        tp.judge_per_tensor('synthetic: one flip, tight cap', ((0.0, flip), (0.0, cpu), (0.0, truth)), flip_cap=1e-3)
+    flip['b.weight'] = hip['b.weight'].clone()
+    flip['b.weight'][1, 2] += 5e-3 * truth['b.weight'].abs().max()    # one element: a flipped decision in layer b
+    rows = judge('synthetic: one flip', flip)
+    assert [r['name'] for r in rows if r['hip'] > r['bar']] == ['b.weight']
+    with pytest.raises(AssertionError, match='b.weight'):              # ... but not beyond the cap
+        judge('synthetic: one flip, tight cap', flip, 1e-3)
+
+    shadow = dict(flip)
+    shadow['a.weight'] = noise(truth['a.weight'], 5e-4)                # IN FRONT of the site (forward order): its shadow, admitted
+    rows = judge('synthetic: a flip and its shadow', shadow)
+    assert sorted(r['name'] for r in rows if r['hip'] > r['bar']) == ['a.weight', 'b.weight']
+    behind = dict(flip)
+    behind['d.weight'] = noise(truth['d.weight'], 5e-4)                # BEHIND the site: no flip can explain it
+    with pytest.raises(AssertionError, match='d.weight'):
+        judge('synthetic: dense excess behind the site', behind)
+    alone = dict(hip)
+    alone['a.weight'] = noise(truth['a.weight'], 5e-4)                 # no site at all
+    with pytest.raises(AssertionError, match='a.weight'):
+        judge('synthetic: dense excess without a site', alone)
 
     stat = dict(hip)
     stat['buffer bn.running_mean'] = hip['buffer bn.running_mean'].clone()
     stat['buffer bn.running_mean'][5] += 1e-3 * truth['buffer bn.running_mean'].abs().max()
     with pytest.raises(AssertionError, match='running_mean'):
-        tp.judge_per_tensor('synthetic: a running statistic off', ((0.0, stat), (0.0, cpu), (0.0, truth)), flip_cap=1e-2)
+        judge('synthetic: a running statistic off', stat)
