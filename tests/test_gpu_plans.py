@@ -111,3 +111,74 @@ def test_layers_share_one_plan_and_one_set_of_taps(hip, oracle):
     assert torch.equal(shared[0], separate[0]) and torch.equal(shared[1], separate[1])
     for a, b_ in zip(shared[2], separate[2]):
         assert torch.equal(a, b_)
+
+
+def _count(be, names):
+    calls, originals = {n: 0 for n in names}, {}
+    for name in names:
+        orig = getattr(be, name)
+        originals[name] = orig
+
+        def counted(*a, _orig=orig, _name=name, **k):
+            calls[_name] += 1
+            return _orig(*a, **k)
+        setattr(be, name, counted)
+    return calls, originals
+
+
+def test_the_reference_seam_reuses_its_plan_and_a_mutated_tensor_invalidates_it(hip, oracle, gen):
+    """the reference's own call pattern (functional/voxelization.py:10-24, devoxelization.py:30-39: `_backend.
+    avg_voxelize_forward(features, coords, r)`, `_backend.trilinear_devoxelize_backward(grad_y, inds, wgts, r)`) gets plan reuse
+    WITHOUT new API: the counting sort is memoised on the tensor object the call was made with.  Second call: apply only; a tensor
+    written in place (coords / inds / wgts, or the ind / cnt handed out): rebuilt; always bit-equal to the oracle and to the one-shot
+    C entries (`seam_plan_memo = False`)."""
+    b, n, r, c = 4, 4096, 16, 24
+    norm, vox = _inputs(gen, b, n, r, 'cube')
+    feat = torch.randn(b, c, n, generator=gen)
+    want, o_ind, o_cnt = oracle.avg_voxelize_forward(feat, vox, r)
+    _, inds, wgts = oracle.trilinear_devoxelize_forward(r, True, norm, torch.zeros(b, 1, r ** 3))
+    g = torch.randn(b, c, n, generator=gen)
+    want_b = oracle.trilinear_devoxelize_backward(g, inds, wgts, r)
+    vox_d, feat_d, inds_d, wgts_d, g_d = vox.to(DEV), feat.to(DEV), inds.to(DEV), wgts.to(DEV), g.to(DEV)
+    calls, originals = _count(hip, ['avg_voxelize_plan', 'avg_voxelize_apply', 'trilinear_devoxelize_backward_plan', 'trilinear_devoxelize_backward_apply'])
+    try:
+        for i in range(3):
+            out, ind, cnt = hip.avg_voxelize_forward(feat_d, vox_d, r)
+            assert torch.equal(out.cpu(), want) and torch.equal(ind.cpu(), o_ind) and torch.equal(cnt.cpu(), o_cnt)
+            assert torch.equal(hip.trilinear_devoxelize_backward(g_d, inds_d, wgts_d, r).cpu(), want_b)
+        assert calls == {'avg_voxelize_plan': 1, 'avg_voxelize_apply': 3, 'trilinear_devoxelize_backward_plan': 1, 'trilinear_devoxelize_backward_apply': 3}, calls
+        # other features on the same coords: the same plan
+        feat2 = torch.randn(b, 7, n, generator=gen)
+        assert torch.equal(hip.avg_voxelize_forward(feat2.to(DEV), vox_d, r)[0].cpu(), oracle.avg_voxelize_forward(feat2, vox, r)[0])
+        assert calls['avg_voxelize_plan'] == 1
+        # coords written IN PLACE: the version counter moves, the plan is rebuilt for the new contents
+        vox2 = vox.clone()
+        vox2[:, :, :100] = (vox2[:, :, :100] + 3) % r
+        vox_d.copy_(vox2.to(DEV))
+        want2, ind2, cnt2 = oracle.avg_voxelize_forward(feat, vox2, r)
+        out, ind, cnt = hip.avg_voxelize_forward(feat_d, vox_d, r)
+        assert calls['avg_voxelize_plan'] == 2 and torch.equal(out.cpu(), want2) and torch.equal(ind.cpu(), ind2) and torch.equal(cnt.cpu(), cnt2)
+        # a caller that scribbles over the `ind` it was handed does not poison the next call
+        ind.zero_()
+        out, ind, cnt = hip.avg_voxelize_forward(feat_d, vox_d, r)
+        assert calls['avg_voxelize_plan'] == 3 and torch.equal(out.cpu(), want2) and torch.equal(ind.cpu(), ind2)
+        # weights written in place: the backward plan is rebuilt
+        wgts_d.mul_(0.5)
+        got = hip.trilinear_devoxelize_backward(g_d, inds_d, wgts_d, r)
+        assert calls['trilinear_devoxelize_backward_plan'] == 2
+        assert torch.equal(got.cpu(), oracle.trilinear_devoxelize_backward(g, inds, wgts * 0.5, r))
+        # a NEW tensor object with the same contents: its own plan (identity, not address or contents, is the key)
+        assert torch.equal(hip.trilinear_devoxelize_backward(g_d, inds_d.clone(), wgts_d, r).cpu(), got.cpu())
+        assert calls['trilinear_devoxelize_backward_plan'] == 3
+        # the one-shot C entries (pvcnn_avg_voxelize_fwd / pvcnn_trilinear_devox_bwd_strided): still there, still the same bits
+        hip.seam_plan_memo = False
+        before = dict(calls)
+        out, ind, cnt = hip.avg_voxelize_forward(feat_d, vox_d, r)
+        assert torch.equal(out.cpu(), want2) and torch.equal(ind.cpu(), ind2) and torch.equal(cnt.cpu(), cnt2)
+        assert torch.equal(hip.trilinear_devoxelize_backward(g_d, inds_d, wgts_d, r).cpu(), got.cpu())
+        assert calls == before
+    finally:
+        for name in originals:
+            delattr(hip, name)
+        if 'seam_plan_memo' in hip.__dict__:
+            del hip.seam_plan_memo

@@ -92,3 +92,24 @@ def test_reference_composition_equals_the_benched_composition(hip, cfg):
     bad = [(k, e) for e, k in rows if e > TOL_GRAD]
     assert not bad, bad[:6]
     assert errs[len(errs) // 2] <= TOL_GRAD_MEDIAN
+
+
+def test_adopt_turns_the_reference_composition_into_the_benched_one(hip):
+    """pvcnn_amd.adopt(model): the instance composed as the reference composes it takes workload's forward (and its classifier head the
+    module-by-module path) without touching a parameter -- afterwards it IS the benched composition: bit-equal logits and gradients."""
+    import pvcnn_amd
+    import reference_composition as rc
+    from pvcnn_amd import workload
+    torch.manual_seed(7)
+    benched = _no_dropout(workload.PVCNN(13, 6, width_multiplier=0.5)).to(DEV).train()
+    adopted = _no_dropout(rc.ReferencePVCNN(13, 6, width_multiplier=0.5)).to(DEV).train()
+    adopted.load_state_dict(benched.state_dict())
+    keys = list(adopted.state_dict().keys())
+    assert pvcnn_amd.adopt(adopted) is adopted and list(adopted.state_dict().keys()) == keys
+    assert type(adopted).forward is workload.PVCNN.forward and type(adopted.classifier).__name__ == '_Head'
+    x, y = workload.make_s3dis_batch(4, 2048, device=DEV)
+    out_b, loss_b, g_b = _step(benched, x, y)
+    out_a, loss_a, g_a = _step(adopted, x, y)
+    assert torch.equal(out_b, out_a) and loss_b == loss_a
+    for k in g_b:
+        assert torch.equal(g_b[k], g_a[k]), k

@@ -230,3 +230,31 @@ def test_reference_composition_shapenet_is_the_reference_forward(ref):
     x, _ = workload.make_shapenet_batch(2, 512)
     with torch.no_grad():
         assert torch.equal(theirs(x), mine(x))
+
+
+def test_adopt_keeps_a_reference_model_and_its_state_dict(ref):
+    """pvcnn_amd.adopt(model) on the reference's own class instance: same parameters / state_dict keys, same outputs and gradients (on
+    CPU tensors the adopted forwards fall back to the modules; the GPU side is tests/test_gpu_reference_composition.py)."""
+    import pvcnn_amd
+    from pvcnn_amd import workload
+    torch.manual_seed(5)
+    for name, n in (('PVCNN', 512), ('PVCNN2', 1024)):
+        plain = getattr(ref.models, name)(13, 6, width_multiplier=0.125)
+        adopted = getattr(ref.models, name)(13, 6, width_multiplier=0.125)
+        adopted.load_state_dict(plain.state_dict())
+        keys = list(adopted.state_dict().keys())
+        assert pvcnn_amd.adopt(adopted) is adopted and list(adopted.state_dict().keys()) == keys
+        assert type(adopted).__name__ == name and isinstance(adopted, getattr(ref.models, name))
+        assert type(adopted).forward is getattr(workload, name).forward
+        for net in (plain, adopted):
+            net.train()
+            for m in net.modules():
+                if isinstance(m, torch.nn.Dropout):
+                    m.p = 0.0
+        x, y = workload.make_s3dis_batch(2, n)
+        la = torch.nn.functional.cross_entropy(plain(x), y)
+        lb = torch.nn.functional.cross_entropy(adopted(x), y)
+        assert torch.equal(la, lb)
+        la.backward(); lb.backward()
+        for (n1, p1), (n2, p2) in zip(plain.named_parameters(), adopted.named_parameters()):
+            assert n1 == n2 and torch.equal(p1.grad, p2.grad), n1

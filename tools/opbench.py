@@ -53,8 +53,12 @@ def main():
     ap.add_argument('--ops', default='vox_fwd,vox_apply,vox_plan,vox_bwd,devox_fwd,devox_bwd,devox_bwd_apply,devox_bwd_plan')
     ap.add_argument('--shapes', default='')
     ap.add_argument('--kind', default='cube', choices=['cube', 'surface'])
+    ap.add_argument('--no-seam-memo', action='store_true',
+                    help='vox_fwd / devox_bwd (the 12-callable seam): the one-shot C entries, counting sort rebuilt per call (the FIRST call on a '
+                         'tensor); default: the memoised plan of the tensor they are called with (every later call)')
     args = ap.parse_args()
     from pvcnn_amd.modules.functional.backend import _backend as hip
+    hip.seam_plan_memo = not args.no_seam_memo
     dev = 'cuda:0'
     shapes = SHAPES if not args.shapes else [tuple(int(v) for v in s.split('x')) for s in args.shapes.split(',')]
     g = torch.Generator().manual_seed(1588147245)
@@ -89,7 +93,7 @@ def main():
         for op in args.ops.split(','):
             fn, nbytes = runs[op]
             med, best = timeit(fn, args.iters)
-            print(json.dumps({'op': op, 'BCNR': [b, c, n, r], 'kind': args.kind, 'median_us': round(med, 2), 'min_us': round(best, 2),
+            print(json.dumps({'op': op + (' (one-shot, plan rebuilt)' if args.no_seam_memo and op in ('vox_fwd', 'devox_bwd') else ''), 'BCNR': [b, c, n, r], 'kind': args.kind, 'median_us': round(med, 2), 'min_us': round(best, 2),
                               'algorithmic_MB': round(nbytes / 1e6, 2), 'GBs': round(nbytes / med / 1e3, 1),
                               'frac_8TBs': round(nbytes / med / 1e3 / 8000, 4)}), flush=True)
 
