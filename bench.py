@@ -275,6 +275,75 @@ def run_variant(config, extra_args=(), env=None, steps=20, warmup=5, timeout=300
         return {'error': f'{type(exc).__name__}: {str(exc)[:200]}'}
 
 
+def _dry_rank(rank, world, port, queue):
+    """One rank of `--dry-collectives`: gloo over CPU tensors, a small pure-torch network with several gradient buckets, the two
+    sequencings pvcnn_amd/graph.py captures on the GPU issued eagerly (capture=False) -- the collectives are the REAL ones of
+    pvcnn_amd/dp.py in the order a replayed graph would issue them."""
+    import torch.nn as nn
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from pvcnn_amd.dp import GradBucketReducer, shard_batch
+        from pvcnn_amd.graph import GraphedTrainStep
+        out = {}
+        gen = torch.Generator().manual_seed(7)
+        x = torch.randn(4 * world, 6, 32, generator=gen)
+        y = torch.randint(0, 5, (4 * world, 32), generator=gen)
+        sl = shard_batch(4 * world, world, rank)
+        for name, overlapped in (('graph+collectives (hooks launch each full bucket during backward)', True),
+                                 ('graph, collectives after replay (fixed bucket order)', False)):
+            torch.manual_seed(100 + rank)                       # different initial weights per rank: the broadcast must fix that
+            model = nn.Sequential(nn.Conv1d(6, 24, 1), nn.GroupNorm(4, 24), nn.ReLU(), nn.Conv1d(24, 24, 1), nn.ReLU(), nn.Conv1d(24, 5, 1))
+            reducer = GradBucketReducer(model, bucket_mb=0.0005)
+            opt = torch.optim.SGD(model.parameters(), lr=0.1)
+            step = GraphedTrainStep(model, lambda: tf.cross_entropy(model(x[sl]), y[sl]), opt, reducer, capture=False, capture_collectives=overlapped)
+            start = [p.detach().numpy().copy() for p in model.parameters()]
+            losses = [float(step().detach()) for _ in range(3)]
+            out[name] = {'buckets': len(reducer.buckets), 'start': start, 'end': [p.detach().numpy().copy() for p in model.parameters()], 'losses': losses}
+        queue.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def dry_collectives(world):
+    """`bench.py --gpus N --dry-collectives` (no GPU): N gloo ranks run the multi-rank step sequencings; rank results are compared with
+    each other (lock-step) and with big-batch SGD in one process.  -> the JSON line (not a performance figure)."""
+    import socket
+    import torch.multiprocessing as mp
+    import torch.nn as nn
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    queue = ctx.Queue()
+    procs = [ctx.Process(target=_dry_rank, args=(r, world, port, queue)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(queue.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    report = {'dry_collectives': True, 'backend': 'gloo (CPU tensors)', 'ranks': world, 'exit_codes': [p.exitcode for p in procs], 'orderings': {}}
+    gen = torch.Generator().manual_seed(7)
+    x = torch.randn(4 * world, 6, 32, generator=gen)
+    y = torch.randint(0, 5, (4 * world, 32), generator=gen)
+    for name, r0 in results[0].items():
+        lock_step = all(all((a == b).all() for a, b in zip(r0['end'], results[r][name]['end'])) for r in range(1, world))
+        model = nn.Sequential(nn.Conv1d(6, 24, 1), nn.GroupNorm(4, 24), nn.ReLU(), nn.Conv1d(24, 24, 1), nn.ReLU(), nn.Conv1d(24, 5, 1))
+        with torch.no_grad():
+            for p, src in zip(model.parameters(), r0['start']):
+                p.copy_(torch.from_numpy(src))
+        opt = torch.optim.SGD(model.parameters(), lr=0.1)
+        for _ in range(3):                                      # (no batch statistics in this stand-in: DP == big-batch SGD exactly)
+            opt.zero_grad()
+            tf.cross_entropy(model(x), y).backward()
+            opt.step()
+        worst = max(float((torch.from_numpy(a) - b.detach()).abs().max()) for a, b in zip(r0['end'], model.parameters()))
+        report['orderings'][name] = {'gradient_buckets': r0['buckets'], 'ranks_in_lock_step': lock_step,
+                                     'max_abs_diff_vs_big_batch_sgd': worst, 'ok': bool(lock_step and worst < 1e-5)}
+    report['ok'] = all(v['ok'] for v in report['orderings'].values()) and all(c == 0 for c in report['exit_codes'])
+    return report
+
+
 def cpu_baseline(args, sample_batch):
     """The same network + step on the host CPU with the oracle as native backend (kind "port")."""
     from oracle.oracle_backend import OracleBackend          # checker / baseline only
@@ -348,6 +417,10 @@ def main():
                          'single-process step on the concatenated batch; prints one JSON line (not a performance figure)')
     args = ap.parse_args()
 
+    if args.dry_collectives:
+        report = dry_collectives(max(2, args.gpus))
+        print(json.dumps(report), flush=True)
+        raise SystemExit(0 if report['ok'] else 1)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -622,6 +695,7 @@ def main():
                                                                                   'after each replay (not overlapped)'}[graphed.mode]
                                       if graphed is not None else 'eager: one Python thread issues every launch; bucket all-reduces launched '
                                                                   'from the autograd hooks (overlapped with backward)'),
+                       'step_mode': graphed.mode if graphed is not None else 'eager',
                        'rccl_ranks': world if multi else 0, 'per_rank_ms_per_step': per_rank_ms,
                        'gradient_buckets': len(reducer.buckets), 'allreduce_alone_us_per_step': comm_us},
             'timed_region': timed,

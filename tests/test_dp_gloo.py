@@ -419,3 +419,17 @@ def test_flatten_parameters_keeps_values_and_aliases_the_flat_buffers():
     model(x).sum().backward()                          # autograd still works on the re-seated parameters
     reducer.finish()
     assert all(p.grad is not None for p in model.parameters())
+
+
+def test_bench_dry_collectives_runs_the_n_rank_sequencing_without_a_gpu():
+    """`python bench.py --gpus 4 --dry-collectives`: 4 gloo ranks, both orderings of the multi-rank step, lock-step and equal to
+    big-batch SGD; one JSON line, exit code 0."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '4', '--dry-collectives'], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-400:]
+    report = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    assert report['ok'] and report['ranks'] == 4 and len(report['orderings']) == 2
+    assert all(v['ranks_in_lock_step'] and v['gradient_buckets'] > 1 for v in report['orderings'].values())
