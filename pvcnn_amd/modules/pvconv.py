@@ -26,25 +26,23 @@ class _VoxelConv3d(nn.Conv3d):
     """nn.Conv3d (same parameters, same state_dict keys) whose 3x3x3 / stride 1 / padding 1 case on the GPU runs this package's
     implicit-GEMM kernels (functional/conv3d.py: f16x2 on the fp16 matrix cores by default) instead of the vendor library."""
 
-    def forward(self, x):
-        fast = (x.is_cuda and getattr(native(), 'has_conv3d', False) and self.kernel_size == (3, 3, 3)
+    def _fast(self, x):
+        """The 3x3x3 / stride 1 / padding 1 cube case this package's implicit-GEMM kernels serve (fp32, or bf16 / fp16 under autocast)."""
+        return (x.is_cuda and getattr(native(), 'has_conv3d', False) and self.kernel_size == (3, 3, 3)
                 and self.stride == (1, 1, 1) and self.padding == (1, 1, 1) and self.dilation == (1, 1, 1)
                 and self.groups == 1 and self.padding_mode == 'zeros' and x.dim() == 5
                 and x.shape[2] == x.shape[3] == x.shape[4] and self.weight.dtype == torch.float32
                 and (x.dtype == torch.float32 or (torch.is_autocast_enabled() and x.dtype in (torch.bfloat16, torch.float16))))
-        if not fast:
+
+    def forward(self, x):
+        if not self._fast(x):
             return super().forward(x)            # other dtypes / shapes: the vendor library
         return voxel_conv3d(x, self.weight, self.bias, False, conv_nsplit())
 
     def forward_with_stats(self, x):
         """-> (y, stats_part) on the fast path: the epilogue also emits the per-channel partial sums the
         BatchNorm behind this convolution needs (functional.bnact.run_layers); else plain forward(x)."""
-        fast = (x.is_cuda and getattr(native(), 'has_conv3d', False) and self.kernel_size == (3, 3, 3)
-                and self.stride == (1, 1, 1) and self.padding == (1, 1, 1) and self.dilation == (1, 1, 1)
-                and self.groups == 1 and self.padding_mode == 'zeros' and x.dim() == 5
-                and x.shape[2] == x.shape[3] == x.shape[4] and self.weight.dtype == torch.float32
-                and (x.dtype == torch.float32 or (torch.is_autocast_enabled() and x.dtype in (torch.bfloat16, torch.float16))))
-        if not fast:
+        if not self._fast(x):
             return self.forward(x)
         return voxel_conv3d(x, self.weight, self.bias, True, conv_nsplit())
 

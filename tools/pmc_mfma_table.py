@@ -7,7 +7,12 @@ usage: pmc_mfma_table.py <set1.json> <set2.json> [min MFMAs per launch]
 Columns.  MFMA pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / (GUI / 8 x 1024 pipes): GRBM_GUI_ACTIVE is summed over the 8 XCDs, the chip has
 256 CUs x 4 SIMDs.  EFFECTIVE CLOCK = (GUI / 8) / launch duration of the same pass: what the chip clocked at under this kernel (2.4 GHz
 nominal) -- the part of a low busy figure that is the power envelope rather than the schedule.  busy at 2.4 GHz = busy x clock / 2.4:
-the utilisation against the chip's nominal peak (what `roofline_mfma.frac` prices)."""
+the utilisation against the chip's nominal peak (what `roofline_mfma.frac` prices).
+SHORT LAUNCHES (< 60 us): GRBM_GUI_ACTIVE also counts the cycles the chip is active around a dispatch (launch ramp, tail), which is a
+large share of a short launch -- (GUI / 8) / duration then reads 2.5-3.5 "GHz", above the 2.4 GHz the chip can clock.  Those rows are
+marked `n/a (short)` in the clock and busy-at-2.4-GHz columns and must not be cited; their busy-of-cycles column
+is still a ratio of two counters of the same pass and stands."""
+SHORT_US = 60.0
 import json
 import sys
 
@@ -29,6 +34,8 @@ for k, a in s1.items():
     rows.append((a['SQ_VALU_MFMA_BUSY_CYCLES'] * a['dispatches'], k, a, b, cyc, us, ghz, busy, wave))
 for _, k, a, b, cyc, us, ghz, busy, wave in sorted(rows, reverse=True):
     name = k.replace('void ', '').split('(')[0] + (' @' + k.split(' @grid=')[1] if ' @grid=' in k else '')
-    print(f"| `{name}` | {a['dispatches']} | {a['SQ_INSTS_MFMA'] / 1e6:.2f} M | {cyc / 1e3:.0f} k | {us:.1f} | **{ghz:.2f}** | **{busy:.2f}** | "
-          f"{busy * ghz / 2.4:.2f} | {a.get('SQ_LDS_BANK_CONFLICT', 0.0) / max(a['SQ_VALU_MFMA_BUSY_CYCLES'], 1.0):.3f} | "
+    short = us < SHORT_US or ghz > 2.45
+    print(f"| `{name}` | {a['dispatches']} | {a['SQ_INSTS_MFMA'] / 1e6:.2f} M | {cyc / 1e3:.0f} k | {us:.1f} | "
+          + ('n/a (short)' if short else f'**{ghz:.2f}**') + f" | **{busy:.2f}** | " + ('n/a (short)' if short else f'{busy * ghz / 2.4:.2f}') + " | "
+          f"{a.get('SQ_LDS_BANK_CONFLICT', 0.0) / max(a['SQ_VALU_MFMA_BUSY_CYCLES'], 1.0):.3f} | "
           f"{b.get('SQ_WAIT_INST_ANY', 0.0) / wave:.2f} | {b.get('SQ_ACTIVE_INST_ANY', 0.0) / wave:.2f} |")
