@@ -47,7 +47,7 @@ extern "C" {
 #define PVCNN_API
 #endif
 
-#define PVCNN_ABI_VERSION 10
+#define PVCNN_ABI_VERSION 11
 #define PVCNN_OK 0
 #define PVCNN_ERR_INVALID_ARGUMENT (-1)
 
@@ -261,7 +261,13 @@ PVCNN_API size_t pvcnn_conv3d_fwd_split_stats_parts(int B, int Co, int R, int ns
 PVCNN_API int pvcnn_conv3d_fwd_split_route(int B, int Ci, int Co, int R, int nsplit);
 PVCNN_API int pvcnn_absmax_bits(const float *x, size_t n, void *out, void *stream);
 PVCNN_API size_t pvcnn_absmax_tiles_count(int B, long L, int seg);      /* 1 + T words */
-PVCNN_API int pvcnn_absmax_tiles(const float *x, int B, int C, long L, int seg, void *out, void *stream);
+/* (ABI v11) `ticket`: NULL, or ONE zeroed 32-bit word in device memory that the call leaves zeroed.  With a ticket the global
+ * maximum out[0] is written by the workgroup of the table pass that finishes last (release / acquire at device scope) instead of a
+ * one-workgroup launch behind it -- a launch costs ~5 us on this chip whatever it does.  The word must not be shared with a launch
+ * that can run concurrently (another stream); launches on one stream may reuse it.  The same convention: `tickets` of
+ * pvcnn_bnact_bwd_strided (C words: the per-channel sums are finalised by the workgroup that writes a channel's last partial),
+ * `ticket` of pvcnn_concat_points. */
+PVCNN_API int pvcnn_absmax_tiles(const float *x, int B, int C, long L, int seg, void *out, void *ticket, void *stream);
 PVCNN_API int pvcnn_conv3d_fwd_split(const float *x, const void *wts, const float *bias, int B, int Ci, int Co, int R, int nsplit,
                            const void *x_absmax, int amax_seg /* 0 | R */, float *y, float *stats_part, void *stream);
 
@@ -328,6 +334,9 @@ PVCNN_API int pvcnn_pwconv_bwd_weight_f16(const float *x, const float *grad_y, c
  *      bwd), or -- amax_zeroed != 0 -- by the pvcnn_bn_finalize call that produced mean / rstd (its zero_words argument, the WHOLE
  *      buffer: on small position counts the pass splits the channels over several workgroups whose table entries meet by atomic
  *      maxima); with training == 0 and amax_zeroed == 0 a one-workgroup reduction of the table is launched behind the pass instead.
+ * tickets (pvcnn_bnact_bwd_strided, ABI v11; NULL, or C zeroed 32-bit words the call leaves zeroed -- see pvcnn_absmax_tiles): the
+ *      per-channel sums grad_gamma / grad_beta are combined by the workgroup that writes a channel's last partial (the same fp64
+ *      combine, the same bits) instead of a finalize launch between the two passes.
  * drop_seed / drop_p (pvcnn_bnact_fwd, pvcnn_bnact_bwd_strided; NULL / 0: off): the nn.Dropout(p) that follows the pair in the
  *      classifier heads (models/utils.py:15-36), fused: fwd writes y = keep ? act(bn(x)) / (1 - p) : 0 (and y's amax buffer of THAT
  *      tensor), bwd takes grad_y as the gradient of the dropped tensor.  keep(e) of element e is a pure function of (e, *drop_seed):
@@ -385,7 +394,7 @@ PVCNN_API int pvcnn_bnact_bwd_strided(const float *x, const float *grad_y, long 
                             const float *beta, const float *mean, const float *rstd, int B, int C, int S,
                             float slope, int training, float *grad_x, float *grad_gamma, float *grad_beta,
                             void *gx_amax, int amax_seg, void *workspace, size_t workspace_bytes, const void *drop_seed,
-                            float drop_p, void *stream);
+                            float drop_p, void *tickets, void *stream);
 /* The two halves of pvcnn_bnact_bwd_strided on their own, for callers that put something between them (PVConv's SE tail,
  * pvcnn_amd/modules/functional/bnact.py: the per-(cloud, channel) sums feed the excitation's backward before the apply pass runs).
  * partial_sums: part (C, B, slices) float pairs, slices = pvcnn_bnact_slices(S): per slice of row (b, c) the sums of g' and g' * xhat
@@ -491,7 +500,7 @@ PVCNN_API int pvcnn_trilinear_devox_bwd_strided(const float *grad_y, long grad_y
  * table of the classifier GEMM that consumes it.  nsrc <= 8 sources; source i has channels[i] channels, its clouds are bstrides[i]
  * elements apart and pstrides[i] is 1 (rows of N points) or 0 (one value per (cloud, channel), broadcast over the points). */
 PVCNN_API int pvcnn_concat_points(const float *const *srcs, const long *bstrides, const int *channels, const int *pstrides, int nsrc, int B,
-                        int N, float *out, void *out_amax, void *stream);
+                        int N, float *out, void *out_amax, void *ticket /* (ABI v11) see pvcnn_absmax_tiles; NULL: a reduce launch */, void *stream);
 
 /* ---- the optimizer update of the training step on flat buffers (csrc/optim.hip) ----------------------------------------------
  * replaces torch.optim.Adam's per-tensor update of train.py:96-119 (optimizer.step()) when the parameters share the flat layout of

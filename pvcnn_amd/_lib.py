@@ -16,7 +16,7 @@ import torch  # noqa: F401  (must be imported before the dlopen, see above)
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 LIB_PATH = os.path.join(_CSRC, 'libpvcnn_hip.so')
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _vp, _i, _f, _sz, _l = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_long
 
@@ -63,7 +63,7 @@ SIGNATURES = {
     'pvcnn_conv3d_fwd_split_route': (_i, [_i, _i, _i, _i, _i]),
     'pvcnn_absmax_bits': (_i, [_vp, _sz, _vp, _vp]),
     'pvcnn_absmax_tiles_count': (_sz, [_i, ctypes.c_long, _i]),
-    'pvcnn_absmax_tiles': (_i, [_vp, _i, _i, ctypes.c_long, _i, _vp, _vp]),
+    'pvcnn_absmax_tiles': (_i, [_vp, _i, _i, ctypes.c_long, _i, _vp, _vp, _vp]),
     'pvcnn_conv3d_bwd_weight_f16_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'pvcnn_conv3d_bwd_weight_f16': (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     'pvcnn_conv3d_fwd_split': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
@@ -110,8 +110,8 @@ SIGNATURES = {
     'pvcnn_bnact_partial_sums': (_i, [_vp, _vp, ctypes.c_long, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp]),
     'pvcnn_bnact_bwd_apply': (_i, [_vp, _vp, ctypes.c_long, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _i, _vp]),
     'pvcnn_bnact_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
-    'pvcnn_bnact_bwd_strided': (_i, [_vp, _vp, ctypes.c_long, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp, _f, _vp]),
-    'pvcnn_concat_points': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    'pvcnn_bnact_bwd_strided': (_i, [_vp, _vp, ctypes.c_long, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp, _f, _vp, _vp]),
+    'pvcnn_concat_points': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'pvcnn_adam_step': (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _vp, _i, _vp]),
     'pvcnn_trilinear_devox_bwd_strided': (_i, [_vp, ctypes.c_long, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
 }

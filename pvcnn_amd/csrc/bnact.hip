@@ -156,6 +156,17 @@ __global__ __launch_bounds__(256) void dropout_keep_mask_kernel(Drop d, long num
   if (e < numel) keep[e] = drop_factor1((size_t)e, (uint32_t)key, (uint32_t)(key >> 32), d.thr, 1.0f) != 0.0f;
 }
 
+// What bnact_bwd_finalize_kernel does, as the tail of the reduce kernel (tickets != NULL): the workgroup that writes the LAST partial of
+// channel c (one ticket word per channel; common.h: last_workgroup_done) combines that channel's partials -- the same fp64 loop and
+// shuffle tree over 64 lanes, so dgamma / dbeta are the same bits -- and every workgroup zeroes its share of grad_x's amax buffer.
+// Fifteen launches of ~5 us less per PVCNN step; the channels finish spread over the last sample's pass (sample-major traversal).
+struct BwdFold {
+  unsigned *tickets;     // C words, zero before and after the launch; NULL: the separate finalize kernel follows
+  float *dgamma, *dbeta;
+  uint32_t *zero_word;
+  long zero_count;
+};
+
 // grid = (slices, B, C): partial (sum g', sum g' * xhat),  g' = gy * act'(z),  z = scale*x + shift
 template <bool DROP = false>
 __global__ __launch_bounds__(kBnThreads) void bnact_bwd_reduce_kernel(const float *__restrict__ x, const float *__restrict__ gy,
@@ -164,7 +175,8 @@ __global__ __launch_bounds__(kBnThreads) void bnact_bwd_reduce_kernel(const floa
                                                                      const float *__restrict__ gamma,
                                                                      const float *__restrict__ beta, float slope, int C,
                                                                      int S, int slices, float2 *__restrict__ part,
-                                                                     long gy_bstride, Drop drop = Drop{nullptr, 0u, 1.0f}) {
+                                                                     long gy_bstride, Drop drop = Drop{nullptr, 0u, 1.0f},
+                                                                     BwdFold fold = BwdFold{nullptr, nullptr, nullptr, nullptr, 0L}) {
   __shared__ float sm[16];
   uint32_t k0 = 0u, k1 = 0u;
   if constexpr (DROP) { const unsigned long long key = *drop.key; k0 = (uint32_t)key; k1 = (uint32_t)(key >> 32); }
@@ -215,6 +227,21 @@ __global__ __launch_bounds__(kBnThreads) void bnact_bwd_reduce_kernel(const floa
   }
   block_sum2(s, q, sm);
   if (threadIdx.x == 0) part[((size_t)c * gridDim.y + b) * slices + sl] = make_float2(s, q);
+  if (fold.tickets == nullptr) return;                         // (uniform over the launch)
+  if (fold.zero_word != nullptr) {                             // arms grad_x's amax buffer for the apply pass (a later launch)
+    const long wgs = (long)gridDim.x * gridDim.y * gridDim.z;
+    const long me = blockIdx.x + (long)gridDim.x * (blockIdx.y + (long)gridDim.y * blockIdx.z);
+    for (long i = me * kBnThreads + threadIdx.x; i < fold.zero_count; i += wgs * kBnThreads) fold.zero_word[i] = 0u;
+  }
+  if (!last_workgroup_done(fold.tickets + c, (unsigned)(gridDim.x * gridDim.y))) return;
+  if (threadIdx.x < 64) {                                      // bnact_bwd_finalize_kernel's combine, operation for operation
+    const int nparts = (int)(gridDim.x * gridDim.y);
+    double ds = 0.0, dq = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 64) { const float2 p = part[(size_t)c * nparts + i]; ds += p.x; dq += p.y; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { ds += __shfl_xor(ds, d); dq += __shfl_xor(dq, d); }
+    if (threadIdx.x == 0) { fold.dbeta[c] = (float)ds; fold.dgamma[c] = (float)dq; }
+  }
 }
 
 // grid = C: dbeta = sum g', dgamma = sum g' xhat (fp64 combine)
@@ -589,7 +616,8 @@ extern "C" int pvcnn_bn_stats(const float *x, float *running_mean, float *runnin
 static int bnact_bwd_impl(const float *x, const float *grad_y, long gy_bstride, const float *gamma, const float *beta,
                           const float *mean, const float *rstd, int B, int C, int S, float slope, int training, float *grad_x,
                           float *grad_gamma, float *grad_beta, void *workspace, size_t workspace_bytes, void *stream,
-                          void *gx_amax = nullptr, int amax_seg = 0, const void *drop_seed = nullptr, float drop_p = 0.0f) {
+                          void *gx_amax = nullptr, int amax_seg = 0, const void *drop_seed = nullptr, float drop_p = 0.0f,
+                          void *tickets = nullptr) {
   PVCNN_REQUIRE(drop_p >= 0.0f && drop_p < 1.0f, "drop_p must be in [0, 1)");
   Drop drop{nullptr, 0u, 1.0f};
   const bool dropping = make_drop(drop_seed, drop_p, &drop);
@@ -603,16 +631,22 @@ static int bnact_bwd_impl(const float *x, const float *grad_y, long gy_bstride, 
   const int slices = ceil_div(S, kBnSlice);
   const dim3 grid(slices, B, C);
   float2 *part = static_cast<float2 *>(workspace);
+  const long zero_count = gx_amax ? 1 + (long)B * ceil_div(S, amax_seg) : 0L;
+  // tickets (C zeroed words, left zeroed): the finalize step is the tail of the reduce launch; NULL: a launch of its own
+  PVCNN_REQUIRE(!tickets || (reinterpret_cast<uintptr_t>(tickets) & 3) == 0, "tickets must be 4-byte aligned");
+  const BwdFold fold{static_cast<unsigned *>(tickets), grad_gamma, grad_beta, static_cast<uint32_t *>(gx_amax), zero_count};
   if (dropping)
     hipLaunchKernelGGL(bnact_bwd_reduce_kernel<true>, grid, dim3(kBnThreads), 0, s, x, grad_y, mean, rstd, gamma, beta, slope, C, S, slices, part,
-                       gy_bstride, drop);
+                       gy_bstride, drop, fold);
   else
     hipLaunchKernelGGL(bnact_bwd_reduce_kernel<false>, grid, dim3(kBnThreads), 0, s, x, grad_y, mean, rstd, gamma, beta, slope, C, S, slices, part,
-                       gy_bstride);
+                       gy_bstride, Drop{nullptr, 0u, 1.0f}, fold);
   if (int e = check_launch("bnact_bwd_reduce")) return e;
-  hipLaunchKernelGGL(bnact_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, part, B * slices, grad_gamma, grad_beta,
-                     static_cast<uint32_t *>(gx_amax), gx_amax ? 1 + (long)B * ceil_div(S, amax_seg) : 0L);
-  if (int e = check_launch("bnact_bwd_finalize")) return e;
+  if (tickets == nullptr) {
+    hipLaunchKernelGGL(bnact_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, part, B * slices, grad_gamma, grad_beta,
+                       static_cast<uint32_t *>(gx_amax), zero_count);
+    if (int e = check_launch("bnact_bwd_finalize")) return e;
+  }
   const float inv_count = (float)(1.0 / ((double)B * S));
   if (gx_amax != nullptr) {                                     // position-block-major pass that also emits grad_x's amax buffer
     const int nseg = ceil_div(S, amax_seg), spb = amax_seg >= 256 ? 1 : 256 / amax_seg;
@@ -646,9 +680,10 @@ extern "C" int pvcnn_bnact_bwd(const float *x, const float *grad_y, const float 
 extern "C" int pvcnn_bnact_bwd_strided(const float *x, const float *grad_y, long grad_y_batch_stride, const float *gamma,
                                        const float *beta, const float *mean, const float *rstd, int B, int C, int S, float slope,
                                        int training, float *grad_x, float *grad_gamma, float *grad_beta, void *gx_amax, int amax_seg,
-                                       void *workspace, size_t workspace_bytes, const void *drop_seed, float drop_p, void *stream) {
+                                       void *workspace, size_t workspace_bytes, const void *drop_seed, float drop_p, void *tickets,
+                                       void *stream) {
   return bnact_bwd_impl(x, grad_y, grad_y_batch_stride, gamma, beta, mean, rstd, B, C, S, slope, training, grad_x, grad_gamma,
-                        grad_beta, workspace, workspace_bytes, stream, gx_amax, amax_seg, drop_seed, drop_p);
+                        grad_beta, workspace, workspace_bytes, stream, gx_amax, amax_seg, drop_seed, drop_p, tickets);
 }
 
 extern "C" int pvcnn_bnact_slices(int S) { return S > 0 ? ceil_div(S, kBnSlice) : 0; }
@@ -704,7 +739,7 @@ struct CatSources {
 };
 
 __global__ __launch_bounds__(256) void concat_points_kernel(CatSources src, int N, int vec, float *__restrict__ out,
-                                                            uint32_t *__restrict__ amax) {
+                                                            uint32_t *__restrict__ amax, unsigned *__restrict__ ticket) {
   __shared__ uint32_t wave_max[4];
   const int b = blockIdx.y, p0 = blockIdx.x * 256;
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, pos = p0 + 4 * lane;
@@ -762,6 +797,8 @@ __global__ __launch_bounds__(256) void concat_points_kernel(CatSources src, int 
       if (gridDim.z > 1) { if (t != 0u) atomicMax(&amax[1 + (size_t)b * gridDim.x + blockIdx.x], t); }
       else amax[1 + (size_t)b * gridDim.x + blockIdx.x] = t;
     }
+    // amax[0] by the workgroup that finishes last (ticket != NULL) instead of a launch of its own (common.h: last_workgroup_done)
+    if (ticket != nullptr && last_workgroup_done(ticket, gridDim.x * gridDim.y * gridDim.z)) amax_table_max(amax, (long)gridDim.x * gridDim.y);
   }
 }
 }  // namespace pvcnn
@@ -770,7 +807,7 @@ __global__ __launch_bounds__(256) void concat_points_kernel(CatSources src, int 
 // bstrides[i] elements apart, pstrides[i] = 1 ((C_i, N) rows contiguous within a cloud) or 0 (one value per (cloud, channel), broadcast).
 // out_amax: NULL, or pvcnn_absmax_tiles_count(B, N, 256) words = the amax buffer of `out` with 256-point segments.
 extern "C" int pvcnn_concat_points(const float *const *srcs, const long *bstrides, const int *channels, const int *pstrides, int nsrc, int B,
-                                   int N, float *out, void *out_amax, void *stream) {
+                                   int N, float *out, void *out_amax, void *ticket, void *stream) {
   PVCNN_REQUIRE(srcs && bstrides && channels && pstrides && out && nsrc > 0 && nsrc <= kCatMaxSrc && B > 0 && N > 0, "bad argument");
   PVCNN_REQUIRE(B <= 65535, "batch > 65535");
   CatSources cs{};
@@ -792,8 +829,10 @@ extern "C" int pvcnn_concat_points(const float *const *srcs, const long *bstride
     hipError_t e = hipMemsetAsync(out_amax, 0, (1 + (size_t)B * blocks) * sizeof(uint32_t), s);
     if (e != hipSuccess) { set_error("concat_points: memset: %s", hipGetErrorString(e)); return (int)e; }
   }
-  hipLaunchKernelGGL(concat_points_kernel, dim3(blocks, B, groups), dim3(256), 0, s, cs, N, vec ? 1 : 0, out, static_cast<uint32_t *>(out_amax));
+  PVCNN_REQUIRE(!ticket || (reinterpret_cast<uintptr_t>(ticket) & 3) == 0, "ticket must be 4-byte aligned");
+  hipLaunchKernelGGL(concat_points_kernel, dim3(blocks, B, groups), dim3(256), 0, s, cs, N, vec ? 1 : 0, out, static_cast<uint32_t *>(out_amax),
+                     static_cast<unsigned *>(out_amax ? ticket : nullptr));
   if (int e = check_launch("concat_points")) return e;
-  if (out_amax != nullptr) return launch_amax_reduce(static_cast<uint32_t *>(out_amax), (long)B * blocks, s);
+  if (out_amax != nullptr && ticket == nullptr) return launch_amax_reduce(static_cast<uint32_t *>(out_amax), (long)B * blocks, s);
   return 0;
 }

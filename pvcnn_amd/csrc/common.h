@@ -45,6 +45,44 @@ static_assert(sizeof(SplitEntry) == 80, "ten 8-byte words");
 // drain while the next phase runs.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// "Last workgroup done": every workgroup that shares `ticket` calls this AFTER its global writes (all threads; contains
+// __syncthreads()).  Returns true -- in every thread -- in exactly one of them: the workgroup that took the last of `total` tickets,
+// with the other workgroups' writes visible to it (release fence before the ticket, acquire fence behind it, both at agent scope: on
+// gfx950 they write back / invalidate the XCD's L2, which is what makes data written behind ANOTHER XCD's L2 visible).  *ticket must
+// be 0 when the launch starts and is 0 again when it ends (the last workgroup resets it: graph replays and later launches reuse the
+// word).  This is how a tiny "finalize" kernel behind a reduction (~5 us of launch latency on this chip for microseconds of work)
+// becomes the tail of the reduction itself.
+__device__ __forceinline__ bool last_workgroup_done(unsigned *ticket, unsigned total) {
+  __shared__ int s_last_workgroup;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned t = atomicAdd(ticket, 1u);
+    s_last_workgroup = (t == total - 1u) ? 1 : 0;
+    if (t == total - 1u) atomicExch(ticket, 0u);
+  }
+  __syncthreads();
+  const bool last = s_last_workgroup != 0;
+  if (last) __threadfence();
+  return last;
+}
+
+// out[0] = max over the table out[1 .. T] of an amax buffer, by the calling workgroup (every thread calls; <= 1024 threads).  Used by
+// the workgroup that finishes last in the kernels that write the table (see last_workgroup_done).
+__device__ __forceinline__ void amax_table_max(uint32_t *out, long T) {
+  __shared__ uint32_t s_amax_red[16];
+  uint32_t m = 0;
+  for (long i = threadIdx.x; i < T; i += blockDim.x) m = max(m, out[1 + i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+  if ((threadIdx.x & 63) == 0) s_amax_red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < (int)((blockDim.x + 63) >> 6); ++w) m = max(m, s_amax_red[w]);
+    out[0] = m;
+  }
+}
+
 // Sum each of 16 per-lane values over the 32 lanes of a half-wave (lanes that differ in bits 0..4) with a
 // transposing butterfly: every step halves the number of values a lane carries (the lane keeps one half and
 // ships the other), so it takes 8+4+2+1+1 = 16 shuffles instead of 16*5.  Returns, in lane j, the total of

@@ -95,7 +95,7 @@ __host__ __device__ inline int amax_segs_per_block(int seg) { return seg >= kAma
 __device__ __forceinline__ uint32_t abs_bits(float v) { return __float_as_uint(fabsf(v)); }
 
 __global__ __launch_bounds__(256) void absmax_tiles_kernel(const float *__restrict__ x, int C, long L, int seg, int nseg, int vec,
-                                                           uint32_t *__restrict__ out) {
+                                                           uint32_t *__restrict__ out, unsigned *__restrict__ ticket) {
   __shared__ uint32_t seg_max[kAmaxBlock];
   const int spb = amax_segs_per_block(seg);
   const int b = blockIdx.y, s0 = blockIdx.x * spb;             // first segment of this workgroup
@@ -143,6 +143,11 @@ __global__ __launch_bounds__(256) void absmax_tiles_kernel(const float *__restri
   }
   __syncthreads();
   if (tid < spb && s0 + tid < nseg) out[1 + (size_t)b * nseg + s0 + tid] = seg_max[tid];
+  // the global maximum out[0]: by the workgroup that finishes LAST (ticket != NULL; common.h: last_workgroup_done) instead of a
+  // one-workgroup launch behind this one (absmax_tiles_reduce_kernel: ~5 us of launch latency, eleven times per PVCNN step)
+  if (ticket == nullptr) return;
+  if (!last_workgroup_done(ticket, gridDim.x * gridDim.y)) return;
+  amax_table_max(out, (long)gridDim.y * nseg);
 }
 
 // out[0] = max over the table out[1 .. T] (one workgroup; T is a few thousand words)
@@ -931,7 +936,7 @@ extern "C" size_t pvcnn_absmax_tiles_count(int B, long L, int seg) {
 }
 
 // x (B, C, L) -> amax buffer `out` (pvcnn_absmax_tiles_count(B, L, seg) uint32): [0] global, [1 + b * nseg + l / seg] per segment
-extern "C" int pvcnn_absmax_tiles(const float *x, int B, int C, long L, int seg, void *out, void *stream) {
+extern "C" int pvcnn_absmax_tiles(const float *x, int B, int C, long L, int seg, void *out, void *ticket, void *stream) {
   PVCNN_REQUIRE(out && B >= 0 && C >= 0 && L >= 0 && seg > 0, "bad argument");
   PVCNN_REQUIRE(B <= 65535, "batch > 65535");
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -946,9 +951,11 @@ extern "C" int pvcnn_absmax_tiles(const float *x, int B, int C, long L, int seg,
   PVCNN_REQUIRE(nseg <= 0x7fffffffL && (long)B * nseg <= 0x7fffffffL, "too many segments");
   const int spb = amax_segs_per_block(seg);
   const int vec = (L % 4 == 0) && (seg % 4 == 0) && aligned16(x);
-  hipLaunchKernelGGL(absmax_tiles_kernel, dim3((unsigned)((nseg + spb - 1) / spb), B), dim3(256), 0, s, x, C, L, seg, (int)nseg, vec, o);
+  PVCNN_REQUIRE(!ticket || (reinterpret_cast<uintptr_t>(ticket) & 3) == 0, "ticket must be 4-byte aligned");
+  hipLaunchKernelGGL(absmax_tiles_kernel, dim3((unsigned)((nseg + spb - 1) / spb), B), dim3(256), 0, s, x, C, L, seg, (int)nseg, vec, o,
+                     static_cast<unsigned *>(ticket));
   if (int rc = check_launch("absmax_tiles")) return rc;
-  return launch_amax_reduce(o, (long)B * nseg, s);
+  return ticket ? 0 : launch_amax_reduce(o, (long)B * nseg, s);
 }
 
 extern "C" int pvcnn_conv3d_weight_split(const float *w, int Co, int Ci, int for_bwd_data, int nsplit, void *wts, void *stream) {

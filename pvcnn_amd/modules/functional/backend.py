@@ -119,6 +119,28 @@ class HipBackend:
         """Caller-owned scratch for the deterministic scatters (torch's caching allocator makes this cheap)."""
         return torch.empty((max(int(nbytes), 16),), dtype=torch.uint8, device=device)
 
+    # ---- "last workgroup done" tickets (include/pvcnn_hip.h, ABI v11): zeroed words a reduction's launch leaves zeroed, so that its
+    # finalize step is the tail of the launch instead of a ~5 us launch of its own.  One persistent pool per device (a captured graph
+    # keeps the addresses); slices are handed out round robin -- launches on one stream never overlap, and PVCNN_FOLD_FINALIZE=0
+    # (read once per process) goes back to the separate finalize / reduce launches (A/B, and the tests that pin the two against each other)
+    fold_finalize = os.environ.get('PVCNN_FOLD_FINALIZE', '1') != '0'
+    _TICKET_POOL = 1 << 16
+
+    def _tickets(self, n, device):
+        """-> a zeroed int32 view of n words (every kernel that takes tickets leaves them zeroed), or None when folding is off."""
+        if not self.fold_finalize or n > self._TICKET_POOL:
+            return None
+        pools = self.__dict__.setdefault('_ticket_pools', {})
+        key = (device.type, device.index)
+        ent = pools.get(key)
+        if ent is None:
+            ent = pools[key] = [torch.zeros((self._TICKET_POOL,), dtype=torch.int32, device=device), 0]
+        if ent[1] + n > self._TICKET_POOL:
+            ent[1] = 0
+        view = ent[0][ent[1]:ent[1] + n]
+        ent[1] += (int(n) + 15) & ~15
+        return view
+
     # ---- sampling.cpp:6-41 ------------------------------------------------------------------
     def gather_features_forward(self, features, indices):
         _f32(features, 'features'); _i32(indices, 'indices')
@@ -545,8 +567,9 @@ class HipBackend:
         b, c, n = x.shape
         seg = int(seg)
         out = torch.empty((self.lib.pvcnn_absmax_tiles_count(b, n, seg),), dtype=torch.int32, device=x.device)
+        ticket = self._tickets(1, x.device)
         with _Launch(x) as s:
-            _lib.check(self.lib.pvcnn_absmax_tiles(_p(x), b, c, n, seg, _p(out), s), 'absmax_tiles')
+            _lib.check(self.lib.pvcnn_absmax_tiles(_p(x), b, c, n, seg, _p(out), _p(ticket) if ticket is not None else None, s), 'absmax_tiles')
         return out
 
     def conv_amax(self, x):
@@ -986,10 +1009,11 @@ class HipBackend:
         k = len(tensors)
         out = torch.empty((b, sum(chans), n), dtype=torch.float32, device=tensors[0].device)
         amax = self.amax_buffer(b, n, self.PW_AMAX_SEG, out.device) if want_amax else None
+        ticket = self._tickets(1, out.device) if want_amax else None
         with _Launch(out) as s:
             _lib.check(self.lib.pvcnn_concat_points((ctypes.c_void_p * k)(*ptrs), (ctypes.c_long * k)(*bstr), (ctypes.c_int * k)(*chans),
-                                                    (ctypes.c_int * k)(*pstr), k, b, n, _p(out), _p(amax) if want_amax else None, s),
-                       'concat_points')
+                                                    (ctypes.c_int * k)(*pstr), k, b, n, _p(out), _p(amax) if want_amax else None,
+                                                    _p(ticket) if ticket is not None else None, s), 'concat_points')
         return out, amax
 
     # ---- the two halves of bnact_backward on their own (PVConv's SE tail puts the excitation's backward between them) ----
@@ -1153,12 +1177,14 @@ class HipBackend:
         nul = ctypes.c_void_p(None)
         amax_seg = int(amax_seg)
         gx_amax = self.amax_buffer(b, s3, amax_seg, dev) if amax_seg > 0 else None
+        tickets = self._tickets(c, dev)                   # one word per channel: the reduce pass finalises its own sums
         with _Launch(x) as s:
             _lib.check(self.lib.pvcnn_bnact_bwd_strided(_p(x), _p(grad_y), gy_bstride, _p(gamma) if gamma is not None else nul,
                                                         _p(beta) if beta is not None else nul, _p(mean), _p(rstd), b, c, s3, float(slope),
                                                         int(bool(training)), _p(gx), _p(gg), _p(gb),
                                                         _p(gx_amax) if amax_seg > 0 else nul, amax_seg, _p(ws), ws.numel(),
-                                                        _p(drop[0]) if drop else nul, float(drop[1]) if drop else 0.0, s), 'bnact_backward')
+                                                        _p(drop[0]) if drop else nul, float(drop[1]) if drop else 0.0,
+                                                        _p(tickets) if tickets is not None else nul, s), 'bnact_backward')
         return (gx, gg, gb, gx_amax) if amax_seg > 0 else (gx, gg, gb)
 
 
