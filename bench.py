@@ -103,6 +103,10 @@ class KernelClock:
                                                                (a[0].shape[0], a[0].shape[1], a[0].shape[2], int(a[2]))),
         'trilinear_devoxelize_backward_plan': lambda a, out: ('trilinear_devoxelize_bwd_plan (counting sort, shared by the layers at this R)',
                                                               4 * a[0].shape[0] * 16 * a[0].shape[2], (a[0].shape[0], 0, a[0].shape[2], int(a[2]))),
+        # (round 5) both of the above from one launch chain, built when the first layer voxelizes a (coords, R): the bytes of the two
+        'pvconv_plans': lambda a, out: ('avg_voxelize_plan + trilinear_devoxelize_bwd_plan in ONE chain (shared by the layers at this R)',
+                                        4 * a[0].shape[0] * (4 * a[0].shape[2] + int(a[2]) ** 3) + 4 * a[0].shape[0] * 16 * a[0].shape[2],
+                                        (a[0].shape[0], 0, a[0].shape[2], int(a[2]))),
     })
 
     # MFMA-bound family: the Conv3d implicit-GEMM launches (forward and backward-data are the same kernel); the "bytes" slot

@@ -122,6 +122,16 @@ PVCNN_API size_t pvcnn_avg_voxelize_plan_bytes(int B, int N, int R);
 PVCNN_API size_t pvcnn_avg_voxelize_plan_scratch_bytes(int B, int N, int R);
 PVCNN_API int pvcnn_avg_voxelize_plan(const int32_t *coords, int B, int N, int R, int32_t *ind, int32_t *cnt, void *plan,
                             size_t plan_bytes, void *scratch, size_t scratch_bytes, void *stream);
+/* (ABI v11) Both plans of one PVConv geometry in ONE chain of three launches: vox_plan as pvcnn_avg_voxelize_plan(vox_coords)
+ * writes it (with ind / cnt), devox_bwd_plan as pvcnn_trilinear_devox_bwd_plan writes it from the (inds, wgts) that
+ * pvcnn_trilinear_devox_fwd(norm_coords) emits -- the corner entries are derived from norm_coords (B,3,N) with the same expressions
+ * (trilinear_devox.cu:41-75), so the plan exists before any layer has devoxelized.  The two sorts run side by side in each launch
+ * (each alone is a latency chain that leaves most of the chip idle).  Plan sizes: the *_plan_bytes queries above;
+ * scratch: pvcnn_pvconv_plans_scratch_bytes.  N > 0. */
+PVCNN_API size_t pvcnn_pvconv_plans_scratch_bytes(int B, int N, int R);
+PVCNN_API int pvcnn_pvconv_plans(const int32_t *vox_coords, const float *norm_coords, int B, int N, int R, int32_t *ind, int32_t *cnt,
+                                 void *vox_plan, size_t vox_plan_bytes, void *devox_bwd_plan, size_t devox_bwd_plan_bytes,
+                                 void *scratch, size_t scratch_bytes, void *stream);
 PVCNN_API int pvcnn_avg_voxelize_apply(const float *feat, const void *plan, size_t plan_bytes, int B, int C, int N, int R,
                              float *out, void *stream);
 PVCNN_API size_t pvcnn_trilinear_devox_bwd_plan_bytes(int B, int N, int R);

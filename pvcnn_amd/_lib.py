@@ -36,6 +36,8 @@ SIGNATURES = {
     'pvcnn_avg_voxelize_plan_scratch_bytes': (_sz, [_i, _i, _i]),
     'pvcnn_avg_voxelize_plan': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),
     'pvcnn_avg_voxelize_apply': (_i, [_vp, _vp, _sz, _i, _i, _i, _i, _vp, _vp]),
+    'pvcnn_pvconv_plans_scratch_bytes': (_sz, [_i, _i, _i]),
+    'pvcnn_pvconv_plans': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp, _sz, _vp, _sz, _vp]),
     'pvcnn_trilinear_devox_bwd_plan_bytes': (_sz, [_i, _i, _i]),
     'pvcnn_trilinear_devox_bwd_plan_scratch_bytes': (_sz, [_i, _i, _i]),
     'pvcnn_trilinear_devox_bwd_plan': (_i, [_vp, _vp, _i, _i, _i, _vp, _sz, _vp, _sz, _vp]),

@@ -136,6 +136,39 @@ struct TapEntries {
   __device__ __forceinline__ float weight(int b, int k, int j) const { return wgts[((size_t)b * NC + k) * J + j]; }
 };
 
+// The devoxelize-backward entries straight from the float grid coordinates (no saved (inds, wgts) planes yet: the plan can be built
+// together with the voxelize plan, before any layer has devoxelized).  Keys and weights are the expressions of
+// TrilinearFromCoords::pack / unpack (slab.h; trilinear_devox.cu:41-75) -- the bits the forward emits as inds / wgts -- so the plan is
+// the one pvcnn_trilinear_devox_bwd_plan builds from those planes.
+struct CoordTapEntries {
+  static constexpr bool kInvCountWeight = false;
+  static constexpr int kPlanes = 8;
+  const float *coords;   // (B,3,N) in [0, R-1]
+  int N, R, R2, L;
+  __device__ __forceinline__ int plane_len() const { return N; }
+  __device__ __forceinline__ int eid(int k, int j) const { return j * 8 + k; }
+  __device__ __forceinline__ int key(int b, int k, int j) const {
+    const float *c = coords + (size_t)b * 3 * N;
+    const float x = c[j], y = c[j + N], z = c[j + 2 * N];
+    const float xl = floorf(x), yl = floorf(y), zl = floorf(z);
+    const float xd1 = x - xl, yd1 = y - yl, zd1 = z - zl;
+    int v = (int)xl * R2 + (int)yl * R + (int)zl;
+    if ((k & 4) && xd1 > 0) v += R2;
+    if ((k & 2) && yd1 > 0) v += R;
+    if ((k & 1) && zd1 > 0) v += 1;
+    return min(max(v, 0), L - 1);
+  }
+  __device__ __forceinline__ int key_first(int b, int k, int j, bool) const { return key(b, k, j); }
+  __device__ __forceinline__ int src(int k, int j) const { return j; }
+  __device__ __forceinline__ float weight(int b, int k, int j) const {
+    const float *c = coords + (size_t)b * 3 * N;
+    const float x = c[j], y = c[j + N], z = c[j + 2 * N];
+    const float xd1 = x - floorf(x), yd1 = y - floorf(y), zd1 = z - floorf(z);
+    const float xd = (k & 4) ? xd1 : 1.0f - xd1, yd = (k & 2) ? yd1 : 1.0f - yd1, zd = (k & 1) ? zd1 : 1.0f - zd1;
+    return (xd * yd) * zd;                                   // w_ab * zd_c with w_ab = xd_a * yd_b, as unpack() rounds it
+  }
+};
+
 // plain index list: grouping bwd (E = M*U), gather bwd (E = M); weight 1.
 struct IndexEntries {
   static constexpr bool kInvCountWeight = false;
@@ -175,7 +208,7 @@ struct CsrSplit {
   int HP;    // LDS ints reserved for the fine histogram
 };
 
-inline CsrSplit csr_split(int B, int L, int E) {
+inline CsrSplit csr_split(int B, int L, int E, int wg_cap = 16) {
   CsrSplit sp{};
   sp.BS = 0;
   while (((long)kCsrCoarse << sp.BS) < L) ++sp.BS;
@@ -183,7 +216,7 @@ inline CsrSplit csr_split(int B, int L, int E) {
   sp.BPM = std::max(1, std::min(kCsrCoarse, kCsrMaxRange / BW));
   const int forced = ceil_div(ceil_div(L, BW), sp.BPM);          // ranges forced by the LDS bound alone
   // workgroups per cloud: the launch should fit the chip in one round (a workgroup takes most of a CU's LDS)
-  int PT = std::max(1, std::min(16, kNumCU / std::max(B, 1)));
+  int PT = std::max(1, std::min(wg_cap, kNumCU / std::max(B, 1)));
   PT = std::min(PT, std::max(1, L / 64));
   PT = std::max(PT, forced);
   const int P0 = PT - forced + 1;                                // entry-balanced ranges on top of the forced cuts
@@ -194,13 +227,12 @@ inline CsrSplit csr_split(int B, int L, int E) {
 }
 
 template <class EP>
-__global__ __launch_bounds__(kCsrThreads) void csr_prep_kernel(EP ep, int E, int L, CsrSplit sp, int32_t *__restrict__ cnt_out,
-                                                              int32_t *__restrict__ start,
-                                                              int32_t *__restrict__ tmp_g, int2 *__restrict__ ent) {
+__device__ __forceinline__ void csr_prep_body(const EP &ep, int E, int L, const CsrSplit &sp, int32_t *__restrict__ cnt_out,
+                                              int32_t *__restrict__ start, int32_t *__restrict__ tmp_g, int2 *__restrict__ ent,
+                                              int part, int b, int *csr_lds) {
   // LDS: coarse[256] | cpre[257] (+3 pad) | 32 wave totals | 4 range words | list_kj[kCsrList] |
   //      list_key[kCsrList] | tmp[kCsrList] | fine histogram (pad32 layout, sp.HP ints)
-  extern __shared__ __attribute__((aligned(16))) int csr_lds[];
-  const int part = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int tid = threadIdx.x;
   int *coarse = csr_lds;
   int *cpre = coarse + kCsrCoarse;               // exclusive prefix, cpre[256] = E
   int *wave_tot = cpre + kCsrCoarse + 4;
@@ -389,6 +421,29 @@ __global__ __launch_bounds__(kCsrThreads) void csr_prep_kernel(EP ep, int E, int
     }
 }
 
+template <class EP>
+__global__ __launch_bounds__(kCsrThreads) void csr_prep_kernel(EP ep, int E, int L, CsrSplit sp, int32_t *__restrict__ cnt_out,
+                                                              int32_t *__restrict__ start,
+                                                              int32_t *__restrict__ tmp_g, int2 *__restrict__ ent) {
+  extern __shared__ __attribute__((aligned(16))) int csr_lds[];
+  csr_prep_body(ep, E, L, sp, cnt_out, start, tmp_g, ent, (int)blockIdx.x, (int)blockIdx.y, csr_lds);
+}
+
+// TWO sorts of the same clouds in one launch (a PVConv geometry: the voxelize plan and the devoxelize-backward plan of one
+// (coords, R)): workgroups [0, P1) of a cloud run the first, [P1, P1 + P2) the second.  The two chains are latency chains of ~8
+// barrier phases each on L2-resident data and never fill the chip alone; side by side they cost the longer of the two.
+template <class EP1, class EP2>
+__global__ __launch_bounds__(kCsrThreads) void csr_prep_pair_kernel(EP1 ep1, int E1, CsrSplit sp1, int32_t *__restrict__ cnt1,
+                                                                   int32_t *__restrict__ start1, int32_t *__restrict__ tmp1,
+                                                                   int2 *__restrict__ ent1, EP2 ep2, int E2, CsrSplit sp2,
+                                                                   int32_t *__restrict__ start2, int32_t *__restrict__ tmp2,
+                                                                   int2 *__restrict__ ent2, int L) {
+  extern __shared__ __attribute__((aligned(16))) int csr_lds[];
+  const int p = (int)blockIdx.x;                             // (uniform per workgroup)
+  if (p < sp1.P) csr_prep_body(ep1, E1, L, sp1, cnt1, start1, tmp1, ent1, p, (int)blockIdx.y, csr_lds);
+  else           csr_prep_body(ep2, E2, L, sp2, static_cast<int32_t *>(nullptr), start2, tmp2, ent2, p - sp1.P, (int)blockIdx.y, csr_lds);
+}
+
 // ---------------------------------------------------------------------------------------------
 // segsum_kernel: grid = (ceil(C/G), B).  acc = acc + (w * src): product rounded, then added --
 // the reference's atomicAdd(dst, w * g) (no contraction; the library is built with
@@ -470,17 +525,16 @@ __global__ __launch_bounds__(THREADS) void segsum_kernel(const float *__restrict
 // lanes walk `ent` directly (the handful of groups at the head of a degenerate distribution).
 // A few microseconds; part of the plan (built once, reused by every apply and every channel slab).
 // ---------------------------------------------------------------------------------------------
-static __global__ __launch_bounds__(kTileThreads) void csr_order_kernel(const int32_t *__restrict__ start, const int2 *__restrict__ ent,
-                                                                        int L, int E, uint16_t *__restrict__ order,
-                                                                        int2 *__restrict__ seg, int32_t *__restrict__ gofs,
-                                                                        int2 *__restrict__ entw) {
+static __device__ __forceinline__ void csr_order_body(const int32_t *__restrict__ start, const int2 *__restrict__ ent, int L, int E,
+                                                      uint16_t *__restrict__ order, int2 *__restrict__ seg,
+                                                      int32_t *__restrict__ gofs, int2 *__restrict__ entw, int r, int b) {
   constexpr int kSlots = kTileTargets / kTileThreads, kGroups = kTileTargets / kWave;
   __shared__ int hist[256];
   __shared__ int wtot[4];
   __shared__ uint16_t l_lt[kTileTargets];
   __shared__ int2 l_seg[kTileTargets];
   __shared__ int gsz[kGroups];
-  const int r = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
   const int t0 = r * kTileTargets, nt = min(kTileTargets, L - t0);
   const int32_t *st = start + (size_t)b * start_stride(L) + t0;
   uint16_t *out = order + (size_t)b * order_stride(L) + t0;
@@ -555,12 +609,37 @@ static __global__ __launch_bounds__(kTileThreads) void csr_order_kernel(const in
   }
 }
 
-// grid = (order_stride(L) / 256, B), 256 threads: one wave per wave group copies the group's entries into the interleaved
-// layout (reads: each lane its own segment, once per plan; writes: 512 contiguous bytes per step).
-static __global__ __launch_bounds__(256) void csr_interleave_kernel(const int2 *__restrict__ ent, const int2 *__restrict__ seg,
-                                                                    const int32_t *__restrict__ gofs, int L, int E,
-                                                                    int2 *__restrict__ entw) {
-  const int b = blockIdx.y, pos = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+static __global__ __launch_bounds__(kTileThreads) void csr_order_kernel(const int32_t *__restrict__ start, const int2 *__restrict__ ent,
+                                                                        int L, int E, uint16_t *__restrict__ order,
+                                                                        int2 *__restrict__ seg, int32_t *__restrict__ gofs,
+                                                                        int2 *__restrict__ entw) {
+  csr_order_body(start, ent, L, E, order, seg, gofs, entw, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// the order / interleave steps of TWO plans over the same L targets in one launch each (see csr_prep_pair_kernel)
+struct CsrPlanRef {
+  const int32_t *start;
+  const int2 *ent;
+  uint16_t *order;
+  int2 *seg;
+  int32_t *gofs;
+  int2 *entw;
+  int E;
+};
+
+[[maybe_unused]] static __global__ __launch_bounds__(kTileThreads) void csr_order_pair_kernel(CsrPlanRef a, CsrPlanRef c, int L, int nr) {   // grid (2 nr, B)
+  const int r = (int)blockIdx.x;
+  const bool f = r < nr;                                     // (uniform; ONE inlined body: its LDS arrays exist once)
+  csr_order_body(f ? a.start : c.start, f ? a.ent : c.ent, L, f ? a.E : c.E, f ? a.order : c.order, f ? a.seg : c.seg,
+                 f ? a.gofs : c.gofs, f ? a.entw : c.entw, f ? r : r - nr, (int)blockIdx.y);
+}
+
+// one wave per wave group copies the group's entries into the interleaved layout (reads: each lane its own segment, once per
+// plan; writes: 512 contiguous bytes per step).
+static __device__ __forceinline__ void csr_interleave_body(const int2 *__restrict__ ent, const int2 *__restrict__ seg,
+                                                           const int32_t *__restrict__ gofs, int L, int E, int2 *__restrict__ entw,
+                                                           int blk, int b) {
+  const int pos = blk * 256 + threadIdx.x, lane = threadIdx.x & 63;
   const int ofs = gofs[(size_t)b * (order_stride(L) / kWave) + (pos >> 6)];
   if (ofs < 0) return;
   const int2 sg = seg[(size_t)b * order_stride(L) + pos];
@@ -573,6 +652,20 @@ static __global__ __launch_bounds__(256) void csr_interleave_kernel(const int2 *
     ew[(size_t)i * 64] = a; ew[(size_t)(i + 1) * 64] = c; ew[(size_t)(i + 2) * 64] = d; ew[(size_t)(i + 3) * 64] = f;
   }
   for (; i < n; ++i) ew[(size_t)i * 64] = en[i];
+}
+
+// grid = (order_stride(L) / 256, B), 256 threads
+static __global__ __launch_bounds__(256) void csr_interleave_kernel(const int2 *__restrict__ ent, const int2 *__restrict__ seg,
+                                                                    const int32_t *__restrict__ gofs, int L, int E,
+                                                                    int2 *__restrict__ entw) {
+  csr_interleave_body(ent, seg, gofs, L, E, entw, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+[[maybe_unused]] static __global__ __launch_bounds__(256) void csr_interleave_pair_kernel(CsrPlanRef a, CsrPlanRef c, int L, int nblk) {   // grid (2 nblk, B)
+  const int k = (int)blockIdx.x;
+  const bool f = k < nblk;
+  csr_interleave_body(f ? a.ent : c.ent, f ? a.seg : c.seg, f ? a.gofs : c.gofs, L, f ? a.E : c.E, f ? a.entw : c.entw, f ? k : k - nblk,
+                      (int)blockIdx.y);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -767,6 +860,42 @@ int launch_csr_prep(const EP &ep, int B, int L, long E_, int32_t *cnt_out, void 
                      pl.gofs, pl.entw);
   if (int e = check_launch(what)) return e;
   hipLaunchKernelGGL(csr_interleave_kernel, dim3(order_stride(L) / 256, B), dim3(256), 0, s, pl.ent, pl.seg, pl.gofs, L, E, pl.entw);
+  return check_launch(what);
+}
+
+// Step 1 for TWO scatters over the same L targets of the same clouds (a PVConv geometry: voxelize + devoxelize-backward of one
+// (coords, R)) in THREE launches instead of six: each step runs both plans side by side (see csr_prep_pair_kernel).
+template <class EP1, class EP2>
+int launch_csr_prep_pair(const EP1 &ep1, long E1_, int32_t *cnt1, void *plan1, size_t plan1_bytes, const EP2 &ep2, long E2_, void *plan2,
+                         size_t plan2_bytes, int B, int L, void *scratch, size_t scratch_bytes, hipStream_t s, const char *what) {
+  const int E1 = (int)E1_, E2 = (int)E2_;
+  if (B == 0) return 0;
+  const size_t s1 = csr_prep_scratch_bytes(B, E1), s2 = csr_prep_scratch_bytes(B, E2);
+  if (!plan1 || !plan2 || plan1_bytes < CsrPlan::bytes(B, L, E1) || plan2_bytes < CsrPlan::bytes(B, L, E2) || !aligned16(plan1) ||
+      !aligned16(plan2) || !scratch || !aligned16(scratch) || scratch_bytes < s1 + s2) {
+    set_error("%s: plans / scratch missing, misaligned or too small (%zu, %zu, %zu bytes needed)", what, CsrPlan::bytes(B, L, E1),
+              CsrPlan::bytes(B, L, E2), s1 + s2);
+    return PVCNN_ERR_INVALID_ARGUMENT;
+  }
+  CsrPlan p1, p2;
+  p1.carve(plan1, B, L, E1);
+  p2.carve(plan2, B, L, E2);
+  // the chip holds kNumCU / B prep workgroups per cloud in one round: a quarter for the light sort, the rest for the heavy one
+  const int total = std::max(2, std::min(16, kNumCU / std::max(B, 1)));
+  const int cap1 = std::max(1, total / 4);
+  const CsrSplit sp1 = csr_split(B, L, E1, cap1), sp2 = csr_split(B, L, E2, std::max(1, total - cap1));
+  const size_t prep_lds = ((size_t)kCsrCoarse * 2 + 4 + 32 + 4 + 3 * kCsrList + std::max(sp1.HP, sp2.HP)) * sizeof(int);
+  auto k = csr_prep_pair_kernel<EP1, EP2>;
+  if (int e = enable_big_lds(k, prep_lds)) { set_error("%s: LDS attribute: %d", what, e); return e; }
+  char *sc = static_cast<char *>(scratch);
+  hipLaunchKernelGGL(k, dim3(sp1.P + sp2.P, B), dim3(kCsrThreads), prep_lds, s, ep1, E1, sp1, cnt1, p1.start, reinterpret_cast<int32_t *>(sc),
+                     p1.ent, ep2, E2, sp2, p2.start, reinterpret_cast<int32_t *>(sc + s1), p2.ent, L);
+  if (int e = check_launch(what)) return e;
+  const CsrPlanRef r1{p1.start, p1.ent, p1.order, p1.seg, p1.gofs, p1.entw, E1}, r2{p2.start, p2.ent, p2.order, p2.seg, p2.gofs, p2.entw, E2};
+  const int nr = ceil_div(L, kTileTargets), nblk = order_stride(L) / 256;
+  hipLaunchKernelGGL(csr_order_pair_kernel, dim3(2 * nr, B), dim3(kTileThreads), 0, s, r1, r2, L, nr);
+  if (int e = check_launch(what)) return e;
+  hipLaunchKernelGGL(csr_interleave_pair_kernel, dim3(2 * nblk, B), dim3(256), 0, s, r1, r2, L, nblk);
   return check_launch(what);
 }
 

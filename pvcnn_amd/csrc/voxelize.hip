@@ -270,6 +270,31 @@ extern "C" int pvcnn_avg_voxelize_plan(const int32_t *coords, int B, int N, int 
                          "avg_voxelize_plan");
 }
 
+// (ABI v11) BOTH scatter plans of one PVConv geometry -- avg_voxelize's (from the integer voxel coordinates) and
+// trilinear_devoxelize backward's (from the float grid coordinates: the corner entries the forward will emit as inds / wgts) -- in one
+// chain of three launches instead of two chains of three.  Outputs exactly what pvcnn_avg_voxelize_plan and
+// pvcnn_trilinear_devox_bwd_plan write (the same plan bytes where a plan defines them, the same ind / cnt).
+extern "C" size_t pvcnn_pvconv_plans_scratch_bytes(int B, int N, int R) {
+  if (B <= 0 || N < 0 || R <= 0) return 0;
+  return csr_prep_scratch_bytes(B, N) + csr_prep_scratch_bytes(B, 8L * N);
+}
+
+extern "C" int pvcnn_pvconv_plans(const int32_t *vox_coords, const float *norm_coords, int B, int N, int R, int32_t *ind, int32_t *cnt,
+                                  void *vox_plan, size_t vox_plan_bytes, void *devox_bwd_plan, size_t devox_bwd_plan_bytes, void *scratch,
+                                  size_t scratch_bytes, void *stream) {
+  PVCNN_REQUIRE(B >= 0 && N > 0 && R > 0, "bad size");
+  PVCNN_REQUIRE((long)R * R * R <= 0x7fffffffL / 4, "resolution too large");
+  const int S = R * R * R;
+  if (B == 0) return 0;
+  PVCNN_REQUIRE(csr_supported(S, 8L * N), "grid too large for a plan: use the one-shot calls");
+  PVCNN_REQUIRE(cnt && ind && vox_coords && norm_coords, "null pointer");
+  PVCNN_REQUIRE(B <= 65535, "batch > 65535");
+  VoxelEntries e1{vox_coords, ind, N, R, S};
+  CoordTapEntries e2{norm_coords, N, R, R * R, S};
+  return launch_csr_prep_pair(e1, /*E1=*/N, cnt, vox_plan, vox_plan_bytes, e2, /*E2=*/8L * N, devox_bwd_plan, devox_bwd_plan_bytes, B, /*L=*/S,
+                              scratch, scratch_bytes, static_cast<hipStream_t>(stream), "pvconv_plans");
+}
+
 extern "C" int pvcnn_avg_voxelize_apply(const float *feat, const void *plan, size_t plan_bytes, int B, int C, int N, int R,
                                         float *out, void *stream) {
   PVCNN_REQUIRE(B >= 0 && C >= 0 && N >= 0 && R > 0, "negative size");

@@ -434,6 +434,34 @@ class HipBackend:
                                                         _p(scratch), scratch.numel(), s), 'avg_voxelize_plan')
         return vp
 
+    # PVCNN_PAIR_PLANS=0 (read once per process): the two plans of a PVConv geometry from their own chains (A/B; the pair is the default)
+    has_pvconv_plans = os.environ.get('PVCNN_PAIR_PLANS', '1') != '0'
+
+    def pvconv_plans(self, vox_coords, norm_coords, resolution):
+        """(vox_coords int32 (B,3,N), norm_coords float (B,3,N), R) -> (VoxelPlan, devoxelize-backward plan tensor): what
+        avg_voxelize_plan(vox_coords, R) and trilinear_devoxelize_backward_plan(inds, wgts, R) of the taps at norm_coords build, from ONE
+        chain of three launches (csrc/csr.h: launch_csr_prep_pair).  None when the grid is too large for a plan."""
+        _i32(vox_coords, 'vox_coords'); _f32(norm_coords, 'norm_coords')
+        _shape(vox_coords.dim() == 3 and vox_coords.shape[1] == 3 and tuple(norm_coords.shape) == tuple(vox_coords.shape),
+               'pvconv_plans: vox_coords / norm_coords (B,3,N) expected')
+        b, _, n = vox_coords.shape
+        r = int(resolution)
+        vbytes, dbytes = self.lib.pvcnn_avg_voxelize_plan_bytes(b, n, r), self.lib.pvcnn_trilinear_devox_bwd_plan_bytes(b, n, r)
+        if vbytes == 0 or dbytes == 0 or n == 0:
+            return None
+        dev = vox_coords.device
+        vp = self.VoxelPlan()
+        vp.r, vp.n, vp.b = r, n, b
+        vp.ind = torch.empty((b, n), dtype=torch.int32, device=dev)
+        vp.cnt = torch.empty((b, r * r * r), dtype=torch.int32, device=dev)
+        vp.plan = torch.empty((vbytes,), dtype=torch.uint8, device=dev)
+        dplan = torch.empty((dbytes,), dtype=torch.uint8, device=dev)
+        scratch = self._scratch(self.lib.pvcnn_pvconv_plans_scratch_bytes(b, n, r), dev)
+        with _Launch(vox_coords) as s:
+            _lib.check(self.lib.pvcnn_pvconv_plans(_p(vox_coords), _p(norm_coords), b, n, r, _p(vp.ind), _p(vp.cnt), _p(vp.plan), vp.plan.numel(),
+                                                   _p(dplan), dplan.numel(), _p(scratch), scratch.numel(), s), 'pvconv_plans')
+        return vp, dplan
+
     def avg_voxelize_apply(self, features, vp):
         """features (B,C,N) -> out (B,C,R^3) with the plan of avg_voxelize_plan (same B, N, R)."""
         _f32(features, 'features')

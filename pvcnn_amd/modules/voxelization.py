@@ -95,10 +95,35 @@ class Voxelization(nn.Module):
         be = native()
         if coords.is_cuda and coords.dtype == torch.float32 and coords.dim() == 3 and getattr(be, 'has_voxel_coords', False):
             norm_coords, vox_coords = self.grid_coordinates(coords)
+            # (training mode: the PVConv around this module devoxelizes with is_training = True and its backward scatters -- also when
+            #  the features themselves need no gradient: the voxel convolutions' weights do)
+            if getattr(be, 'has_pvconv_plans', False) and torch.is_grad_enabled() and self.training:
+                self._plan_pair(be, norm_coords, vox_coords)
         else:
             norm_coords = self.normalized_coords(coords)
             vox_coords = torch.round(norm_coords).to(torch.int32)
         return F.avg_voxelize(features, vox_coords, self.r), norm_coords
+
+    def _plan_pair(self, be, norm_coords, vox_coords):
+        """Training: the voxelize plan of (vox_coords, R) AND the devoxelize-backward plan of (norm_coords, R) -- the PVConv around this
+        module devoxelizes there (modules/pvconv.py:36) and its backward scatters through that plan -- from one launch chain
+        (backend.pvconv_plans) the first time a layer voxelizes these coordinates.  Both land where the functional layer looks for
+        them: the memo of functional.voxelization.AvgVoxelization and the CornerTaps holder of functional.devoxelization."""
+        from .functional import _cache
+        from .functional.devoxelization import CornerTaps
+        built = []
+
+        def make():
+            pair = be.pvconv_plans(vox_coords, norm_coords.contiguous(), self.r) if norm_coords.is_contiguous() and vox_coords.is_contiguous() else None
+            if pair is None:
+                return be.avg_voxelize_plan(vox_coords.contiguous(), self.r)
+            built.append(pair[1])
+            return pair[0]
+        _cache.memo(vox_coords, ('avg_voxelize_plan', self.r), make)
+        if built:
+            taps = CornerTaps.of(norm_coords, self.r)
+            if taps.plan is None:
+                taps.plan = built[0]
 
     def extra_repr(self):
         tail = f', normalized eps = {self.eps}' if self.normalize else ''

@@ -70,7 +70,7 @@ def test_layers_share_one_plan_and_one_set_of_taps(hip, oracle):
     be = seam._backend
     originals = {}
     for name in ('voxel_coords_tail', 'avg_voxelize_plan', 'avg_voxelize_apply', 'trilinear_devoxelize_backward_plan',
-                 'trilinear_devoxelize_backward_apply', 'trilinear_devoxelize_bnact_forward'):
+                 'trilinear_devoxelize_backward_apply', 'trilinear_devoxelize_bnact_forward', 'pvconv_plans'):
         orig = getattr(be, name)
         originals[name] = orig
 
@@ -105,9 +105,13 @@ def test_layers_share_one_plan_and_one_set_of_taps(hip, oracle):
         _cache.enabled = True
         for name in originals:
             delattr(be, name)
-    assert counts['voxel_coords_tail'] == 1 and counts['avg_voxelize_plan'] == 1 and counts['avg_voxelize_apply'] == 3
+    assert counts['voxel_coords_tail'] == 1 and counts['avg_voxelize_apply'] == 3
     assert counts['trilinear_devoxelize_bnact_forward/emit'] == 1 and counts['trilinear_devoxelize_bnact_forward'] == 2
-    assert counts['trilinear_devoxelize_backward_plan'] == 1 and counts['trilinear_devoxelize_backward_apply'] == 3
+    assert counts['trilinear_devoxelize_backward_apply'] == 3
+    if be.has_pvconv_plans:      # (round 5) both plans of the geometry from ONE chain, built when the first layer voxelizes
+        assert counts['pvconv_plans'] == 1 and 'avg_voxelize_plan' not in counts and 'trilinear_devoxelize_backward_plan' not in counts, counts
+    else:
+        assert counts['avg_voxelize_plan'] == 1 and counts['trilinear_devoxelize_backward_plan'] == 1, counts
     assert torch.equal(shared[0], separate[0]) and torch.equal(shared[1], separate[1])
     for a, b_ in zip(shared[2], separate[2]):
         assert torch.equal(a, b_)
@@ -182,3 +186,59 @@ def test_the_reference_seam_reuses_its_plan_and_a_mutated_tensor_invalidates_it(
             delattr(hip, name)
         if 'seam_plan_memo' in hip.__dict__:
             del hip.seam_plan_memo
+
+
+def _plan_regions(plan, b, l, e):
+    """The fully defined regions of an opaque plan buffer (csrc/csr.h: CsrPlan::carve): start, ent, order, seg, gofs -- everything but
+    the wave-interleaved entry copy, whose padding between wave groups is never written (compared through the apply instead)."""
+    a16 = lambda x: (x + 15) & ~15
+    start_stride, order_stride = (l + 1 + 3) & ~3, -(-l // 4096) * 4096
+    sizes = [b * start_stride * 4, b * e * 8, b * order_stride * 2, b * order_stride * 8, b * (order_stride // 64) * 4]
+    out, off = [], 0
+    for n in sizes:
+        out.append(plan[off:off + n])
+        off += a16(n)
+    return out
+
+
+@pytest.mark.parametrize('b,n,r', [(16, 4096, 16), (16, 4096, 32), (8, 8192, 32), (8, 1024, 8), (32, 1024, 12), (3, 1000, 12), (2, 37, 5), (1, 1, 2), (8, 2048, 16)])
+@pytest.mark.parametrize('kind', ['cube', 'surface'])
+def test_both_plans_of_a_geometry_from_one_chain(hip, oracle, gen, b, n, r, kind):
+    """pvcnn_pvconv_plans (ABI v11): the voxelize plan and the devoxelize-backward plan of one (coords, R) from one chain of three
+    launches -- the latter from the float coordinates instead of saved (inds, wgts).  Same ind / cnt, the same bytes in every defined
+    region of both plan buffers as the two separate chains write, and applies that equal the oracle."""
+    norm, vox = _inputs(gen, b, n, r, kind)
+    norm_d, vox_d = norm.to(DEV), vox.to(DEV)
+    pair = hip.pvconv_plans(vox_d, norm_d, r)
+    assert pair is not None
+    vp, dplan = pair
+    want_v = hip.avg_voxelize_plan(vox_d, r)
+    _, inds, wgts = hip.trilinear_devoxelize_forward(r, True, norm_d, torch.zeros(b, 1, r ** 3, device=DEV))
+    want_d = hip.trilinear_devoxelize_backward_plan(inds, wgts, r)
+    assert torch.equal(vp.ind, want_v.ind) and torch.equal(vp.cnt, want_v.cnt)
+    for got, want, e, what in ((vp.plan, want_v.plan, n, 'voxelize'), (dplan, want_d, 8 * n, 'devoxelize backward')):
+        assert got.numel() == want.numel()
+        for i, (x, y) in enumerate(zip(_plan_regions(got, b, r ** 3, e), _plan_regions(want, b, r ** 3, e))):
+            assert torch.equal(x, y), (what, ('start', 'ent', 'order', 'seg', 'gofs')[i])
+    for c in (1, 9, 64):
+        if b * c * max(n, r ** 3) > 40e6:
+            continue
+        feat = torch.randn(b, c, n, generator=gen)
+        assert torch.equal(hip.avg_voxelize_apply(feat.to(DEV), vp).cpu(), oracle.avg_voxelize_forward(feat, vox, r)[0]), c
+        assert torch.equal(hip.trilinear_devoxelize_backward_apply(feat.to(DEV), dplan, r).cpu(),
+                           oracle.trilinear_devoxelize_backward(feat, inds.cpu(), wgts.cpu(), r)), c
+
+
+def test_pair_plans_on_boundary_and_integral_coordinates(hip, oracle, gen):
+    """Coordinates ON grid points (fractions exactly 0: the hi corners collapse onto the lo ones with weight 0), at 0 and at R - 1, and a
+    cloud inside ONE voxel: the coordinate-derived entries are the emitted (inds, wgts), duplicates and zero weights included."""
+    from conftest import grid_coords
+    b, n, r = 4, 2048, 16
+    norm = grid_coords(gen, b, n, r)
+    norm[3] = 7.25
+    vox = torch.round(norm).to(torch.int32)
+    vp, dplan = hip.pvconv_plans(vox.to(DEV).contiguous(), norm.to(DEV), r)
+    _, inds, wgts = oracle.trilinear_devoxelize_forward(r, True, norm, torch.zeros(b, 1, r ** 3))
+    feat = torch.randn(b, 5, n, generator=gen)
+    assert torch.equal(hip.trilinear_devoxelize_backward_apply(feat.to(DEV), dplan, r).cpu(), oracle.trilinear_devoxelize_backward(feat, inds, wgts, r))
+    assert torch.equal(hip.avg_voxelize_apply(feat.to(DEV), vp).cpu(), oracle.avg_voxelize_forward(feat, vox, r)[0])
