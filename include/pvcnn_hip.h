@@ -512,6 +512,24 @@ PVCNN_API int pvcnn_trilinear_devox_bwd_strided(const float *grad_y, long grad_y
 PVCNN_API int pvcnn_concat_points(const float *const *srcs, const long *bstrides, const int *channels, const int *pstrides, int nsrc, int B,
                         int N, float *out, void *out_amax, void *ticket /* (ABI v11) see pvcnn_absmax_tiles; NULL: a reduce launch */, void *stream);
 
+/* ---- (ABI v11) Linear + BatchNorm1d + ReLU on a handful of rows: the `_linear_bn_relu` blocks of models/utils.py:11-12 -- the cloud
+ * descriptor head of models/s3dis/pvcnn.py:22-25 ((B, 1024) -> 256 -> 128) and the dense heads of the Frustum nets -- where B is the
+ * batch (16 ... 32 rows).  With so few rows the workgroup that owns an output channel owns that channel's whole batch, so the layer is
+ * ONE launch forward (dot products, batch statistics, running statistics + num_batches_tracked, normalise, ReLU; torch modules: 5) and
+ * ONE launch backward for everything but grad_x (ReLU mask, the BatchNorm backward, grad_z and the four parameter gradients; torch: 6
+ * with the two GEMMs); grad_x = grad_z (rows, Cout) . weight (Cout, Cin) is left to the caller's GEMM.
+ * x (rows, Cin), weight (Cout, Cin), z / y / grad_y / grad_z (rows, Cout) row-major fp32; bias / gamma / beta may be NULL;
+ * running_mean / running_var NULL = not tracked; num_batches_tracked: NULL or one int64 in device memory (incremented).
+ * z (the Linear's output) and mean / rstd are what backward needs.  Training mode only (batch statistics); 2 <= rows <= 64 and
+ * rows * Cin * 4 bytes <= 144 KiB: ask pvcnn_dense_bn_relu_supported. */
+PVCNN_API int pvcnn_dense_bn_relu_supported(int rows, int Cin, int Cout);
+PVCNN_API int pvcnn_dense_bn_relu_fwd(const float *x, const float *weight, const float *bias, const float *gamma, const float *beta,
+                                      float *running_mean, float *running_var, void *num_batches_tracked, int rows, int Cin, int Cout,
+                                      float eps, float momentum, float *z, float *y, float *mean, float *rstd, void *stream);
+PVCNN_API int pvcnn_dense_bn_relu_bwd(const float *x, const float *grad_y, const float *z, const float *mean, const float *rstd,
+                                      const float *gamma, const float *beta, int rows, int Cin, int Cout, float *grad_z,
+                                      float *grad_weight, float *grad_bias, float *grad_gamma, float *grad_beta, void *stream);
+
 /* ---- the optimizer update of the training step on flat buffers (csrc/optim.hip) ----------------------------------------------
  * replaces torch.optim.Adam's per-tensor update of train.py:96-119 (optimizer.step()) when the parameters share the flat layout of
  * the gradient buckets (pvcnn_amd/dp.py): p, m (exp_avg), v (exp_avg_sq) updated in place, g read; arithmetic of torch.optim.Adam

@@ -114,6 +114,9 @@ SIGNATURES = {
     'pvcnn_bnact_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     'pvcnn_bnact_bwd_strided': (_i, [_vp, _vp, ctypes.c_long, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp, _f, _vp, _vp]),
     'pvcnn_concat_points': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    'pvcnn_dense_bn_relu_supported': (_i, [_i, _i, _i]),
+    'pvcnn_dense_bn_relu_fwd': (_i, [_vp] * 8 + [_i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    'pvcnn_dense_bn_relu_bwd': (_i, [_vp] * 7 + [_i, _i, _i] + [_vp] * 6),
     'pvcnn_adam_step': (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _vp, _i, _vp]),
     'pvcnn_trilinear_devox_bwd_strided': (_i, [_vp, ctypes.c_long, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
 }

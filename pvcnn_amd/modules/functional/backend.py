@@ -1047,6 +1047,49 @@ class HipBackend:
     # ---- the two halves of bnact_backward on their own (PVConv's SE tail puts the excitation's backward between them) ----
     has_bnact_split_bwd = True
 
+    # ---- Linear + BatchNorm1d + ReLU on a handful of rows (models/utils.py:11-12: the cloud-descriptor heads), csrc/dense.hip ----
+    has_dense_bn_relu = True
+
+    def dense_bn_relu_supported(self, rows, cin, cout):
+        return bool(self.lib.pvcnn_dense_bn_relu_supported(int(rows), int(cin), int(cout)))
+
+    def dense_bn_relu_forward(self, x, weight, bias, gamma, beta, running_mean, running_var, counter, eps, momentum):
+        """x (rows, Cin) -> (y (rows, Cout), z, mean, rstd): y = relu(batch_norm(x W^T + bias)) with batch statistics in ONE launch;
+        running statistics / num_batches_tracked updated in place (None: not tracked)."""
+        _f32(x, 'x'); _f32(weight, 'weight')
+        _shape(x.dim() == 2 and weight.dim() == 2 and weight.shape[1] == x.shape[1], 'dense_bn_relu: x (rows, Cin), weight (Cout, Cin) expected')
+        rows, cin = x.shape
+        cout = weight.shape[0]
+        dev = x.device
+        z = torch.empty((rows, cout), dtype=torch.float32, device=dev)
+        y = torch.empty((rows, cout), dtype=torch.float32, device=dev)
+        mean = torch.empty((cout,), dtype=torch.float32, device=dev)
+        rstd = torch.empty((cout,), dtype=torch.float32, device=dev)
+        opt = lambda t: _p(t) if t is not None else ctypes.c_void_p(None)
+        with _Launch(x) as s:
+            _lib.check(self.lib.pvcnn_dense_bn_relu_fwd(_p(x), _p(weight), opt(bias), opt(gamma), opt(beta), opt(running_mean), opt(running_var),
+                                                        opt(counter), rows, cin, cout, float(eps), float(momentum), _p(z), _p(y), _p(mean),
+                                                        _p(rstd), s), 'dense_bn_relu_forward')
+        return y, z, mean, rstd
+
+    def dense_bn_relu_backward(self, x, grad_y, z, mean, rstd, gamma, beta, out_w=None, out_b=None, out_gamma=None, out_beta=None):
+        """-> (grad_z (rows, Cout), grad_weight (Cout, Cin), grad_bias, grad_gamma, grad_beta) in ONE launch (grad_x = grad_z @ weight is
+        the caller's GEMM).  out_*: where to write the parameter gradients (slots of a flat gradient bucket), else fresh tensors."""
+        _f32(x, 'x'); _f32(grad_y, 'grad_y')
+        rows, cin = x.shape
+        cout = z.shape[1]
+        dev = x.device
+        gz = torch.empty((rows, cout), dtype=torch.float32, device=dev)
+        gw = self._grad_out(out_w, (cout, cin), dev)
+        gb = self._grad_out(out_b, (cout,), dev)
+        gg = self._grad_out(out_gamma, (cout,), dev)
+        gbeta = self._grad_out(out_beta, (cout,), dev)
+        opt = lambda t: _p(t) if t is not None else ctypes.c_void_p(None)
+        with _Launch(x) as s:
+            _lib.check(self.lib.pvcnn_dense_bn_relu_bwd(_p(x), _p(grad_y), _p(z), _p(mean), _p(rstd), opt(gamma), opt(beta), rows, cin, cout,
+                                                        _p(gz), _p(gw), _p(gb), _p(gg), _p(gbeta), s), 'dense_bn_relu_backward')
+        return gz, gw, gb, gg, gbeta
+
     # ---- max over the neighbours of a centre (modules/pointnet.py:85) ------------------------------------------------
     has_neighbor_max = True
 

@@ -21,6 +21,7 @@ import torch.nn as nn
 
 from .modules import PVConv, PointNetAModule, PointNetFPModule, PointNetSAModule, SharedMLP
 from .modules.functional.bnact import emit_row_max, run_layers
+from .modules.functional.dense import run_dense
 
 SEED = 1588147245
 
@@ -236,7 +237,7 @@ class PVCNN(nn.Module):
                 feats, _ = stage((feats, coords))
             taps.append(feats)
         taps[-1], pooled = tap_and_pool(feats)             # the last stage's features: a tap AND the global max pool
-        cloud = self.cloud_features(pooled)
+        cloud = run_dense(self.cloud_features, pooled)    # (Linear + BatchNorm1d + ReLU on 16 rows: one launch per block, csrc/dense.hip)
         # (expand, not repeat: torch.cat reads the broadcast view -- the repeated (B,128,N) tensor is never written on its own)
         taps.append(cloud.unsqueeze(-1).expand(-1, -1, coords.size(-1)))
         return _classify(self.classifier, concat_points(taps))
@@ -416,7 +417,7 @@ class _CloudRegressor(nn.Module):
         up = lambda t: t.float() if t.dtype in (torch.bfloat16, torch.float16) else t
         joined = torch.cat([up(desc), up(inputs['one_hot_vectors'])], dim=1)
         with torch.autocast(joined.device.type, enabled=False):
-            return getattr(self, self._head_attr)(joined)
+            return run_dense(getattr(self, self._head_attr), joined)     # (the Linear + BatchNorm1d + ReLU blocks: one launch each)
 
 
 class FrustumPVCNNE(nn.Module):
