@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/r05b; mkdir -p $O
 cd $R
 export PVCNN_PARITY_DUMP=$O/parity
-timeout 900 python -m pytest tests/test_gpu_fold.py tests/test_gpu_plans.py tests/test_gpu_reference_composition.py tests/test_gpu_optim.py tests/test_gpu_bnact.py tests/test_golden.py \
+timeout 900 python -m pytest tests/test_gpu_dense.py tests/test_gpu_fold.py tests/test_gpu_plans.py tests/test_gpu_reference_composition.py tests/test_gpu_optim.py tests/test_gpu_bnact.py tests/test_golden.py \
   -q -m gpu -p no:cacheprovider -s > $O/new_tests.log 2>&1
 echo "new tests: $(grep -E 'passed|failed' $O/new_tests.log | tail -1)"
 grep -E "^FAILED|^ERROR|^\[reference composition\]" $O/new_tests.log | cut -c1-600 | head -30
