@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void dropout_keep_mask_kernel(Drop d, long num
 }
 
 // What bnact_bwd_finalize_kernel does, as the tail of the reduce kernel (tickets != NULL): the workgroup that writes the LAST partial of
-// channel c (one ticket word per channel; common.h: last_workgroup_done) combines that channel's partials -- the same fp64 loop and
+// channel c (one ticket word per channel; common.h: ticket_take) combines that channel's partials -- the same fp64 loop and
 // shuffle tree over 64 lanes, so dgamma / dbeta are the same bits -- and every workgroup zeroes its share of grad_x's amax buffer.
 // Fifteen launches of ~5 us less per PVCNN step; the channels finish spread over the last sample's pass (sample-major traversal).
 struct BwdFold {
@@ -226,18 +226,26 @@ __global__ __launch_bounds__(kBnThreads) void bnact_bwd_reduce_kernel(const floa
     }
   }
   block_sum2(s, q, sm);
-  if (threadIdx.x == 0) part[((size_t)c * gridDim.y + b) * slices + sl] = make_float2(s, q);
-  if (fold.tickets == nullptr) return;                         // (uniform over the launch)
+  float2 *mine = part + ((size_t)c * gridDim.y + b) * slices + sl;
+  if (fold.tickets == nullptr) {                               // (uniform over the launch)
+    if (threadIdx.x == 0) *mine = make_float2(s, q);
+    return;
+  }
+  if (threadIdx.x == 0)                                        // published: the workgroup that takes the channel's last ticket reads it
+    publish64(reinterpret_cast<unsigned long long *>(mine), ((unsigned long long)__float_as_uint(q) << 32) | __float_as_uint(s));
   if (fold.zero_word != nullptr) {                             // arms grad_x's amax buffer for the apply pass (a later launch)
     const long wgs = (long)gridDim.x * gridDim.y * gridDim.z;
     const long me = blockIdx.x + (long)gridDim.x * (blockIdx.y + (long)gridDim.y * blockIdx.z);
     for (long i = me * kBnThreads + threadIdx.x; i < fold.zero_count; i += wgs * kBnThreads) fold.zero_word[i] = 0u;
   }
-  if (!last_workgroup_done(fold.tickets + c, (unsigned)(gridDim.x * gridDim.y))) return;
+  if (!ticket_take(fold.tickets + c, (unsigned)(gridDim.x * gridDim.y))) return;
   if (threadIdx.x < 64) {                                      // bnact_bwd_finalize_kernel's combine, operation for operation
     const int nparts = (int)(gridDim.x * gridDim.y);
     double ds = 0.0, dq = 0.0;
-    for (int i = threadIdx.x; i < nparts; i += 64) { const float2 p = part[(size_t)c * nparts + i]; ds += p.x; dq += p.y; }
+    for (int i = threadIdx.x; i < nparts; i += 64) {
+      const unsigned long long w = peek64(reinterpret_cast<const unsigned long long *>(part + (size_t)c * nparts + i));
+      ds += __uint_as_float((uint32_t)w); dq += __uint_as_float((uint32_t)(w >> 32));
+    }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { ds += __shfl_xor(ds, d); dq += __shfl_xor(dq, d); }
     if (threadIdx.x == 0) { fold.dbeta[c] = (float)ds; fold.dgamma[c] = (float)dq; }
@@ -794,11 +802,15 @@ __global__ __launch_bounds__(256) void concat_points_kernel(CatSources src, int 
     lds_barrier();
     if (tid == 0) {
       const uint32_t t = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
-      if (gridDim.z > 1) { if (t != 0u) atomicMax(&amax[1 + (size_t)b * gridDim.x + blockIdx.x], t); }
-      else amax[1 + (size_t)b * gridDim.x + blockIdx.x] = t;
+      uint32_t *slot = &amax[1 + (size_t)b * gridDim.x + blockIdx.x];
+      if (gridDim.z > 1) {                                   // (a returning atomic when a ticket follows: it has been performed)
+        if (ticket != nullptr) { const uint32_t old = atomicMax(slot, t); asm volatile("" ::"v"(old) : "memory"); }
+        else if (t != 0u) atomicMax(slot, t);
+      } else if (ticket != nullptr) publish32(slot, t);
+      else *slot = t;
     }
-    // amax[0] by the workgroup that finishes last (ticket != NULL) instead of a launch of its own (common.h: last_workgroup_done)
-    if (ticket != nullptr && last_workgroup_done(ticket, gridDim.x * gridDim.y * gridDim.z)) amax_table_max(amax, (long)gridDim.x * gridDim.y);
+    // amax[0] by the workgroup that takes the last ticket (ticket != NULL) instead of a launch of its own (common.h: ticket_take)
+    if (ticket != nullptr && ticket_take(ticket, gridDim.x * gridDim.y * gridDim.z)) amax_table_max(amax, (long)gridDim.x * gridDim.y);
   }
 }
 }  // namespace pvcnn

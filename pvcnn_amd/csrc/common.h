@@ -45,34 +45,47 @@ static_assert(sizeof(SplitEntry) == 80, "ten 8-byte words");
 // drain while the next phase runs.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// "Last workgroup done": every workgroup that shares `ticket` calls this AFTER its global writes (all threads; contains
-// __syncthreads()).  Returns true -- in every thread -- in exactly one of them: the workgroup that took the last of `total` tickets,
-// with the other workgroups' writes visible to it (release fence before the ticket, acquire fence behind it, both at agent scope: on
-// gfx950 they write back / invalidate the XCD's L2, which is what makes data written behind ANOTHER XCD's L2 visible).  *ticket must
-// be 0 when the launch starts and is 0 again when it ends (the last workgroup resets it: graph replays and later launches reuse the
-// word).  This is how a tiny "finalize" kernel behind a reduction (~5 us of launch latency on this chip for microseconds of work)
-// becomes the tail of the reduction itself.
-__device__ __forceinline__ bool last_workgroup_done(unsigned *ticket, unsigned total) {
+// "Last workgroup done" WITHOUT fences.  A workgroup PUBLISHES the few words the finalize step needs with returning device-scope
+// atomics (publish32 / publish64: an exchange executes at the level where all XCDs meet and its return says it has), then takes a
+// ticket; the workgroup that takes the last of `total` tickets reads the published words with device-scope atomic loads (peek32 /
+// peek64: they do not hit in this XCD's L2) and finishes the job.  No __threadfence(): on gfx950 an agent-scope release fence writes
+// back the XCD's whole L2 -- measured (profiles/ab/r05c_last_workgroup_fences.md): with one fence per workgroup the folded kernels of a
+// PVCNN step (~100 k workgroups) cost 6.3 ms MORE than the ~26 launches of ~5 us they replaced.  *ticket must be 0 when the launch starts and is 0
+// again when it ends (the last workgroup resets it: graph replays and later launches reuse the word).
+// ticket_take: every workgroup, AFTER its published words have returned; contains __syncthreads(); true in every thread of exactly one
+// workgroup.
+__device__ __forceinline__ void publish32(uint32_t *p, uint32_t v) {
+  const uint32_t old = atomicExch(p, v);
+  asm volatile("" ::"v"(old) : "memory");                   // the exchange has returned (performed) before anything below is issued
+}
+__device__ __forceinline__ void publish64(unsigned long long *p, unsigned long long v) {
+  const unsigned long long old = atomicExch(p, v);
+  asm volatile("" ::"v"(old) : "memory");
+}
+__device__ __forceinline__ uint32_t peek32(const uint32_t *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long peek64(const unsigned long long *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool ticket_take(unsigned *ticket, unsigned total) {
   __shared__ int s_last_workgroup;
-  __threadfence();
-  __syncthreads();
+  __syncthreads();                                           // every thread's publishes have returned
   if (threadIdx.x == 0) {
     const unsigned t = atomicAdd(ticket, 1u);
     s_last_workgroup = (t == total - 1u) ? 1 : 0;
     if (t == total - 1u) atomicExch(ticket, 0u);
   }
   __syncthreads();
-  const bool last = s_last_workgroup != 0;
-  if (last) __threadfence();
-  return last;
+  return s_last_workgroup != 0;
 }
 
 // out[0] = max over the table out[1 .. T] of an amax buffer, by the calling workgroup (every thread calls; <= 1024 threads).  Used by
-// the workgroup that finishes last in the kernels that write the table (see last_workgroup_done).
+// the workgroup that takes the last ticket in the kernels that PUBLISH the table (see ticket_take): the entries are peeked.
 __device__ __forceinline__ void amax_table_max(uint32_t *out, long T) {
   __shared__ uint32_t s_amax_red[16];
   uint32_t m = 0;
-  for (long i = threadIdx.x; i < T; i += blockDim.x) m = max(m, out[1 + i]);
+  for (long i = threadIdx.x; i < T; i += blockDim.x) m = max(m, peek32(out + 1 + i));
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
   if ((threadIdx.x & 63) == 0) s_amax_red[threadIdx.x >> 6] = m;

@@ -142,11 +142,15 @@ __global__ __launch_bounds__(256) void absmax_tiles_kernel(const float *__restri
     }
   }
   __syncthreads();
-  if (tid < spb && s0 + tid < nseg) out[1 + (size_t)b * nseg + s0 + tid] = seg_max[tid];
-  // the global maximum out[0]: by the workgroup that finishes LAST (ticket != NULL; common.h: last_workgroup_done) instead of a
-  // one-workgroup launch behind this one (absmax_tiles_reduce_kernel: ~5 us of launch latency, eleven times per PVCNN step)
-  if (ticket == nullptr) return;
-  if (!last_workgroup_done(ticket, gridDim.x * gridDim.y)) return;
+  // the global maximum out[0]: by the workgroup that takes the LAST ticket (ticket != NULL; common.h: ticket_take -- the table
+  // entries are then published with returning atomics and peeked, no fences) instead of a one-workgroup launch behind this one
+  // (absmax_tiles_reduce_kernel: ~5 us of launch latency, eleven times per PVCNN step)
+  if (ticket == nullptr) {
+    if (tid < spb && s0 + tid < nseg) out[1 + (size_t)b * nseg + s0 + tid] = seg_max[tid];
+    return;
+  }
+  if (tid < spb && s0 + tid < nseg) publish32(out + 1 + (size_t)b * nseg + s0 + tid, seg_max[tid]);
+  if (!ticket_take(ticket, gridDim.x * gridDim.y)) return;
   amax_table_max(out, (long)gridDim.y * nseg);
 }
 

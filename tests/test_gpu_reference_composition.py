@@ -68,7 +68,17 @@ def test_reference_composition_equals_the_benched_composition(hip, cfg):
     assert list(benched.state_dict().keys()) == list(composed.state_dict().keys())
     composed.load_state_dict(benched.state_dict())
     x, y = batch(workload)
-    out_b, loss_b, g_b = _step(benched, x, y)
+    # (round 5: workload.PVCNN runs its cloud-descriptor head -- Linear + BatchNorm1d + ReLU on 16 rows -- on csrc/dense.hip, another
+    #  summation order than the torch modules of the reference composition; that is a difference IN FRONT of the classifier's ReLUs,
+    #  i.e. one that can flip them.  It has its own parity test (tests/test_gpu_dense.py); here both sides take the modules, so that what
+    #  is compared is the COMPOSITION)
+    from pvcnn_amd.modules.functional import dense
+    keep = dense._servable
+    dense._servable = lambda *a: False
+    try:
+        out_b, loss_b, g_b = _step(benched, x, y)
+    finally:
+        dense._servable = keep
     out_c, loss_c, g_c = _step(composed, x, y)
     fwd = ((out_b - out_c).abs().max() / out_b.abs().max()).item()
     assert g_b.keys() == g_c.keys()
