@@ -231,15 +231,17 @@ __global__ __launch_bounds__(kBnThreads) void bnact_bwd_reduce_kernel(const floa
     if (threadIdx.x == 0) *mine = make_float2(s, q);
     return;
   }
-  if (threadIdx.x == 0)                                        // published: the workgroup that takes the channel's last ticket reads it
-    publish64(reinterpret_cast<unsigned long long *>(mine), ((unsigned long long)__float_as_uint(q) << 32) | __float_as_uint(s));
+  // (published below by wave 0; the other waves are done)
   if (fold.zero_word != nullptr) {                             // arms grad_x's amax buffer for the apply pass (a later launch)
     const long wgs = (long)gridDim.x * gridDim.y * gridDim.z;
     const long me = blockIdx.x + (long)gridDim.x * (blockIdx.y + (long)gridDim.y * blockIdx.z);
     for (long i = me * kBnThreads + threadIdx.x; i < fold.zero_count; i += wgs * kBnThreads) fold.zero_word[i] = 0u;
   }
-  if (!ticket_take(fold.tickets + c, (unsigned)(gridDim.x * gridDim.y))) return;
-  if (threadIdx.x < 64) {                                      // bnact_bwd_finalize_kernel's combine, operation for operation
+  if (threadIdx.x >= 64) return;                               // wave 0 alone: publish, ticket, and -- for the last one -- the combine
+  if (threadIdx.x == 0)
+    publish64(reinterpret_cast<unsigned long long *>(mine), ((unsigned long long)__float_as_uint(q) << 32) | __float_as_uint(s));
+  if (!ticket_take_wave(fold.tickets + c, (unsigned)(gridDim.x * gridDim.y))) return;
+  {                                                            // bnact_bwd_finalize_kernel's combine, operation for operation
     const int nparts = (int)(gridDim.x * gridDim.y);
     double ds = 0.0, dq = 0.0;
     for (int i = threadIdx.x; i < nparts; i += 64) {
@@ -809,8 +811,10 @@ __global__ __launch_bounds__(256) void concat_points_kernel(CatSources src, int 
       } else if (ticket != nullptr) publish32(slot, t);
       else *slot = t;
     }
-    // amax[0] by the workgroup that takes the last ticket (ticket != NULL) instead of a launch of its own (common.h: ticket_take)
-    if (ticket != nullptr && ticket_take(ticket, gridDim.x * gridDim.y * gridDim.z)) amax_table_max(amax, (long)gridDim.x * gridDim.y);
+    // amax[0] by the wave that takes the last ticket (ticket != NULL) instead of a launch of its own (common.h: ticket_take_wave;
+    // the host passes a ticket only for tables of <= kFoldTableMax words)
+    if (ticket != nullptr && tid < 64 && ticket_take_wave(ticket, gridDim.x * gridDim.y * gridDim.z))
+      amax_table_max_wave(amax, (long)gridDim.x * gridDim.y);
   }
 }
 }  // namespace pvcnn
@@ -842,6 +846,7 @@ extern "C" int pvcnn_concat_points(const float *const *srcs, const long *bstride
     if (e != hipSuccess) { set_error("concat_points: memset: %s", hipGetErrorString(e)); return (int)e; }
   }
   PVCNN_REQUIRE(!ticket || (reinterpret_cast<uintptr_t>(ticket) & 3) == 0, "ticket must be 4-byte aligned");
+  if ((long)B * blocks > kFoldTableMax) ticket = nullptr;    // a long table is read faster by the 1024 threads of the reduce launch
   hipLaunchKernelGGL(concat_points_kernel, dim3(blocks, B, groups), dim3(256), 0, s, cs, N, vec ? 1 : 0, out, static_cast<uint32_t *>(out_amax),
                      static_cast<unsigned *>(out_amax ? ticket : nullptr));
   if (int e = check_launch("concat_points")) return e;

@@ -22,6 +22,8 @@ __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; 
 inline int grid_pad_shift(int R) { int s = 0; while ((1 << s) < R) ++s; return ((1 << s) == R && R >= 4) ? s : 0; }
 __host__ __device__ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// tables longer than this keep the separate reduce launch (one wave peeks a folded table: 64 words per step)
+constexpr long kFoldTableMax = 1024;
 // out[0] = max over out[1 .. T] of an amax buffer whose table has just been written on stream s (conv3d_bf16.hip)
 int launch_amax_reduce(uint32_t *out, long T, hipStream_t s);
 
@@ -68,6 +70,16 @@ __device__ __forceinline__ uint32_t peek32(const uint32_t *p) {
 __device__ __forceinline__ unsigned long long peek64(const unsigned long long *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// ticket_take_wave: the same for ONE wave of the workgroup (all 64 lanes call it, after their publishes have returned; the other waves
+// have left: a workgroup of short-lived waves must not wait at a barrier for two atomic round trips -- measured, r05d)
+__device__ __forceinline__ bool ticket_take_wave(unsigned *ticket, unsigned total) {
+  unsigned t = 0u;
+  if ((threadIdx.x & 63) == 0) {
+    t = atomicAdd(ticket, 1u);
+    if (t == total - 1u) atomicExch(ticket, 0u);
+  }
+  return (unsigned)__builtin_amdgcn_readfirstlane((int)t) == total - 1u;
+}
 __device__ __forceinline__ bool ticket_take(unsigned *ticket, unsigned total) {
   __shared__ int s_last_workgroup;
   __syncthreads();                                           // every thread's publishes have returned
@@ -82,6 +94,14 @@ __device__ __forceinline__ bool ticket_take(unsigned *ticket, unsigned total) {
 
 // out[0] = max over the table out[1 .. T] of an amax buffer, by the calling workgroup (every thread calls; <= 1024 threads).  Used by
 // the workgroup that takes the last ticket in the kernels that PUBLISH the table (see ticket_take): the entries are peeked.
+// (single wave: the 64 lanes of the wave that took the last ticket; T small -- see the callers' bounds)
+__device__ __forceinline__ void amax_table_max_wave(uint32_t *out, long T) {
+  uint32_t m = 0;
+  for (long i = threadIdx.x & 63; i < T; i += 64) m = max(m, peek32(out + 1 + i));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+  if ((threadIdx.x & 63) == 0) out[0] = m;
+}
 __device__ __forceinline__ void amax_table_max(uint32_t *out, long T) {
   __shared__ uint32_t s_amax_red[16];
   uint32_t m = 0;

@@ -149,9 +149,10 @@ __global__ __launch_bounds__(256) void absmax_tiles_kernel(const float *__restri
     if (tid < spb && s0 + tid < nseg) out[1 + (size_t)b * nseg + s0 + tid] = seg_max[tid];
     return;
   }
+  if (tid >= 64) return;                                     // wave 0 alone (spb <= 64: its lanes hold every entry of the workgroup)
   if (tid < spb && s0 + tid < nseg) publish32(out + 1 + (size_t)b * nseg + s0 + tid, seg_max[tid]);
-  if (!ticket_take(ticket, gridDim.x * gridDim.y)) return;
-  amax_table_max(out, (long)gridDim.y * nseg);
+  if (!ticket_take_wave(ticket, gridDim.x * gridDim.y)) return;
+  amax_table_max_wave(out, (long)gridDim.y * nseg);
 }
 
 // out[0] = max over the table out[1 .. T] (one workgroup; T is a few thousand words)
@@ -956,6 +957,7 @@ extern "C" int pvcnn_absmax_tiles(const float *x, int B, int C, long L, int seg,
   const int spb = amax_segs_per_block(seg);
   const int vec = (L % 4 == 0) && (seg % 4 == 0) && aligned16(x);
   PVCNN_REQUIRE(!ticket || (reinterpret_cast<uintptr_t>(ticket) & 3) == 0, "ticket must be 4-byte aligned");
+  if ((long)B * nseg > kFoldTableMax || spb > 64) ticket = nullptr;   // a long table is read faster by the 1024 threads of the reduce launch
   hipLaunchKernelGGL(absmax_tiles_kernel, dim3((unsigned)((nseg + spb - 1) / spb), B), dim3(256), 0, s, x, C, L, seg, (int)nseg, vec, o,
                      static_cast<unsigned *>(ticket));
   if (int rc = check_launch("absmax_tiles")) return rc;

@@ -386,8 +386,10 @@ def test_last_point_stage_hands_its_row_maxima_to_the_max_pool(hip):
 
 
 def test_row_maxima_handed_over_by_the_batchnorm_pass_die_with_an_in_place_update(hip):
-    """ADVICE r04: the (winners, values) a BatchNorm + ReLU pass attaches to its output are keyed by the tensor's in-place version;
-    after `y.add_(...)` tap_and_pool reduces the tensor as it is now instead of trusting them."""
+    """the (winners, values) a BatchNorm + ReLU pass attaches to its output are keyed by the tensor's in-place version.
+    Two lines of defence: autograd itself refuses to use the output of the fused node after an in-place update (it is a view made
+    inside a custom Function: RuntimeError, measured in round 5), and where a version moved without that error -- emulated here by a
+    tag from an older version -- tap_and_pool reduces the tensor as it is instead of trusting the tag."""
     from pvcnn_amd import workload
     from pvcnn_amd.modules import SharedMLP
     from pvcnn_amd.modules.functional.bnact import emit_row_max
@@ -396,12 +398,16 @@ def test_row_maxima_handed_over_by_the_batchnorm_pass_die_with_an_in_place_updat
     x = torch.randn(2, 16, 512, device=DEV).requires_grad_()
     with emit_row_max(workload._last_norm(mlp)):
         y = mlp(x)
-    assert y._pvcnn_row_max is not None
-    bump = torch.zeros_like(y)
-    bump[:, :, 7] = 1e3                                   # position 7 becomes every row's maximum
-    # (autograd forbids an in-place op on the node's output itself; an alias that shares its storage AND its version counter is how
-    #  such an update reaches it: `y.detach()` / `.data` in user code, an optimizer-style `add_` on a view)
-    y.detach().add_(bump)
-    assert y._version != y._pvcnn_row_max[2]
+    winners, values, version = y._pvcnn_row_max
+    assert version == y._version
     _, pooled = workload.tap_and_pool(y)
-    assert torch.equal(pooled, y.max(dim=-1).values) and (pooled > 999).all()
+    assert torch.equal(pooled, y.max(dim=-1).values)
+    # a stale tag (older version, wrong contents): ignored
+    y._pvcnn_row_max = (torch.zeros_like(winners), torch.full_like(values, -1.0), version - 1)
+    _, pooled = workload.tap_and_pool(y)
+    assert torch.equal(pooled, y.max(dim=-1).values)
+    # ... and the in-place update itself is refused by autograd for this tensor
+    y2 = mlp(x)
+    y2.detach().add_(1.0)
+    with pytest.raises(RuntimeError, match='modified inplace'):
+        workload.tap_and_pool(y2)

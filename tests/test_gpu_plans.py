@@ -189,8 +189,10 @@ def test_the_reference_seam_reuses_its_plan_and_a_mutated_tensor_invalidates_it(
 
 
 def _plan_regions(plan, b, l, e):
-    """The fully defined regions of an opaque plan buffer (csrc/csr.h: CsrPlan::carve): start, ent, order, seg, gofs -- everything but
-    the wave-interleaved entry copy, whose padding between wave groups is never written (compared through the apply instead)."""
+    """The DETERMINISTIC regions of an opaque plan buffer (csrc/csr.h: CsrPlan::carve): start (prefix offsets per target) and ent (the
+    entries grouped by target in the reference's serial order).  The lane assignment behind them (order / seg / gofs / entw: targets
+    sorted by entry count with integer LDS atomics) may list targets of EQUAL count in any order from build to build -- every target's
+    sum is the same whichever lane owns it -- and is compared through the applies."""
     a16 = lambda x: (x + 15) & ~15
     start_stride, order_stride = (l + 1 + 3) & ~3, -(-l // 4096) * 4096
     sizes = [b * start_stride * 4, b * e * 8, b * order_stride * 2, b * order_stride * 8, b * (order_stride // 64) * 4]
@@ -200,15 +202,15 @@ def _plan_regions(plan, b, l, e):
         off += a16(n)
     # (start: L + 1 defined words per cloud, padded to a multiple of 4 that nobody writes)
     out[0] = out[0].view(torch.int32).view(b, start_stride)[:, :l + 1].contiguous()
-    return out
+    return out[:2]
 
 
 @pytest.mark.parametrize('b,n,r', [(16, 4096, 16), (16, 4096, 32), (8, 8192, 32), (8, 1024, 8), (32, 1024, 12), (3, 1000, 12), (2, 37, 5), (1, 1, 2), (8, 2048, 16)])
 @pytest.mark.parametrize('kind', ['cube', 'surface'])
 def test_both_plans_of_a_geometry_from_one_chain(hip, oracle, gen, b, n, r, kind):
     """pvcnn_pvconv_plans (ABI v11): the voxelize plan and the devoxelize-backward plan of one (coords, R) from one chain of three
-    launches -- the latter from the float coordinates instead of saved (inds, wgts).  Same ind / cnt, the same bytes in every defined
-    region of both plan buffers as the two separate chains write, and applies that equal the oracle."""
+    launches -- the latter from the float coordinates instead of saved (inds, wgts).  Same ind / cnt, the same bytes in the deterministic
+    regions of both plan buffers as the two separate chains write, and applies that equal the oracle."""
     norm, vox = _inputs(gen, b, n, r, kind)
     norm_d, vox_d = norm.to(DEV), vox.to(DEV)
     pair = hip.pvconv_plans(vox_d, norm_d, r)
@@ -221,7 +223,7 @@ def test_both_plans_of_a_geometry_from_one_chain(hip, oracle, gen, b, n, r, kind
     for got, want, e, what in ((vp.plan, want_v.plan, n, 'voxelize'), (dplan, want_d, 8 * n, 'devoxelize backward')):
         assert got.numel() == want.numel()
         for i, (x, y) in enumerate(zip(_plan_regions(got, b, r ** 3, e), _plan_regions(want, b, r ** 3, e))):
-            assert torch.equal(x, y), (what, ('start', 'ent', 'order', 'seg', 'gofs')[i])
+            assert torch.equal(x, y), (what, ('start', 'ent')[i])
     for c in (1, 9, 64):
         if b * c * max(n, r ** 3) > 40e6:
             continue
