@@ -120,10 +120,12 @@ class HipBackend:
         return torch.empty((max(int(nbytes), 16),), dtype=torch.uint8, device=device)
 
     # ---- "last workgroup done" tickets (include/pvcnn_hip.h, ABI v11): zeroed words a reduction's launch leaves zeroed, so that its
-    # finalize step is the tail of the launch instead of a ~5 us launch of its own.  One persistent pool per device (a captured graph
-    # keeps the addresses); slices are handed out round robin -- launches on one stream never overlap, and PVCNN_FOLD_FINALIZE=0
-    # (read once per process) goes back to the separate finalize / reduce launches (A/B, and the tests that pin the two against each other)
-    fold_finalize = os.environ.get('PVCNN_FOLD_FINALIZE', '1') != '0'
+    # finalize step is the tail of the launch instead of a ~5 us launch of its own.  MEASURED AND NOT THE DEFAULT (round 5,
+    # profiles/ab/r05d_fold_without_fences.md): the published atomics + tickets of ~100 k workgroups per step cost what the 26 launches
+    # cost (PVCNN 6.636 vs 6.605 ms, Frustum-PVCNN 6.19 vs 6.07 ms); with fences, twice the step.  PVCNN_FOLD_FINALIZE=1 (read once per
+    # process) switches it on; the tests pin both paths against each other.  One persistent pool per device (a captured graph keeps the
+    # addresses); slices are handed out round robin -- launches on one stream never overlap
+    fold_finalize = os.environ.get('PVCNN_FOLD_FINALIZE', '0') == '1'
     _TICKET_POOL = 1 << 16
 
     def _tickets(self, n, device):

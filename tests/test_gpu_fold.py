@@ -1,7 +1,8 @@
-"""ABI v11: the finalize step of three reductions is the TAIL of the reduction's own launch ("last workgroup done" tickets,
+"""ABI v11: the finalize step of three reductions CAN be the tail of the reduction's own launch ("last workgroup done" tickets,
 csrc/common.h) instead of a ~5 us launch behind it: the per-channel sums of the BatchNorm backward, the global maximum of an amax
-buffer behind pvcnn_absmax_tiles and behind pvcnn_concat_points.  Bit-identical to the separate launches (`fold_finalize = False` on the
-backend object: NULL tickets through the C ABI), on repeated calls that reuse the ticket words, and the tickets are left zeroed."""
+buffer behind pvcnn_absmax_tiles and behind pvcnn_concat_points.  Bit-identical to the separate launches (NULL tickets through the
+C ABI: the default since the A/B of round 5 -- the atomics of ~100 k workgroups per step cost what the launches cost), on repeated
+calls that reuse the ticket words, and the tickets are left zeroed."""
 import pytest
 import torch
 
@@ -10,9 +11,13 @@ DEV = 'cuda:0'
 
 
 def _both(hip, fn):
-    assert hip.fold_finalize
-    folded = fn()
-    hip.fold_finalize = False
+    """-> (fn() with the finalize step folded into the reduction's launch, fn() with the separate launches: the default -- the fold
+    was measured and lost, profiles/ab/r05d_fold_without_fences.md; it stays selectable and pinned here)."""
+    hip.fold_finalize = True
+    try:
+        folded = fn()
+    finally:
+        hip.fold_finalize = False
     try:
         separate = fn()
     finally:
@@ -61,7 +66,11 @@ def test_folded_sums_are_the_fp64_sums(hip):
     gamma, beta = torch.ones(c, device=DEV), torch.zeros(c, device=DEV)
     mean = x.mean(dim=(0, 2))
     rstd = 1.0 / torch.sqrt(x.var(dim=(0, 2), unbiased=False) + 1e-5)
-    gx, gg, gb = hip.bnact_backward(x, gy, gamma, beta, mean, rstd, 0.0, True)
+    hip.fold_finalize = True
+    try:
+        gx, gg, gb = hip.bnact_backward(x, gy, gamma, beta, mean, rstd, 0.0, True)
+    finally:
+        del hip.fold_finalize
     xd, gd = x.double(), gy.double()
     xhat = (xd - mean.double().view(1, -1, 1)) * rstd.double().view(1, -1, 1)
     gp = gd * (xhat > 0)
@@ -95,17 +104,16 @@ def test_concat_points_global_maximum_from_the_copy(hip, b, n, chans):
 
 
 def test_fold_switch_reaches_the_c_abi(hip, monkeypatch):
-    """`fold_finalize = False` passes NULL tickets: then (and only then) the separate finalize / reduce kernels run -- counted through
-    the ticket pool: a folded call advances the pool's cursor, an unfolded one does not."""
+    """Without `fold_finalize` the calls pass NULL tickets (no pool is even created); with it a folded call advances the pool's cursor."""
     x = torch.randn(4, 8, 1024, device=DEV)
+    assert not hip.fold_finalize                        # the default: NULL tickets, no pool
     hip.absmax_tiles(x, 256)
-    cursor = hip._ticket_pools[('cuda', 0)][1]
-    hip.absmax_tiles(x, 256)
-    assert hip._ticket_pools[('cuda', 0)][1] > cursor
-    cursor = hip._ticket_pools[('cuda', 0)][1]
-    hip.fold_finalize = False
+    assert not hip.__dict__.get('_ticket_pools')
+    hip.fold_finalize = True
     try:
         hip.absmax_tiles(x, 256)
+        cursor = hip._ticket_pools[('cuda', 0)][1]
+        hip.absmax_tiles(x, 256)
+        assert hip._ticket_pools[('cuda', 0)][1] > cursor
     finally:
         del hip.fold_finalize
-    assert hip._ticket_pools[('cuda', 0)][1] == cursor
