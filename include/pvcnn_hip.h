@@ -273,8 +273,10 @@ PVCNN_API int pvcnn_absmax_bits(const float *x, size_t n, void *out, void *strea
 PVCNN_API size_t pvcnn_absmax_tiles_count(int B, long L, int seg);      /* 1 + T words */
 /* (ABI v11) `ticket`: NULL, or ONE zeroed 32-bit word in device memory that the call leaves zeroed.  With a ticket the global
  * maximum out[0] is written by the workgroup of the table pass that finishes last (release / acquire at device scope) instead of a
- * one-workgroup launch behind it -- a launch costs ~5 us on this chip whatever it does.  The word must not be shared with a launch
- * that can run concurrently (another stream); launches on one stream may reuse it.  The same convention: `tickets` of
+ * one-workgroup launch behind it (tables of <= 1024 words; longer ones keep the launch).  MEASURED (round 5, profiles/ab/r05c_*,
+ * r05d_*): correct and bit-identical, but NOT faster on gfx950 -- the published atomics and tickets of every workgroup cross the
+ * eight XCDs and cost what the ~5 us launches cost; pvcnn_amd passes NULL unless PVCNN_FOLD_FINALIZE=1.  The word must not be shared
+ * with a launch that can run concurrently (another stream); launches on one stream may reuse it.  The same convention: `tickets` of
  * pvcnn_bnact_bwd_strided (C words: the per-channel sums are finalised by the workgroup that writes a channel's last partial),
  * `ticket` of pvcnn_concat_points. */
 PVCNN_API int pvcnn_absmax_tiles(const float *x, int B, int C, long L, int seg, void *out, void *ticket, void *stream);
