@@ -222,6 +222,10 @@ def pmc_traffic(kernel, shape):
         table = json.load(open(path))
     except (OSError, ValueError):
         return {'traffic': None}
+    from pvcnn_amd._lib import sources_digest
+    if table.get('sources_digest') != sources_digest():        # counters of OTHER kernel sources say nothing about this run
+        return {'traffic': None, 'traffic_note': f"profiles/pmc_traffic.json was collected on kernel sources {table.get('sources_digest')}, "
+                                                 f"this run executes {sources_digest()}: not cited"}
     for row in table.get('kernels', []):
         if row.get('op') == kernel and list(row.get('shape_BCNR', [])) == list(shape):
             out = {'traffic': int((2 * row['FETCH_SIZE_KiB'] + row['WRITE_SIZE_KiB']) * 1024),

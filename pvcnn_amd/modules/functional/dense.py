@@ -52,8 +52,12 @@ class LinearBnRelu(Function):
                 None, None, None, None, None)
 
 
+# PVCNN_DENSE_HEAD=0 (read once per process): the torch modules for every block (A/B)
+_ENABLED = __import__('os').environ.get('PVCNN_DENSE_HEAD', '1') != '0'
+
+
 def _servable(lin, bn, act, x):
-    be = native() if x.is_cuda else None
+    be = native() if (x.is_cuda and _ENABLED) else None
     return (be is not None and getattr(be, 'has_dense_bn_relu', False) and type(lin) is nn.Linear and type(bn) is nn.BatchNorm1d
             and type(act) is nn.ReLU and bn.training and bn.momentum is not None and x.dim() == 2 and x.dtype == torch.float32
             and lin.weight.dtype == torch.float32 and not torch.is_autocast_enabled()

@@ -8,6 +8,20 @@ import os
 import sys
 
 d = sys.argv[1]
+# argv[2] (optional): a bench.py JSON line of the same code -- the headline launch's shape is read from its roofline entry instead of being
+# assumed
+headline_shape = None
+if len(sys.argv) > 2:
+    try:
+        headline_shape = json.load(open(sys.argv[2]))['roofline']['shape_BCNR']
+    except (OSError, ValueError, KeyError, TypeError):
+        headline_shape = None
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+try:
+    from pvcnn_amd._lib import sources_digest
+    digest = sources_digest()
+except Exception:                                        # noqa: BLE001
+    digest = None
 
 
 def load(name):
@@ -35,8 +49,8 @@ for key, vf in sorted(fb.items()):
     name, _, grid = key.partition(' @grid=')
     row = {'op': op, 'kernel_name': name[:120], 'grid_threads': int(grid) if grid.isdigit() else None, 'where': 'inside bench.py steps',
            'FETCH_SIZE_KiB': round(vf['FETCH_SIZE'], 1), 'WRITE_SIZE_KiB': round(vw['WRITE_SIZE'], 1), 'dispatches': vf['dispatches']}
-    if op == 'trilinear_devoxelize_fwd' and 'XfBnAct' in name:      # the headline launch: the R = 32 stage of the step
-        row['shape_BCNR'] = [16, 64, 4096, 32]
+    if op == 'trilinear_devoxelize_fwd' and 'XfBnAct' in name and headline_shape:      # the headline launch: the largest-R stage of the step
+        row['shape_BCNR'] = headline_shape
     rows.append(row)
 calib = []
 fo, wo = load('pmc_FETCH_SIZE_opbench.json'), load('pmc_WRITE_SIZE_opbench.json')
@@ -46,7 +60,7 @@ for key, vf in sorted(fo.items()):
         name, _, grid = key.partition(' @grid=')
         calib.append({'kernel_name': name[:120], 'grid_threads': int(grid) if grid.isdigit() else None,
                       'FETCH_SIZE_KiB': round(vf['FETCH_SIZE'], 1), 'WRITE_SIZE_KiB': round(vw['WRITE_SIZE'], 1), 'dispatches': vf['dispatches']})
-print(json.dumps({'command': 'rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace (separate passes) -- python bench.py ..., tools/collect_evidence.sh',
+print(json.dumps({'sources_digest': digest, 'trace_commit': os.environ.get('PVCNN_TRACE_COMMIT'), 'command': 'rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace (separate passes) -- python bench.py ..., tools/collect_evidence.sh',
                   'units': 'KiB per launch, averaged over dispatches; HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 on gfx950',
                   'kernels': rows,
                   'calibration': {'what': 'the same counters over tools/opbench.py (one op at one shape per launch: algorithmic bytes known, inputs '
