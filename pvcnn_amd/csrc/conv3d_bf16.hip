@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256, (NS == 3 || TX * TY * TZ == 512 || TZ <= 16) ?
                                                                    int Ci, int Co, int R, int tiles_x, int tiles_y, int tiles_z,
                                                                    float2 *__restrict__ stats_part,
                                                                    const uint32_t *__restrict__ x_absmax, const int *__restrict__ wexp,
-                                                                   int amax_seg, int nt_store) {
+                                                                   int amax_seg) {
   static_assert(TX * TY * TZ == 64 || TX * TY * TZ == 128 || TX * TY * TZ == 256 || TX * TY * TZ == 512, "a workgroup tile is 4 waves x NBW x 32 voxels");
   constexpr int HX = TX + 2, HY = TY + 2, HZ = TZ + 2, HS = HX * HY * HZ;
   // Wave arrangement inside the 64-channel x (TX*TY*TZ)-voxel workgroup tile.  Every lane fetches its own A (weight) fragments from
@@ -604,12 +604,7 @@ __global__ __launch_bounds__(256, (NS == 3 || TX * TY * TZ == 512 || TZ <= 16) ?
           qq[r] += m * m;
         }
         v += bv[r];
-        if (vok[nb] && co < Co) {
-          // (nt_store: experiment switch PVCNN_CONV_NT_STORE -- streaming stores, as in the BatchNorm apply passes, for an output
-          //  that the NEXT kernels read with 16-byte streaming loads: profiles/ab/r05e_conv_streaming_stores.md)
-          if (nt_store) __builtin_nontemporal_store(v, yb + (size_t)co * S + voff[nb]);
-          else yb[(size_t)co * S + voff[nb]] = v;
-        }
+        if (vok[nb] && co < Co) yb[(size_t)co * S + voff[nb]] = v;
       }
     if (want_stats) {
       const float st = half_wave_sum16(ss, j), qt = half_wave_sum16(qq, j);
@@ -902,9 +897,8 @@ static int launch_igemm_bf16(const float *x, const uint16_t *wts, const float *b
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { set_error("conv3d(bf16): LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
   }
-  static const int nt_store = [] { const char *e = getenv("PVCNN_CONV_NT_STORE"); return (e && e[0] == '1') ? 1 : 0; }();
   hipLaunchKernelGGL(k, dim3((unsigned)((long)B * tx * ty * tz), ceil_div(Co, kCoTileB)), dim3(256), lds, s, x, wts, bias, y,
-                     Ci, Co, R, tx, ty, tz, stats_part, x_absmax, wexp, amax_seg, nt_store);
+                     Ci, Co, R, tx, ty, tz, stats_part, x_absmax, wexp, amax_seg);
   return check_launch("conv3d_igemm_bf16");
 }
 

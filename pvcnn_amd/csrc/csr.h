@@ -681,7 +681,7 @@ static __global__ __launch_bounds__(256) void csr_interleave_kernel(const int2 *
 //     empty or not, is written exactly once: no memset, no float atomics, no transposed copy of the source.
 //   nsplit > 1 spreads the ranges of one (cloud, channel slab) over several workgroups (few channels: voxelize C = 9).
 // ---------------------------------------------------------------------------------------------
-template <int G, bool PF = false>
+template <int G>
 __global__ __launch_bounds__(kTileThreads) void segsum_tile_kernel(const float *__restrict__ src, const int2 *__restrict__ seg,
                                                                    const int2 *__restrict__ ent, const uint16_t *__restrict__ order,
                                                                    const int32_t *__restrict__ gofs, const int2 *__restrict__ entw,
@@ -756,32 +756,6 @@ __global__ __launch_bounds__(kTileThreads) void segsum_tile_kernel(const float *
 #pragma unroll
       for (int c = 0; c < G; ++c) acc[c] = 0.0f;
       int i = 0;
-      if constexpr (PF) {
-        // experiment (PVCNN_SEGSUM_PREFETCH=1, profiles/ab/r05e): the NEXT batch's eight entries are requested before this batch is
-        // summed -- a heavy target's walk is a chain of entry-load round trips with a few FMAs in between; the prefetch is
-        // unconditional from a clamped index (a branch around it would make the compiler wait for it with vmcnt(0))
-        int2 tn[8];
-        if (n >= 8) {
-#pragma unroll
-          for (int u = 0; u < 8; ++u) tn[u] = ep[(size_t)u * estep];
-        }
-        for (; i + 8 <= n; i += 8) {
-          int2 t[8];
-          vecG x[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) t[u] = tn[u];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) tn[u] = ep[(size_t)min(i + 8 + u, n - 1) * estep];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const vecG *>(srcI + (size_t)t[u].x * G);
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const float w = __int_as_float(t[u].y);
-#pragma unroll
-            for (int c = 0; c < G; ++c) acc[c] = acc[c] + w * x[u][c];
-          }
-        }
-      }
       for (; i + 8 <= n; i += 8) {       // 8 entries' loads in flight; the adds stay in entry order
         int2 t[8];
         vecG x[8];
@@ -961,10 +935,9 @@ inline int launch_csr_apply(const float *src, const void *plan, size_t plan_byte
     nsplit = std::min(nsplit, nr);
     const size_t lds = (size_t)G * (JP + kTileTargets) * sizeof(float);
     const dim3 grid(slabs, nsplit, B);
-    static const bool prefetch = [] { const char *e = getenv("PVCNN_SEGSUM_PREFETCH"); return e && e[0] == '1'; }();
 #define PVCNN_TILE(GV)                                                                                                   \
   do {                                                                                                                   \
-    auto k = prefetch ? segsum_tile_kernel<GV, true> : segsum_tile_kernel<GV, false>;                                    \
+    auto k = segsum_tile_kernel<GV>;                                                                                     \
     if (int e = enable_big_lds(k, lds)) { set_error("%s: LDS attribute: %d", what, e); return e; }                       \
     hipLaunchKernelGGL(k, grid, dim3(kTileThreads), lds, s, src, pl.seg, pl.ent, pl.order, pl.gofs, pl.entw, dst, C, L, J, E,  \
                        src_bstride, nsplit, JP);                                                                                      \
