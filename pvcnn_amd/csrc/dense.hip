@@ -31,6 +31,24 @@ __device__ __forceinline__ float dense_wave_sum(float v) {
   return v;
 }
 
+// x (n floats) -> LDS with 16-byte loads, four in flight per thread (the staging IS most of these launches: 64 KiB per workgroup)
+__device__ __forceinline__ void dense_stage(float *__restrict__ lds, const float *__restrict__ x, int n) {
+  const int tid = threadIdx.x;
+  if ((n & 3) == 0 && aligned16(x)) {
+    const int nq = n >> 2;
+    const float4 *xq = reinterpret_cast<const float4 *>(x);
+    float4 *lq = reinterpret_cast<float4 *>(lds);
+    int q = tid;
+    for (; q + 3 * kDenseThreads < nq; q += 4 * kDenseThreads) {
+      const float4 a = xq[q], b = xq[q + kDenseThreads], c = xq[q + 2 * kDenseThreads], d = xq[q + 3 * kDenseThreads];
+      lq[q] = a; lq[q + kDenseThreads] = b; lq[q + 2 * kDenseThreads] = c; lq[q + 3 * kDenseThreads] = d;
+    }
+    for (; q < nq; q += kDenseThreads) lq[q] = xq[q];
+  } else {
+    for (int i = tid; i < n; i += kDenseThreads) lds[i] = x[i];
+  }
+}
+
 // rows <= RT (RT = 16 | 32 | 64: the accumulators are registers).  z: (rows, Cout) = x W^T + bias, kept for backward.
 template <int RT>
 __global__ __launch_bounds__(kDenseThreads) void dense_bn_relu_fwd_kernel(const float *__restrict__ x, const float *__restrict__ w,
@@ -42,7 +60,7 @@ __global__ __launch_bounds__(kDenseThreads) void dense_bn_relu_fwd_kernel(const 
                                                                          float *__restrict__ mean, float *__restrict__ rstd) {
   extern __shared__ __attribute__((aligned(16))) float dense_lds[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  for (int i = tid; i < rows * Cin; i += kDenseThreads) dense_lds[i] = x[i];
+  dense_stage(dense_lds, x, rows * Cin);
   if (counter != nullptr && blockIdx.x == 0 && tid == 0) *counter += 1;      // BatchNorm's num_batches_tracked
   __syncthreads();
   const int co = blockIdx.x * 4 + wave;
@@ -51,11 +69,20 @@ __global__ __launch_bounds__(kDenseThreads) void dense_bn_relu_fwd_kernel(const 
 #pragma unroll
   for (int r = 0; r < RT; ++r) acc[r] = 0.0f;
   const float *wr = w + (size_t)co * Cin;
-  for (int ci = lane; ci < Cin; ci += 64) {
-    const float wv = wr[ci];
+  // (eight weight loads in flight per lane: a loop of load -> 16 FMAs -> load is a chain of Cin / 64 memory round trips)
+  for (int ci0 = lane; ci0 < Cin; ci0 += 8 * 64) {
+    float wv[8];
 #pragma unroll
-    for (int r = 0; r < RT; ++r)
-      if (r < rows) acc[r] = fmaf(wv, dense_lds[r * Cin + ci], acc[r]);
+    for (int u = 0; u < 8; ++u) wv[u] = (ci0 + 64 * u < Cin) ? wr[ci0 + 64 * u] : 0.0f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int ci = ci0 + 64 * u;
+      if (ci < Cin) {
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+          if (r < rows) acc[r] = fmaf(wv[u], dense_lds[r * Cin + ci], acc[r]);
+      }
+    }
   }
   // every lane ends up with the totals of all rows; lane r keeps row r
   float mine = 0.0f;
@@ -98,7 +125,7 @@ __global__ __launch_bounds__(kDenseThreads) void dense_bn_relu_bwd_kernel(const 
                                                                          float *__restrict__ gbeta) {
   extern __shared__ __attribute__((aligned(16))) float dense_lds[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  for (int i = tid; i < rows * Cin; i += kDenseThreads) dense_lds[i] = x[i];
+  dense_stage(dense_lds, x, rows * Cin);
   __syncthreads();
   const int co = blockIdx.x * 4 + wave;
   if (co >= Cout) return;
