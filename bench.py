@@ -720,9 +720,9 @@ def main():
                 'effective_fp32_TFLOPs': mfma['effective_TFLOPs'], 'x_fp32_mfma_peak_157TF': mfma['x_fp32_mfma_peak'],
                 'note': 'achieved = MFMA flops actually executed (f16x2: 3 fp16 partial products per fp32 product; bf16x3: 6) / launch time; '
                         'effective = algorithmic 2*B*R^3*27*Ci*Co / launch time; frac is priced on the slower of live events and the '
-                        'committed in-graph rocprofv3 average (in_graph_us).  By the counters (profiles/r04_pmc_mfma_bench_table.md, '
-                        'r04_pmc_mfma_fill_probe.jsonl) the matrix pipes are busy in 0.46-0.57 of the shader cycles and the chip clocks '
-                        '2.0-2.2 GHz under these kernels on real operands (2.4 GHz on constant ones): frac = busy x clock / 2.4'},
+                        'committed in-graph rocprofv3 average (in_graph_us).  By the counters (profiles/r05_pmc_mfma_bench_table.md, '
+                        'r05_pmc_mfma_fill_probe.jsonl) the matrix pipes are busy in 0.41-0.53 of the shader cycles and the chip clocks '
+                        '2.0-2.1 GHz under these kernels on real operands (2.4 GHz on constant ones): frac = busy x clock / 2.4'},
             'kernels': kernels,
         }
         if graph_error:
