@@ -456,10 +456,15 @@ PVCNN_API int pvcnn_row_argmax(const float *x, long rows, int K, long long *winn
  * argument must have zeroed BOTH y_amax (pvcnn_absmax_tiles_count(B, S, amax_seg) words) and row_keys (B * C uint64, 8-byte aligned)
  * -- e.g. one buffer holding the two.  S % 256 == 0, amax_seg a multiple of 4 that DIVIDES 256 (4, 8, 16, 32, 64, 128, 256: every lane
  * of a workgroup's 256 positions takes part in the row butterfly), x / y 16-byte aligned. */
+/* (ABI v11) y_batch_stride (0 = C * S): the samples of y may be that many elements apart -- the pass writes its output INTO a channel
+ * slice of a wider (B, C_total, S) tensor, the concatenation in front of the classifier (models/s3dis/pvcnn.py:45), so that
+ * pvcnn_concat_points has nothing to copy for the widest of its sources (`src_amax` there).  pvcnn_row_keys_decode reads the values
+ * back from such a y with C and the same stride (C <= 0: a contiguous (rows, S) tensor). */
 PVCNN_API int pvcnn_bnact_apply_rowmax(const float *x, const float *gamma, const float *beta, const float *mean, const float *rstd, int B,
-                                       int C, int S, float slope, float *y, void *y_amax, int amax_seg, void *row_keys, void *stream);
+                                       int C, int S, float slope, float *y, long y_batch_stride, void *y_amax, int amax_seg,
+                                       void *row_keys, void *stream);
 PVCNN_API int pvcnn_row_keys_decode(const void *row_keys, const float *y, long rows, int S, long long *winners, float *values,
-                                    void *stream);
+                                    int C, long y_batch_stride, void *stream);
 
 /* (ABI v10) The box part of Frustum-PointNet's multi-task loss (modules/frustum.py:43-124: FrustumPointNetLoss without the
  * foreground-mask cross entropy) AND its gradient, one launch:
@@ -511,8 +516,12 @@ PVCNN_API int pvcnn_trilinear_devox_bwd_strided(const float *grad_y, long grad_y
  * models/shapenet/pvcnn.py:41) in one pass that also emits the amax buffer (256-point segments) of its output, i.e. the f16x2 scale
  * table of the classifier GEMM that consumes it.  nsrc <= 8 sources; source i has channels[i] channels, its clouds are bstrides[i]
  * elements apart and pstrides[i] is 1 (rows of N points) or 0 (one value per (cloud, channel), broadcast over the points). */
-PVCNN_API int pvcnn_concat_points(const float *const *srcs, const long *bstrides, const int *channels, const int *pstrides, int nsrc, int B,
-                        int N, float *out, void *out_amax, void *ticket /* (ABI v11) see pvcnn_absmax_tiles; NULL: a reduce launch */, void *stream);
+PVCNN_API int pvcnn_concat_points(const float *const *srcs, const long *bstrides, const int *channels, const int *pstrides,
+                        const void *const *src_amax /* (ABI v11) NULL, or per source: NULL = copy it; else the source ALREADY IS its channel
+                        slice of out (srcs[i] == out + c0_i * N, bstrides[i] == C_total * N: the pass that produced it wrote it there) and
+                        this is its amax buffer (256-point segments), merged into out_amax; nothing is copied for it */,
+                        int nsrc, int B, int N, float *out, void *out_amax,
+                        void *ticket /* (ABI v11) see pvcnn_absmax_tiles; NULL: a reduce launch */, void *stream);
 
 /* ---- (ABI v11) Linear + BatchNorm1d + ReLU on a handful of rows: the `_linear_bn_relu` blocks of models/utils.py:11-12 -- the cloud
  * descriptor head of models/s3dis/pvcnn.py:22-25 ((B, 1024) -> 256 -> 128) and the dense heads of the Frustum nets -- where B is the

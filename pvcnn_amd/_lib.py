@@ -103,8 +103,8 @@ SIGNATURES = {
     'pvcnn_neighbor_max_fwd': (_i, [_vp, _l, _i, _vp, _vp, _vp]),
     'pvcnn_neighbor_max_bwd': (_i, [_vp, _vp, _l, _i, _vp, _vp]),
     'pvcnn_row_argmax': (_i, [_vp, _l, _i, _vp, _vp, _vp]),
-    'pvcnn_bnact_apply_rowmax': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _i, _vp, _vp]),
-    'pvcnn_row_keys_decode': (_i, [_vp, _vp, _l, _i, _vp, _vp, _vp]),
+    'pvcnn_bnact_apply_rowmax': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _l, _vp, _i, _vp, _vp]),
+    'pvcnn_row_keys_decode': (_i, [_vp, _vp, _l, _i, _vp, _vp, _i, _l, _vp]),
     'pvcnn_frustum_box_loss_grad_floats': (_sz, [_i, _i, _i]),
     'pvcnn_frustum_box_loss': (_i, [_vp] * 15 + [_i, _i, _i, _f, _f, _f, _f, _vp, _vp, _vp]),
     'pvcnn_se_excite_fwd': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -113,7 +113,7 @@ SIGNATURES = {
     'pvcnn_bnact_bwd_apply': (_i, [_vp, _vp, ctypes.c_long, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _i, _vp]),
     'pvcnn_bnact_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     'pvcnn_bnact_bwd_strided': (_i, [_vp, _vp, ctypes.c_long, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp, _f, _vp, _vp]),
-    'pvcnn_concat_points': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    'pvcnn_concat_points': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'pvcnn_dense_bn_relu_supported': (_i, [_i, _i, _i]),
     'pvcnn_dense_bn_relu_fwd': (_i, [_vp] * 8 + [_i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     'pvcnn_dense_bn_relu_bwd': (_i, [_vp] * 7 + [_i, _i, _i] + [_vp] * 6),

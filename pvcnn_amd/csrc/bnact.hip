@@ -322,12 +322,14 @@ __device__ __forceinline__ uint32_t max_order_bits(float v) {
 }
 
 __global__ __launch_bounds__(256) void row_keys_decode_kernel(const unsigned long long *__restrict__ keys, const float *__restrict__ y, long rows,
-                                                              int S, long long *__restrict__ winners, float *__restrict__ values) {
+                                                              int S, long long *__restrict__ winners, float *__restrict__ values, int C,
+                                                              long y_bstride) {
   const long row = (long)blockIdx.x * 256 + threadIdx.x;
   if (row >= rows) return;
   const uint32_t k = ~(uint32_t)keys[row];
   winners[row] = (long long)k;
-  if (values) values[row] = y[(size_t)row * S + k];               // (the element itself: a -0 stays a -0)
+  // (the element itself: a -0 stays a -0); y's samples may be y_bstride elements apart (a channel slice of a wider tensor)
+  if (values) values[row] = y[(size_t)(row / C) * y_bstride + (size_t)(row % C) * S + k];
 }
 
 // ---- the two apply passes in POSITION-BLOCK-MAJOR form: a workgroup owns <= 256 consecutive positions of one sample and walks ALL
@@ -357,7 +359,7 @@ __global__ __launch_bounds__(256) void bnact_apply_pb_kernel(const float *__rest
                                                              int global_by_atomic, const float *__restrict__ bc_mul = nullptr,
                                                              const float *__restrict__ bc_add = nullptr, int cgroup = 0x7fffffff,
                                                              int table_by_atomic = 0, Drop drop = Drop{nullptr, 0u, 1.0f},
-                                                             unsigned long long *__restrict__ row_keys = nullptr) {
+                                                             unsigned long long *__restrict__ row_keys = nullptr, long out_bstride = 0) {
   static_assert(!ROWMAX || (!BWD && !DROP), "row maxima: plain forward pass only");
   __shared__ uint32_t seg_max[256];
   // SAMPLE-MAJOR traversal: workgroups are dispatched in linear block order, and consecutive ones take the channel groups of one
@@ -377,7 +379,9 @@ __global__ __launch_bounds__(256) void bnact_apply_pb_kernel(const float *__rest
   __syncthreads();
   const float *xb = x + (size_t)b * C * S + p0;
   const float *gb = BWD ? gy + (size_t)b * gy_bstride + p0 : nullptr;
-  float *ob = out + (size_t)b * C * S + p0;
+  // (out_bstride: the output's samples that many elements apart -- the pass writes INTO a channel slice of a wider tensor, the
+  //  concatenation in front of the classifier: pvcnn_bnact_apply_rowmax; 0 = C * S)
+  float *ob = out + (size_t)b * (out_bstride > 0 ? (size_t)out_bstride : (size_t)C * S) + p0;
   uint32_t mx[4] = {0u, 0u, 0u, 0u};
   struct Par { float scale, shift, m, r, db, dg, gmul, gadd; };
   auto par_of = [&](int c) {
@@ -567,8 +571,10 @@ extern "C" int pvcnn_bnact_fwd(const float *x, const float *gamma, const float *
 // The apply pass alone (statistics known: pvcnn_bn_finalize, which also ZEROED y_amax and row_keys -- its zero_words argument), with the
 // row maxima of y: row_keys[b * C + c] (uint64, see the kernel) for pvcnn_row_keys_decode.  S % 256 == 0, amax_seg % 4 == 0, 256 % amax_seg == 0.
 extern "C" int pvcnn_bnact_apply_rowmax(const float *x, const float *gamma, const float *beta, const float *mean, const float *rstd, int B,
-                                        int C, int S, float slope, float *y, void *y_amax, int amax_seg, void *row_keys, void *stream) {
+                                        int C, int S, float slope, float *y, long y_batch_stride, void *y_amax, int amax_seg, void *row_keys,
+                                        void *stream) {
   PVCNN_REQUIRE(B > 0 && C > 0 && S > 0 && x && y && mean && rstd && y_amax && row_keys, "bad argument");
+  PVCNN_REQUIRE(y_batch_stride == 0 || (y_batch_stride >= (long)C * S && y_batch_stride % 4 == 0), "y_batch_stride: 0, or >= C * S and a multiple of 4");
   PVCNN_REQUIRE(B <= 65535 && C <= 65535, "batch or channel count > 65535");
   // (256 % amax_seg == 0: the row-maximum butterfly assumes every lane of the workgroup's 256 positions is active -- a segment length
   //  that does not divide 256, e.g. 12 -> span 252, would leave lanes out of the __shfl_xor / __ballot: undefined winners)
@@ -580,17 +586,19 @@ extern "C" int pvcnn_bnact_apply_rowmax(const float *x, const float *gamma, cons
   const int groups = pb_channel_groups((long)ceil_div(nseg, spb) * B, C);
   hipLaunchKernelGGL((bnact_apply_pb_kernel<false, false, true>), dim3(ceil_div(nseg, spb), B, groups), dim3(256), 0, s, x, nullptr, 0L, mean, rstd,
                      gamma, beta, nullptr, nullptr, slope, 0.0f, 0, C, S, amax_seg, nseg, 1, y, static_cast<uint32_t *>(y_amax), 1, nullptr, nullptr,
-                     ceil_div(C, groups), groups > 1 ? 1 : 0, Drop{nullptr, 0u, 1.0f}, static_cast<unsigned long long *>(row_keys));
+                     ceil_div(C, groups), groups > 1 ? 1 : 0, Drop{nullptr, 0u, 1.0f}, static_cast<unsigned long long *>(row_keys), y_batch_stride);
   return check_launch("bnact_apply_rowmax");
 }
 
 // row_keys (rows uint64) of a (rows, S) tensor y -> winners (int64 position of the row maximum: torch.max's) and, unless NULL, values
-extern "C" int pvcnn_row_keys_decode(const void *row_keys, const float *y, long rows, int S, long long *winners, float *values, void *stream) {
+extern "C" int pvcnn_row_keys_decode(const void *row_keys, const float *y, long rows, int S, long long *winners, float *values, int C,
+                                     long y_batch_stride, void *stream) {
   PVCNN_REQUIRE(rows >= 0 && S > 0, "negative size");
   if (rows == 0) return 0;
   PVCNN_REQUIRE(row_keys && y && winners, "null pointer");
+  if (C <= 0 || y_batch_stride <= 0) { C = 1; y_batch_stride = S; }          // rows of a contiguous (rows, S) tensor
   hipLaunchKernelGGL(row_keys_decode_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     static_cast<const unsigned long long *>(row_keys), y, rows, S, winners, values);
+                     static_cast<const unsigned long long *>(row_keys), y, rows, S, winners, values, C, y_batch_stride);
   return check_launch("row_keys_decode");
 }
 
@@ -745,6 +753,8 @@ struct CatSources {
   long bstride[kCatMaxSrc];     // elements between clouds
   int c0[kCatMaxSrc + 1];       // first output channel of each source (c0[n] = total)
   int pstride[kCatMaxSrc];      // 1: (B, C, N) rows; 0: one value per (cloud, channel), broadcast over the points
+  const uint32_t *pre[kCatMaxSrc];   // NULL, or: this source already IS its channel slice of `out` (the pass that produced it wrote it
+                                     // there); nothing to copy, and this is its amax buffer (256-point segments) for the output's table
   int n;
 };
 
@@ -764,6 +774,10 @@ __global__ __launch_bounds__(256) void concat_points_kernel(CatSources src, int 
   for (int s = 0; s < src.n; ++s) {
     const int cb = src.c0[s], lo = max(gbeg, cb) - cb, cn = min(gend, src.c0[s + 1]) - cb;      // this group's rows [lo, cn) of source s
     if (lo >= cn) continue;
+    if (src.pre[s] != nullptr) {                             // in place: only its share of the table (a maximum: adding it twice is harmless)
+      if (tid == 0 && amax != nullptr) m = max(m, src.pre[s][1 + (size_t)b * gridDim.x + blockIdx.x]);
+      continue;
+    }
     const float *sp = src.p[s] + (size_t)b * src.bstride[s];
     if (src.pstride[s] == 0) {                               // broadcast rows
       for (int c = lo + wave; c < cn; c += 4) {
@@ -822,8 +836,9 @@ __global__ __launch_bounds__(256) void concat_points_kernel(CatSources src, int 
 // out (B, sum C_i, N) = concatenation of nsrc <= 8 sources along the channels; source i: srcs[i] with channels[i] channels, clouds
 // bstrides[i] elements apart, pstrides[i] = 1 ((C_i, N) rows contiguous within a cloud) or 0 (one value per (cloud, channel), broadcast).
 // out_amax: NULL, or pvcnn_absmax_tiles_count(B, N, 256) words = the amax buffer of `out` with 256-point segments.
-extern "C" int pvcnn_concat_points(const float *const *srcs, const long *bstrides, const int *channels, const int *pstrides, int nsrc, int B,
-                                   int N, float *out, void *out_amax, void *ticket, void *stream) {
+extern "C" int pvcnn_concat_points(const float *const *srcs, const long *bstrides, const int *channels, const int *pstrides,
+                                   const void *const *src_amax, int nsrc, int B, int N, float *out, void *out_amax, void *ticket,
+                                   void *stream) {
   PVCNN_REQUIRE(srcs && bstrides && channels && pstrides && out && nsrc > 0 && nsrc <= kCatMaxSrc && B > 0 && N > 0, "bad argument");
   PVCNN_REQUIRE(B <= 65535, "batch > 65535");
   CatSources cs{};
@@ -833,10 +848,14 @@ extern "C" int pvcnn_concat_points(const float *const *srcs, const long *bstride
   for (int i = 0; i < nsrc; ++i) {
     PVCNN_REQUIRE(srcs[i] && channels[i] > 0 && (pstrides[i] == 0 || pstrides[i] == 1), "bad source");
     cs.p[i] = srcs[i]; cs.bstride[i] = bstrides[i]; cs.pstride[i] = pstrides[i]; cs.c0[i] = c;
+    cs.pre[i] = (src_amax != nullptr) ? static_cast<const uint32_t *>(src_amax[i]) : nullptr;
     c += channels[i];
-    if (pstrides[i] == 1) vec = vec && aligned16(srcs[i]) && (bstrides[i] % 4 == 0);
+    if (pstrides[i] == 1 && cs.pre[i] == nullptr) vec = vec && aligned16(srcs[i]) && (bstrides[i] % 4 == 0);
   }
   cs.c0[nsrc] = c;
+  for (int i = 0; i < nsrc; ++i)                               // an in-place source must BE its slice of out
+    PVCNN_REQUIRE(cs.pre[i] == nullptr || (srcs[i] == out + (size_t)cs.c0[i] * N && bstrides[i] == (long)c * N && pstrides[i] == 1),
+                  "a source with src_amax must already be its channel slice of out (srcs[i] == out + c0 * N, bstride == C_total * N)");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int blocks = ceil_div(N, 256);
   int groups = 1;                                            // ~4 workgroups per CU, >= 64 channels each

@@ -922,22 +922,32 @@ class HipBackend:
         whole = torch.empty((off + 2 * int(b) * int(c),), dtype=torch.int32, device=device)
         return whole, whole[:words], whole[off:]
 
-    def bnact_apply_rowmax(self, x, gamma, beta, mean, rstd, slope, amax_seg, y_amax, row_keys):
+    def bnact_apply_rowmax(self, x, gamma, beta, mean, rstd, slope, amax_seg, y_amax, row_keys, out=None):
         """The apply pass of bnact_forward on known statistics, also emitting the row maxima of y: x (B,C,S) -> (y, winners (B,C) int64,
         values (B,C)) == (y, *y.max(dim=-1)[::-1]).  y_amax / row_keys: the views of amax_and_row_keys, ZEROED (bn_finalize)."""
         _f32(x, 'x')
         b, c, s3 = x.shape
         _shape(s3 % 256 == 0 and amax_seg % 4 == 0 and 0 < amax_seg <= 256 and 256 % amax_seg == 0,
                'bnact_apply_rowmax: S % 256 == 0 and an amax_seg that is a multiple of 4 and divides 256 expected')
-        y = torch.empty_like(x)
+        # out: where y goes -- a (B, C, S) view whose rows are contiguous inside a sample and whose samples may be further apart: the
+        # channel slice of the classifier's concatenation that this tensor will be (the concatenation then copies nothing for it)
+        if out is None:
+            y = torch.empty_like(x)
+        else:
+            y = out
+            _dev(y, 'out')
+            _shape(tuple(y.shape) == tuple(x.shape) and y.dtype == torch.float32 and y.stride(2) == 1 and y.stride(1) == s3
+                   and y.stride(0) >= c * s3 and y.stride(0) % 4 == 0 and y.data_ptr() % 16 == 0,
+                   'bnact_apply_rowmax: out must be a (B, C, S) float32 view with contiguous, 16-byte aligned rows')
+        ybs = int(y.stride(0)) if b > 1 else c * s3
         winners = torch.empty((b, c), dtype=torch.int64, device=x.device)
         values = torch.empty((b, c), dtype=torch.float32, device=x.device)
         nul = ctypes.c_void_p(None)
         with _Launch(x) as s:
             _lib.check(self.lib.pvcnn_bnact_apply_rowmax(_p(x), _p(gamma) if gamma is not None else nul, _p(beta) if beta is not None else nul,
-                                                         _p(mean), _p(rstd), b, c, s3, float(slope), _p(y), _p(y_amax), int(amax_seg),
+                                                         _p(mean), _p(rstd), b, c, s3, float(slope), _p(y), ybs, _p(y_amax), int(amax_seg),
                                                          _p(row_keys), s), 'bnact_apply_rowmax')
-            _lib.check(self.lib.pvcnn_row_keys_decode(_p(row_keys), _p(y), b * c, s3, _p(winners), _p(values), s), 'row_keys_decode')
+            _lib.check(self.lib.pvcnn_row_keys_decode(_p(row_keys), _p(y), b * c, s3, _p(winners), _p(values), c, ybs, s), 'row_keys_decode')
         return y, winners, values
 
     has_devox_bnact = True
@@ -1019,9 +1029,11 @@ class HipBackend:
     # ---- torch.cat(features, dim=1) of the classifier input + the amax buffer of its output in one pass (csrc/bnact.hip) ----
     has_concat_points = True
 
-    def concat_points(self, tensors, want_amax=True):
+    def concat_points(self, tensors, want_amax=True, out=None, in_place=None):
         """tensors: (B, C_i, N) float32, each with contiguous rows inside a cloud (a channel slice is fine) or broadcast over the points
-        (stride 0 along N, contiguous (B, C_i)) -> (out (B, sum C_i, N), its amax buffer with 256-point segments | None)."""
+        (stride 0 along N, contiguous (B, C_i)) -> (out (B, sum C_i, N), its amax buffer with 256-point segments | None).
+        out: the (B, sum C_i, N) buffer to fill; in_place = {i: amax buffer of tensors[i]}: those sources ALREADY ARE their channel slice
+        of `out` (the pass that produced them wrote them there: bnact_apply_rowmax(..., out=)): nothing is copied for them."""
         _shape(0 < len(tensors) <= 8, 'concat_points: 1..8 sources')
         b, n = tensors[0].shape[0], tensors[0].shape[2]
         ptrs, bstr, chans, pstr = [], [], [], []
@@ -1037,12 +1049,21 @@ class HipBackend:
                 pstr.append(1); bstr.append(t.stride(0) if b > 1 else c * n)
             ptrs.append(t.data_ptr()); chans.append(c)
         k = len(tensors)
-        out = torch.empty((b, sum(chans), n), dtype=torch.float32, device=tensors[0].device)
+        if out is None:
+            out = torch.empty((b, sum(chans), n), dtype=torch.float32, device=tensors[0].device)
+        else:
+            _f32(out, 'out')
+            _shape(tuple(out.shape) == (b, sum(chans), n), 'concat_points: out (B, sum C_i, N) expected')
+        pre = [None] * k
+        for i, table in (in_place or {}).items():
+            _shape(want_amax and table is not None and table.dtype == torch.int32 and table.is_cuda, 'concat_points: an in-place source comes with its amax buffer')
+            pre[i] = table.data_ptr()
         amax = self.amax_buffer(b, n, self.PW_AMAX_SEG, out.device) if want_amax else None
         ticket = self._tickets(1, out.device) if want_amax else None
         with _Launch(out) as s:
             _lib.check(self.lib.pvcnn_concat_points((ctypes.c_void_p * k)(*ptrs), (ctypes.c_long * k)(*bstr), (ctypes.c_int * k)(*chans),
-                                                    (ctypes.c_int * k)(*pstr), k, b, n, _p(out), _p(amax) if want_amax else None,
+                                                    (ctypes.c_int * k)(*pstr), (ctypes.c_void_p * k)(*pre) if in_place else None, k, b, n,
+                                                    _p(out), _p(amax) if want_amax else None,
                                                     _p(ticket) if ticket is not None else None, s), 'concat_points')
         return out, amax
 

@@ -95,7 +95,10 @@ class BatchNormAct(Function):
                 stats = native().bn_finalize(stats_part, x3.shape[0] * x3.shape[2], running_mean, running_var, momentum, eps, stats_shift,
                                              zero_word=whole, counter=counter)
                 ctx.slope, ctx.training, ctx.shape, ctx.drop = slope, training, shape, None
-                y, winners, values = native().bnact_apply_rowmax(x3, w, b, stats[0], stats[1], slope, amax_seg, armed, keys)
+                dest = getattr(_ROW_MAX, 'out', None)       # (emit_row_max(bn, out=...): y goes straight into its slice of the concatenation)
+                if dest is not None and not (dest.is_cuda and tuple(dest.shape) == tuple(x3.shape) and dest.dtype == torch.float32):
+                    dest = None
+                y, winners, values = native().bnact_apply_rowmax(x3, w, b, stats[0], stats[1], slope, amax_seg, armed, keys, out=dest)
                 ctx.save_for_backward(x3, w, b, stats[0], stats[1])
                 ctx.mark_non_differentiable(armed, winners, values)
                 ctx.set_materialize_grads(False)
@@ -137,17 +140,20 @@ _ROW_MAX = threading.local()
 
 
 @contextlib.contextmanager
-def emit_row_max(bn):
+def emit_row_max(bn, out=None):
     """with emit_row_max(bn): inside, the fused (BatchNorm `bn`, activation) pass ALSO emits the row maxima of the (B, C, N) tensor it
     writes; the tensor then carries them as `_pvcnn_row_max` = (winners (B,C) int64, values (B,C)) == y.max(dim=-1)'s (indices, values)
     -- what the global max-pool of models/s3dis/pvcnn.py:41-43 needs, without a read of the tensor.  Only the training path whose
-    statistics come from the producing convolution's epilogue takes it; elsewhere nothing is attached and the caller reduces itself."""
-    prev = getattr(_ROW_MAX, 'bn', None)
-    _ROW_MAX.bn = bn
+    statistics come from the producing convolution's epilogue takes it; elsewhere nothing is attached and the caller reduces itself.
+    out (round 5): a (B, C, N) view -- the channel slice of the classifier's concatenation (models/s3dis/pvcnn.py:45) this tensor will
+    be -- that the same pass writes INSTEAD of a tensor of its own: `workload.concat_points(..., out=)` then copies nothing for it (the
+    widest source: 268 of PVCNN's 386 MB).  Ignored wherever the row-maxima pass itself is not taken."""
+    prev = (getattr(_ROW_MAX, 'bn', None), getattr(_ROW_MAX, 'out', None))
+    _ROW_MAX.bn, _ROW_MAX.out = bn, out
     try:
         yield
     finally:
-        _ROW_MAX.bn = prev
+        _ROW_MAX.bn, _ROW_MAX.out = prev
 
 
 def _bn_mode(bn, finalize_counts=False):

@@ -74,12 +74,16 @@ class _ConcatPoints(torch.autograd.Function):
     reads.  Backward hands every source its channel slice of the gradient as a view (what torch.cat's backward does)."""
 
     @staticmethod
-    def forward(ctx, *taps):
-        from .modules.functional import _cache
+    def forward(ctx, spec, *taps):
+        """spec: None, or (out buffer (B, sum C_i, N), {source index: that source's amax buffer}) -- sources that the pass which
+        produced them already wrote into their channel slice of the buffer (emit_row_max(bn, out=...)): nothing is copied for them."""
         from .modules.functional._autograd import native
         be = native()
         ctx.splits = [t.shape[1] for t in taps]
-        out, amax = be.concat_points([t.detach() for t in taps])
+        if spec is None:
+            out, amax = be.concat_points([t.detach() for t in taps])
+        else:
+            out, amax = be.concat_points([t.detach() for t in taps], out=spec[0], in_place=spec[1])
         ctx.mark_non_differentiable(amax)
         ctx.set_materialize_grads(False)
         return out, amax
@@ -87,8 +91,8 @@ class _ConcatPoints(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad, _grad_amax=None):
         if grad is None:
-            return (None,) * len(ctx.splits)
-        grads, off = [], 0
+            return (None,) * (1 + len(ctx.splits))
+        grads, off = [None], 0
         for c in ctx.splits:
             piece = grad.narrow(1, off, c)              # a broadcast source: expand's own backward sums its slice over the points
             piece._pvcnn_private_slice = True           # (disjoint views of a buffer only this node holds: _TapAndPool may add in place)
@@ -97,8 +101,39 @@ class _ConcatPoints(torch.autograd.Function):
         return tuple(grads)
 
 
-def concat_points(taps):
-    """torch.cat(taps, dim=1); on the GPU path one kernel that also tags the result with its f16x2 scale table."""
+class _Slot:
+    """Where the LAST point stage's output goes: its channel slice of the buffer the classifier's concatenation will be, so that
+    the BatchNorm + ReLU pass writes it there (268 of PVCNN's 386 MB are then never copied).  Made before that stage runs
+    (`concat_slot`), handed to `emit_row_max(bn, out=slot.view)` and to `concat_points(taps, slot=...)`; if the pass did not take
+    it (another route: CPU, eval, no row maxima) the tap simply is not in place and is copied like the others."""
+
+    def __init__(self, buffer, index, c0, c1):
+        self.buffer, self.index, self.view = buffer, index, buffer[:, c0:c1, :]
+
+    def holds(self, tap):
+        v = self.view
+        return (tap.data_ptr() == v.data_ptr() and tuple(tap.shape) == tuple(v.shape) and tuple(tap.stride()) == tuple(v.stride()))
+
+
+def concat_slot(taps_so_far, stage_channels, total_channels, like):
+    """-> _Slot for the stage that comes next (its output: (B, stage_channels, N)) inside a fresh (B, total_channels, N) buffer, or None
+    where the GPU path with row maxima is not available."""
+    from .modules.functional._autograd import native
+    if not (like.is_cuda and like.dtype == torch.float32 and torch.is_grad_enabled()):
+        return None
+    be = native()
+    if not (getattr(be, 'has_concat_points', False) and getattr(be, 'has_bnact_rowmax', False)) or like.shape[-1] % 256:
+        return None
+    c0 = sum(int(t.shape[1]) for t in taps_so_far)
+    if c0 + stage_channels > total_channels:
+        return None
+    buf = torch.empty((like.shape[0], int(total_channels), like.shape[-1]), dtype=torch.float32, device=like.device)
+    return _Slot(buf, len(taps_so_far), c0, c0 + int(stage_channels))
+
+
+def concat_points(taps, slot=None, slot_amax=None):
+    """torch.cat(taps, dim=1); on the GPU path one kernel that also tags the result with its f16x2 scale table.  slot / slot_amax: the
+    _Slot one of the taps was written into and that tap's amax buffer (concat_slot)."""
     from .modules.functional import _cache
     from .modules.functional._autograd import native
     be = native()
@@ -110,10 +145,35 @@ def concat_points(taps):
              ((t.shape[2] == 1 or t.stride(2) == 1) and (t.shape[1] == 1 or t.stride(1) == t.shape[2])) for t in taps)
     if not ok:
         return torch.cat(taps, dim=1)
-    out, amax = _ConcatPoints.apply(*taps)
+    spec = None
+    if (slot is not None and slot_amax is not None and slot.index < len(taps) and slot.holds(taps[slot.index])
+            and sum(int(t.shape[1]) for t in taps) == slot.buffer.shape[1] and sum(int(t.shape[1]) for t in taps[:slot.index]) * 1 ==
+            (slot.view.data_ptr() - slot.buffer.data_ptr()) // (4 * slot.buffer.shape[2])):
+        spec = (slot.buffer, {slot.index: slot_amax})
+    out, amax = _ConcatPoints.apply(spec, *taps)
     if getattr(be, 'pw_math', '') == 'f16x2':
         _cache.tag_amax(out, be.PW_AMAX_SEG, amax)
     return out
+
+
+def _out_channels(stage):
+    """Output channels of a point stage (PVConv | SharedMLP)."""
+    if hasattr(stage, 'out_channels'):
+        return int(stage.out_channels)
+    convs = [m for m in stage.modules() if isinstance(m, (nn.Conv1d, nn.Conv2d))]
+    return int(convs[-1].out_channels)
+
+
+def _in_channels(head):
+    """Input channels of a point-wise head [SharedMLP, ...]: its first convolution's."""
+    return int(next(m for m in head.modules() if isinstance(m, (nn.Conv1d, nn.Conv2d))).in_channels)
+
+
+def _amax_tag(t):
+    """The f16x2 scale table the pass that wrote `t` left on it (256-point segments), or None."""
+    from .modules.functional import _cache
+    from .modules.functional._autograd import native
+    return _cache.amax_of(t, getattr(native(), 'PW_AMAX_SEG', 0))
 
 
 def _last_norm(stage):
@@ -231,16 +291,22 @@ class PVCNN(nn.Module):
         coords = inputs[:, :3, :]
         feats, taps = inputs, []
         last = len(self.point_features) - 1
+        slot = slot_amax = None
         for i, stage in enumerate(self.point_features):
-            # (the last stage's BatchNorm + ReLU pass also emits the row maxima the global max-pool needs: no read of that tensor)
-            with (emit_row_max(_last_norm(stage)) if i == last else contextlib.nullcontext()):
+            # (the last stage's BatchNorm + ReLU pass also emits the row maxima the global max-pool needs: no read of that tensor --
+            #  and writes its output straight into its slice of the classifier's concatenation: no copy of that tensor either)
+            if i == last:
+                slot = concat_slot(taps, _out_channels(stage), _in_channels(self.classifier), feats)
+            with (emit_row_max(_last_norm(stage), out=slot.view if slot is not None else None) if i == last else contextlib.nullcontext()):
                 feats, _ = stage((feats, coords))
             taps.append(feats)
+        if slot is not None and slot.holds(feats):
+            slot_amax = _amax_tag(feats)
         taps[-1], pooled = tap_and_pool(feats)             # the last stage's features: a tap AND the global max pool
         cloud = run_dense(self.cloud_features, pooled)    # (Linear + BatchNorm1d + ReLU on 16 rows: one launch per block, csrc/dense.hip)
         # (expand, not repeat: torch.cat reads the broadcast view -- the repeated (B,128,N) tensor is never written on its own)
         taps.append(cloud.unsqueeze(-1).expand(-1, -1, coords.size(-1)))
-        return _classify(self.classifier, concat_points(taps))
+        return _classify(self.classifier, concat_points(taps, slot, slot_amax))
 
 
 class PVCNN2(nn.Module):
@@ -345,14 +411,20 @@ class PVCNNShapeNet(nn.Module):
         taps = [inputs[:, -self.num_shapes:, :]]
         coords = feats[:, :3, :]
         last = len(self.point_features) - 1
+        slot = slot_amax = None
         for i, stage in enumerate(self.point_features):
-            # (the last stage's BatchNorm + ReLU pass also emits the row maxima the global max-pool needs: no read of that tensor)
-            with (emit_row_max(_last_norm(stage)) if i == last else contextlib.nullcontext()):
+            # (the last stage's BatchNorm + ReLU pass also emits the row maxima the global max-pool needs and writes its output into its
+            #  slice of the classifier's concatenation: see PVCNN.forward)
+            if i == last:
+                slot = concat_slot(taps, _out_channels(stage), _in_channels(self.classifier), feats)
+            with (emit_row_max(_last_norm(stage), out=slot.view if slot is not None else None) if i == last else contextlib.nullcontext()):
                 feats, _ = stage((feats, coords))
             taps.append(feats)
+        if slot is not None and slot.holds(feats):
+            slot_amax = _amax_tag(feats)
         taps[-1], pooled = tap_and_pool(feats)             # the last stage's features: a tap AND the global max pool
         taps.append(pooled.unsqueeze(-1).expand(-1, -1, coords.size(-1)))
-        return _classify(self.classifier, concat_points(taps))
+        return _classify(self.classifier, concat_points(taps, slot, slot_amax))
 
 
 class _FrustumSegmentation(nn.Module):
