@@ -101,6 +101,10 @@ class _ConcatPoints(torch.autograd.Function):
         return tuple(grads)
 
 
+# PVCNN_CONCAT_SLOT=0 (read once per process): the last stage in a tensor of its own, copied by the concatenation like the others (A/B)
+_SLOT_ENABLED = __import__('os').environ.get('PVCNN_CONCAT_SLOT', '1') != '0'
+
+
 class _Slot:
     """Where the LAST point stage's output goes: its channel slice of the buffer the classifier's concatenation will be, so that
     the BatchNorm + ReLU pass writes it there (268 of PVCNN's 386 MB are then never copied).  Made before that stage runs
@@ -119,7 +123,7 @@ def concat_slot(taps_so_far, stage_channels, total_channels, like):
     """-> _Slot for the stage that comes next (its output: (B, stage_channels, N)) inside a fresh (B, total_channels, N) buffer, or None
     where the GPU path with row maxima is not available."""
     from .modules.functional._autograd import native
-    if not (like.is_cuda and like.dtype == torch.float32 and torch.is_grad_enabled()):
+    if not (_SLOT_ENABLED and like.is_cuda and like.dtype == torch.float32 and torch.is_grad_enabled()):
         return None
     be = native()
     if not (getattr(be, 'has_concat_points', False) and getattr(be, 'has_bnact_rowmax', False)) or like.shape[-1] % 256:
