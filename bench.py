@@ -19,7 +19,7 @@ Extra objects on the JSON line:
   roofline     : the hot path's headline kernel (trilinear_devoxelize fwd at the R=32 stage,
                  16x64x4096 points from a 16x64x32^3 grid), timed twice: LIVE in this process with HIP events on the
                  launch stream around every launch of it in instrumented eager steps AFTER the timed region (a replayed
-                 graph cannot carry per-kernel events; mean event-pair time - the calibrated time of an empty event pair
+                 graph cannot carry per-kernel events; median event-pair time - the calibrated time of an empty event pair
                  on a busy stream), and from the committed rocprofv3 trace of this command, the average of the SAME launch
                  inside the replayed graph (profiles/kernel_durations.json).  achieved = SURVEY 8(d) algorithmic bytes /
                  the SLOWER of the two; both are on the line.
@@ -169,13 +169,14 @@ class KernelClock:
         return t[len(t) // 2]
 
     def summary(self, overhead_us=0.0):
-        agg = {}
+        # MEDIAN of the event pairs of a launch shape (round 5): one host hiccup between the two records of a pair -- the stream is
+        # fed launch by launch from Python here -- used to move the mean by 10 us (a 47.9 us "live" reading of a 35.9 us kernel in one
+        # evidence run), and the roofline is priced on the slower of this figure and the in-graph one
+        import statistics
+        samples = {}
         for (kernel, nbytes, shape), e0, e1 in self.records:
-            k = (kernel, shape)
-            ms = e0.elapsed_time(e1)
-            a = agg.setdefault(k, [0, 0.0, nbytes])
-            a[0] += 1
-            a[1] += ms
+            samples.setdefault((kernel, shape), [nbytes, []])[1].append(e0.elapsed_time(e1))
+        agg = {k: [len(v[1]), statistics.median(v[1]) * len(v[1]), v[0]] for k, v in samples.items()}
         out = []
         for (kernel, shape), (calls, ms, nbytes) in sorted(agg.items()):
             raw_us = ms * 1e3 / calls
@@ -672,7 +673,7 @@ def main():
                         'avg_us': head['avg_us'], 'event_pair_us': head['event_pair_us'], 'calls': head['calls'],
                         'event_overhead_us': round(event_overhead_us, 2),
                         'timing': f'avg_us: HIP events on the launch stream around each launch of this kernel in {eager_steps} eager steps after the '
-                                  'timed region (mean event-pair time - the time an empty event pair reads on a busy stream: a replayed graph '
+                                  'timed region (MEDIAN event-pair time - the time an empty event pair reads on a busy stream: a replayed graph '
                                   'cannot carry per-kernel events); in_graph_us: rocprofv3 average of the same kernel inside the replayed graph, '
                                   'from the committed trace of this command; achieved / frac use the slower of the two'}
             roofline.update(pmc_traffic('trilinear_devoxelize_fwd', head['shape_BCNR']))
