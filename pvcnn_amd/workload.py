@@ -455,12 +455,30 @@ class _FrustumSegmentation(nn.Module):
         # (expand, not repeat: the concatenation reads the broadcast views -- the repeated (B, 3, N) / (B, 1024, N) tensors are never
         # written on their own; reference: .repeat([1, 1, npts]), models/kitti/frustum/segmentation/pointnet.py:52-57, same values)
         one_hot = inputs['one_hot_vectors'].unsqueeze(-1).expand(-1, -1, npts)
-        per_point, coords = self.point_features((feats, feats[:, :3, :]))
-        pooled, _ = self.cloud_features((per_point, coords)) if len(self.cloud_features) else (per_point, coords)
-        pooled = pooled.max(dim=-1, keepdim=True).values.expand(-1, -1, npts)
+        if len(self.cloud_features):                               # (a variant with cloud stages: the modules as the reference chains them)
+            per_point, coords = self.point_features((feats, feats[:, :3, :]))
+            pooled, _ = self.cloud_features((per_point, coords))
+            pooled = pooled.max(dim=-1, keepdim=True).values.expand(-1, -1, npts)
+            return _classify(self.classifier, concat_points([one_hot, per_point, pooled]))
+        # The PVCNN variant: the last stage's output is BOTH a source of the classifier's concatenation and max-pooled over the points
+        # (reference: .max(dim=-1, keepdim=True) on the 134 MB tensor, then torch.cat).  As in workload.PVCNN (round 5): its BatchNorm
+        # + ReLU pass emits the row maxima and writes the tensor straight into its slice of the concatenation; the pool's gradient
+        # joins the tap's at the winners (_TapAndPool) instead of a dense scatter + a full-tensor addition.
+        stages = list(self.point_features)
+        coords, x, slot, slot_amax = feats[:, :3, :], feats, None, None
+        for i, stage in enumerate(stages):
+            if i + 1 == len(stages):
+                slot = concat_slot([one_hot], _out_channels(stage), _in_channels(self.classifier), x)
+            with (emit_row_max(_last_norm(stage), out=slot.view if slot is not None else None) if i + 1 == len(stages)
+                  else contextlib.nullcontext()):
+                x, coords = stage((x, coords))
+        if slot is not None and slot.holds(x):
+            slot_amax = _amax_tag(x)
+        per_point, pooled = tap_and_pool(x)
+        pooled = pooled.unsqueeze(-1).expand(-1, -1, npts)
         # (the classifier head module by module on this package's kernels -- under torch.autocast the bare nn.Conv1d at its end would
         # otherwise be a vendor bf16 GEMM with casts either side: _classify; its input from concat_points: one pass, amax table included)
-        return _classify(self.classifier, concat_points([one_hot, per_point, pooled]))
+        return _classify(self.classifier, concat_points([one_hot, per_point, pooled], slot, slot_amax))
 
 
 class _CloudRegressor(nn.Module):

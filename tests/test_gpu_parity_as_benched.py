@@ -259,6 +259,17 @@ def _frustum_three_ways(build, in0, targets, loss_of, autocast):
         return out
     seam._backend.mask_select = recording_select
     winners, rounding = PinMaxWinners(), Bf16RoundingRecorder()
+    # (round 5) the segmentation net's global max-pool no longer goes through `Tensor.max` on the GPU -- its winners come out of the
+    # BatchNorm pass (workload.tap_and_pool) --, so PinMaxWinners cannot see it: record the winners of the tensor it pools at the
+    # same place, where the CPU stacks' tap_and_pool WILL ask `x.max(dim=-1)` and be served from the list
+    from pvcnn_amd import workload as _wl
+    orig_tap_and_pool = _wl.tap_and_pool
+
+    def recording_tap_and_pool(x):
+        if x.requires_grad and torch.is_grad_enabled():
+            winners.winners.append(x.detach().max(dim=-1).indices.cpu())
+        return orig_tap_and_pool(x)
+    _wl.tap_and_pool = recording_tap_and_pool
     try:
         with winners, rounding.recording():
             inp, leaf = make(DEV, torch.float32)
@@ -268,6 +279,7 @@ def _frustum_three_ways(build, in0, targets, loss_of, autocast):
             torch.cuda.synchronize()
     finally:
         del seam._backend.mask_select
+        _wl.tap_and_pool = orig_tap_and_pool
     res_g = (loss_g.item(), _grads(gpu_net, leaf))
 
     # ---- CPU stacks: the same discrete decisions, the same bf16 rounding errors ----
