@@ -124,6 +124,7 @@ class KernelClock:
 
     def __init__(self, backend):
         self.backend, self.records, self.enabled, self._orig, self.only = backend, [], False, {}, None
+        self.last_call = {}                     # (kernel, shape) -> (callable, args, kw) of its last watched call: burst()
 
     def install(self):
         for name, describe in list(self.WATCH.items()) + list(self.WATCH_FLOPS.items()):
@@ -141,7 +142,9 @@ class KernelClock:
                 e0.record()
                 out = _orig(*args, **kw)
                 e1.record()
-                self.records.append((_describe(args, out), e0, e1))
+                key = _describe(args, out)
+                self.records.append((key, e0, e1))
+                self.last_call[(key[0], tuple(key[2]))] = (_orig, args, kw)
                 return out
             setattr(self.backend, name, timed)
 
@@ -163,6 +166,31 @@ class KernelClock:
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(pairs)]
         for e0, e1 in evs:
             e0.record()
+            e1.record()
+        torch.cuda.synchronize()
+        t = sorted(e0.elapsed_time(e1) * 1e3 for e0, e1 in evs)
+        return t[len(t) // 2]
+
+    def burst(self, kernel, shape, launches=64):
+        """The last watched call of (kernel, shape) again, `launches` times back to back behind a long filler kernel, an event pair
+        around each (median; the caller subtracts event_pair_overhead_us, calibrated the same way): us per launch with
+        the GPU -- not the Python thread that feeds the stream -- setting the pace.  An event pair around a single launch inside an
+        eager step reads the HOST's gap whenever the host is the slower side: one evidence run of round 5 read 62 us (median of 60
+        pairs) for the kernel rocprofv3 saw at 35.9 us inside the replayed graph on the same box (profiles/r05_bench_20_5.json as
+        committed in 24f205d)."""
+        call = self.last_call.get((kernel, tuple(shape)))
+        if call is None:
+            return None
+        fn, args, kw = call
+        for _ in range(4):
+            fn(*args, **kw)
+        filler = torch.randn(8192, 8192, device='cuda')
+        for _ in range(3):                       # ~30 ms of queued work: the launches below are all queued before the first one starts
+            filler = (filler @ filler) * 1e-4
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(launches)]
+        for e0, e1 in evs:
+            e0.record()
+            fn(*args, **kw)
             e1.record()
         torch.cuda.synchronize()
         t = sorted(e0.elapsed_time(e1) * 1e3 for e0, e1 in evs)
@@ -650,6 +678,13 @@ def main():
             # (the step's slowest devoxelize gather IS the one at the largest resolution; nothing about the shape is hard-coded)
             needles = ('gather_lds_pipe_kernel', 'TrilinearFromCoords', 'XfBnAct') if (pipe and fused and args.config == 'cfg2') else ('gather_lds', 'TrilinearFromCoords')
             graph_us, graph_kernel = in_graph_us(needles, config=args.config)
+            # live figure: the step's own launch of this kernel (same arguments) replayed back to back with the GPU setting the pace;
+            # the per-launch pairs inside the eager steps stay on the line as `in_step_event_pair_us` (host-paced: an upper bound)
+            in_step_us = head['avg_us']
+            burst_raw = clock.burst('trilinear_devoxelize_fwd', head['shape_BCNR'])
+            if burst_raw is not None:
+                head = dict(head, avg_us=round(max(burst_raw - event_overhead_us, 1e-3), 2), event_pair_us=round(burst_raw, 2))
+                head['achieved_GBs'] = round(head['algorithmic_MB'] * 1e6 / (head['avg_us'] * 1e-6) / 1e9, 1)
             # ALWAYS the slower of the two: the live figure of this run, and the in-graph average only while the committed
             # trace was taken on the kernel sources this run executes (sources digest) -- a stale trace never prices a run
             priced_us = max(head['avg_us'], graph_us or 0.0)
@@ -671,11 +706,15 @@ def main():
                                               'frac': round(head['achieved_GBs'] / HBM_PEAK_GBS, 4)},
                         'frac_of_achievable_6300': round(survey_bytes / (priced_us * 1e-6) / 1e9 / 6300.0, 4),
                         'avg_us': head['avg_us'], 'event_pair_us': head['event_pair_us'], 'calls': head['calls'],
+                        'in_step_event_pair_us': in_step_us,
                         'event_overhead_us': round(event_overhead_us, 2),
-                        'timing': f'avg_us: HIP events on the launch stream around each launch of this kernel in {eager_steps} eager steps after the '
-                                  'timed region (MEDIAN event-pair time - the time an empty event pair reads on a busy stream: a replayed graph '
-                                  'cannot carry per-kernel events); in_graph_us: rocprofv3 average of the same kernel inside the replayed graph, '
-                                  'from the committed trace of this command; achieved / frac use the slower of the two'}
+                        'timing': 'avg_us: HIP events on the launch stream around each of 64 back-to-back launches of this kernel with the '
+                                  'arguments of its last launch in the step, queued behind 30 ms of other work so that the GPU and not the '
+                                  'Python thread sets the pace (MEDIAN event-pair time - the time an empty event pair reads under the same '
+                                  f'conditions); in_step_event_pair_us: the same pairs around its launches inside {eager_steps} eager steps '
+                                  '(host-paced: over-reads when the host is the slower side; a replayed graph cannot carry per-kernel '
+                                  'events); in_graph_us: rocprofv3 average of the same kernel inside the replayed graph, from the committed '
+                                  'trace of this command; achieved / frac use the SLOWER of avg_us and in_graph_us'}
             roofline.update(pmc_traffic('trilinear_devoxelize_fwd', head['shape_BCNR']))
         # the 64->64 forward at 32^3 is the SECOND launch of its template in a step (behind the 9->64 one, same grid): priced like the
         # HBM roofline on the slower of live events and the committed in-graph rocprofv3 average
@@ -725,6 +764,8 @@ def main():
                         'r05_pmc_mfma_fill_probe.jsonl) the matrix pipes are busy in 0.41-0.53 of the shader cycles and the chip clocks '
                         '2.0-2.1 GHz under these kernels on real operands (2.4 GHz on constant ones): frac = busy x clock / 2.4'},
             'kernels': kernels,
+            'kernels_note': 'per-launch HIP event pairs inside the eager steps behind the timed region (median per launch shape, minus the '
+                            'empty-pair time): host-paced, i.e. an upper bound per kernel; the in-graph durations are profiles/kernel_durations*.json',
         }
         if graph_error:
             line['graph_error'] = graph_error
