@@ -106,12 +106,8 @@ __device__ __forceinline__ float fps_max3(float a, float b, float c) { float r; 
 // the tie rule in full.
 template <int THREADS, int PPT, bool LDSC>
 __global__ __launch_bounds__(THREADS) void fps_kernel(const float *__restrict__ coords, int N, int M, float *__restrict__ distances,
-                                                      int32_t *__restrict__ indices, int hi_prio) {
+                                                      int32_t *__restrict__ indices) {
   static_assert(PPT % 2 == 0 && (THREADS % 512 == 0 || 512 % THREADS == 0), "launch shape");
-  // a chain of M - 1 barrier-separated steps on ONE CU per cloud: when the caller runs it on a stream of its own next to kernels that
-  // fill the chip (PVCNN++: next to the first stage's convolutions), its waves take the issue slots first -- a wave of the other
-  // kernel that waits one cycle loses nothing measurable, a step of this chain that waits stretches the whole chain
-  if (hi_prio) __builtin_amdgcn_s_setprio(3);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int W = THREADS / kWave, H = PPT / 2, GS = PPT < 8 ? PPT : 8, NG = PPT / GS;
   unsigned long long *slots = reinterpret_cast<unsigned long long *>(smem);   // [2][W]
@@ -263,7 +259,6 @@ __global__ __launch_bounds__(1024) void fps_global_kernel(const float *__restric
 template <int THREADS, int PPT>
 static int launch_fps(const float *coords, int B, int N, int M, float *distances, int32_t *indices, hipStream_t s) {
   constexpr int W = THREADS / kWave;
-  static const int hi_prio = [] { const char *e = getenv("PVCNN_FPS_PRIO"); return e && e[0] == '0' ? 0 : 1; }();
   const size_t slots = 2 * W * sizeof(unsigned long long), cloud = (size_t)3 * N * sizeof(float);
   if (cloud + slots <= 144 * 1024) {     // the cloud in LDS: the newest sample's coordinates are one broadcast read away
     auto k = fps_kernel<THREADS, PPT, true>;
@@ -271,9 +266,9 @@ static int launch_fps(const float *coords, int B, int N, int M, float *distances
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(cloud + slots));
       if (e != hipSuccess) { set_error("fps: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
     }
-    hipLaunchKernelGGL(k, dim3(B), dim3(THREADS), cloud + slots, s, coords, N, M, distances, indices, hi_prio);
+    hipLaunchKernelGGL(k, dim3(B), dim3(THREADS), cloud + slots, s, coords, N, M, distances, indices);
   } else {
-    hipLaunchKernelGGL((fps_kernel<THREADS, PPT, false>), dim3(B), dim3(THREADS), slots, s, coords, N, M, distances, indices, hi_prio);
+    hipLaunchKernelGGL((fps_kernel<THREADS, PPT, false>), dim3(B), dim3(THREADS), slots, s, coords, N, M, distances, indices);
   }
   return check_launch("fps");
 }
