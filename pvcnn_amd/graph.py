@@ -20,7 +20,7 @@ import contextlib
 
 import torch
 
-from .modules.functional import _cache
+from .modules.functional import _cache, _sidepath
 
 __all__ = ['GraphedTrainStep']
 
@@ -177,6 +177,7 @@ class GraphedTrainStep:
         with self.autocast():
             loss = self.loss_fn()
         loss.backward()
+        _sidepath.join()                                 # (the weight-gradient path of backward: joined INSIDE a capture, whatever its mode)
         return loss
 
     def eager_step(self):
