@@ -24,8 +24,6 @@ Works with any torch.distributed backend: `nccl` (= RCCL) on GPUs, `gloo` in the
 import torch
 import torch.distributed as dist
 
-from .modules.functional import _sidepath
-
 __all__ = ['GradBucketReducer', 'shard_batch']
 
 
@@ -134,7 +132,6 @@ class GradBucketReducer:
             return
         b.pending -= 1
         if b.pending == 0:
-            _sidepath.join()                  # the weight-gradient launches of this bucket may still be on the side stream
             b.pack()
             if self.collective and self.launch_from_hooks:
                 b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -156,7 +153,6 @@ class GradBucketReducer:
     def finish(self):
         """Wait for the in-flight all-reduces, launch those of buckets that never filled (unused
         parameters) and turn sums into means.  Call after backward, before optimizer.step()."""
-        _sidepath.join()                              # (functional/_sidepath.py: the weight gradients written on the side stream)
         for b in self.buckets:
             if not b.packed:                          # never filled (unused parameters), or only accumulated under no_sync()
                 b.pack()

@@ -20,7 +20,7 @@ import contextlib
 
 import torch
 
-from .modules.functional import _cache, _sidepath
+from .modules.functional import _cache
 
 __all__ = ['GraphedTrainStep']
 
@@ -177,7 +177,6 @@ class GraphedTrainStep:
         with self.autocast():
             loss = self.loss_fn()
         loss.backward()
-        _sidepath.join()                                 # (the weight-gradient path of backward: joined INSIDE a capture, whatever its mode)
         return loss
 
     def eager_step(self):

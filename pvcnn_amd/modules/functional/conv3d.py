@@ -8,7 +8,7 @@ backward-weight kernel does not serve.  The bias gradient rides on the backward-
 import torch
 from torch.autograd import Function
 
-from . import _cache, _gradslots, _sidepath
+from . import _cache, _gradslots
 from ._autograd import native, amp_fwd, amp_bwd
 
 __all__ = ['voxel_conv3d', 'conv_nsplit']
@@ -94,10 +94,8 @@ class VoxelConv3d(Function):
         if ctx.needs_input_grad[1]:
             # the bias gradient is accumulated by the same kernel from the grad_y tiles it stages anyway
             dst = _gradslots.destinations(be, weight, ctx.bias_param if want_bias else None)   # the parameters' slots in a flat gradient bucket
-            # (nobody reads a weight gradient in its slot before the reducer's join: a parallel path next to the input-gradient chain)
-            with _sidepath.forked(grad_y, (x, grad_y, ctx.x_amax, g_amax), _sidepath.usable(dst, want_bias, grad_y)):
-                res = (be.conv3d_backward_weight_f16(x, grad_y, ctx.x_amax, g_amax, with_bias=want_bias, **dst) if wgrad_f16
-                       else be.conv3d_backward_weight(x, grad_y, with_bias=want_bias, **dst))
+            res = (be.conv3d_backward_weight_f16(x, grad_y, ctx.x_amax, g_amax, with_bias=want_bias, **dst) if wgrad_f16
+                   else be.conv3d_backward_weight(x, grad_y, with_bias=want_bias, **dst))
             gw, gb = res if want_bias else (res, None)
         elif want_bias:
             gb = grad_y.sum(dim=(0, 2, 3, 4))

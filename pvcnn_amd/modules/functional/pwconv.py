@@ -8,7 +8,7 @@ cores (csrc/pointwise_bf16.hip, pointwise_wgrad_f16.hip: fp32 tensors, operands 
 import torch
 from torch.autograd import Function
 
-from . import _cache, _gradslots, _sidepath
+from . import _cache, _gradslots
 from ._autograd import native, amp_fwd, amp_bwd
 
 __all__ = ['pointwise_conv', 'pw_nsplit']
@@ -97,10 +97,8 @@ class PointwiseConv(Function):
         if ctx.needs_input_grad[1]:
             # (x_amax / g_amax None -- the bf16 mode measured neither: backward-weight takes the global maxima in one read each)
             dst = _gradslots.destinations(be, w2, ctx.bias_param if want_bias else None)   # the parameters' slots in a flat gradient bucket
-            # (nobody reads a weight gradient in its slot before the reducer's join: a parallel path next to the input-gradient chain)
-            with _sidepath.forked(g3, (x3, g3, ctx.x_amax, g_amax), _sidepath.usable(dst, want_bias, g3)):
-                res = (be.pwconv_backward_weight_f16(x3, g3, ctx.x_amax, g_amax, with_bias=want_bias, **dst) if wgrad_f16
-                       else be.pwconv_backward_weight(x3, g3, with_bias=want_bias, **dst))
+            res = (be.pwconv_backward_weight_f16(x3, g3, ctx.x_amax, g_amax, with_bias=want_bias, **dst) if wgrad_f16
+                   else be.pwconv_backward_weight(x3, g3, with_bias=want_bias, **dst))
             gw, gb = res if want_bias else (res, None)
             gw = gw.view(ctx.w_shape)
         elif want_bias:

@@ -664,30 +664,3 @@ def test_the_per_tensor_judge_fails_a_dense_error_and_passes_a_sparse_flip():
     stat['buffer bn.running_mean'][5] += 1e-3 * truth['buffer bn.running_mean'].abs().max()
     with pytest.raises(AssertionError, match='running_mean'):
         judge('synthetic: a running statistic off', stat)
-
-
-def test_the_weight_gradient_side_path_is_inert_without_a_gpu():
-    """functional/_sidepath.py: CPU tensors, a missing slot or the switch never fork; join() with nothing open is a no-op."""
-    import torch
-    from pvcnn_amd.modules.functional import _sidepath
-    t = torch.zeros(4)
-    assert not _sidepath.usable({'out_w': t}, False, t)                       # not a CUDA tensor
-    assert not _sidepath.usable({}, False, t)
-    ran = []
-    with _sidepath.forked(t, (t, None), on=False):
-        ran.append(1)
-    assert ran == [1] and not _sidepath._open
-    _sidepath.join()
-    # the bias gradient must have a slot too, or the node returns a fresh tensor that autograd touches on the main stream
-
-    class _Cuda:
-        is_cuda = True
-    keep, _sidepath.enabled = _sidepath.enabled, True
-    try:
-        assert _sidepath.usable({'out_w': t, 'out_b': t}, True, _Cuda)
-        assert not _sidepath.usable({'out_w': t}, True, _Cuda)
-        assert _sidepath.usable({'out_w': t}, False, _Cuda)
-        _sidepath.enabled = False
-        assert not _sidepath.usable({'out_w': t, 'out_b': t}, True, _Cuda)
-    finally:
-        _sidepath.enabled = keep
