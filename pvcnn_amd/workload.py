@@ -296,7 +296,6 @@ class PVCNN(nn.Module):
         feats, taps = inputs, []
         last = len(self.point_features) - 1
         slot = slot_amax = None
-        plans_ahead(self.point_features, coords)
         for i, stage in enumerate(self.point_features):
             # (the last stage's BatchNorm + ReLU pass also emits the row maxima the global max-pool needs: no read of that tensor --
             #  and writes its output straight into its slice of the classifier's concatenation: no copy of that tensor either)
@@ -316,54 +315,6 @@ class PVCNN(nn.Module):
 
 _CENTERS_AHEAD = __import__('os').environ.get('PVCNN_CENTERS_AHEAD', '1') != '0'
 _side_streams = {}
-_PLANS_AHEAD = __import__('os').environ.get('PVCNN_PLANS_AHEAD', '1') != '0'
-
-
-def _side_stream(device):
-    side = _side_streams.get(device)
-    if side is None:
-        side = _side_streams[device] = torch.cuda.Stream(device=device)
-    return side
-
-
-def plans_ahead(stages, coords):
-    """Every PVConv of PVCNN sees the SAME coordinates (models/s3dis/pvcnn.py:38-42), so the grid coordinates and the two scatter
-    plans of the LATER resolutions (PVCNN: the three PVConvs at R = 16 behind the one at R = 32) depend on nothing the first stage
-    computes: a chain of four short launches (~65 us, one round of workgroups each) that sits in front of the second stage when
-    issued in line.  Issued here on a stream of its own -- behind the coordinate statistics, which the first resolution computes
-    on the main stream and every resolution shares -- it runs next to the first stage; the products land in the per-tensor memo
-    where `Voxelization.forward` looks for them, with the event the first consumer waits for.  Training mode only (that is when the
-    pair of plans is built ahead of the scatter); same kernels on the same coordinates -- bit-identical."""
-    if not (_PLANS_AHEAD and coords.is_cuda and torch.is_grad_enabled()):
-        return
-    from .modules.functional import _cache
-    from .modules.functional._autograd import native
-    be = native()
-    if not (getattr(be, 'has_voxel_coords', False) and getattr(be, 'has_pvconv_plans', False)):
-        return
-    voxs, seen = [], set()
-    for stage in stages:
-        for m in (stage.modules() if isinstance(stage, nn.Module) else ()):
-            if isinstance(m, PVConv) and m.training:
-                v = m.voxelization
-                key = v.ahead_key()
-                if key not in seen:
-                    seen.add(key)
-                    voxs.append(v)
-    if len(voxs) < 2:
-        return
-    voxs[0].grid_coordinates(coords)                      # main stream: seeds the shared statistics (and the first stage's own pair)
-    main = torch.cuda.current_stream()
-    side = _side_stream(coords.device)
-    side.wait_stream(main)
-    with torch.cuda.stream(side), torch.no_grad():
-        for v in voxs[1:]:
-            norm, vox = v.grid_coordinates(coords)
-            v._plan_pair(be, norm, vox)
-            done = torch.cuda.Event()
-            done.record(side)
-            _cache.memo(coords, ('ahead',) + v.ahead_key(), lambda done=done: done)
-    coords.record_stream(side)
 
 
 def centers_ahead(sa_layers, coords):
@@ -379,7 +330,9 @@ def centers_ahead(sa_layers, coords):
     from .modules.functional._autograd import native
     be = native()
     main = torch.cuda.current_stream()
-    side = _side_stream(coords.device)
+    side = _side_streams.get(coords.device)
+    if side is None:
+        side = _side_streams[coords.device] = torch.cuda.Stream(device=coords.device)
     side.wait_stream(main)
     with torch.cuda.stream(side), torch.no_grad():
         c = coords.detach()
@@ -502,7 +455,6 @@ class PVCNNShapeNet(nn.Module):
         coords = feats[:, :3, :]
         last = len(self.point_features) - 1
         slot = slot_amax = None
-        plans_ahead(self.point_features, coords)
         for i, stage in enumerate(self.point_features):
             # (the last stage's BatchNorm + ReLU pass also emits the row maxima the global max-pool needs and writes its output into its
             #  slice of the classifier's concatenation: see PVCNN.forward)

@@ -87,66 +87,3 @@ def test_sampling_ahead_inside_a_captured_step(hip, monkeypatch):
     assert losses0 == losses1
     for a, b in zip(inline, ahead):
         assert torch.equal(a, b)
-
-
-# ---- PVCNN / ShapeNet PVCNN: the plans of the later resolutions ahead (pvcnn_amd.workload.plans_ahead) ------------------------------
-def _pvcnn(kind):
-    from pvcnn_amd import workload
-    torch.manual_seed(5)
-    net = (workload.PVCNN(13, 6, width_multiplier=0.25) if kind == 'PVCNN' else workload.PVCNNShapeNet(50, 16, 3, width_multiplier=0.25)).to(DEV).train()
-    for m in net.modules():
-        if isinstance(m, torch.nn.Dropout):
-            m.p = 0.0
-    return net
-
-
-@pytest.mark.parametrize('kind', ['PVCNN', 'PVCNNShapeNet'])
-def test_plans_ahead_is_the_in_line_network_bit_for_bit(hip, monkeypatch, kind):
-    from pvcnn_amd import workload
-    from pvcnn_amd.modules import voxelization
-    net = _pvcnn(kind)
-    x, y = (workload.make_s3dis_batch(2, 2048, device=DEV) if kind == 'PVCNN' else workload.make_shapenet_batch(2, 1024, device=DEV))
-    state = {k: v.clone() for k, v in net.state_dict().items()}
-    waited = []
-    orig = torch.cuda.Stream.wait_event
-
-    def counting(self, ev):
-        waited.append(ev)
-        return orig(self, ev)
-    monkeypatch.setattr(workload, '_PLANS_AHEAD', False)
-    out0, gx0, g0 = _step(net, x, y)
-    net.load_state_dict(state)
-    monkeypatch.setattr(workload, '_PLANS_AHEAD', True)
-    monkeypatch.setattr(torch.cuda.Stream, 'wait_event', counting)
-    out1, gx1, g1 = _step(net, x, y)
-    monkeypatch.setattr(torch.cuda.Stream, 'wait_event', orig)
-    distinct = {m.voxelization.ahead_key() for m in net.modules() if hasattr(m, 'voxelization')}
-    assert len(distinct) >= 2 and len(waited) == len(distinct) - 1          # one wait per resolution built ahead, by its FIRST consumer only
-    assert torch.equal(out0, out1) and torch.equal(gx0, gx1)
-    for k in g0:
-        assert torch.equal(g0[k], g1[k]), k
-
-
-def test_plans_ahead_inside_a_captured_step(hip, monkeypatch):
-    from pvcnn_amd import workload
-    from pvcnn_amd.dp import GradBucketReducer
-    from pvcnn_amd.graph import GraphedTrainStep
-    from pvcnn_amd.optim import FlatAdam
-    x, y = workload.make_s3dis_batch(2, 2048, device=DEV)
-
-    def train(ahead):
-        monkeypatch.setattr(workload, '_PLANS_AHEAD', ahead)
-        net = _pvcnn('PVCNN')
-        reducer = GradBucketReducer(net)
-        opt = FlatAdam(reducer, lr=1e-3)
-        step = GraphedTrainStep(net, lambda: tf.cross_entropy(net(x), y), opt, reducer, warmup=2)
-        assert step.mode == 'graph'
-        losses = [step().item() for _ in range(3)]
-        torch.cuda.synchronize()
-        return losses, [p.detach().clone() for p in net.parameters()]
-
-    losses0, inline = train(False)
-    losses1, ahead = train(True)
-    assert losses0 == losses1
-    for a, b in zip(inline, ahead):
-        assert torch.equal(a, b)
