@@ -687,7 +687,10 @@ def main():
                 head['achieved_GBs'] = round(head['algorithmic_MB'] * 1e6 / (head['avg_us'] * 1e-6) / 1e9, 1)
             # ALWAYS the slower of the two: the live figure of this run, and the in-graph average only while the committed
             # trace was taken on the kernel sources this run executes (sources digest) -- a stale trace never prices a run
-            priced_us = max(head['avg_us'], graph_us or 0.0)
+            # (the burst re-reads one grid 64 times: the 256 MB memory-side cache serves part of it, so it UNDER-reads the launch of
+            #  the step, whose grid the convolution in front has just written; without an in-graph figure of the running sources the
+            #  host-paced in-step pair -- an upper bound -- prices the line instead)
+            priced_us = max(head['avg_us'], graph_us) if graph_us else max(head['avg_us'], in_step_us)
             roofline = {'bound': 'hbm',
                         'kernel': ('pvcnn::gather_lds_pipe_kernel<TrilinearFromCoords, XfBnAct>' if pipe else 'pvcnn::gather_lds_kernel<TrilinearFromCoords>')
                                   + ' = trilinear_devoxelize fwd' + (' with PVConv\'s last BatchNorm+LeakyReLU applied in its LDS staging and the point branch added in its store' if fused else ''),
@@ -696,6 +699,7 @@ def main():
                         'frac': round(survey_bytes / (priced_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                         'priced_on_us': round(priced_us, 2),
                         'priced_on': ('rocprofv3 in-graph average (profiles/kernel_durations*.json)' if graph_us and priced_us == graph_us
+                                      else 'live HIP events of this run (in-step pairs: no trace of the running kernel sources)' if not graph_us and priced_us == in_step_us
                                       else 'live HIP events of this run'),
                         'in_graph_us': graph_us, 'in_graph_kernel': graph_kernel, 'in_graph_trace': trace_table(args.config)[1],
                         'live_frac': round(survey_bytes / (head['avg_us'] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
@@ -714,7 +718,8 @@ def main():
                                   f'conditions); in_step_event_pair_us: the same pairs around its launches inside {eager_steps} eager steps '
                                   '(host-paced: over-reads when the host is the slower side; a replayed graph cannot carry per-kernel '
                                   'events); in_graph_us: rocprofv3 average of the same kernel inside the replayed graph, from the committed '
-                                  'trace of this command; achieved / frac use the SLOWER of avg_us and in_graph_us'}
+                                  'trace of this command; achieved / frac use the SLOWER of avg_us and in_graph_us (of avg_us and in_step_event_pair_us '
+                                  'when the committed trace is not of the running kernel sources)'}
             roofline.update(pmc_traffic('trilinear_devoxelize_fwd', head['shape_BCNR']))
         # the 64->64 forward at 32^3 is the SECOND launch of its template in a step (behind the 9->64 one, same grid): priced like the
         # HBM roofline on the slower of live events and the committed in-graph rocprofv3 average
