@@ -65,14 +65,18 @@ class PointNetSAModule(nn.Module):
     def forward(self, inputs):
         features, coords = inputs
         ahead = self.__dict__.pop('_centers_ahead', None)
-        if ahead is not None and coords.is_cuda and ahead[2] == tuple(coords.shape):
+        centers = None
+        if ahead is not None and coords.is_cuda:
             # (pvcnn_amd.workload.centers_ahead: the sampling of the whole pyramid depends on the input coordinates alone and was
-            #  issued on a stream of its own at the top of the network's forward; the SAME indices F.furthest_point_sample computes)
-            picked, done, _ = ahead
-            torch.cuda.current_stream().wait_event(done)
-            picked.record_stream(torch.cuda.current_stream())
-            centers = F.gather(coords.contiguous(), picked)
-        else:
+            #  issued on a stream of its own at the top of the network's forward; the SAME indices F.furthest_point_sample computes,
+            #  valid for exactly the tensor the level before returned -- anything else samples in line)
+            picked, done, chain = ahead
+            torch.cuda.current_stream().wait_event(done)      # always: the side path joins here (a capture must not end with it open)
+            if chain.accepts(coords):
+                picked.record_stream(torch.cuda.current_stream())
+                centers = F.gather(coords.contiguous(), picked)
+                chain.expect(centers)
+        if centers is None:
             centers = F.furthest_point_sample(coords, self.num_centers)
         # (the max over the neighbours: one streaming pass each way on the GPU, csrc/pool.hip; elsewhere torch.max itself)
         pooled = [neighbor_max(mlp(grouper(coords, centers, features)))

@@ -317,13 +317,37 @@ _CENTERS_AHEAD = __import__('os').environ.get('PVCNN_CENTERS_AHEAD', '1') != '0'
 _side_streams = {}
 
 
+class _SamplingChain:
+    """What ties the levels of `centers_ahead` together: level l was sampled from the centres of level l - 1, so its indices are valid
+    for exactly ONE tensor -- the one level l - 1 returned -- in the state it was returned in (identity + in-place version, like
+    every entry of functional/_cache.py).  A module that receives anything else (a hook that jitters the coordinates, a caller that
+    feeds its own) samples in line and breaks the chain for the levels behind it."""
+    __slots__ = ('expected', 'version', 'broken')
+
+    def __init__(self, coords):
+        self.broken = False
+        self.expect(coords)
+
+    def expect(self, tensor):
+        import weakref
+        self.expected, self.version = weakref.ref(tensor), tensor._version
+
+    def accepts(self, coords):
+        ok = (not self.broken) and self.expected() is coords and coords._version == self.version
+        if not ok:
+            self.broken = True
+        return ok
+
+
 def centers_ahead(sa_layers, coords):
     """The furthest-point sampling of the whole set-abstraction pyramid, issued NOW on a stream of its own: level l + 1 samples
     from the centres of level l, so the chain depends on the input coordinates alone (pvcnnpp.py:44-52 calls it in front of each
     set-abstraction module, behind that stage's PVConvs).  One workgroup per cloud for M - 1 dependent steps (0.87 + 0.13 ms at
     B = 8, N = 8192 -> 1024 -> 256: 8 of 256 CUs busy) runs next to the first stage's convolutions instead of in front of the
     first set-abstraction module; every module waits for ITS level's event only.  Under a graph capture the side stream joins the
-    capture: a parallel path of the graph.  Same indices, same gather -- bit-identical to the in-line order."""
+    capture: a parallel path of the graph.  Same indices, same gather -- bit-identical to the in-line order
+    (profiles/ab/r05i_sampling_ahead.md: +1.3 %, and the trace of what overlaps).  Each module takes its hand-off only for the very
+    tensor the level before it returned (_SamplingChain)."""
     sas = [m for stage in sa_layers for m in (stage if isinstance(stage, nn.Sequential) else [stage]) if isinstance(m, PointNetSAModule)]
     if not (_CENTERS_AHEAD and coords.is_cuda and sas):
         return
@@ -334,13 +358,14 @@ def centers_ahead(sa_layers, coords):
     if side is None:
         side = _side_streams[coords.device] = torch.cuda.Stream(device=coords.device)
     side.wait_stream(main)
+    chain = _SamplingChain(coords)
     with torch.cuda.stream(side), torch.no_grad():
         c = coords.detach()
         for sa in sas:
             picked = be.furthest_point_sampling(c, sa.num_centers)
             done = torch.cuda.Event()
             done.record(side)
-            sa._centers_ahead = (picked, done, tuple(c.shape))
+            sa._centers_ahead = (picked, done, chain)
             if sa is not sas[-1]:
                 c = be.gather_features_forward(c, picked)
     coords.record_stream(side)

@@ -47,19 +47,37 @@ def test_sampling_ahead_is_the_in_line_network_bit_for_bit(hip, monkeypatch):
     assert not any('_centers_ahead' in m.__dict__ for m in net.modules() if isinstance(m, PointNetSAModule))
 
 
-def test_a_stale_hand_off_is_not_taken(hip):
-    """The hand-off names the coordinate shape it was computed for: a module that finds one for another shape samples in line."""
+def test_a_hand_off_is_taken_only_for_the_tensor_it_was_sampled_from(hip, monkeypatch):
+    """The hand-off is valid for exactly the tensor the level before returned, in the state it was returned in (identity + in-place
+    version): a module that receives another tensor, or that one modified in place, samples in line -- and so do the levels behind it."""
+    from pvcnn_amd import workload
     from pvcnn_amd.modules import PointNetSAModule
     import pvcnn_amd.modules.functional as F
     torch.manual_seed(0)
     sa = PointNetSAModule(num_centers=64, radius=0.3, num_neighbors=8, in_channels=4, out_channels=(8,)).to(DEV).train()
     coords = torch.rand(2, 3, 512, device=DEV)
     feats = torch.randn(2, 4, 512, device=DEV)
-    want = F.furthest_point_sample(coords, 64)
-    ev = torch.cuda.Event(); ev.record()
-    sa._centers_ahead = (torch.zeros(2, 64, dtype=torch.int32, device=DEV), ev, (2, 3, 999))
+    monkeypatch.setattr(workload, '_CENTERS_AHEAD', True)
+
+    # taken: the very tensor
+    workload.centers_ahead([sa], coords)
+    chain = sa._centers_ahead[2]
     _, centers = sa((feats, coords))
-    assert torch.equal(centers, want) and '_centers_ahead' not in sa.__dict__
+    assert not chain.broken and chain.expected() is centers and torch.equal(centers, F.furthest_point_sample(coords, 64))
+    # not taken: an equal copy (another object)
+    workload.centers_ahead([sa], coords)
+    chain = sa._centers_ahead[2]
+    other = coords.clone()
+    _, centers = sa((feats, other))
+    assert chain.broken and torch.equal(centers, F.furthest_point_sample(other, 64)) and '_centers_ahead' not in sa.__dict__
+    # not taken: the tensor itself, modified in place after the sampling was issued
+    moved = coords.clone()
+    workload.centers_ahead([sa], moved)
+    chain = sa._centers_ahead[2]
+    moved.mul_(-1.0).add_(torch.rand_like(moved))
+    _, centers = sa((feats, moved))
+    torch.cuda.synchronize()
+    assert chain.broken and torch.equal(centers, F.furthest_point_sample(moved, 64))
 
 
 def test_sampling_ahead_inside_a_captured_step(hip, monkeypatch):

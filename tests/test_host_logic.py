@@ -664,3 +664,23 @@ def test_the_per_tensor_judge_fails_a_dense_error_and_passes_a_sparse_flip():
     stat['buffer bn.running_mean'][5] += 1e-3 * truth['buffer bn.running_mean'].abs().max()
     with pytest.raises(AssertionError, match='running_mean'):
         judge('synthetic: a running statistic off', stat)
+
+
+def test_the_sampling_chain_accepts_only_the_tensor_it_expects():
+    """pvcnn_amd.workload._SamplingChain (PVCNN++'s sampling ahead): identity + in-place version, and a refusal breaks the chain for good."""
+    import torch
+    from pvcnn_amd.workload import _SamplingChain
+    a = torch.zeros(2, 3, 8)
+    chain = _SamplingChain(a)
+    assert chain.accepts(a) and not chain.broken
+    b = torch.zeros(2, 3, 4)
+    chain.expect(b)
+    assert chain.accepts(b)
+    assert not chain.accepts(a) and chain.broken               # another tensor
+    assert not chain.accepts(b)                                # ... and broken stays broken
+    chain = _SamplingChain(a)
+    a.add_(1.0)
+    assert not chain.accepts(a) and chain.broken               # the same tensor, modified in place
+    chain = _SamplingChain(a)
+    del a
+    assert not chain.accepts(torch.zeros(2, 3, 8))             # the expected tensor is gone
