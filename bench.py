@@ -144,7 +144,8 @@ class KernelClock:
                 e1.record()
                 key = _describe(args, out)
                 self.records.append((key, e0, e1))
-                self.last_call[(key[0], tuple(key[2]))] = (_orig, args, kw)
+                if key[0] == 'trilinear_devoxelize_fwd':      # (the roofline kernel's family: burst() replays its last launch)
+                    self.last_call[(key[0], tuple(key[2]))] = (_orig, args, kw)
                 return out
             setattr(self.backend, name, timed)
 
