@@ -314,6 +314,9 @@ class PVCNN(nn.Module):
 
 
 _CENTERS_AHEAD = __import__('os').environ.get('PVCNN_CENTERS_AHEAD', '1') != '0'
+# how many levels of the pyramid are sampled ahead (0 = all): a branch of a replayed graph costs ~3 us per main-chain launch while it
+# is open (profiles/ab/r05l), so a level pays only if its chain is long compared with the stage it runs next to
+_CENTERS_AHEAD_LEVELS = int(__import__('os').environ.get('PVCNN_CENTERS_AHEAD_LEVELS', '0'))
 _side_streams = {}
 
 
@@ -349,6 +352,8 @@ def centers_ahead(sa_layers, coords):
     (profiles/ab/r05i_sampling_ahead.md: +1.3 %, and the trace of what overlaps).  Each module takes its hand-off only for the very
     tensor the level before it returned (_SamplingChain)."""
     sas = [m for stage in sa_layers for m in (stage if isinstance(stage, nn.Sequential) else [stage]) if isinstance(m, PointNetSAModule)]
+    if _CENTERS_AHEAD_LEVELS > 0:
+        sas = sas[:_CENTERS_AHEAD_LEVELS]
     if not (_CENTERS_AHEAD and coords.is_cuda and sas):
         return
     from .modules.functional._autograd import native
