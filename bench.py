@@ -228,6 +228,21 @@ class KernelClock:
         return out
 
 
+def price_launch_us(burst_us, in_step_us, graph_us):
+    """Which of the three timings of the roofline launch `achieved` / `frac` are priced on -> (us, label).  ALWAYS the slower of two
+    (ADVICE r04): the GPU-paced burst of this run and the rocprofv3 in-graph average -- the latter only while the committed trace was
+    taken on the kernel sources this run executes (`graph_us` is None otherwise: a stale trace never prices a run).  The burst
+    re-reads one grid 64 times, the 256 MB memory-side cache serves part of it: it UNDER-reads the launch of the step, whose grid the
+    convolution in front has just written.  So without an in-graph figure the host-paced in-step event pair -- an upper bound --
+    prices the line with it."""
+    if graph_us:
+        us = max(burst_us, graph_us)
+        return us, ('rocprofv3 in-graph average (profiles/kernel_durations*.json)' if us == graph_us else 'live HIP events of this run')
+    us = max(burst_us, in_step_us)
+    return us, ('live HIP events of this run (in-step pairs: no trace of the running kernel sources)' if us == in_step_us and in_step_us != burst_us
+                else 'live HIP events of this run')
+
+
 def dtype_label(backend):
     """fp32 tensors and fp32 accumulation everywhere; what differs is how the dense-convolution PRODUCTS are formed."""
     if getattr(backend, 'conv_math', 'fp32') == 'f16x2':
@@ -686,12 +701,7 @@ def main():
             if burst_raw is not None:
                 head = dict(head, avg_us=round(max(burst_raw - event_overhead_us, 1e-3), 2), event_pair_us=round(burst_raw, 2))
                 head['achieved_GBs'] = round(head['algorithmic_MB'] * 1e6 / (head['avg_us'] * 1e-6) / 1e9, 1)
-            # ALWAYS the slower of the two: the live figure of this run, and the in-graph average only while the committed
-            # trace was taken on the kernel sources this run executes (sources digest) -- a stale trace never prices a run
-            # (the burst re-reads one grid 64 times: the 256 MB memory-side cache serves part of it, so it UNDER-reads the launch of
-            #  the step, whose grid the convolution in front has just written; without an in-graph figure of the running sources the
-            #  host-paced in-step pair -- an upper bound -- prices the line instead)
-            priced_us = max(head['avg_us'], graph_us) if graph_us else max(head['avg_us'], in_step_us)
+            priced_us, priced_on = price_launch_us(head['avg_us'], in_step_us, graph_us)
             roofline = {'bound': 'hbm',
                         'kernel': ('pvcnn::gather_lds_pipe_kernel<TrilinearFromCoords, XfBnAct>' if pipe else 'pvcnn::gather_lds_kernel<TrilinearFromCoords>')
                                   + ' = trilinear_devoxelize fwd' + (' with PVConv\'s last BatchNorm+LeakyReLU applied in its LDS staging and the point branch added in its store' if fused else ''),
@@ -699,9 +709,7 @@ def main():
                         'achieved': round(survey_bytes / (priced_us * 1e-6) / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                         'frac': round(survey_bytes / (priced_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                         'priced_on_us': round(priced_us, 2),
-                        'priced_on': ('rocprofv3 in-graph average (profiles/kernel_durations*.json)' if graph_us and priced_us == graph_us
-                                      else 'live HIP events of this run (in-step pairs: no trace of the running kernel sources)' if not graph_us and priced_us == in_step_us
-                                      else 'live HIP events of this run'),
+                        'priced_on': priced_on,
                         'in_graph_us': graph_us, 'in_graph_kernel': graph_kernel, 'in_graph_trace': trace_table(args.config)[1],
                         'live_frac': round(survey_bytes / (head['avg_us'] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                         'algorithmic_MB': round(survey_bytes / 1e6, 3),

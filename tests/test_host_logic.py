@@ -684,3 +684,25 @@ def test_the_sampling_chain_accepts_only_the_tensor_it_expects():
     chain = _SamplingChain(a)
     del a
     assert not chain.accepts(torch.zeros(2, 3, 8))             # the expected tensor is gone
+
+
+def test_the_roofline_launch_is_priced_on_the_slower_trustworthy_timing():
+    """bench.py price_launch_us: max(burst, in-graph) with a trace of the running sources, max(burst, in-step pairs) without one --
+    never the optimistic figure alone."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location('bench_for_pricing', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    us, label = bench.price_launch_us(31.1, 35.3, 36.4)
+    assert us == 36.4 and 'in-graph' in label
+    us, label = bench.price_launch_us(38.0, 35.3, 36.4)              # a burst slower than the trace prices the line
+    assert us == 38.0 and label == 'live HIP events of this run'
+    us, label = bench.price_launch_us(31.1, 62.3, 36.4)              # host-paced pairs never beat a matching trace
+    assert us == 36.4
+    us, label = bench.price_launch_us(12.2, 34.7, None)              # no trace of the running sources: the in-step upper bound
+    assert us == 34.7 and 'no trace' in label
+    us, label = bench.price_launch_us(40.0, 34.7, None)
+    assert us == 40.0 and label == 'live HIP events of this run'
+    assert bench.price_launch_us(31.1, 35.3, 0.0)[0] == 35.3         # (in_graph_us() reports a stale trace as None / nothing)
