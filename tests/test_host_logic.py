@@ -706,3 +706,32 @@ def test_the_roofline_launch_is_priced_on_the_slower_trustworthy_timing():
     us, label = bench.price_launch_us(40.0, 34.7, None)
     assert us == 40.0 and label == 'live HIP events of this run'
     assert bench.price_launch_us(31.1, 35.3, 0.0)[0] == 35.3         # (in_graph_us() reports a stale trace as None / nothing)
+
+
+def test_trace_overlap_reports_what_ran_next_to_a_kernel(tmp_path):
+    """tools/trace_overlap.py (the evidence of profiles/ab/r05i): per launch of the named kernel its duration, whether anything else
+    was on the chip, and the time each other kernel shared with it."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    rows = ['Kernel_Name,Start_Timestamp,End_Timestamp']
+    t = 0
+    for step in range(3):
+        base = step * 5_000_000
+        rows.append(f'"void pvcnn::fps_kernel<512, 16, true>(float const*)",{base},{base + 900_000}')          # 900 us chain
+        rows.append(f'"void pvcnn::conv3d_igemm(float const*)",{base + 100_000},{base + 400_000}')               # 300 us inside it
+        rows.append(f'"pvcnn::bn_finalize_kernel(int)",{base + 800_000},{base + 1_000_000}')                      # 100 us of its 200 inside
+        rows.append(f'"pvcnn::later_kernel(int)",{base + 2_000_000},{base + 2_100_000}')                          # not next to it
+    rows.append(f'"void pvcnn::fps_kernel<512, 16, true>(float const*)",{20_000_000},{20_880_000}')               # one launch alone
+    trace = tmp_path / 'kernel_trace.csv'
+    trace.write_text('\n'.join(rows) + '\n')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'trace_overlap.py'), str(trace), 'fps_kernel<512', '10'],
+                         capture_output=True, text=True, check=True).stdout
+    head = out.splitlines()[0]
+    assert '4 launches' in head and '1 ran with nothing else on the chip' in head, head
+    assert 'median 900.0 us (min 880.0, max 900.0)' in head, head
+    body = '\n'.join(out.splitlines()[1:])
+    assert '225.0 us per launch next to  void pvcnn::conv3d_igemm' in body, body           # 3 x 300 us over 4 launches
+    assert '75.0 us per launch next to  pvcnn::bn_finalize_kernel' in body, body            # 3 x 100 us over 4 launches
+    assert 'later_kernel' not in body
