@@ -341,7 +341,10 @@ PVCNN_API int pvcnn_pwconv_bwd_weight_f16(const float *x, const float *grad_y, c
  * gamma / beta may be NULL (affine = False).  `workspace`: >= pvcnn_bnact_workspace_bytes(B,C,S).
  * y_amax / gx_amax (NULL, or pvcnn_absmax_tiles_count(B, S, amax_seg) words): the amax buffer of the tensor the call writes (y
  *      resp. grad_x) with segments of amax_seg positions, emitted by the apply pass itself -- the f16x2 convolution that consumes
- *      that tensor needs no pass of its own over it.  Requires amax_seg <= 256.  Word [0] (the global maximum) is accumulated with
+ *      that tensor needs no pass of its own over it.  amax_seg: ANY length in 1..256 on every entry that takes one (a z row of an
+ *      R = 12 grid is a segment of 12; a workgroup then owns floor(256 / amax_seg) whole segments) -- the one exception is
+ *      pvcnn_bnact_apply_rowmax, whose row-maximum butterfly needs all 256 lanes: amax_seg must DIVIDE 256 there and it says so.
+ *      Word [0] (the global maximum) is accumulated with
  *      one atomic per workgroup when it was zeroed beforehand: by the call's own finalize kernel (training != 0, and always in
  *      bwd), or -- amax_zeroed != 0 -- by the pvcnn_bn_finalize call that produced mean / rstd (its zero_words argument, the WHOLE
  *      buffer: on small position counts the pass splits the channels over several workgroups whose table entries meet by atomic

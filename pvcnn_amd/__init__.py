@@ -33,6 +33,31 @@ def install_dropin(name='modules'):
     return impl
 
 
+_ADOPTED = {}          # (original class, donor forward) -> the derived class, registered in this module under an importable name
+
+
+def _adopted_class(cls, forward, extra=None):
+    """`cls` with `forward` replaced, created ONCE per (class, forward) and registered as an attribute of this module under its own
+    `__qualname__`, so that `pickle` / `torch.save(model)` / mp-spawn find it again by name (a class created inside a
+    function call cannot be pickled)."""
+    key = (cls, forward, tuple(sorted((extra or {}).items())))
+    if key not in _ADOPTED:
+        name = '_Adopted_' + ''.join(c if c.isalnum() else '_' for c in f'{cls.__module__}.{cls.__qualname__}')
+        if any(k[0] is cls for k in _ADOPTED):                      # the same class with another donor: a name of its own
+            name += f'_{len(_ADOPTED)}'
+        body = {'forward': forward, '__module__': __name__, '__qualname__': name, '_adopted_from': cls}
+        body.update(extra or {})
+        derived = type(cls.__name__, (cls,), body)                  # keeps the class NAME (repr, logs); pickle goes by __qualname__
+        setattr(sys.modules[__name__], name, derived)
+        _ADOPTED[key] = derived
+    return _ADOPTED[key]
+
+
+def _classify_forward(self, x):
+    from . import workload
+    return workload._classify(self, x)
+
+
 def adopt(model):
     """Opt-in, ONE line in the caller's script -- `model = pvcnn_amd.adopt(model)` after building a reference network on top of
     `install_dropin()` -- for what a swapped `modules` package cannot reach: the torch glue the reference's `models/` put BETWEEN the
@@ -42,9 +67,15 @@ def adopt(model):
       * a point-wise head [SharedMLP, Dropout, ..., Conv1d] runs module by module on this package's kernels (Dropout on the BatchNorm
         passes, the last Conv1d on the 1x1 GEMM): any `nn.Sequential` of that shape inside `model`;
       * a network with the attribute structure of the reference's S3DIS PVCNN / ShapeNet PVCNN / S3DIS PVCNN++ takes the matching
-        workload forward (max-pool winners out of the BatchNorm pass, one concatenation kernel that also emits the scale table).
+        workload forward (max-pool winners out of the BatchNorm pass, one concatenation kernel that also emits the scale table);
+      * (round 6) a Frustum network (`inst_seg_net` / `center_reg_net` / `box_est_net`, models/kitti/frustum/frustum_net.py:14-76): its
+        segmentation net takes workload's forward (the last stage into its slice of the concatenation, row maxima out of the BatchNorm
+        pass), its two regression nets the dense-head kernel behind their global max.
     Anything it does not recognise is left as it is; CPU tensors, eval mode and hooked modules fall back to the modules themselves
-    inside those forwards.  `bench.py` reports both compositions (`value` and `reference_composition_value`)."""
+    inside those forwards.  `bench.py` reports both compositions (`value` and `reference_composition_value`).
+    The swapped classes are registered in this module by name: an adopted model pickles (`torch.save(model)`) in a process that has
+    imported `pvcnn_amd` and adopted a model of the same class first (the derived class is created by `adopt`, not at import time);
+    `state_dict()` checkpoints are unaffected."""
     import torch.nn as nn
     from . import workload
     from .modules import SharedMLP
@@ -54,20 +85,30 @@ def adopt(model):
         return (len(kids) >= 2 and isinstance(kids[0], SharedMLP) and isinstance(kids[-1], (nn.Conv1d, SharedMLP))
                 and all(isinstance(k, (SharedMLP, nn.Dropout, nn.Conv1d)) for k in kids))
 
-    class _Head(nn.Sequential):
-        def forward(self, x):
-            return workload._classify(self, x)
+    def take(module, donor_forward, extra=None):
+        if type(module).forward is not donor_forward:
+            module.__class__ = _adopted_class(type(module), donor_forward, extra)
 
     for m in model.modules():
         if type(m) is nn.Sequential and is_head(m):
-            m.__class__ = _Head
+            m.__class__ = _adopted_class(nn.Sequential, _classify_forward)
+    has = lambda obj, *names: all(hasattr(obj, a) for a in names)
+    if has(model, 'inst_seg_net', 'center_reg_net', 'box_est_net'):
+        seg, ctr, box = model.inst_seg_net, model.center_reg_net, model.box_est_net
+        if has(seg, 'point_features', 'cloud_features', 'classifier', 'in_channels'):
+            take(seg, workload._FrustumSegmentation.forward)
+        if has(ctr, 'features', 'regression'):
+            take(ctr, workload._CloudRegressor.forward, {'_head_attr': 'regression', '_coords_tuple': False})
+        if has(box, 'features', 'classifier'):
+            take(box, workload._CloudRegressor.forward, {'_head_attr': 'classifier', '_coords_tuple': True})
+        return model
     donor = None
-    if all(hasattr(model, a) for a in ('sa_layers', 'fp_layers', 'classifier')):
+    if has(model, 'sa_layers', 'fp_layers', 'classifier'):
         donor = workload.PVCNN2
-    elif all(hasattr(model, a) for a in ('point_features', 'classifier', 'num_shapes', 'in_channels')) and isinstance(model.point_features, nn.ModuleList):
+    elif has(model, 'point_features', 'classifier', 'num_shapes', 'in_channels') and isinstance(model.point_features, nn.ModuleList):
         donor = workload.PVCNNShapeNet
-    elif all(hasattr(model, a) for a in ('point_features', 'cloud_features', 'classifier')) and isinstance(model.point_features, nn.ModuleList):
+    elif has(model, 'point_features', 'cloud_features', 'classifier') and isinstance(model.point_features, nn.ModuleList):
         donor = workload.PVCNN
-    if donor is not None and type(model).forward is not donor.forward:
-        model.__class__ = type(type(model).__name__, (type(model),), {'forward': donor.forward, '__module__': type(model).__module__})
+    if donor is not None:
+        take(model, donor.forward)
     return model

@@ -491,6 +491,10 @@ __global__ __launch_bounds__(256) void bnact_apply_pb_kernel(const float *__rest
 using namespace pvcnn;
 
 // channel groups of the position-block-major apply pass (see the kernel): enough workgroups for ~4 per CU, >= 32 channels each
+// The one statement of the segment-length contract of every entry that emits an amax buffer (include/pvcnn_hip.h, "amax_seg").
+static const char kAmaxSegRange[] = "amax_seg must be in 1..256";
+static bool amax_seg_in_range(int seg) { return seg > 0 && seg <= 256; }
+
 static int pb_channel_groups(long position_blocks, int C) {
   int g = 1;
   while (position_blocks * g < 4 * kNumCU && C / (2 * g) >= 32) g *= 2;
@@ -531,7 +535,7 @@ extern "C" int pvcnn_bnact_fwd(const float *x, const float *gamma, const float *
   const bool dropping = make_drop(drop_seed, drop_p, &drop);
   PVCNN_REQUIRE(!dropping || (y_amax && (size_t)B * C * S < ((size_t)1 << 33)), "fused dropout needs the amax-emitting pass (y_amax) and < 2^33 elements");
   PVCNN_REQUIRE(B <= 65535 && C <= 65535, "batch or channel count > 65535");
-  PVCNN_REQUIRE(!y_amax || (amax_seg > 0 && amax_seg <= 256), "amax_seg must be in 1..256");
+  PVCNN_REQUIRE(!y_amax || amax_seg_in_range(amax_seg), kAmaxSegRange);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int slices = ceil_div(S, kBnSlice);
   const dim3 grid(slices, B, C);
@@ -578,8 +582,9 @@ extern "C" int pvcnn_bnact_apply_rowmax(const float *x, const float *gamma, cons
   PVCNN_REQUIRE(B <= 65535 && C <= 65535, "batch or channel count > 65535");
   // (256 % amax_seg == 0: the row-maximum butterfly assumes every lane of the workgroup's 256 positions is active -- a segment length
   //  that does not divide 256, e.g. 12 -> span 252, would leave lanes out of the __shfl_xor / __ballot: undefined winners)
-  PVCNN_REQUIRE(amax_seg >= 4 && amax_seg <= 256 && amax_seg % 4 == 0 && 256 % amax_seg == 0 && S % 256 == 0,
-                "needs S % 256 == 0 and amax_seg a multiple of 4 that divides 256");
+  PVCNN_REQUIRE(amax_seg_in_range(amax_seg), kAmaxSegRange);
+  PVCNN_REQUIRE(amax_seg % 4 == 0 && 256 % amax_seg == 0 && S % 256 == 0,
+                "the row-maximum pass additionally needs S % 256 == 0 and amax_seg a multiple of 4 that divides 256");
   PVCNN_REQUIRE(aligned16(x) && aligned16(y) && ((uintptr_t)row_keys & 7) == 0, "x / y must be 16-byte aligned, row_keys 8-byte aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int nseg = ceil_div(S, amax_seg), spb = amax_seg >= 256 ? 1 : 256 / amax_seg;
@@ -644,7 +649,7 @@ static int bnact_bwd_impl(const float *x, const float *grad_y, long gy_bstride, 
   PVCNN_REQUIRE(B <= 65535 && C <= 65535, "batch or channel count > 65535");
   PVCNN_REQUIRE(gy_bstride >= (long)C * S, "grad_y batch stride smaller than one sample");
   PVCNN_REQUIRE(workspace && workspace_bytes >= pvcnn_bnact_workspace_bytes(B, C, S), "workspace too small");
-  PVCNN_REQUIRE(!gx_amax || (amax_seg > 0 && amax_seg <= 256), "amax_seg must be in 1..256");
+  PVCNN_REQUIRE(!gx_amax || amax_seg_in_range(amax_seg), kAmaxSegRange);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int slices = ceil_div(S, kBnSlice);
   const dim3 grid(slices, B, C);
@@ -726,7 +731,7 @@ extern "C" int pvcnn_bnact_bwd_apply(const float *x, const float *grad_y, long g
   PVCNN_REQUIRE(!training || (sum_gamma && sum_beta), "training mode needs the two per-channel sums");
   PVCNN_REQUIRE(B <= 65535 && C <= 65535, "batch or channel count > 65535");
   PVCNN_REQUIRE(grad_y_batch_stride >= (long)C * S, "grad_y batch stride smaller than one sample");
-  PVCNN_REQUIRE(!gx_amax || (amax_seg > 0 && amax_seg <= 256), "amax_seg must be in 1..256");
+  PVCNN_REQUIRE(!gx_amax || amax_seg_in_range(amax_seg), kAmaxSegRange);
   hipStream_t s = static_cast<hipStream_t>(stream);
   // the position-block-major pass (it carries the per-(cloud, channel) factors); without an amax request the table goes to a dummy
   // segmentation of 256 positions that is simply not written out (amax == NULL is not supported by the kernel: give it scratch)

@@ -1037,7 +1037,7 @@ class HipBackend:
         _shape(0 < len(tensors) <= 8, 'concat_points: 1..8 sources')
         b, n = tensors[0].shape[0], tensors[0].shape[2]
         ptrs, bstr, chans, pstr = [], [], [], []
-        for t in tensors:
+        for i, t in enumerate(tensors):
             _dev(t, 'source')
             _shape(t.dim() == 3 and t.dtype == torch.float32 and t.shape[0] == b and t.shape[2] == n, 'concat_points: (B, C_i, N) float sources expected')
             c = t.shape[1]
@@ -1046,7 +1046,9 @@ class HipBackend:
                 pstr.append(0); bstr.append(t.stride(0) if b > 1 else c)
             else:
                 _shape((n == 1 or t.stride(2) == 1) and (c == 1 or t.stride(1) == n), 'concat_points: rows must be contiguous inside a cloud')
-                pstr.append(1); bstr.append(t.stride(0) if b > 1 else c * n)
+                # (a single cloud: torch leaves stride(0) of a size-1 dimension arbitrary, so it is stated -- except for a source that
+                #  already IS its channel slice of `out`, whose cloud stride is the buffer's and is checked as such by the library)
+                pstr.append(1); bstr.append(t.stride(0) if (b > 1 or (in_place and i in in_place)) else c * n)
             ptrs.append(t.data_ptr()); chans.append(c)
         k = len(tensors)
         if out is None:

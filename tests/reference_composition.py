@@ -9,6 +9,8 @@ statement by statement -- what the reference's forward() methods do, on this pac
     ReferencePVCNN          models/s3dis/pvcnn.py:34-46      .max(dim=-1).values, .unsqueeze(-1).repeat, torch.cat, self.classifier(...)
     ReferencePVCNN2         models/s3dis/pvcnnpp.py:44-59    the SA / FP loops, self.classifier(...)
     ReferencePVCNNShapeNet  models/shapenet/pvcnn.py:30-42   .max(dim=-1, keepdim=True).values.repeat, torch.cat, self.classifier(...)
+    ReferenceFrustumPVCNNE  models/kitti/frustum/frustum_net.py:36-67 on segmentation/pointnet.py:34-44, center_regression_net.py:25-32,
+                            box_estimation/pointnet.py:33-40  (.repeat, .max, torch.cat, the heads as plain nn.Sequentials)
 
 with `self.classifier` / `self.cloud_features` the plain `nn.Sequential`s of models/utils.py:15-46 (SharedMLP, nn.Dropout, nn.Conv1d /
 Linear + BatchNorm1d + ReLU) called as modules.  The constructors are workload's (same sub-module tree, same state_dict keys as the
@@ -21,7 +23,7 @@ import torch
 
 from pvcnn_amd import workload
 
-__all__ = ['ReferencePVCNN', 'ReferencePVCNN2', 'ReferencePVCNNShapeNet', 'BY_CONFIG']
+__all__ = ['ReferencePVCNN', 'ReferencePVCNN2', 'ReferencePVCNNShapeNet', 'ReferenceFrustumPVCNNE', 'BY_CONFIG']
 
 
 class ReferencePVCNN(workload.PVCNN):
@@ -66,6 +68,42 @@ class ReferencePVCNNShapeNet(workload.PVCNNShapeNet):
             collected.append(feats)
         collected.append(feats.max(dim=-1, keepdim=True).values.repeat([1, 1, npts]))
         return self.classifier(torch.cat(collected, dim=1))
+
+
+class _ReferenceFrustumSegmentation(workload._FrustumSegmentation):
+    def forward(self, inputs):
+        feats = inputs['features']
+        npts = feats.size(-1)
+        one_hot = inputs['one_hot_vectors'].unsqueeze(-1).repeat([1, 1, npts])
+        per_point, xyz = self.point_features((feats, feats[:, :3, :]))
+        pooled, _ = self.cloud_features((per_point, xyz))
+        pooled = pooled.max(dim=-1, keepdim=True).values.repeat([1, 1, npts])
+        return self.classifier(torch.cat([one_hot, per_point, pooled], dim=1))
+
+
+class _ReferenceCenterRegression(workload._CloudRegressor):
+    def forward(self, inputs):
+        desc = self.features(inputs['coords']).max(dim=-1, keepdim=False).values
+        return self.regression(torch.cat([desc, inputs['one_hot_vectors']], dim=1))
+
+
+class _ReferenceBoxEstimation(workload._CloudRegressor):
+    def forward(self, inputs):
+        xyz = inputs['coords']
+        desc, _ = self.features((xyz, xyz))
+        desc = desc.max(dim=-1, keepdim=False).values
+        return self.classifier(torch.cat([desc, inputs['one_hot_vectors']], dim=1))
+
+
+class ReferenceFrustumPVCNNE(workload.FrustumPVCNNE):
+    """workload's constructor (the reference's sub-module tree and state_dict keys), the three sub-nets with the reference's forward();
+    FrustumNet.forward itself (frustum_net.py:36-67) is what workload.FrustumPVCNNE.forward states."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.inst_seg_net.__class__ = _ReferenceFrustumSegmentation
+        self.center_reg_net.__class__ = _ReferenceCenterRegression
+        self.box_est_net.__class__ = _ReferenceBoxEstimation
 
 
 # bench.py --reference-composition: BASELINE config -> (class, constructor arguments before width_multiplier)

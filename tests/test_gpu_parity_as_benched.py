@@ -274,13 +274,14 @@ def _frustum_three_ways(build, in0, targets, loss_of, autocast):
         with winners, rounding.recording():
             inp, leaf = make(DEV, torch.float32)
             with (torch.autocast('cuda', dtype=torch.bfloat16) if autocast else contextlib.nullcontext()):
-                loss_g = loss_of(gpu_net(inp), tgt_on(DEV, torch.float32), DEV, torch.float32)
+                out_g = gpu_net(inp)
+                loss_g = loss_of(out_g, tgt_on(DEV, torch.float32), DEV, torch.float32)
             loss_g.backward()
             torch.cuda.synchronize()
     finally:
         del seam._backend.mask_select
         _wl.tap_and_pool = orig_tap_and_pool
-    res_g = (loss_g.item(), _grads(gpu_net, leaf))
+    res_g = (loss_g.item(), _grads(gpu_net, leaf, out_g))           # every returned head is judged per element (round 6)
 
     # ---- CPU stacks: the same discrete decisions, the same bf16 rounding errors ----
     def pinned_logits_mask(coords, logits, num_points_per_object, rng=None, choices=None):
@@ -293,13 +294,14 @@ def _frustum_three_ways(build, in0, targets, loss_of, autocast):
         try:
             with cpu_stack(backend), PinMaxWinners(winners.winners), MatchedBf16Convs(pending):
                 inp, leaf = make('cpu', dtype)
-                loss = loss_of(net(inp), tgt_on('cpu', dtype), 'cpu', dtype)
+                out = net(inp)
+                loss = loss_of(out, tgt_on('cpu', dtype), 'cpu', dtype)
                 loss.backward()
         finally:
             sampling.logits_mask, PF.logits_mask = prev
         left = {k: len(v) for k, v in pending.items() if v}
         assert not left, f'bf16 launches of the GPU run without a counterpart in the CPU stack: {left}'
-        return loss.item(), _grads(net, leaf)
+        return loss.item(), _grads(net, leaf, out)
 
     res_t = cpu_run(f64_net, TruthBackend(oracle), torch.float64)
     res_c = cpu_run(cpu_net, oracle, torch.float32)

@@ -116,10 +116,104 @@ def test_adopt_turns_the_reference_composition_into_the_benched_one(hip):
     adopted.load_state_dict(benched.state_dict())
     keys = list(adopted.state_dict().keys())
     assert pvcnn_amd.adopt(adopted) is adopted and list(adopted.state_dict().keys()) == keys
-    assert type(adopted).forward is workload.PVCNN.forward and type(adopted.classifier).__name__ == '_Head'
+    assert type(adopted).forward is workload.PVCNN.forward and type(adopted.classifier)._adopted_from is torch.nn.Sequential
     x, y = workload.make_s3dis_batch(4, 2048, device=DEV)
     out_b, loss_b, g_b = _step(benched, x, y)
     out_a, loss_a, g_a = _step(adopted, x, y)
     assert torch.equal(out_b, out_a) and loss_b == loss_a
     for k in g_b:
         assert torch.equal(g_b[k], g_a[k]), k
+
+
+ADOPTED = {
+    'cfg3 PVCNN2': ('PVCNN2', 'ReferencePVCNN2', (13, 6), lambda wl: wl.make_s3dis_batch(4, 4096, device=DEV)),
+    'cfg4 PVCNNShapeNet': ('PVCNNShapeNet', 'ReferencePVCNNShapeNet', (50, 16, 3), lambda wl: wl.make_shapenet_batch(4, 2048, device=DEV)),
+}
+
+
+@pytest.mark.parametrize('case', list(ADOPTED))
+def test_adopt_of_the_other_reference_compositions_is_the_benched_composition(hip, case):
+    """(round 6) `adopt()` of a PVCNN++ / ShapeNet-PVCNN instance composed the reference's way: workload's forward on the same
+    parameters, at FULL width (the launch shapes of the bench line's networks) -- bit-equal logits, loss, gradients, running statistics."""
+    import pickle
+    import pvcnn_amd
+    import reference_composition as rc
+    from pvcnn_amd import workload
+    mine_name, ref_name, ctor, batch = ADOPTED[case]
+    torch.manual_seed(7)
+    benched = _no_dropout(getattr(workload, mine_name)(*ctor, width_multiplier=1)).to(DEV).train()
+    adopted = _no_dropout(getattr(rc, ref_name)(*ctor, width_multiplier=1)).to(DEV).train()
+    adopted.load_state_dict(benched.state_dict())
+    keys = list(adopted.state_dict().keys())
+    assert pvcnn_amd.adopt(adopted) is adopted and list(adopted.state_dict().keys()) == keys
+    assert type(adopted).forward is getattr(workload, mine_name).forward and type(adopted).__name__ == ref_name
+    x, y = batch(workload)
+    out_b, loss_b, g_b = _step(benched, x, y)
+    out_a, loss_a, g_a = _step(adopted, x, y)
+    assert torch.equal(out_b, out_a) and loss_b == loss_a
+    assert g_b.keys() == g_a.keys()
+    for k in g_b:
+        assert torch.equal(g_b[k], g_a[k]), k
+    print(f'[adopt] {case}: logits, loss and {len(g_b)} tensors bit-equal to the benched composition')
+    clone = pickle.loads(pickle.dumps(adopted.cpu()))                     # ADVICE r05: an adopted model pickles
+    assert type(clone) is type(adopted) and list(clone.state_dict().keys()) == keys
+
+
+def _frustum_step(net, inputs, targets, crit, autocast):
+    torch.manual_seed(5)                                                  # the device draws of logits_mask: the same stream both times
+    feats = inputs['features'].clone().requires_grad_()
+    with (torch.autocast('cuda', dtype=torch.bfloat16) if autocast else torch.autocast('cuda', enabled=False)):
+        out = net({'features': feats, 'one_hot_vectors': inputs['one_hot_vectors']})
+        loss = crit({k: (v.float() if v.dtype.is_floating_point else v) for k, v in out.items()}, targets)
+    loss.backward()
+    torch.cuda.synchronize()
+    grads = {'<input>': feats.grad.detach().double()}
+    grads.update({k: p.grad.detach().double() for k, p in net.named_parameters() if p.grad is not None})
+    grads.update({'buffer ' + k: b.detach().double() for k, b in net.named_buffers() if b.dtype.is_floating_point})
+    return {k: v.detach().double() for k, v in out.items() if v.dtype.is_floating_point}, loss.item(), grads
+
+
+@pytest.mark.parametrize('autocast', [False, True], ids=['fp32', 'bf16-autocast'])
+def test_adopt_of_the_reference_composed_frustum_net_is_the_benched_composition(hip, autocast):
+    """(round 6) cfg5: Frustum-PVCNN composed as models/kitti/frustum/ compose it (tests/reference_composition.ReferenceFrustumPVCNNE:
+    .repeat / .max / torch.cat, the heads as nn.Sequentials) -> `adopt()` -> bit-equal to workload.FrustumPVCNNE in every returned
+    head, the multi-task loss and every gradient, full width, fp32 and under cfg5's autocast; and BEFORE adopt() the reference
+    composition itself agrees with it to fp32 round-off in fp32 mode (same operators, other glue)."""
+    import pvcnn_amd
+    import reference_composition as rc
+    from pvcnn_amd import workload
+    from pvcnn_amd.modules import FrustumPointNetLoss
+    templates = workload.frustum_size_templates()
+    ctor = (3, 12, 8, 512, templates, 1, 1)
+    torch.manual_seed(7)
+    benched = _no_dropout(workload.FrustumPVCNNE(*ctor)).to(DEV).train()
+    adopted = _no_dropout(rc.ReferenceFrustumPVCNNE(*ctor)).to(DEV).train()
+    assert list(benched.state_dict().keys()) == list(adopted.state_dict().keys())
+    adopted.load_state_dict(benched.state_dict())
+    inputs, _ = workload.make_frustum_batch(16, 1024, device=DEV)
+    targets = workload.make_frustum_targets(16, 1024, device=DEV)
+    crit = FrustumPointNetLoss(12, 8, templates).to(DEV)
+    out_b, loss_b, g_b = _frustum_step(benched, inputs, targets, crit, autocast)
+    if not autocast:
+        state = {k: v.clone() for k, v in adopted.state_dict().items()}
+        out_r, loss_r, g_r = _frustum_step(adopted, inputs, targets, crit, autocast)     # the reference composition as it is
+        adopted.load_state_dict(state)                                                   # (running statistics back to the start)
+        dist = {k: ((out_b[k] - out_r[k]).abs().max() / out_b[k].abs().max().clamp_min(1e-30)).item() for k in out_b}
+        print(f'[reference composition] cfg5 fp32: loss benched {loss_b:.7f} composed {loss_r:.7f}; heads differ (of the largest) by '
+              + ', '.join(f'{k} {v:.1e}' for k, v in dist.items()))
+        # the per-point logits are the same operators in another composition: round-off.  (What follows them is held to the same bar only
+        # while no point's foreground decision `logits[0] < logits[1]` sits within that round-off -- the sampled points change otherwise.)
+        assert dist['mask_logits'] <= 1e-5, dist
+    keys = list(adopted.state_dict().keys())
+    assert pvcnn_amd.adopt(adopted) is adopted and list(adopted.state_dict().keys()) == keys
+    assert type(adopted.inst_seg_net).forward is workload._FrustumSegmentation.forward
+    assert type(adopted.center_reg_net).forward is workload._CloudRegressor.forward
+    assert type(adopted.box_est_net).forward is workload._CloudRegressor.forward and adopted.box_est_net._coords_tuple
+    out_a, loss_a, g_a = _frustum_step(adopted, inputs, targets, crit, autocast)
+    assert out_b.keys() == out_a.keys() and g_b.keys() == g_a.keys()
+    for k in out_b:
+        assert torch.equal(out_b[k], out_a[k]), k
+    assert loss_b == loss_a
+    for k in g_b:
+        assert torch.equal(g_b[k], g_a[k]), k
+    print(f'[adopt] cfg5 ({"bf16 autocast" if autocast else "fp32"}): {len(out_b)} heads, loss and {len(g_b)} tensors bit-equal to the benched composition')

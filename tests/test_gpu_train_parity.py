@@ -91,9 +91,28 @@ class PinMaxWinners(torch.overrides.TorchFunctionMode):
         return func(*args, **kwargs)
 
 
-def _grads(net, leaf):
-    """name -> gradient (CPU, float64) of the input leaf, every parameter, and the float buffers (running stats)."""
-    out = {'<input>': leaf.grad}
+def _outputs(output):
+    """The tensors a network RETURNS, by name: `<logits>` for the (B, classes, N) tensor of the segmentation nets
+    (models/s3dis/pvcnn.py:46), `<output k>` for every floating-point entry of a tuple / dict (PVConv's pair, Frustum-PVCNN's heads)."""
+    if output is None:
+        return {}
+    if torch.is_tensor(output):
+        return {'<logits>': output}
+    items = output.items() if isinstance(output, dict) else enumerate(output)
+    return {f'<output {k}>': v for k, v in items if torch.is_tensor(v) and v.dtype.is_floating_point}
+
+
+def is_forward_only(name):
+    """Forward-only quantities (what the network returns, BatchNorm running statistics): no allowance for flipped decisions."""
+    return name.startswith(('buffer ', '<logits>', '<output '))
+
+
+def _grads(net, leaf, output=None):
+    """name -> (CPU, float64) what the network RETURNED (`output`, round 6: the north_star's "outputs within 1e-5 of reference" is
+    held per element at every size the whole-network tests run), the gradient of the input leaf and of every parameter, and the
+    float buffers (running stats)."""
+    out = dict(_outputs(output))
+    out['<input>'] = leaf.grad
     for name, p in net.named_parameters():
         if p.grad is not None:
             out[name] = p.grad
@@ -131,23 +150,26 @@ def _run_three(build, make_inputs, loss_fn, oracle, pin_winners=False):
     record = PinMaxWinners()
     with cpu_stack(TruthBackend(oracle)), (record if pin_winners else contextlib.nullcontext()):
         inp, leaf, tgt = make_inputs('cpu', torch.float64)
-        loss_t = loss_fn(f64_net(inp), tgt)
+        out_t = f64_net(inp)
+        loss_t = loss_fn(out_t, tgt)
         loss_t.backward()
-    res_t = (loss_t.item(), _grads(f64_net, leaf))
+    res_t = (loss_t.item(), _grads(f64_net, leaf, out_t))
 
     def replay():
         return PinMaxWinners(record.winners) if pin_winners else contextlib.nullcontext()
     with replay():
         inp, leaf, tgt = make_inputs(DEV, torch.float32)
-        loss_g = loss_fn(gpu_net(inp), tgt)
+        out_g = gpu_net(inp)
+        loss_g = loss_fn(out_g, tgt)
         loss_g.backward()
     torch.cuda.synchronize()
-    res_g = (loss_g.item(), _grads(gpu_net, leaf))
+    res_g = (loss_g.item(), _grads(gpu_net, leaf, out_g))
     with cpu_stack(oracle), replay():
         inp, leaf, tgt = make_inputs('cpu', torch.float32)
-        loss_c = loss_fn(cpu_net(inp), tgt)
+        out_c = cpu_net(inp)
+        loss_c = loss_fn(out_c, tgt)
         loss_c.backward()
-    res_c = (loss_c.item(), _grads(cpu_net, leaf))
+    res_c = (loss_c.item(), _grads(cpu_net, leaf, out_c))
     return res_g, res_c, res_t
 
 
@@ -219,7 +241,7 @@ def per_tensor_rows(res_g, res_c, res_t):
         eh = ((gg[k] - gt[k]).abs() / sc).flatten()
         ec = ((gc[k] - gt[k]).abs() / sc).flatten()
         rows.append({'name': k, 'n': eh.numel(), 'hip': eh.max().item(), 'cpu': ec.max().item(),
-                     'hip_q': _kth(eh, SPARSE_Q), 'cpu_q': _kth(ec, SPARSE_Q), 'forward_only': k.startswith('buffer ')})
+                     'hip_q': _kth(eh, SPARSE_Q), 'cpu_q': _kth(ec, SPARSE_Q), 'forward_only': is_forward_only(k)})
     return rows
 
 
@@ -263,6 +285,10 @@ def judge_per_tensor(label, res, flip_cap, max_allowance_share=0.25):
     print(f'[per tensor] {label}: {len(rows)} tensors: {len(strict)} within their own bar max({NET_FACTOR:g} x oracle-vs-truth_t, floor_t), '
           f'{len(sites)} flip sites (sparse excess), {len(shadow)} in the shadow of a flip site (dense excess), cap {flip_cap:.1e}; '
           f'{len(bad)} FAILED; hip-vs-truth median {errs[len(errs) // 2]:.2e}, 90th percentile {errs[int(0.9 * len(errs))]:.2e}, worst {errs[-1]:.2e}')
+    for r in rows:                                     # what the network RETURNS: one line per tensor, always printed
+        if r['forward_only'] and not r['name'].startswith('buffer '):
+            print(f"    output {r['name']}: n={r['n']}  hip-vs-truth {r['hip']:.2e}  oracle-vs-truth {r['cpu']:.2e}  bar {r['bar']:.1e}  "
+                  f"{'ok' if r['hip'] <= r['bar'] else 'BEYOND'}")
     for cls, members in (('site', sites), ('shadow', shadow), ('FAILED', bad)):
         for r in sorted(members, key=lambda r: -r['hip'])[:12]:
             print(f"    {cls:6s} hip {r['hip']:.2e} (q{int(SPARSE_Q * 100)} {r['hip_q']:.2e})  oracle {r['cpu']:.2e} (q{int(SPARSE_Q * 100)} {r['cpu_q']:.2e})  "

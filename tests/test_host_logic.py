@@ -665,6 +665,28 @@ def test_the_per_tensor_judge_fails_a_dense_error_and_passes_a_sparse_flip():
     with pytest.raises(AssertionError, match='running_mean'):
         judge('synthetic: a running statistic off', stat)
 
+    # round 6: what the network RETURNS is a forward-only row too -- one point's logits off by 1e-3 of the largest fails whatever the
+    # gradients do; _grads puts the rows in front of `<input>`
+    class _Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.ones(3))
+    leaf = torch.ones(2, 3, requires_grad=True)
+    out = (leaf * _Net().w).sum()
+    out.backward()
+    assert list(tp._grads(_Net(), leaf, leaf.detach() * 2))[:2] == ['<logits>', '<input>']
+    assert list(tp._grads(_Net(), leaf, {'mask_logits': leaf.detach(), 'n': torch.zeros(2, dtype=torch.long)}))[0] == '<output mask_logits>'
+    with_out = lambda d, o: {'<logits>': o, **d}
+    logits = torch.randn(2, 13, 64, generator=g).double()
+    cpu['<logits>'] = noise(logits, 1e-7)
+    truth['<logits>'] = logits
+    rows = judge('synthetic: logits within 1e-5', with_out(hip, noise(logits, 1e-6)))
+    assert [r['forward_only'] for r in rows if r['name'] == '<logits>'] == [True]
+    off = noise(logits, 1e-7)
+    off[1, 3, 7] += 1e-3 * logits.abs().max()
+    with pytest.raises(AssertionError, match='<logits>'):
+        judge('synthetic: one point of the logits off', with_out(hip, off))
+
 
 def test_the_sampling_chain_accepts_only_the_tensor_it_expects():
     """pvcnn_amd.workload._SamplingChain (PVCNN++'s sampling ahead): identity + in-place version, and a refusal breaks the chain for good."""

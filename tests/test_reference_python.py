@@ -258,3 +258,45 @@ def test_adopt_keeps_a_reference_model_and_its_state_dict(ref):
         la.backward(); lb.backward()
         for (n1, p1), (n2, p2) in zip(plain.named_parameters(), adopted.named_parameters()):
             assert n1 == n2 and torch.equal(p1.grad, p2.grad), n1
+
+
+def test_adopt_of_the_reference_frustum_net(ref):
+    """(round 6) pvcnn_amd.adopt(model) on the reference's own models.kitti.frustum.FrustumPVCNNE instance (frustum_net.py:105-113):
+    the three sub-nets take workload's forwards, parameters / state_dict keys / class names stay, every returned head and every
+    gradient is the plain instance's (CPU: the adopted forwards fall back to the modules), and the adopted model pickles."""
+    import pickle
+    import numpy as np
+    import pvcnn_amd
+    from pvcnn_amd import workload
+    frustum = importlib.import_module('models.kitti.frustum')
+    templates = workload.frustum_size_templates()
+    torch.manual_seed(6)
+    plain = frustum.FrustumPVCNNE(3, 12, 8, 64, templates, 1, 0.125)
+    adopted = frustum.FrustumPVCNNE(3, 12, 8, 64, templates, 1, 0.125)
+    adopted.load_state_dict(plain.state_dict())
+    keys = list(adopted.state_dict().keys())
+    assert pvcnn_amd.adopt(adopted) is adopted and list(adopted.state_dict().keys()) == keys
+    assert type(adopted.inst_seg_net).forward is workload._FrustumSegmentation.forward
+    assert type(adopted.inst_seg_net).__name__ == 'InstanceSegmentationPVCNN'
+    assert type(adopted.center_reg_net).forward is workload._CloudRegressor.forward and not adopted.center_reg_net._coords_tuple
+    assert type(adopted.box_est_net).forward is workload._CloudRegressor.forward and adopted.box_est_net._coords_tuple
+    assert pvcnn_amd.adopt(adopted) is adopted                          # idempotent
+    inputs, _ = workload.make_frustum_batch(3, 256)
+    outs = []
+    for net in (plain, adopted):
+        net.train()
+        for m in net.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        np.random.seed(3)                                               # logits_mask's host draws (functional/sampling.py:69-82)
+        out = net(inputs)
+        sum(v.float().square().mean() for v in out.values() if v.dtype.is_floating_point).backward()
+        outs.append(out)
+    assert outs[0].keys() == outs[1].keys()
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k
+    for (n1, p1), (n2, p2) in zip(plain.named_parameters(), adopted.named_parameters()):
+        assert n1 == n2 and (p1.grad is None) == (p2.grad is None) and (p1.grad is None or torch.equal(p1.grad, p2.grad)), n1
+    clone = pickle.loads(pickle.dumps(adopted))
+    assert type(clone) is type(adopted) and type(clone.inst_seg_net) is type(adopted.inst_seg_net)
+    assert list(clone.state_dict().keys()) == keys
