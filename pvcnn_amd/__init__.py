@@ -54,7 +54,10 @@ def _adopted_class(cls, forward, extra=None):
 
 
 def _classify_forward(self, x):
+    import torch
     from . import workload
+    if not torch.is_tensor(x):             # a stack fed with (features, coords) tuples (box_estimation/pointnet.py:37): the modules as they are
+        return torch.nn.Sequential.forward(self, x)
     return workload._classify(self, x)
 
 

@@ -133,6 +133,21 @@ __device__ __forceinline__ float half_wave_sum16(const float (&v)[16], int lane)
   d += __shfl_xor(d, 1);
   return d;
 }
+// The same for 8 values per lane (7 + 2 shuffles): returns, in lane j, the total of value index (j >> 2) & 7.  Every total is the
+// butterfly over the lane bits 4, 3, 2, 1, 0 in that order, like half_wave_sum16's: value q of an 8-value call carries the same
+// bits as value q of a 16-value call on the same numbers (fp32 addition commutes; the tree is the same).
+__device__ __forceinline__ float half_wave_sum8(const float (&v)[8], int lane) {
+  float a[4], b[2];
+  const bool b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) a[r] = (b4 ? v[r + 4] : v[r]) + __shfl_xor(b4 ? v[r] : v[r + 4], 16);
+#pragma unroll
+  for (int r = 0; r < 2; ++r) b[r] = (b3 ? a[r + 2] : a[r]) + __shfl_xor(b3 ? a[r] : a[r + 2], 8);
+  float c = (b2 ? b[1] : b[0]) + __shfl_xor(b2 ? b[0] : b[1], 4);
+  c += __shfl_xor(c, 2);
+  c += __shfl_xor(c, 1);
+  return c;
+}
 #endif
 
 }  // namespace pvcnn

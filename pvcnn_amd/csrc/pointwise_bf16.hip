@@ -23,6 +23,7 @@
 // of each chunk's first MFMA because the prefetch sat behind bounds checks -- and moved the conversion between the MFMAs
 // (pw_gemm_f16_pipe_kernel below).  Arithmetic is selected with `backend.pw_math` (f16x2 default, bf16x3, fp32).
 #include <algorithm>
+#include <type_traits>
 #include <stdlib.h>
 
 #include "common.h"
@@ -528,6 +529,312 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_f16_pipe_kernel(const float *_
   pb_epilogue<NS, MB, WM>(acc, xs, bias, y, M, N, b, n0, m0, tile, tiles_total, stats_part, wexp, x_shift);
 }
 
+// ---- the 256 x 256 f16x2 tile, ONE workgroup per CU, persistent (round 6) ---------------------------------------------------------
+// pw_gemm_f16_pipe_kernel owns 128 output channels x 256 points and meets at a barrier every 24 MFMAs per wave; by the counters its
+// matrix pipes are busy in 0.40 of the cycles (issue-stalled 0.52): every chunk starts with the LDS reads of its B fragments exposed,
+// the conversion of a staged element is amortised over 128 output channels only (4 m-tiles re-convert x at M = 512), and the epilogue
+// of a workgroup overlaps nothing but the other workgroup of its CU.  Here:
+//   * a workgroup owns 256 output channels (two 128-row blocks of the SAME weight image) x 256 points: the four waves sit 2 x 2, each
+//     with 128 channels x 128 points = 16 accumulator tiles (256 registers: the kernel takes the whole register file of its SIMD,
+//     one wave per SIMD), 48 MFMAs per 16-channel step and wave against 8 A and 8 B fragment loads and ~70 conversion instructions;
+//   * everything a step needs was requested earlier: the B fragments of step s + 1 are read from LDS at the top of step s (the staged
+//     tiles live in a ring of THREE buffers, a tile is published two steps before it is multiplied), the A fragments of step s + 1
+//     are requested from the image at the top of step s, the fp32 rows of step s + 6 are requested when the registers of step s + 2's
+//     rows have been converted (a ring of four register sets: ~3 us of latency budget per load); the conversion of step s + 2 sits
+//     between the MFMAs of step s; ONE LDS-only barrier per step;
+//   * the workgroup is PERSISTENT: it walks its (point tile, channel block) items in the XCD-aware order of the kernels above (the
+//     M / 256 workgroups that stream the same 256 points run side by side behind one L2), and all the request streams simply run on
+//     into the next item -- when an item's last MFMA has been issued the first two tiles of the next one are already published.  The
+//     epilogue's stores drain behind the next item's MFMAs.
+// Needs K % 64 == 0 (the step loop is unrolled four times: register-ring indices are compile-time, an item is a whole number of
+// groups), an even number of 128-row blocks in the image, N % 256 == 0 (no ragged point tile: loads and stores go through
+// wave-uniform buffer descriptors whose bounds check drops the padded rows of the last channel block).  Per output element the same products in the same order as
+// pw_gemm_f16_pipe_kernel: bit-identical results (tests/test_gpu_pwconv.py).  PVCNN_PW_WIDE=0 keeps the 128-row kernel.
+constexpr int kWideBufs = 3;
+constexpr int kWideTile = 2 * 8 * kPbN;                         // words of one staged 16-channel tile (two planes)
+constexpr size_t kWideLds = (size_t)kWideBufs * kWideTile * sizeof(uint32_t) + (size_t)(2 + 2) * 256 * sizeof(float2);
+
+__global__ __launch_bounds__(256, 1) void pw_gemm_f16_wide_kernel(const float *__restrict__ x, const uint16_t *__restrict__ wts,
+                                                                  const float *__restrict__ bias, float *__restrict__ y, int K, int M,
+                                                                  int N, int tiles_n, int tiles_total, float2 *__restrict__ stats_part,
+                                                                  const uint32_t *__restrict__ x_absmax, const int *__restrict__ wexp,
+                                                                  int amax_seg) {
+  constexpr int NS = 2, MBW = 4, NBW = 4, TMI = 128, WBLK = NS * TMI * kPbK, TILE = kWideTile, ITEMS = 2, XR = 2;
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) uint32_t wide_lds[];
+  uint32_t *xs = wide_lds;
+  float2 *stat_lds = reinterpret_cast<float2 *>(wide_lds + kWideBufs * TILE);     // [2 point groups][256 rows]
+  float2 *row_lds = stat_lds + 2 * 256;                         // [item parity][256 rows] (bias, 2^-wexp) of the item's rows
+  const int mtiles = ceil_div(M, TMI), mpairs = mtiles >> 1;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+  const int items_local = ((tiles_total + 7) >> 3) * mpairs;   // items of this XCD: (its point tiles) x (channel-block pairs)
+  if (slot >= items_local) return;
+  const int rounds = (items_local - slot + nslots - 1) / nslots, chunks = K / kPbK;
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, kh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave & 1, wn = wave >> 1;
+
+  // item of round r (clamped: the request streams run past the last item and re-read it; nothing of that is used)
+  auto item_tile = [&](int r, int &mp) {
+    const int jdx = slot + min(r, rounds - 1) * nslots, tl = jdx / mpairs;
+    mp = jdx - tl * mpairs;
+    return tl * 8 + xcd;                                        // may be >= tiles_total in the padded tail: never stored
+  };
+  auto tile_shift = [&](int tile) { return scale_shift(amax_seg > 0 ? x_absmax[1 + min(tile, tiles_total - 1)] : *x_absmax); };
+
+  // byte offset of the lane's A fragment of row block 0 inside one plane slab; row block mb is mb KiB further (the swizzle bit is
+  // bit 3 of the row, which a multiple of 32 does not touch)
+  const uint32_t a_off = (uint32_t)(j * 8 + ((kh ^ ((j >> 3) & 1)) * 4)) * 4u;
+  // B fragment of (column block nb, plane s): [plane][kh][128-point block = wn][h][128 points][2 words], h = 0 / 1 are 1 KiB apart
+  const uint32_t b_base = (uint32_t)((((kh * 2 + wn) * 2) * 128 + j) * 2);                 // words, plane 0, nb = 0
+  // staging item of this thread: channel pairs 2 * wave, 2 * wave + 1 of point quad `lane` (pw_gemm_f16_pipe_kernel's)
+  const int kp0 = 2 * wave;
+  const uint32_t st = (uint32_t)(((((wave >> 1) * 2 + (lane >> 5)) * 2 + (wave & 1)) * 128 + ((4 * lane) & 127)) * 2);
+
+  // ---- the three request streams, each with its own (round, chunk) cursor ----
+  int xr_ = 0, xc_ = 0;                                         // rows (fp32, global -> registers)
+  // wave-uniform descriptor of the item's cloud (K x N floats) + ONE 32-bit lane offset: no 64-bit per-lane address in the loop
+  auto descriptor = [](const void *base, uint32_t bytes) {
+    const uintptr_t p = reinterpret_cast<uintptr_t>(base);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p), hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((uintptr_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+  };
+  const uint32_t row_bytes = (uint32_t)N * 4u;
+  __amdgpu_buffer_rsrc_t xrsrc;
+  uint32_t xoff;                                                // bytes: this thread's point quad + channel pair 2 * wave inside chunk 0
+  auto x_item = [&]() {
+    int mp;
+    const int tile = min(item_tile(xr_, mp), tiles_total - 1), b = tile / tiles_n, n0 = (tile - b * tiles_n) * kPbN;
+    xrsrc = descriptor(x + (size_t)b * K * N, (uint32_t)K * row_bytes);
+    xoff = (uint32_t)(n0 + 4 * lane) * 4u + (uint32_t)(2 * kp0) * row_bytes;
+  };
+  x_item();
+  auto load_x = [&](float4 (&va)[ITEMS], float4 (&vb)[ITEMS]) {
+    const uint32_t soff = (uint32_t)xc_ * (kPbK * row_bytes);   // the chunk: a scalar offset
+#pragma unroll
+    for (int u = 0; u < ITEMS; ++u) {
+      const u32x4 ra = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xoff + (uint32_t)(2 * u) * row_bytes, soff, 0);
+      const u32x4 rb = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xoff + (uint32_t)(2 * u + 1) * row_bytes, soff, 0);
+      va[u] = make_float4(__uint_as_float(ra.x), __uint_as_float(ra.y), __uint_as_float(ra.z), __uint_as_float(ra.w));
+      vb[u] = make_float4(__uint_as_float(rb.x), __uint_as_float(rb.y), __uint_as_float(rb.z), __uint_as_float(rb.w));
+    }
+    if (++xc_ == chunks) { xc_ = 0; ++xr_; x_item(); }
+  };
+  int vr_ = 0, vc_ = 0;                                         // conversion: the scale of the item the converted tile belongs to
+  float vscale;
+  { int mp; vscale = exp2_int(tile_shift(item_tile(0, mp))); }
+  // conversion of ONE of the thread's two channel pairs (u): eight fp32 -> 2 planes x 4 words
+  auto convert = [&](const float4 &va, const float4 &vb, uint32_t (&t4)[NS][4]) {
+    const float a[4] = {va.x, va.y, va.z, va.w}, bq[4] = {vb.x, vb.y, vb.z, vb.w};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      uint32_t pw[NS];
+      split_pair<NS>(a[t] * vscale, bq[t] * vscale, pw);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) t4[s][t] = pw[s];
+    }
+  };
+  auto convert_done = [&]() {                                   // the converted tile's cursor (its scale is its item's)
+    if (++vc_ == chunks) { vc_ = 0; ++vr_; int mp; vscale = exp2_int(tile_shift(item_tile(vr_, mp))); }
+  };
+  // w[s][h] = words (point 2h, pair 0), (point 2h, pair 1), (point 2h + 1, pair 0), (point 2h + 1, pair 1) of plane s
+  auto store = [&](int buf, const uint32_t (&t0)[NS][4], const uint32_t (&t1)[NS][4]) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        *reinterpret_cast<uint4 *>(xs + buf * TILE + s * 8 * kPbN + st + 4 * h) = make_uint4(t0[s][2 * h], t1[s][2 * h], t0[s][2 * h + 1], t1[s][2 * h + 1]);
+  };
+  int ar_ = 0, ac_ = 0;                                         // weight fragments (image -> registers)
+  const char *wrow;                                             // this wave's 128-row block of the item's pair, chunk 0
+  auto a_item = [&]() {
+    int mp;
+    item_tile(ar_, mp);
+    wrow = reinterpret_cast<const char *>(wts + (size_t)(2 * mp + wm) * WBLK);
+  };
+  a_item();
+  // plane 0 = hi, plane 1 = lo (split_pair).  The hi fragments of step s + 1 are requested at the top of step s into a second
+  // register set; the lo fragments -- dead after a step's first (A) / second (B) group of 16 MFMAs -- into the SAME registers
+  // behind that group: 48 + 48 fragment registers instead of 64 + 64.
+  auto load_a = [&](int plane, u32x4 (&af)[MBW]) {
+    const char *wq = wrow + (size_t)ac_ * mtiles * WBLK * sizeof(uint16_t);
+#pragma unroll
+    for (int mb = 0; mb < MBW; ++mb) af[mb] = *reinterpret_cast<const u32x4 *>(wq + a_off + (plane * (TMI * kPbK * 2) + mb * 1024));
+  };
+  auto mma = [](const u32x4 &a, const u32x4 &b, const f32x16 &c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  };
+  auto a_done = [&]() { if (++ac_ == chunks) { ac_ = 0; ++ar_; a_item(); } };
+  // ONE ds_read2_b64 per fragment, written by hand: (h = 0, h = 1) of column block nb are 1 KiB apart, the column blocks 256 bytes --
+  // all immediates of one address.  (From C++ the compiler pairs the eight 8-byte reads the other way round -- two column blocks per
+  // instruction -- and assembles the operands with v_mov behind a wait at the top of every step: seen in the ISA.)  An inline-asm
+  // LDS read is NOT tracked by the compiler's lgkmcnt bookkeeping: every fragment read here is first used behind the NEXT step
+  // barrier, whose s_waitcnt lgkmcnt(0) (lds_barrier) covers it; the prologue waits explicitly.
+  const uint32_t lds_xs = (uint32_t)reinterpret_cast<uintptr_t>(xs) + b_base * 4u;
+  auto load_b = [&](int buf, int plane, u32x4 (&bf)[NBW]) {
+    const uint32_t addr = lds_xs + (uint32_t)(buf * TILE + plane * 8 * kPbN) * 4u;
+#define PVCNN_PW_READ2(NB)                                                                                                        \
+    asm volatile("ds_read2_b64 %0, %1 offset0:%2 offset1:%3" : "=v"(bf[NB]) : "v"(addr), "n"(NB * 32), "n"(NB * 32 + 128) : "memory")
+    PVCNN_PW_READ2(0); PVCNN_PW_READ2(1); PVCNN_PW_READ2(2); PVCNN_PW_READ2(3);
+#undef PVCNN_PW_READ2
+  };
+
+  // ---- prologue: tiles 0 and 1 published, rows of tiles 2 .. 5 in flight, fragments of step 0 in registers ----
+  float4 va_[XR][ITEMS], vb_[XR][ITEMS];
+  u32x4 a_hi[2][MBW], a_lo[MBW], b_hi[2][NBW], b_lo[NBW];
+  uint32_t t0[NS][4], t1[NS][4];
+  load_x(va_[0], vb_[0]);
+  load_x(va_[1], vb_[1]);
+  load_a(0, a_hi[0]);
+  load_a(1, a_lo);
+  a_done();
+  convert(va_[0][0], vb_[0][0], t0); convert(va_[0][1], vb_[0][1], t1); convert_done();
+  store(0, t0, t1);
+  convert(va_[1][0], vb_[1][0], t0); convert(va_[1][1], vb_[1][1], t1); convert_done();
+  store(1, t0, t1);
+  if constexpr (XR == 4) {
+    load_x(va_[2 % XR], vb_[2 % XR]);
+    load_x(va_[3 % XR], vb_[3 % XR]);
+  }
+  load_x(va_[0], vb_[0]);
+  load_x(va_[1], vb_[1]);
+  lds_barrier();
+  load_b(0, 0, b_hi[0]);
+  load_b(0, 1, b_lo);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  int b_cur = 0;                                                // ring position of the tile being multiplied (step % 3)
+
+  f32x16 acc[MBW][NBW];                                         // (every element is defined by the first group of an item)
+  // one group of four steps.  FIRST: the item's first group -- its very first MFMAs start from C = 0 (an inline constant), so the
+  // accumulators are not carried from item to item (no zeroing pass, no register shuffle at the loop boundary: seen in the ISA)
+  auto group = [&](auto first_tag) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const int b_nxt = b_cur == 2 ? 0 : b_cur + 1, b_st = b_nxt == 2 ? 0 : b_nxt + 1;
+      float4 (&va)[ITEMS] = va_[(d + 2) % XR];                  // rows of step s + 2
+      float4 (&vb)[ITEMS] = vb_[(d + 2) % XR];
+      load_b(b_nxt, 0, b_hi[(d + 1) & 1]);                      // hi fragments of step s + 1 (its tile was published at the last barrier)
+      load_a(0, a_hi[(d + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      convert(va[0], vb[0], t0);
+      // lo x hi
+#pragma unroll
+      for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+        for (int mb = 0; mb < MBW; ++mb) {
+          if constexpr (FIRST) { if (d == 0) { acc[mb][nb] = mma(a_lo[mb], b_hi[0][nb], f32x16{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}); continue; } }
+          acc[mb][nb] = mma(a_lo[mb], b_hi[d & 1][nb], acc[mb][nb]);
+        }
+#define PVCNN_PW_INTERLEAVE()                                                                                            \
+      _Pragma("unroll") for (int i = 0; i < MBW * NBW; ++i) {                /* 1 MFMA, 2 vector-ALU; 16 times */        \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                               \
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                                                               \
+      }                                                                                                                  \
+      __builtin_amdgcn_sched_barrier(0)
+      PVCNN_PW_INTERLEAVE();
+      load_a(1, a_lo);                                          // ... of step s + 1, into the registers the group above has just read
+      a_done();
+      convert(va[1], vb[1], t1);
+      convert_done();
+      // hi x lo
+#pragma unroll
+      for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+        for (int mb = 0; mb < MBW; ++mb) acc[mb][nb] = mma(a_hi[d & 1][mb], b_lo[nb], acc[mb][nb]);
+      PVCNN_PW_INTERLEAVE();
+      load_b(b_nxt, 1, b_lo);
+      store(b_st, t0, t1);
+      load_x(va, vb);                                           // rows of step s + 2 + XR into the registers just converted
+      // hi x hi
+#pragma unroll
+      for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+        for (int mb = 0; mb < MBW; ++mb) acc[mb][nb] = mma(a_hi[d & 1][mb], b_hi[d & 1][nb], acc[mb][nb]);
+      PVCNN_PW_INTERLEAVE();
+#undef PVCNN_PW_INTERLEAVE
+      lds_barrier();
+      b_cur = b_nxt;
+    }
+  };
+  for (int r = 0; r < rounds; ++r) {
+    // the epilogue's per-row constants: requested now, parked in LDS behind the first group of steps (one read per row there instead
+    // of 128 predicated loads that the compiler hoists to the top of the epilogue: seen in the ISA, 90 spilled registers)
+    float2 row_const;
+    {
+      int mp;
+      item_tile(r, mp);
+      const int m = mp * 256 + tid;
+      row_const = make_float2((bias != nullptr && m < M) ? bias[m] : 0.0f, exp2_int(-wexp[m]));   // wexp covers the padded rows of the image
+    }
+    group(std::true_type{});
+    row_lds[(r & 1) * 256 + tid] = row_const;                   // (published by the barriers of the steps that follow, or the epilogue's)
+    for (int c0 = 4; c0 < chunks; c0 += 4) group(std::false_type{});
+    // ---- the item's epilogue: D[i = m][j = point]; lanes = consecutive points (128-byte rows); bias; BatchNorm partial sums ----
+    if (chunks == 4) lds_barrier();                             // (K = 64: no step barrier between the row constants' store and their readers)
+    int mp;
+    const int tile = item_tile(r, mp);
+    if (tile < tiles_total) {
+      // (the lane's coordinates are re-derived from the thread index HERE: kept across the step loop they cost registers that the
+      //  loop does not have -- the compiler parked them in scratch)
+      int tid_e = tid;
+      asm volatile("" : "+v"(tid_e));
+      const int j = tid_e & 31, kh = (tid_e >> 5) & 1;
+      const int b = tile / tiles_n, n0 = (tile - b * tiles_n) * kPbN, m0 = mp * 256 + wm * TMI;
+      const int x_shift = tile_shift(tile);
+      const float x_unscale = exp2_int(-x_shift);
+      const bool want_stats = stats_part != nullptr;
+      // stores through a descriptor of the cloud's M x N outputs: rows >= M (the padded rows of the last channel block) are dropped by
+      // the bounds check; the lane's offset is ONE register, the row / column block a scalar offset (N % 256 == 0: no ragged tile)
+      const __amdgpu_buffer_rsrc_t yrsrc = descriptor(y + (size_t)b * M * N, (uint32_t)M * row_bytes);
+      const uint32_t yoff = (uint32_t)(m0 + 4 * kh) * row_bytes + (uint32_t)(n0 + wn * 128 + j) * 4u;
+      // (eight rows at a time: the request streams of the NEXT item hold ~190 registers across this epilogue)
+#pragma unroll
+      for (int mb = 0; mb < MBW; ++mb)
+#pragma unroll
+        for (int h8 = 0; h8 < 2; ++h8) {
+          float bv[8], unscale[8], ss[8], qq[8];
+#pragma unroll
+          for (int qi = 0; qi < 8; ++qi) {
+            const int q = h8 * 8 + qi;
+            const float2 rc = row_lds[(r & 1) * 256 + wm * TMI + mb * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh];
+            bv[qi] = rc.x;
+            unscale[qi] = rc.y;
+            ss[qi] = qq[qi] = 0.0f;
+          }
+#pragma unroll
+          for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+            for (int qi = 0; qi < 8; ++qi) {
+              const int q = h8 * 8 + qi;
+              float v = acc[mb][nb][q] * unscale[qi] * x_unscale;        // powers of two: exact
+              if (want_stats) {                                 // statistics of (y - bias), see bn_finalize_kernel
+                ss[qi] += v;
+                qq[qi] += v * v;
+              }
+              v += bv[qi];
+              // (row q: a scalar multiple of the row pitch added to the lane's offset; the column block is an immediate)
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yrsrc,
+                                                    yoff + (uint32_t)(mb * 32 + (q & 3) + 8 * (q >> 2)) * row_bytes + (uint32_t)(nb * 128), 0, 0);
+            }
+          if (want_stats) {
+            const float st2 = half_wave_sum8(ss, j), qt = half_wave_sum8(qq, j);
+            const int q = h8 * 8 + ((j >> 2) & 7);
+            if ((j & 3) == 0) stat_lds[wn * 256 + wm * TMI + mb * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh] = make_float2(st2, qt);
+          }
+          __builtin_amdgcn_sched_barrier(0);                    // eight rows at a time, really
+        }
+      if (want_stats) {                                         // (uniform over the workgroup: every wave has the same item)
+        lds_barrier();
+        const int m = mp * 256 + tid_e;
+        if (m < M) {
+          const float2 t0 = stat_lds[tid_e], t1 = stat_lds[256 + tid_e];
+          stats_part[(size_t)m * tiles_total + tile] = make_float2(t0.x + t1.x, t0.y + t1.y);
+        }
+      }
+    }
+  }
+}
+
 static int pb_mb(int M) { return M > 64 ? 4 : 2; }
 
 }  // namespace pvcnn
@@ -671,7 +978,16 @@ extern "C" int pvcnn_pwconv_fwd_split(const float *x, const void *wts, const flo
   else if (nsplit == 2) {
     // measured (profiles/ab/r03k_*, 1472 -> 512 over 65 536 points, forward): round-3 start 0.483 ms; straight-line chunk loop
     // (VEC) 0.347 ms; + conversion between the MFMAs, one barrier per chunk (pipe kernel) 0.306 ms; the step 1925 -> 2103 -> 2108 clouds/s
-    if (MB == 4 && vec)
+    // round 6: 256 output channels per workgroup, one persistent workgroup per CU (pw_gemm_f16_wide_kernel)
+    static const bool wide_on = [] { const char *e = getenv("PVCNN_PW_WIDE"); return !(e && e[0] == '0'); }();
+    const int mtiles128 = ceil_div(M, 128);
+    if (wide_on && MB == 4 && vec && K % 64 == 0 && N % kPbN == 0 && M >= 256 && mtiles128 % 2 == 0 &&
+        (long)std::max(K, M) * N * 4 < 0x7fffffffL) {            // (buffer descriptors: 32-bit byte offsets inside a cloud)
+      const long items_local = ((tiles_total + 7) / 8) * (mtiles128 / 2);
+      const unsigned wide_grid = 8u * (unsigned)std::min<long>(kNumCU / 8, items_local);
+      hipLaunchKernelGGL(pw_gemm_f16_wide_kernel, dim3(wide_grid), dim3(256), kWideLds, s, x, w16, bias, y, K, M, N, tiles_n, (int)tiles_total,
+                         sp, am, wexp, amax_seg);
+    } else if (MB == 4 && vec)
       hipLaunchKernelGGL(pw_gemm_f16_pipe_kernel<2>, grid, dim3(256), 0, s, x, w16, bias, y, K, M, N, tiles_n, (int)tiles_total, sp, am, wexp,
                          amax_seg);
     else if (MB == 4) PVCNN_PB_LAUNCH_PF(2, 4, 2);
