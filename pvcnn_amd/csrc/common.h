@@ -152,6 +152,33 @@ __device__ __forceinline__ float half_wave_sum8(const float (&v)[8], int lane) {
 
 }  // namespace pvcnn
 
+// ---- phase clocks (tools/probe/: a SEPARATE build of a kernel's translation unit with -DPVCNN_PHASE_PROBE; the library itself never
+// defines it, there these macros are nothing).  s_memtime per wave at named points of a kernel, the time since the previous point
+// added to the slot's accumulator (scalar registers); at the end lane 0 of every wave adds its accumulators to
+// pvcnn::phase_probe_buf[slot] and counts itself in slot 31.  A stamp waits for the wave's outstanding LDS / scalar loads
+// (s_waitcnt lgkmcnt(0)): an instrumented kernel runs ~10 % slower than the real one; the SHARES are what is read.
+#ifdef PVCNN_PHASE_PROBE
+namespace pvcnn { static __device__ unsigned long long *phase_probe_buf = nullptr; }     // (one kernel translation unit per probe build)
+#ifdef PVCNN_PHASE_PROBE_SETTER
+extern "C" __attribute__((visibility("default"))) int pvcnn_probe_set_buffer(void *device_ptr) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(pvcnn::phase_probe_buf), &device_ptr, sizeof(device_ptr));
+}
+#endif
+#define PVCNN_PROBE_BEGIN() unsigned long long probe_t_ = __builtin_amdgcn_s_memtime(); unsigned probe_acc_[16] = {}
+#define PVCNN_PROBE(k) do { const unsigned long long probe_n_ = __builtin_amdgcn_s_memtime(); probe_acc_[k] += (unsigned)(probe_n_ - probe_t_); probe_t_ = probe_n_; } while (0)
+#define PVCNN_PROBE_END()                                                                                              \
+  do {                                                                                                                   \
+    if ((threadIdx.x & 63) == 0 && pvcnn::phase_probe_buf != nullptr) {                                                  \
+      for (int probe_k_ = 0; probe_k_ < 16; ++probe_k_) atomicAdd(pvcnn::phase_probe_buf + probe_k_, (unsigned long long)probe_acc_[probe_k_]); \
+      atomicAdd(pvcnn::phase_probe_buf + 31, 1ull);                                                                      \
+    }                                                                                                                    \
+  } while (0)
+#else
+#define PVCNN_PROBE_BEGIN() do { } while (0)
+#define PVCNN_PROBE(k) do { } while (0)
+#define PVCNN_PROBE_END() do { } while (0)
+#endif
+
 #define PVCNN_REQUIRE(cond, msg)                                       \
   do {                                                                 \
     if (!(cond)) {                                                     \

@@ -679,6 +679,7 @@ __global__ __launch_bounds__(256, 1) void pw_gemm_f16_wide_kernel(const float *_
   };
 
   // ---- prologue: tiles 0 and 1 published, rows of tiles 2 .. 5 in flight, fragments of step 0 in registers ----
+  PVCNN_PROBE_BEGIN();
   float4 va_[XR][ITEMS], vb_[XR][ITEMS];
   u32x4 a_hi[2][MBW], a_lo[MBW], b_hi[2][NBW], b_lo[NBW];
   uint32_t t0[NS][4], t1[NS][4];
@@ -701,6 +702,7 @@ __global__ __launch_bounds__(256, 1) void pw_gemm_f16_wide_kernel(const float *_
   load_b(0, 0, b_hi[0]);
   load_b(0, 1, b_lo);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  PVCNN_PROBE(6);                                               // slot 6: prologue
   int b_cur = 0;                                                // ring position of the tile being multiplied (step % 3)
 
   f32x16 acc[MBW][NBW];                                         // (every element is defined by the first group of an item)
@@ -716,6 +718,7 @@ __global__ __launch_bounds__(256, 1) void pw_gemm_f16_wide_kernel(const float *_
       load_b(b_nxt, 0, b_hi[(d + 1) & 1]);                      // hi fragments of step s + 1 (its tile was published at the last barrier)
       load_a(0, a_hi[(d + 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);
+      PVCNN_PROBE(0);                                           // slot 0: the step's first requests issued
       convert(va[0], vb[0], t0);
       // lo x hi
 #pragma unroll
@@ -732,6 +735,7 @@ __global__ __launch_bounds__(256, 1) void pw_gemm_f16_wide_kernel(const float *_
       }                                                                                                                  \
       __builtin_amdgcn_sched_barrier(0)
       PVCNN_PW_INTERLEAVE();
+      PVCNN_PROBE(1);                                           // slot 1: lo x hi (16 MFMAs, half of the conversion, the wait for a_lo)
       load_a(1, a_lo);                                          // ... of step s + 1, into the registers the group above has just read
       a_done();
       convert(va[1], vb[1], t1);
@@ -742,6 +746,7 @@ __global__ __launch_bounds__(256, 1) void pw_gemm_f16_wide_kernel(const float *_
 #pragma unroll
         for (int mb = 0; mb < MBW; ++mb) acc[mb][nb] = mma(a_hi[d & 1][mb], b_lo[nb], acc[mb][nb]);
       PVCNN_PW_INTERLEAVE();
+      PVCNN_PROBE(2);                                           // slot 2: hi x lo (the other half of the conversion: waits for the rows)
       load_b(b_nxt, 1, b_lo);
       store(b_st, t0, t1);
       load_x(va, vb);                                           // rows of step s + 2 + XR into the registers just converted
@@ -752,7 +757,9 @@ __global__ __launch_bounds__(256, 1) void pw_gemm_f16_wide_kernel(const float *_
         for (int mb = 0; mb < MBW; ++mb) acc[mb][nb] = mma(a_hi[d & 1][mb], b_hi[d & 1][nb], acc[mb][nb]);
       PVCNN_PW_INTERLEAVE();
 #undef PVCNN_PW_INTERLEAVE
+      PVCNN_PROBE(3);                                           // slot 3: hi x hi (+ the tile's store, the next requests)
       lds_barrier();
+      PVCNN_PROBE(4);                                           // slot 4: the step barrier
       b_cur = b_nxt;
     }
   };
@@ -832,7 +839,9 @@ __global__ __launch_bounds__(256, 1) void pw_gemm_f16_wide_kernel(const float *_
         }
       }
     }
+    PVCNN_PROBE(5);                                             // slot 5: the item's epilogue
   }
+  PVCNN_PROBE_END();
 }
 
 static int pb_mb(int M) { return M > 64 ? 4 : 2; }
