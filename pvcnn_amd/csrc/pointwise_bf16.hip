@@ -537,31 +537,46 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_f16_pipe_kernel(const float *_
 //   * a workgroup owns 256 output channels (two 128-row blocks of the SAME weight image) x 256 points: the four waves sit 2 x 2, each
 //     with 128 channels x 128 points = 16 accumulator tiles (256 registers: the kernel takes the whole register file of its SIMD,
 //     one wave per SIMD), 48 MFMAs per 16-channel step and wave against 8 A and 8 B fragment loads and ~70 conversion instructions;
-//   * everything a step needs was requested earlier: the B fragments of step s + 1 are read from LDS at the top of step s (the staged
-//     tiles live in a ring of THREE buffers, a tile is published two steps before it is multiplied), the A fragments of step s + 1
-//     are requested from the image at the top of step s, the fp32 rows of step s + 6 are requested when the registers of step s + 2's
-//     rows have been converted (a ring of four register sets: ~3 us of latency budget per load); the conversion of step s + 2 sits
-//     between the MFMAs of step s; ONE LDS-only barrier per step;
+//   * everything a step needs was requested earlier: the fragments of step s + 1 (A from the image, B from LDS: the staged tiles live
+//     in a ring of THREE buffers, a tile is published two steps before it is multiplied) during the first 16 MFMAs of step s into a
+//     second register set, the fp32 rows of step s + 4 when the registers of step s + 2's rows have been converted; the conversion
+//     of step s + 2 sits between the MFMAs of step s; ONE LDS-only barrier per step;
+//   * NO memory instruction stands between two groups of MFMAs: a step is ONE basic block -- the request streams are branch-free (a
+//     stream is at most one item ahead of the multiply: its scalar offset is a select between this item's and the next item's base) --
+//     of 48 PINNED slots, each one MFMA + at most one request + a few vector-ALU instructions (see `group`).  What that bought, by
+//     the ablation builds of tools/probe (1472 -> 512 over 65 536 points, normal fill, us per launch): requests in blocks between
+//     the MFMA groups 350 (first version; the 128-row kernel on the same box: 396) -> scheduler-placed 347 -> pinned slots 334 ->
+//     conversion packed along the points 330; of those 330, the conversion costs ~70 (leaving it out: 227), the row requests ~30,
+//     the step barrier ~25, and the MFMAs alone (no request, no conversion, no barrier) take 204: the matrix pipes at the clock the
+//     chip sustains under a dense fp16 MFMA stream on random operands;
 //   * the workgroup is PERSISTENT: it walks its (point tile, channel block) items in the XCD-aware order of the kernels above (the
-//     M / 256 workgroups that stream the same 256 points run side by side behind one L2), and all the request streams simply run on
-//     into the next item -- when an item's last MFMA has been issued the first two tiles of the next one are already published.  The
-//     epilogue's stores drain behind the next item's MFMAs.
+//     M / 256 workgroups that stream the same 256 points run side by side behind one L2); when an item's last MFMA has been issued
+//     the first two tiles of the next one are already published and its first fragments are in registers.  An item's first MFMAs
+//     start from C = 0 (the accumulators are not carried across items), the epilogue's stores drain behind the next item's MFMAs.
 // Needs K % 64 == 0 (the step loop is unrolled four times: register-ring indices are compile-time, an item is a whole number of
-// groups), an even number of 128-row blocks in the image, N % 256 == 0 (no ragged point tile: loads and stores go through
-// wave-uniform buffer descriptors whose bounds check drops the padded rows of the last channel block).  Per output element the same products in the same order as
-// pw_gemm_f16_pipe_kernel: bit-identical results (tests/test_gpu_pwconv.py).  PVCNN_PW_WIDE=0 keeps the 128-row kernel.
+// groups), an even number of 128-row blocks in the image, N % 256 == 0 and tensors below 4 GiB (no ragged point tile: loads and
+// stores go through wave-uniform buffer descriptors with 32-bit offsets; the bounds check drops the padded rows of the last channel
+// block).  Per output element the same products in the same order as pw_gemm_f16_pipe_kernel: bit-identical results, BatchNorm partial
+// sums included (tests/test_gpu_pw_wide.py).  PVCNN_PW_WIDE=0 keeps the 128-row kernel.
 constexpr int kWideBufs = 3;
 constexpr int kWideTile = 2 * 8 * kPbN;                         // words of one staged 16-channel tile (two planes)
 constexpr size_t kWideLds = (size_t)kWideBufs * kWideTile * sizeof(uint32_t) + (size_t)(2 + 2) * 256 * sizeof(float2);
 
+// AB (ablation bits, tools/probe builds only; the library instantiates 0): 1 = no A requests in the step loop, 2 = no row requests,
+// 4 = no conversion / tile store, 8 = no B reads, 16 = no step barrier -- the step then multiplies stale fragments: wrong results, the
+// MFMAs and everything else stay, and the difference in time is what the removed part costs (phase clocks perturb too much here).
+template <int AB = 0>
 __global__ __launch_bounds__(256, 1) void pw_gemm_f16_wide_kernel(const float *__restrict__ x, const uint16_t *__restrict__ wts,
                                                                   const float *__restrict__ bias, float *__restrict__ y, int K, int M,
                                                                   int N, int tiles_n, int tiles_total, float2 *__restrict__ stats_part,
                                                                   const uint32_t *__restrict__ x_absmax, const int *__restrict__ wexp,
-                                                                  int amax_seg) {
-  constexpr int NS = 2, MBW = 4, NBW = 4, TMI = 128, WBLK = NS * TMI * kPbK, TILE = kWideTile, ITEMS = 2, XR = 2;
+                                                                  int amax_seg, unsigned x_bytes, unsigned w_bytes) {
+  constexpr int NS = 2, MBW = 4, NBW = 4, TMI = 128, WBLK = NS * TMI * kPbK, TILE = kWideTile, XR = 2;
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
   extern __shared__ __attribute__((aligned(16))) uint32_t wide_lds[];
+  // staged tiles: [buffer][plane][kh][256 points][4 words]; word w of (kh, point) = channel pair 4 kh + w: a lane's B fragment (the 8
+  // channels 8 kh .. 8 kh + 7 of its point) is ONE 16-byte read, 32 consecutive points = 512 contiguous bytes (conflict-free)
   uint32_t *xs = wide_lds;
   float2 *stat_lds = reinterpret_cast<float2 *>(wide_lds + kWideBufs * TILE);     // [2 point groups][256 rows]
   float2 *row_lds = stat_lds + 2 * 256;                         // [item parity][256 rows] (bias, 2^-wexp) of the item's rows
@@ -572,193 +587,177 @@ __global__ __launch_bounds__(256, 1) void pw_gemm_f16_wide_kernel(const float *_
   const int rounds = (items_local - slot + nslots - 1) / nslots, chunks = K / kPbK;
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, kh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave & 1, wn = wave >> 1;
+  const uint32_t row_bytes = (uint32_t)N * 4u;
 
-  // item of round r (clamped: the request streams run past the last item and re-read it; nothing of that is used)
-  auto item_tile = [&](int r, int &mp) {
+  // ---- the items of this workgroup and what the request streams need of an item: three scalars ----
+  struct Item { int tile, mp; uint32_t x_base, a_base; float scale; };
+  auto item_at = [&](int r) {                                   // (clamped: past the last item the streams re-read it; nothing of that is used)
+    Item it;
     const int jdx = slot + min(r, rounds - 1) * nslots, tl = jdx / mpairs;
-    mp = jdx - tl * mpairs;
-    return tl * 8 + xcd;                                        // may be >= tiles_total in the padded tail: never stored
+    it.mp = jdx - tl * mpairs;
+    it.tile = tl * 8 + xcd;                                     // may be >= tiles_total in the padded tail: never stored
+    const int tc = min(it.tile, tiles_total - 1), b = tc / tiles_n, n0 = (tc - b * tiles_n) * kPbN;
+    it.x_base = (uint32_t)b * (uint32_t)K * row_bytes + (uint32_t)n0 * 4u;              // bytes from x to (cloud, row 0, point n0)
+    it.a_base = (uint32_t)(2 * it.mp + wm) * (uint32_t)(WBLK * 2);                      // bytes from the image to this wave's row block, chunk 0
+    it.scale = exp2_int(scale_shift(amax_seg > 0 ? x_absmax[1 + tc] : *x_absmax));
+    // (wave-uniform, all of it: say so -- a scale that the compiler keeps in a vector register is one more register across the step loop)
+    it.x_base = __builtin_amdgcn_readfirstlane(it.x_base);
+    it.a_base = __builtin_amdgcn_readfirstlane(it.a_base);
+    it.scale = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(it.scale)));
+    return it;
   };
-  auto tile_shift = [&](int tile) { return scale_shift(amax_seg > 0 ? x_absmax[1 + min(tile, tiles_total - 1)] : *x_absmax); };
-
-  // byte offset of the lane's A fragment of row block 0 inside one plane slab; row block mb is mb KiB further (the swizzle bit is
-  // bit 3 of the row, which a multiple of 32 does not touch)
-  const uint32_t a_off = (uint32_t)(j * 8 + ((kh ^ ((j >> 3) & 1)) * 4)) * 4u;
-  // B fragment of (column block nb, plane s): [plane][kh][128-point block = wn][h][128 points][2 words], h = 0 / 1 are 1 KiB apart
-  const uint32_t b_base = (uint32_t)((((kh * 2 + wn) * 2) * 128 + j) * 2);                 // words, plane 0, nb = 0
-  // staging item of this thread: channel pairs 2 * wave, 2 * wave + 1 of point quad `lane` (pw_gemm_f16_pipe_kernel's)
-  const int kp0 = 2 * wave;
-  const uint32_t st = (uint32_t)(((((wave >> 1) * 2 + (lane >> 5)) * 2 + (wave & 1)) * 128 + ((4 * lane) & 127)) * 2);
-
-  // ---- the three request streams, each with its own (round, chunk) cursor ----
-  int xr_ = 0, xc_ = 0;                                         // rows (fp32, global -> registers)
-  // wave-uniform descriptor of the item's cloud (K x N floats) + ONE 32-bit lane offset: no 64-bit per-lane address in the loop
   auto descriptor = [](const void *base, uint32_t bytes) {
     const uintptr_t p = reinterpret_cast<uintptr_t>(base);
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p), hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
     return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((uintptr_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
   };
-  const uint32_t row_bytes = (uint32_t)N * 4u;
-  __amdgpu_buffer_rsrc_t xrsrc;
-  uint32_t xoff;                                                // bytes: this thread's point quad + channel pair 2 * wave inside chunk 0
-  auto x_item = [&]() {
-    int mp;
-    const int tile = min(item_tile(xr_, mp), tiles_total - 1), b = tile / tiles_n, n0 = (tile - b * tiles_n) * kPbN;
-    xrsrc = descriptor(x + (size_t)b * K * N, (uint32_t)K * row_bytes);
-    xoff = (uint32_t)(n0 + 4 * lane) * 4u + (uint32_t)(2 * kp0) * row_bytes;
-  };
-  x_item();
-  auto load_x = [&](float4 (&va)[ITEMS], float4 (&vb)[ITEMS]) {
-    const uint32_t soff = (uint32_t)xc_ * (kPbK * row_bytes);   // the chunk: a scalar offset
+  const __amdgpu_buffer_rsrc_t xrsrc = descriptor(x, x_bytes), wrsrc = descriptor(wts, w_bytes);
+  const uint32_t a_chunk = (uint32_t)mtiles * (uint32_t)(WBLK * 2), x_chunk = (uint32_t)kPbK * row_bytes;   // bytes per step
+
+  // per-lane offsets (bytes), the same in every step
+  // A fragment: row mb * 32 + j of the 128-row block (the swizzle bit is bit 3 of the row, which a multiple of 32 does not touch)
+  const uint32_t a_off = (uint32_t)(j * 8 + ((kh ^ ((j >> 3) & 1)) * 4)) * 4u;
+  // staging item: channel pairs 2 * wave, 2 * wave + 1 (= words 2 (wave & 1) + {0, 1} of half kh' = wave >> 1) of point quad `lane`
+  const uint32_t x_off = (uint32_t)lane * 16u + (uint32_t)(4 * wave) * row_bytes;
+  const uint32_t st_off = (uint32_t)((((wave >> 1) * 256 + 4 * lane) * 4 + 2 * (wave & 1)) * 4);
+  const uint32_t b_off = (uint32_t)((kh * 256 + wn * 128 + j) * 16);
+  unsigned char *xs8 = reinterpret_cast<unsigned char *>(xs);
+
+  // conversion of channel pair u (rows 2u, 2u + 1 of the thread's four), points 2 h2 and 2 h2 + 1, in two halves that are issued
+  // between different MFMAs: (1) scale + round to the hi fp16 pairs, (2) the residuals' fp16 pairs.  split_pair's arithmetic with the
+  // packed vector ALU running ALONG THE POINTS (two neighbouring points of one row sit in neighbouring registers of the 16-byte load;
+  // the two rows of a pair do not): 2 packed multiplies + 2 packs, then 4 conversions back + 2 packed fused multiply-subtracts
+  // (a * scale - hi in ONE rounding = the exact residual, like the product minus hi) + 2 packs: 6 instructions per (pair, point)
+  // instead of ~10 (the ablation builds of tools/probe price the first form of this conversion at a quarter of the kernel).
+  f16x2 th[2][4];                                               // hi pairs, kept from half 1 to half 2
+  uint32_t tw[NS][2][4];                                        // [plane][pair u][point q]: the converted tile of this thread
+  auto conv_hi = [&](const float4 (&v)[4], float scale, int u, int h2) {
+    const f32x2 a = h2 == 0 ? f32x2{v[2 * u].x, v[2 * u].y} : f32x2{v[2 * u].z, v[2 * u].w};
+    const f32x2 c = h2 == 0 ? f32x2{v[2 * u + 1].x, v[2 * u + 1].y} : f32x2{v[2 * u + 1].z, v[2 * u + 1].w};
+    const f32x2 sa = a * scale, sc = c * scale;
 #pragma unroll
-    for (int u = 0; u < ITEMS; ++u) {
-      const u32x4 ra = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xoff + (uint32_t)(2 * u) * row_bytes, soff, 0);
-      const u32x4 rb = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xoff + (uint32_t)(2 * u + 1) * row_bytes, soff, 0);
-      va[u] = make_float4(__uint_as_float(ra.x), __uint_as_float(ra.y), __uint_as_float(ra.z), __uint_as_float(ra.w));
-      vb[u] = make_float4(__uint_as_float(rb.x), __uint_as_float(rb.y), __uint_as_float(rb.z), __uint_as_float(rb.w));
-    }
-    if (++xc_ == chunks) { xc_ = 0; ++xr_; x_item(); }
-  };
-  int vr_ = 0, vc_ = 0;                                         // conversion: the scale of the item the converted tile belongs to
-  float vscale;
-  { int mp; vscale = exp2_int(tile_shift(item_tile(0, mp))); }
-  // conversion of ONE of the thread's two channel pairs (u): eight fp32 -> 2 planes x 4 words
-  auto convert = [&](const float4 &va, const float4 &vb, uint32_t (&t4)[NS][4]) {
-    const float a[4] = {va.x, va.y, va.z, va.w}, bq[4] = {vb.x, vb.y, vb.z, vb.w};
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      uint32_t pw[NS];
-      split_pair<NS>(a[t] * vscale, bq[t] * vscale, pw);
-#pragma unroll
-      for (int s = 0; s < NS; ++s) t4[s][t] = pw[s];
+    for (int e = 0; e < 2; ++e) {
+      th[u][2 * h2 + e] = __builtin_convertvector(f32x2{sa[e], sc[e]}, f16x2);
+      tw[0][u][2 * h2 + e] = __builtin_bit_cast(uint32_t, th[u][2 * h2 + e]);
     }
   };
-  auto convert_done = [&]() {                                   // the converted tile's cursor (its scale is its item's)
-    if (++vc_ == chunks) { vc_ = 0; ++vr_; int mp; vscale = exp2_int(tile_shift(item_tile(vr_, mp))); }
-  };
-  // w[s][h] = words (point 2h, pair 0), (point 2h, pair 1), (point 2h + 1, pair 0), (point 2h + 1, pair 1) of plane s
-  auto store = [&](int buf, const uint32_t (&t0)[NS][4], const uint32_t (&t1)[NS][4]) {
+  auto conv_lo = [&](const float4 (&v)[4], float scale, int u, int h2) {
+    const f32x2 a = h2 == 0 ? f32x2{v[2 * u].x, v[2 * u].y} : f32x2{v[2 * u].z, v[2 * u].w};
+    const f32x2 c = h2 == 0 ? f32x2{v[2 * u + 1].x, v[2 * u + 1].y} : f32x2{v[2 * u + 1].z, v[2 * u + 1].w};
+    const f32x2 ha = {(float)th[u][2 * h2][0], (float)th[u][2 * h2 + 1][0]}, hc = {(float)th[u][2 * h2][1], (float)th[u][2 * h2 + 1][1]};
+    const f32x2 sv = {scale, scale};
+    const f32x2 ra = __builtin_elementwise_fma(a, sv, -ha), rc = __builtin_elementwise_fma(c, sv, -hc);     // exact (see split_pair)
 #pragma unroll
-    for (int s = 0; s < NS; ++s)
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-        *reinterpret_cast<uint4 *>(xs + buf * TILE + s * 8 * kPbN + st + 4 * h) = make_uint4(t0[s][2 * h], t1[s][2 * h], t0[s][2 * h + 1], t1[s][2 * h + 1]);
+    for (int e = 0; e < 2; ++e) tw[1][u][2 * h2 + e] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{ra[e], rc[e]}, f16x2));
   };
-  int ar_ = 0, ac_ = 0;                                         // weight fragments (image -> registers)
-  const char *wrow;                                             // this wave's 128-row block of the item's pair, chunk 0
-  auto a_item = [&]() {
-    int mp;
-    item_tile(ar_, mp);
-    wrow = reinterpret_cast<const char *>(wts + (size_t)(2 * mp + wm) * WBLK);
+  auto store_pt = [&](int buf, int s2, int q) {                 // 8 bytes: the thread's two words of (plane s2, point q)
+    *reinterpret_cast<u32x2 *>(xs8 + (buf * TILE + s2 * 8 * kPbN) * 4 + st_off + q * 16) = u32x2{tw[s2][0][q], tw[s2][1][q]};
   };
-  a_item();
-  // plane 0 = hi, plane 1 = lo (split_pair).  The hi fragments of step s + 1 are requested at the top of step s into a second
-  // register set; the lo fragments -- dead after a step's first (A) / second (B) group of 16 MFMAs -- into the SAME registers
-  // behind that group: 48 + 48 fragment registers instead of 64 + 64.
-  auto load_a = [&](int plane, u32x4 (&af)[MBW]) {
-    const char *wq = wrow + (size_t)ac_ * mtiles * WBLK * sizeof(uint16_t);
-#pragma unroll
-    for (int mb = 0; mb < MBW; ++mb) af[mb] = *reinterpret_cast<const u32x4 *>(wq + a_off + (plane * (TMI * kPbK * 2) + mb * 1024));
+  // plane 0 = hi, plane 1 = lo (split_pair)
+  auto load_a1 = [&](uint32_t soff, int plane, int mb) {
+    return __builtin_amdgcn_raw_buffer_load_b128(wrsrc, a_off + (uint32_t)(plane * (TMI * kPbK * 2) + mb * 1024), soff, 0);
+  };
+  auto load_b1 = [&](int buf, int plane, int nb) {
+    return *reinterpret_cast<const u32x4 *>(xs8 + (buf * TILE + plane * 8 * kPbN) * 4 + b_off + nb * 512);
+  };
+  auto load_x1 = [&](uint32_t soff, int k) {
+    const u32x4 r4 = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, x_off + (uint32_t)k * row_bytes, soff, 0);
+    return make_float4(__uint_as_float(r4.x), __uint_as_float(r4.y), __uint_as_float(r4.z), __uint_as_float(r4.w));
   };
   auto mma = [](const u32x4 &a, const u32x4 &b, const f32x16 &c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
   };
-  auto a_done = [&]() { if (++ac_ == chunks) { ac_ = 0; ++ar_; a_item(); } };
-  // ONE ds_read2_b64 per fragment, written by hand: (h = 0, h = 1) of column block nb are 1 KiB apart, the column blocks 256 bytes --
-  // all immediates of one address.  (From C++ the compiler pairs the eight 8-byte reads the other way round -- two column blocks per
-  // instruction -- and assembles the operands with v_mov behind a wait at the top of every step: seen in the ISA.)  An inline-asm
-  // LDS read is NOT tracked by the compiler's lgkmcnt bookkeeping: every fragment read here is first used behind the NEXT step
-  // barrier, whose s_waitcnt lgkmcnt(0) (lds_barrier) covers it; the prologue waits explicitly.
-  const uint32_t lds_xs = (uint32_t)reinterpret_cast<uintptr_t>(xs) + b_base * 4u;
-  auto load_b = [&](int buf, int plane, u32x4 (&bf)[NBW]) {
-    const uint32_t addr = lds_xs + (uint32_t)(buf * TILE + plane * 8 * kPbN) * 4u;
-#define PVCNN_PW_READ2(NB)                                                                                                        \
-    asm volatile("ds_read2_b64 %0, %1 offset0:%2 offset1:%3" : "=v"(bf[NB]) : "v"(addr), "n"(NB * 32), "n"(NB * 32 + 128) : "memory")
-    PVCNN_PW_READ2(0); PVCNN_PW_READ2(1); PVCNN_PW_READ2(2); PVCNN_PW_READ2(3);
-#undef PVCNN_PW_READ2
-  };
 
-  // ---- prologue: tiles 0 and 1 published, rows of tiles 2 .. 5 in flight, fragments of step 0 in registers ----
+  // ---- prologue (item 0): tiles 0 and 1 published, rows of tiles 2 and 3 in flight, fragments of step 0 in registers ----
   PVCNN_PROBE_BEGIN();
-  float4 va_[XR][ITEMS], vb_[XR][ITEMS];
-  u32x4 a_hi[2][MBW], a_lo[MBW], b_hi[2][NBW], b_lo[NBW];
-  uint32_t t0[NS][4], t1[NS][4];
-  load_x(va_[0], vb_[0]);
-  load_x(va_[1], vb_[1]);
-  load_a(0, a_hi[0]);
-  load_a(1, a_lo);
-  a_done();
-  convert(va_[0][0], vb_[0][0], t0); convert(va_[0][1], vb_[0][1], t1); convert_done();
-  store(0, t0, t1);
-  convert(va_[1][0], vb_[1][0], t0); convert(va_[1][1], vb_[1][1], t1); convert_done();
-  store(1, t0, t1);
-  if constexpr (XR == 4) {
-    load_x(va_[2 % XR], vb_[2 % XR]);
-    load_x(va_[3 % XR], vb_[3 % XR]);
+  Item cur = item_at(0), nxt = item_at(1);
+  float4 xv[XR][4];
+  u32x4 a_hi[2][MBW], a_lo[2][MBW], b_hi[2][NBW], b_lo[2][NBW];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) xv[t][k] = load_x1(cur.x_base + (uint32_t)t * x_chunk, k);
   }
-  load_x(va_[0], vb_[0]);
-  load_x(va_[1], vb_[1]);
+#pragma unroll
+  for (int mb = 0; mb < MBW; ++mb) { a_hi[0][mb] = load_a1(cur.a_base, 0, mb); a_lo[0][mb] = load_a1(cur.a_base, 1, mb); }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) { conv_hi(xv[t], cur.scale, u, h2); conv_lo(xv[t], cur.scale, u, h2); }
+#pragma unroll
+    for (int s2 = 0; s2 < NS; ++s2)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) store_pt(t, s2, q);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) xv[t][k] = load_x1(cur.x_base + (uint32_t)(2 + t) * x_chunk, k);
+  }
   lds_barrier();
-  load_b(0, 0, b_hi[0]);
-  load_b(0, 1, b_lo);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int nb = 0; nb < NBW; ++nb) { b_hi[0][nb] = load_b1(0, 0, nb); b_lo[0][nb] = load_b1(0, 1, nb); }
   PVCNN_PROBE(6);                                               // slot 6: prologue
   int b_cur = 0;                                                // ring position of the tile being multiplied (step % 3)
 
   f32x16 acc[MBW][NBW];                                         // (every element is defined by the first group of an item)
-  // one group of four steps.  FIRST: the item's first group -- its very first MFMAs start from C = 0 (an inline constant), so the
-  // accumulators are not carried from item to item (no zeroing pass, no register shuffle at the loop boundary: seen in the ISA)
-  auto group = [&](auto first_tag) {
+  // One group of four steps, compute chunks c0 .. c0 + 3 of item `cur`.  FIRST: the item's first group -- its very first MFMAs start
+  // from C = 0 (an inline constant), so the accumulators are not carried from item to item (no zeroing pass, no register shuffle at
+  // the loop boundary: seen in the ISA of the first version).
+  // A step is 48 SLOTS, each one MFMA followed by at most one request and a few vector-ALU instructions, PINNED in this order
+  // (sched_barrier after every slot): left to itself -- also under sched_group_barrier -- the scheduler bunches the MFMAs (12 back
+  // to back, then 40 instructions with the matrix pipe idle: the second version of this kernel, phase clocks 2300 cycles per step
+  // for 1536 of MFMA).  In-order issue lets ~7 other instructions go between two MFMAs for free; no slot has more.
+  //     slots  0 .. 15  lo x hi   + the fragments of step s + 1: B hi, B lo (LDS), A hi, A lo (image) -- second register sets
+  //     slots 16 .. 31  hi x lo   + the conversion of the rows of step s + 2 (16 half-conversions)
+  //     slots 32 .. 47  hi x hi   + the converted tile's 8 stores, the row requests of step s + 2 + XR
+  auto group = [&](auto first_tag, int c0) {
     constexpr bool FIRST = decltype(first_tag)::value;
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
+      const int c = c0 + d, cs = d & 1, ns = cs ^ 1;
       const int b_nxt = b_cur == 2 ? 0 : b_cur + 1, b_st = b_nxt == 2 ? 0 : b_nxt + 1;
-      float4 (&va)[ITEMS] = va_[(d + 2) % XR];                  // rows of step s + 2
-      float4 (&vb)[ITEMS] = vb_[(d + 2) % XR];
-      load_b(b_nxt, 0, b_hi[(d + 1) & 1]);                      // hi fragments of step s + 1 (its tile was published at the last barrier)
-      load_a(0, a_hi[(d + 1) & 1]);
+      // the three request streams: chunk c + 1 (fragments), c + 2 (conversion), c + 2 + XR (rows) -- of this item or of the next
+      const bool na = c + 1 >= chunks, nv = c + 2 >= chunks, nx = c + 2 + XR >= chunks;
+      const uint32_t a_soff = (na ? nxt.a_base : cur.a_base) + (uint32_t)(c + 1 - (na ? chunks : 0)) * a_chunk;
+      const uint32_t x_soff = (nx ? nxt.x_base : cur.x_base) + (uint32_t)(c + 2 + XR - (nx ? chunks : 0)) * x_chunk;
+      const float vscale = nv ? nxt.scale : cur.scale;
+      float4 (&v)[4] = xv[d % XR];                              // rows of step s + 2
       __builtin_amdgcn_sched_barrier(0);
-      PVCNN_PROBE(0);                                           // slot 0: the step's first requests issued
-      convert(va[0], vb[0], t0);
-      // lo x hi
 #pragma unroll
-      for (int nb = 0; nb < NBW; ++nb)
-#pragma unroll
-        for (int mb = 0; mb < MBW; ++mb) {
-          if constexpr (FIRST) { if (d == 0) { acc[mb][nb] = mma(a_lo[mb], b_hi[0][nb], f32x16{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}); continue; } }
-          acc[mb][nb] = mma(a_lo[mb], b_hi[d & 1][nb], acc[mb][nb]);
+      for (int i = 0; i < 16; ++i) {                            // ---- lo x hi
+        const int nb = i >> 2, mb = i & 3;
+        if constexpr (FIRST) {
+          if (d == 0) acc[mb][nb] = mma(a_lo[cs][mb], b_hi[cs][nb], f32x16{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f});
+          else acc[mb][nb] = mma(a_lo[cs][mb], b_hi[cs][nb], acc[mb][nb]);
+        } else {
+          acc[mb][nb] = mma(a_lo[cs][mb], b_hi[cs][nb], acc[mb][nb]);
         }
-#define PVCNN_PW_INTERLEAVE()                                                                                            \
-      _Pragma("unroll") for (int i = 0; i < MBW * NBW; ++i) {                /* 1 MFMA, 2 vector-ALU; 16 times */        \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                               \
-        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                                                               \
-      }                                                                                                                  \
-      __builtin_amdgcn_sched_barrier(0)
-      PVCNN_PW_INTERLEAVE();
-      PVCNN_PROBE(1);                                           // slot 1: lo x hi (16 MFMAs, half of the conversion, the wait for a_lo)
-      load_a(1, a_lo);                                          // ... of step s + 1, into the registers the group above has just read
-      a_done();
-      convert(va[1], vb[1], t1);
-      convert_done();
-      // hi x lo
+        if (i < 4) { if constexpr (!(AB & 8)) b_hi[ns][i] = load_b1(b_nxt, 0, i); else b_hi[ns][i] = b_hi[cs][i]; }     // (the tile of step s + 1 was published at the last barrier)
+        else if (i < 8) { if constexpr (!(AB & 1)) a_lo[ns][i - 4] = load_a1(a_soff, 1, i - 4); else a_lo[ns][i - 4] = a_lo[cs][i - 4]; }
+        else if (i < 12) { if constexpr (!(AB & 1)) a_hi[ns][i - 8] = load_a1(a_soff, 0, i - 8); else a_hi[ns][i - 8] = a_hi[cs][i - 8]; }
+        else { if constexpr (!(AB & 8)) b_lo[ns][i - 12] = load_b1(b_nxt, 1, i - 12); else b_lo[ns][i - 12] = b_lo[cs][i - 12]; }
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
-      for (int nb = 0; nb < NBW; ++nb)
+      for (int i = 0; i < 16; ++i) {                            // ---- hi x lo
+        const int nb = i >> 2, mb = i & 3;
+        acc[mb][nb] = mma(a_hi[cs][mb], b_lo[cs][nb], acc[mb][nb]);
+        if constexpr (!(AB & 4)) {
+          // (8 half-conversions of two points each over the 16 slots: one every other slot)
+          if ((i & 1) == 0) { if (i < 8) conv_hi(v, vscale, (i >> 2) & 1, (i >> 1) & 1); else conv_lo(v, vscale, ((i - 8) >> 2) & 1, (i >> 1) & 1); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
-        for (int mb = 0; mb < MBW; ++mb) acc[mb][nb] = mma(a_hi[d & 1][mb], b_lo[nb], acc[mb][nb]);
-      PVCNN_PW_INTERLEAVE();
-      PVCNN_PROBE(2);                                           // slot 2: hi x lo (the other half of the conversion: waits for the rows)
-      load_b(b_nxt, 1, b_lo);
-      store(b_st, t0, t1);
-      load_x(va, vb);                                           // rows of step s + 2 + XR into the registers just converted
-      // hi x hi
-#pragma unroll
-      for (int nb = 0; nb < NBW; ++nb)
-#pragma unroll
-        for (int mb = 0; mb < MBW; ++mb) acc[mb][nb] = mma(a_hi[d & 1][mb], b_hi[d & 1][nb], acc[mb][nb]);
-      PVCNN_PW_INTERLEAVE();
-#undef PVCNN_PW_INTERLEAVE
-      PVCNN_PROBE(3);                                           // slot 3: hi x hi (+ the tile's store, the next requests)
-      lds_barrier();
+      for (int i = 0; i < 16; ++i) {                            // ---- hi x hi
+        const int nb = i >> 2, mb = i & 3;
+        acc[mb][nb] = mma(a_hi[cs][mb], b_hi[cs][nb], acc[mb][nb]);
+        if (i < 8) { if constexpr (!(AB & 4)) store_pt(b_st, i >> 2, i & 3); }
+        else if (i < 12) { if constexpr (!(AB & 2)) v[i - 8] = load_x1(x_soff, i - 8); }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      PVCNN_PROBE(3);                                           // slot 3: the step's 48 MFMAs and everything between them
+      if constexpr (!(AB & 16)) lds_barrier();
       PVCNN_PROBE(4);                                           // slot 4: the step barrier
       b_cur = b_nxt;
     }
@@ -768,33 +767,28 @@ __global__ __launch_bounds__(256, 1) void pw_gemm_f16_wide_kernel(const float *_
     // of 128 predicated loads that the compiler hoists to the top of the epilogue: seen in the ISA, 90 spilled registers)
     float2 row_const;
     {
-      int mp;
-      item_tile(r, mp);
-      const int m = mp * 256 + tid;
+      const int m = cur.mp * 256 + tid;
       row_const = make_float2((bias != nullptr && m < M) ? bias[m] : 0.0f, exp2_int(-wexp[m]));   // wexp covers the padded rows of the image
     }
-    group(std::true_type{});
+    group(std::true_type{}, 0);
     row_lds[(r & 1) * 256 + tid] = row_const;                   // (published by the barriers of the steps that follow, or the epilogue's)
-    for (int c0 = 4; c0 < chunks; c0 += 4) group(std::false_type{});
+    for (int c0 = 4; c0 < chunks; c0 += 4) group(std::false_type{}, c0);
     // ---- the item's epilogue: D[i = m][j = point]; lanes = consecutive points (128-byte rows); bias; BatchNorm partial sums ----
     if (chunks == 4) lds_barrier();                             // (K = 64: no step barrier between the row constants' store and their readers)
-    int mp;
-    const int tile = item_tile(r, mp);
-    if (tile < tiles_total) {
+    if (cur.tile < tiles_total) {
       // (the lane's coordinates are re-derived from the thread index HERE: kept across the step loop they cost registers that the
       //  loop does not have -- the compiler parked them in scratch)
       int tid_e = tid;
       asm volatile("" : "+v"(tid_e));
       const int j = tid_e & 31, kh = (tid_e >> 5) & 1;
-      const int b = tile / tiles_n, n0 = (tile - b * tiles_n) * kPbN, m0 = mp * 256 + wm * TMI;
-      const int x_shift = tile_shift(tile);
-      const float x_unscale = exp2_int(-x_shift);
+      const int b = cur.tile / tiles_n, n0 = (cur.tile - b * tiles_n) * kPbN, m0 = cur.mp * 256 + wm * TMI;
+      const float x_unscale = 1.0f / cur.scale;                 // (a power of two: exact)
       const bool want_stats = stats_part != nullptr;
       // stores through a descriptor of the cloud's M x N outputs: rows >= M (the padded rows of the last channel block) are dropped by
-      // the bounds check; the lane's offset is ONE register, the row / column block a scalar offset (N % 256 == 0: no ragged tile)
+      // the bounds check; the lane's offset is ONE register, the row a scalar multiple of the row pitch, the column block an immediate
       const __amdgpu_buffer_rsrc_t yrsrc = descriptor(y + (size_t)b * M * N, (uint32_t)M * row_bytes);
       const uint32_t yoff = (uint32_t)(m0 + 4 * kh) * row_bytes + (uint32_t)(n0 + wn * 128 + j) * 4u;
-      // (eight rows at a time: the request streams of the NEXT item hold ~190 registers across this epilogue)
+      // (eight rows at a time: the request streams of the NEXT item hold ~130 registers across this epilogue)
 #pragma unroll
       for (int mb = 0; mb < MBW; ++mb)
 #pragma unroll
@@ -819,7 +813,6 @@ __global__ __launch_bounds__(256, 1) void pw_gemm_f16_wide_kernel(const float *_
                 qq[qi] += v * v;
               }
               v += bv[qi];
-              // (row q: a scalar multiple of the row pitch added to the lane's offset; the column block is an immediate)
               __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yrsrc,
                                                     yoff + (uint32_t)(mb * 32 + (q & 3) + 8 * (q >> 2)) * row_bytes + (uint32_t)(nb * 128), 0, 0);
             }
@@ -832,13 +825,15 @@ __global__ __launch_bounds__(256, 1) void pw_gemm_f16_wide_kernel(const float *_
         }
       if (want_stats) {                                         // (uniform over the workgroup: every wave has the same item)
         lds_barrier();
-        const int m = mp * 256 + tid_e;
+        const int m = cur.mp * 256 + tid_e;
         if (m < M) {
-          const float2 t0 = stat_lds[tid_e], t1 = stat_lds[256 + tid_e];
-          stats_part[(size_t)m * tiles_total + tile] = make_float2(t0.x + t1.x, t0.y + t1.y);
+          const float2 s0 = stat_lds[tid_e], s1 = stat_lds[256 + tid_e];
+          stats_part[(size_t)m * tiles_total + cur.tile] = make_float2(s0.x + s1.x, s0.y + s1.y);
         }
       }
     }
+    cur = nxt;
+    nxt = item_at(r + 2);
     PVCNN_PROBE(5);                                             // slot 5: the item's epilogue
   }
   PVCNN_PROBE_END();
@@ -991,11 +986,29 @@ extern "C" int pvcnn_pwconv_fwd_split(const float *x, const void *wts, const flo
     static const bool wide_on = [] { const char *e = getenv("PVCNN_PW_WIDE"); return !(e && e[0] == '0'); }();
     const int mtiles128 = ceil_div(M, 128);
     if (wide_on && MB == 4 && vec && K % 64 == 0 && N % kPbN == 0 && M >= 256 && mtiles128 % 2 == 0 &&
-        (long)std::max(K, M) * N * 4 < 0x7fffffffL) {            // (buffer descriptors: 32-bit byte offsets inside a cloud)
+        (long)B * std::max(K, M) * N * 4 < 0xffffffffL) {        // (buffer descriptors: 32-bit byte offsets inside a tensor)
       const long items_local = ((tiles_total + 7) / 8) * (mtiles128 / 2);
       const unsigned wide_grid = 8u * (unsigned)std::min<long>(kNumCU / 8, items_local);
-      hipLaunchKernelGGL(pw_gemm_f16_wide_kernel, dim3(wide_grid), dim3(256), kWideLds, s, x, w16, bias, y, K, M, N, tiles_n, (int)tiles_total,
-                         sp, am, wexp, amax_seg);
+#define PVCNN_WIDE_LAUNCH(ABV)                                                                                                      \
+      hipLaunchKernelGGL(pw_gemm_f16_wide_kernel<ABV>, dim3(wide_grid), dim3(256), kWideLds, s, x, w16, bias, y, K, M, N, tiles_n,        \
+                         (int)tiles_total, sp, am, wexp, amax_seg, (unsigned)((size_t)B * K * N * 4), (unsigned)pb_image_bytes(K, M, 2))
+#ifdef PVCNN_ABLATE
+      const char *ab_env = getenv("PVCNN_PW_ABLATE");
+      switch (ab_env ? atoi(ab_env) : 0) {
+        case 1: PVCNN_WIDE_LAUNCH(1); break;
+        case 2: PVCNN_WIDE_LAUNCH(2); break;
+        case 4: PVCNN_WIDE_LAUNCH(4); break;
+        case 8: PVCNN_WIDE_LAUNCH(8); break;
+        case 16: PVCNN_WIDE_LAUNCH(16); break;
+        case 6: PVCNN_WIDE_LAUNCH(6); break;
+        case 15: PVCNN_WIDE_LAUNCH(15); break;
+        case 31: PVCNN_WIDE_LAUNCH(31); break;
+        default: PVCNN_WIDE_LAUNCH(0);
+      }
+#else
+      PVCNN_WIDE_LAUNCH(0);
+#endif
+#undef PVCNN_WIDE_LAUNCH
     } else if (MB == 4 && vec)
       hipLaunchKernelGGL(pw_gemm_f16_pipe_kernel<2>, grid, dim3(256), 0, s, x, w16, bias, y, K, M, N, tiles_n, (int)tiles_total, sp, am, wexp,
                          amax_seg);

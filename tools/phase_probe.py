@@ -19,9 +19,7 @@ import torch  # noqa: E402
 
 from pvcnn_amd.modules.functional.backend import HipBackend  # noqa: E402
 
-PW_SLOTS = {0: "the step's first requests issued (B hi reads, A hi loads)", 1: 'lo x hi: 16 MFMAs + half of the conversion (waits for a_lo)',
-            2: 'hi x lo: 16 MFMAs + the other half of the conversion (waits for the rows)', 3: 'hi x hi: 16 MFMAs (+ tile store, next requests)',
-            4: 'the step barrier', 5: "the item's epilogue", 6: 'prologue'}
+PW_SLOTS = {3: "a step's 48 MFMAs with its requests, conversion and stores between them", 4: 'the step barrier', 5: "the item's epilogue", 6: 'prologue'}
 
 
 def _p(t):
@@ -43,7 +41,9 @@ def _time(fn, n=10):
 
 def probe_pw(shape, bwd_data):
     be = HipBackend()
-    lib = ctypes.CDLL(os.path.join(ROOT, 'tools', 'probe', 'libprobe_pointwise_bf16.so'))
+    ablate = int(os.environ.get('PVCNN_PW_ABLATE', '0'))
+    clocks = '--ablate' not in sys.argv
+    lib = ctypes.CDLL(os.path.join(ROOT, 'tools', 'probe', ('libprobe' if clocks else 'libablate') + '_pointwise_bf16.so'))
     b, ci, co, n = shape
     dev = 'cuda:0'
     g = torch.Generator(device=dev).manual_seed(3)
@@ -55,7 +55,7 @@ def probe_pw(shape, bwd_data):
     amax = be.pw_amax(x)
     y = torch.empty(b, m, n, device=dev)
     buf = torch.zeros(32, dtype=torch.int64, device=dev)
-    assert lib.pvcnn_probe_set_buffer(_p(buf)) == 0
+    assert not clocks or lib.pvcnn_probe_set_buffer(_p(buf)) == 0
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     def launch():
@@ -64,13 +64,17 @@ def probe_pw(shape, bwd_data):
     launch()
     torch.cuda.synchronize()
     ref = be.pwconv_gemm_split(x, wts, bias, m, 2, False, amax)
-    assert torch.equal(ref, y), 'the probe build computes something else'
+    assert ablate or torch.equal(ref, y), 'the probe build computes something else'
     buf.zero_()
     launch()
     torch.cuda.synchronize()
     slots = buf.cpu().tolist()
     probed_us = _time(launch)
     plain_us = _time(lambda: be.pwconv_gemm_split(x, wts, bias, m, 2, False, amax))
+    if not clocks:
+        print(json.dumps({'ablate': ablate, 'BCiCoN': list(shape), 'direction': 'backward-data' if bwd_data else 'forward',
+                          'launch_us': round(_time(launch, 20), 1), 'launch_us_product': round(_time(lambda: be.pwconv_gemm_split(x, wts, bias, m, 2, False, amax), 20), 1)}))
+        return
     waves, total = slots[31], sum(slots[:16])
     rows = [{'slot': k_, 'what': PW_SLOTS.get(k_, ''), 'share': round(v / total, 4), 'cycles_per_wave': round(v / max(waves, 1))}
             for k_, v in enumerate(slots[:16]) if v]
@@ -78,7 +82,7 @@ def probe_pw(shape, bwd_data):
     if k % 64 == 0 and m >= 256:
         items = b * (n // 256) * ((m + 255) // 256)
         steps_per_wave = items * (k // 16) / (waves / 4)
-    out = {'kernel': '1x1 GEMM f16x2 (pointwise_bf16.hip)', 'BCiCoN': list(shape), 'direction': 'backward-data' if bwd_data else 'forward', 'K': k, 'M': m,
+    out = {'ablate': ablate, 'kernel': '1x1 GEMM f16x2 (pointwise_bf16.hip)', 'BCiCoN': list(shape), 'direction': 'backward-data' if bwd_data else 'forward', 'K': k, 'M': m,
            'waves': waves, 'cycles_per_wave': round(total / max(waves, 1)), 'steps_per_wave': steps_per_wave,
            'cycles_per_step': round(total / max(waves, 1) / steps_per_wave) if steps_per_wave else None,
            'ideal_mfma_cycles_per_step': 48 * 32, 'launch_us_instrumented': round(probed_us, 1), 'launch_us_product': round(plain_us, 1), 'phases': rows}
