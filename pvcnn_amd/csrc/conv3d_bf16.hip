@@ -30,6 +30,8 @@
 //     optional BatchNorm partial sums of (y - bias).
 // Backward-data is the same kernel on the flipped, channel-transposed weights (the split kernel's for_bwd_data mode).
 #include <algorithm>
+#include <stdlib.h>
+#include <type_traits>
 
 #include "common.h"
 #include <string.h>
@@ -853,6 +855,351 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_f16_pipe_kernel(const flo
   }
 }
 
+// ---- the 512-voxel f16x2 tile of the R = 32 grids, ONE workgroup per CU, persistent (round 6) -----------------------------------
+// conv3d_igemm_bf16_kernel<2, 4, 4, 32> stages a 16-channel chunk of its halo tile between two barriers (request the rows in three
+// batches, wait, convert, 4-byte LDS stores whose lanes are 32 words apart) and relies on the second workgroup of the CU to keep the
+// matrix pipes busy meanwhile: by the counters they are busy in 0.47 of the cycles.  This kernel is pw_gemm_f16_wide_kernel's
+// structure (pointwise_bf16.hip) on the implicit GEMM:
+//   * the same 4 x 4 x 32 voxel x 64 channel tile and the same wave arrangement (a wave = 64 channels x the 128 voxels of one x plane
+//     of the tile: per output element the same products in the same order -- bit-identical results, BatchNorm partials included), but
+//     ONE workgroup per CU with the halo tile DOUBLE-buffered in LDS ([plane][channel half][halo voxel][8 channels = 16 bytes]: a B
+//     fragment is one ds_read_b128, a tap an immediate offset, 32 consecutive z voxels 512 contiguous bytes) and ONE barrier per chunk;
+//   * a chunk is 27 taps x 24 MFMAs per wave, every tap 24 PINNED slots (one MFMA + at most one request or a few vector-ALU
+//     instructions): the B fragments of tap t + 1 (LDS) and the A fragments of tap t + 2 (weight image, L2) are requested between the
+//     MFMAs of tap t; the rows of the NEXT chunk -- in registers since the previous chunk -- are converted and stored into the other
+//     buffer between the MFMAs of taps 1 .. 12 (16-byte stores, packed arithmetic along z), and the rows of the chunk after that
+//     are requested between the MFMAs of taps 13 .. 24: a whole chunk (~10 us) of latency budget per row;
+//   * the workgroup is PERSISTENT over its tiles (XCD-contiguous ranges of the tile list, as xcd_tile_order): all request streams run
+//     on into the next tile, whose first chunk is staged while this tile's last one is multiplied; an item's first MFMAs start from
+//     C = 0; the epilogue's stores drain behind the next tile's MFMAs.
+// Needs R == 32, Ci % 16 == 0, Ci >= 32, tensors below 4 GiB.  PVCNN_CONV_WIDE=0 keeps the two-workgroup kernel.
+constexpr int kCwHX = 6, kCwHY = 6, kCwHZ = 34, kCwHS = kCwHX * kCwHY * kCwHZ;      // halo of the 4 x 4 x 32 tile
+constexpr int kCwHalfB = kCwHS * 16, kCwTileB = 4 * kCwHalfB;                      // bytes of one (plane, half) slab / of one buffer
+constexpr size_t kCwLds = (size_t)2 * kCwTileB + (size_t)4 * kCoTileB * sizeof(float2);
+
+template <int AB = 0>
+__global__ __launch_bounds__(256, 1) void conv3d_igemm_f16_wide_kernel(const float *__restrict__ x, const uint16_t *__restrict__ wts,
+                                                                       const float *__restrict__ bias, float *__restrict__ y, int Ci, int Co,
+                                                                       int B, float2 *__restrict__ stats_part,
+                                                                       const uint32_t *__restrict__ x_absmax, const int *__restrict__ wexp,
+                                                                       int amax_seg, unsigned x_bytes, unsigned w_bytes, int stats_parts) {
+  constexpr int NS = 2, R = 32, TX = 4, TY = 4, HX = kCwHX, HY = kCwHY, HZ = kCwHZ, HS = kCwHS, NBW = 4, MBW = 2;
+  constexpr int HALFB = kCwHalfB, TILEB = kCwTileB, WBLK = 3 * NS * kCoTileB * kKc;
+  constexpr int RR = R * R, S = RR * R, tiles_x = R / TX, tiles_y = R / TY;
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) uint32_t cw_lds[];
+  unsigned char *xs8 = reinterpret_cast<unsigned char *>(cw_lds);
+  float2 *stat_lds = reinterpret_cast<float2 *>(xs8 + 2 * TILEB);                 // [4 voxel groups][64 channels]
+
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, kh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                     // = the x plane of the tile this wave owns
+  const int cotiles = ceil_div(Co, kCoTileB), chunks = Ci / kKc;
+  const int n_tiles = B * tiles_x * tiles_y;
+  // this workgroup's tiles: XCD x owns a contiguous range of the tile list (xcd_tile_order's), its workgroups take it round by round
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+  const int xq = n_tiles >> 3, xr8 = n_tiles & 7;
+  const int x_start = xcd * xq + min(xcd, xr8), x_count = xq + (xcd < xr8 ? 1 : 0);
+  const int items_local = x_count * cotiles;
+  if (slot >= items_local) return;
+  const int rounds = (items_local - slot + nslots - 1) / nslots;
+
+  auto descriptor = [](const void *base, uint32_t bytes) {
+    const uintptr_t p = reinterpret_cast<uintptr_t>(base);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p), hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((uintptr_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t xrsrc = descriptor(x, x_bytes), wrsrc = descriptor(wts, w_bytes);
+
+  // ---- an item = (tile, 64-channel block); what the request streams need of it ----
+  // staging items of a thread: e = tid + 256 i, i < 3 (576 = 2 channel octets x 36 halo rows x 8 z quads; i = 2 exists for tid < 64:
+  // the other threads stage their item 0 twice -- the same bytes to the same place -- so that the chunk stays straight-line code)
+  struct Item {
+    int b, x0, y0, cot, stat_slot, shift;
+    uint32_t x_base, a_base;         // bytes: x -> (cloud b, channel 0); image -> (chunk 0, dxy 0, cotile)
+    float scale;
+    uint32_t xoff[3];                // per thread: byte offset of (octet, clamped halo row, z quad) inside the cloud's chunk
+    float sc[3];                     // per thread: the scale, or 0 for a row outside the grid / an item that does not exist
+  };
+  auto item_at = [&](int r) {
+    Item it;
+    const int jdx = slot + min(r, rounds - 1) * nslots, tl = jdx / cotiles;
+    it.cot = jdx - tl * cotiles;
+    int p = x_start + tl;                                       // position in the permuted tile list
+    it.stat_slot = tl * 8 + xcd;                                // = the block index of the two-workgroup kernel that computes this tile
+    const int tyi = p % tiles_y; p /= tiles_y;
+    const int txi = p % tiles_x;
+    it.b = p / tiles_x;
+    it.x0 = txi * TX; it.y0 = tyi * TY;
+    uint32_t tm = 0;
+    if (amax_seg > 0) {                                         // max over the z rows of the halo tile: uniform scalar loads
+      const int sx = min(max(it.x0 - 1, 0), R - HX), sy = min(max(it.y0 - 1, 0), R - HY);
+      const uint32_t *tab = x_absmax + 1 + ((size_t)it.b * R + sx) * R + sy;
+      for (int ix = 0; ix < HX; ++ix)
+        for (int iy = 0; iy < HY; ++iy) tm = max(tm, tab[(size_t)ix * R + iy]);
+    } else {
+      tm = *x_absmax;
+    }
+    it.shift = __builtin_amdgcn_readfirstlane(scale_shift(tm)); // (a zero tile: shift 0, the products are exact zeros, y = bias)
+    it.scale = exp2_int(it.shift);
+    it.x_base = __builtin_amdgcn_readfirstlane((uint32_t)it.b * (uint32_t)Ci * (uint32_t)(S * 4));
+    it.a_base = __builtin_amdgcn_readfirstlane((uint32_t)it.cot * (uint32_t)(WBLK * 2));
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int e = tid + 256 * i, ec = e < 576 ? e : tid;
+      const int q = ec & 7, row = (ec >> 3) % (HX * HY), cg = (ec >> 3) / (HX * HY), hy = row % HY, hx = row / HY;
+      const int gx = it.x0 + hx - 1, gy = it.y0 + hy - 1;
+      const bool in = (unsigned)gx < (unsigned)R && (unsigned)gy < (unsigned)R;
+      it.sc[i] = in ? it.scale : 0.0f;
+      it.xoff[i] = (uint32_t)((cg * 8) * S + min(max(gx, 0), R - 1) * RR + min(max(gy, 0), R - 1) * R + 4 * q) * 4u;
+    }
+    return it;
+  };
+  // LDS byte offset of staging item i's quad (plane 0, buffer 0), the same for every item
+  uint32_t st_off[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int e = tid + 256 * i, ec = e < 576 ? e : tid;
+    const int q = ec & 7, row = (ec >> 3) % (HX * HY), cg = (ec >> 3) / (HX * HY);
+    st_off[i] = (uint32_t)(cg * HS + row * HZ + 1 + 4 * q) * 16u;
+  }
+  // B fragment: lane j = voxel z of row (x plane = wave, y = nb) of the tile; tap (dx, dy, dz) and nb are immediates
+  const uint32_t b_off = (uint32_t)(kh * HS + (wave * HY) * HZ + j) * 16u;
+  // A fragment: row mb * 32 + j of the 64-row slab (bytes); the swizzle bit is bit 3 of the row
+  const uint32_t a_off = (uint32_t)(j * 8 + ((kh ^ ((j >> 3) & 1)) * 4)) * 4u;
+  const uint32_t a_chunk = (uint32_t)(9 * cotiles) * (uint32_t)(WBLK * 2);      // bytes from a chunk's block to the next chunk's
+
+  auto load_a1 = [&](uint32_t soff, int tap, int plane, int mb) {          // (tap: compile-time)
+    const int dxy = tap / 3, dz = tap - dxy * 3;
+    return __builtin_amdgcn_raw_buffer_load_b128(wrsrc, a_off + (uint32_t)(mb * 32 * 32),
+                                                 soff + (uint32_t)dxy * (uint32_t)(cotiles * WBLK * 2) + (uint32_t)((dz * NS + plane) * kCoTileB * kKc * 2), 0);
+  };
+  auto load_b1 = [&](int buf, int tap, int plane, int nb) {
+    const int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
+    return *reinterpret_cast<const u32x4 *>(xs8 + buf * TILEB + plane * 2 * HALFB + b_off + ((dx * HY + nb + dy) * HZ + dz) * 16);
+  };
+  auto load_x1 = [&](uint32_t voff, uint32_t soff, int k) {               // channel k of the item's octet
+    const u32x4 r4 = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff, soff + (uint32_t)k * (uint32_t)(S * 4), 0);
+    return make_float4(__uint_as_float(r4.x), __uint_as_float(r4.y), __uint_as_float(r4.z), __uint_as_float(r4.w));
+  };
+  auto mma = [](const u32x4 &a, const u32x4 &b, const f32x16 &c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  };
+  // conversion of one UNIT = staging item i, z voxels 2 h2 and 2 h2 + 1 (8 channels each), in 12 PIECES that are issued between
+  // different MFMAs: pieces 0 .. 3 scale + round channel pair k2 to its hi fp16 pairs, 4 .. 7 the residuals' fp16 pairs, 8 .. 11 one
+  // 16-byte store each (voxel, plane).  split_pair's arithmetic, packed along z (two neighbouring voxels of a channel sit in
+  // neighbouring registers of the 16-byte load); the fused multiply-subtract a * scale - hi rounds once and is exact.
+  f16x2 ch[2][4];                                               // [voxel][channel pair]: hi pairs of the unit in flight
+  uint32_t cl[2][4];                                            // ... and its lo pairs
+  auto conv_piece = [&](const float4 (&v)[8], float scale, int buf, uint32_t st, int h2, int piece) {
+    const f32x2 sv = {scale, scale};
+    if (piece < 8) {
+      const int k2 = piece & 3;
+      const f32x2 a = h2 == 0 ? f32x2{v[2 * k2].x, v[2 * k2].y} : f32x2{v[2 * k2].z, v[2 * k2].w};
+      const f32x2 c = h2 == 0 ? f32x2{v[2 * k2 + 1].x, v[2 * k2 + 1].y} : f32x2{v[2 * k2 + 1].z, v[2 * k2 + 1].w};
+      if (piece < 4) {
+        const f32x2 sa = a * sv, sc2 = c * sv;
+        ch[0][k2] = __builtin_convertvector(f32x2{sa[0], sc2[0]}, f16x2);
+        ch[1][k2] = __builtin_convertvector(f32x2{sa[1], sc2[1]}, f16x2);
+      } else {
+        const f32x2 ha = {(float)ch[0][k2][0], (float)ch[1][k2][0]}, hc = {(float)ch[0][k2][1], (float)ch[1][k2][1]};
+        const f32x2 ra = __builtin_elementwise_fma(a, sv, -ha), rc = __builtin_elementwise_fma(c, sv, -hc);
+        cl[0][k2] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{ra[0], rc[0]}, f16x2));
+        cl[1][k2] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{ra[1], rc[1]}, f16x2));
+      }
+    } else {
+      const int e = (piece - 8) & 1, plane = (piece - 8) >> 1;
+      unsigned char *dst = xs8 + buf * TILEB + st + (2 * h2 + e) * 16 + plane * 2 * HALFB;
+      if (plane == 0)
+        *reinterpret_cast<u32x4 *>(dst) = u32x4{__builtin_bit_cast(uint32_t, ch[e][0]), __builtin_bit_cast(uint32_t, ch[e][1]),
+                                                __builtin_bit_cast(uint32_t, ch[e][2]), __builtin_bit_cast(uint32_t, ch[e][3])};
+      else
+        *reinterpret_cast<u32x4 *>(dst) = u32x4{cl[e][0], cl[e][1], cl[e][2], cl[e][3]};
+    }
+  };
+
+  // ---- prologue: the z halo of both buffers is padding for good; chunk 0 of item 0 staged, chunk 1 in registers ----
+  for (int z = tid; z < 2 * 4 * HX * HY * 2 * 4; z += 256) {
+    const int w = z & 3, side = (z >> 2) & 1, row = (z >> 3) % (HX * HY), slab = (z >> 3) / (HX * HY);       // slab: (buffer, plane, kh)
+    cw_lds[(slab * HS + row * HZ + side * (HZ - 1)) * 4 + w] = 0u;
+  }
+  Item cur = item_at(0), nxt = item_at(1);
+  float4 xv[3][8];                                              // the rows of the next chunk to convert
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) xv[i][k] = load_x1(cur.xoff[i], cur.x_base, k);
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+      for (int piece = 0; piece < 12; ++piece) conv_piece(xv[i], cur.sc[i], 0, st_off[i], h2, piece);
+  {
+    const bool n1 = 1 >= chunks;                                // (chunks >= 2: never; kept for the form of the stream)
+    const uint32_t soff = (n1 ? nxt.x_base : cur.x_base) + (uint32_t)(n1 ? 0 : 1) * (uint32_t)(kKc * S * 4);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) xv[i][k] = load_x1(n1 ? nxt.xoff[i] : cur.xoff[i], soff, k);
+  }
+  u32x4 af[3][NS][MBW], bf[2][NS][NBW];                          // A ring: taps t, t + 1, t + 2; B: taps t, t + 1
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int s2 = 0; s2 < NS; ++s2)
+#pragma unroll
+      for (int mb = 0; mb < MBW; ++mb) af[t][s2][mb] = load_a1(cur.a_base, t, s2, mb);
+  lds_barrier();
+  int buf = 0;                                                  // the buffer the current chunk multiplies
+
+  f32x16 acc[MBW][NBW];                                         // (every element is defined by the first chunk of an item)
+  // One chunk: 27 taps x 24 pinned slots.  FIRST: the item's first chunk (tap 0 starts from C = 0).
+  //   tap t, slots 0 .. 7   lo x hi   + the B fragments of tap t + 1 (8 LDS reads)
+  //          slots 8 .. 15  hi x lo   + the A fragments of tap t + 2 (4 image reads), + the staging work of the tap (below)
+  //          slots 16 .. 23 hi x hi   + the staging work of the tap
+  //   staging: taps 1 .. 12 convert + store the six (item, z pair) units of the next chunk's rows, one unit per two taps, six of
+  //   its twelve pieces per tap; taps 13 .. 24 request the rows of the chunk after the next (24 loads, 2 per tap)
+  auto chunk_body = [&](auto first_tag, int chunk) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    // streams: the NEXT chunk's rows are in xv (converted here, stored into buffer buf ^ 1 with the scale of ITS item); the rows
+    // requested here are those of chunk + 2; the A fragments of taps 25, 26 request taps 0, 1 of chunk + 1
+    const bool n1 = chunk + 1 >= chunks, n2 = chunk + 2 >= chunks;
+    const uint32_t a_cur = cur.a_base + (uint32_t)chunk * a_chunk;
+    const uint32_t a_nxt = n1 ? nxt.a_base : a_cur + a_chunk;
+    const uint32_t x_soff = (n2 ? nxt.x_base : cur.x_base) + (uint32_t)(chunk + 2 - (n2 ? chunks : 0)) * (uint32_t)(kKc * S * 4);
+    float csc[3];
+    uint32_t cxo[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { csc[i] = n1 ? nxt.sc[i] : cur.sc[i]; cxo[i] = n2 ? nxt.xoff[i] : cur.xoff[i]; }
+    // B fragments of tap 0: behind the barrier that published this chunk's tile
+#pragma unroll
+    for (int s2 = 0; s2 < NS; ++s2)
+#pragma unroll
+      for (int nb = 0; nb < NBW; ++nb) bf[0][s2][nb] = load_b1(buf, 0, s2, nb);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) {
+      const int ac = tap % 3, an = (tap + 2) % 3, bc = tap & 1, bn = bc ^ 1;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {                             // ---- lo x hi
+        const int nb = i >> 1, mb = i & 1;
+        if constexpr (FIRST) {
+          if (tap == 0) acc[mb][nb] = mma(af[ac][1][mb], bf[bc][0][nb], f32x16{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f});
+          else acc[mb][nb] = mma(af[ac][1][mb], bf[bc][0][nb], acc[mb][nb]);
+        } else {
+          acc[mb][nb] = mma(af[ac][1][mb], bf[bc][0][nb], acc[mb][nb]);
+        }
+        if constexpr (!(AB & 8)) { if (tap + 1 < 27) bf[bn][i >> 2][i & 3] = load_b1(buf, tap + 1 < 27 ? tap + 1 : 0, i >> 2, i & 3); }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {                             // ---- hi x lo
+        const int nb = i >> 1, mb = i & 1;
+        acc[mb][nb] = mma(af[ac][0][mb], bf[bc][1][nb], acc[mb][nb]);
+        if constexpr (!(AB & 1)) {
+          if (i < 4) {
+            if (tap + 2 < 27) af[an][i >> 1][i & 1] = load_a1(a_cur, tap + 2 < 27 ? tap + 2 : 0, i >> 1, i & 1);
+            else af[an][i >> 1][i & 1] = load_a1(a_nxt, tap + 2 - 27 >= 0 ? tap + 2 - 27 : 0, i >> 1, i & 1);
+          }
+        }
+        if constexpr (!(AB & 4)) {
+          // taps 1 .. 12: unit (tap - 1) / 2 = (item, z pair), 6 of its 12 pieces per tap: here pieces 0, 1 (slots 4, 5)
+          if ((i == 4 || i == 5) && tap >= 1 && tap <= 12) {
+            const int u = (tap - 1) >> 1, piece = ((tap - 1) & 1) * 6 + (i - 4);
+            conv_piece(xv[u >> 1], csc[u >> 1], buf ^ 1, st_off[u >> 1], u & 1, piece);
+          }
+        }
+        if constexpr (!(AB & 2)) {
+          if (i >= 6 && tap >= 13 && tap <= 24) {               // 2 row requests per tap: (item, channel) = (tap - 13) * 2 + (i - 6)
+            const int l = (tap - 13) * 2 + (i - 6), it3 = l >> 3, k = l & 7;
+            xv[it3][k] = load_x1(cxo[it3], x_soff, k);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {                             // ---- hi x hi
+        const int nb = i >> 1, mb = i & 1;
+        acc[mb][nb] = mma(af[ac][0][mb], bf[bc][0][nb], acc[mb][nb]);
+        if constexpr (!(AB & 4)) {
+          if ((i & 1) == 0 && tap >= 1 && tap <= 12) {          // ... pieces 2 .. 5 of the tap (slots 0, 2, 4, 6)
+            const int u = (tap - 1) >> 1, piece = ((tap - 1) & 1) * 6 + 2 + (i >> 1);
+            conv_piece(xv[u >> 1], csc[u >> 1], buf ^ 1, st_off[u >> 1], u & 1, piece);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if constexpr (!(AB & 16)) lds_barrier();
+    buf ^= 1;
+  };
+
+  for (int r = 0; r < rounds; ++r) {
+    chunk_body(std::true_type{}, 0);
+    for (int chunk = 1; chunk < chunks; ++chunk) chunk_body(std::false_type{}, chunk);
+    // ---- the item's epilogue: D[i = co][j = voxel]; lane -> z of row (x plane = wave, y = nb); register q -> co row ----
+    {
+      int tid_e = tid;
+      asm volatile("" : "+v"(tid_e));                           // (re-derived here: see pw_gemm_f16_wide_kernel)
+      const int je = tid_e & 31, khe = (tid_e >> 5) & 1;
+      const int co0 = cur.cot * kCoTileB;
+      const bool want_stats = stats_part != nullptr;
+      const float x_unscale = exp2_int(-cur.shift);
+      const __amdgpu_buffer_rsrc_t yrsrc = descriptor(y + (size_t)cur.b * Co * S, (uint32_t)Co * (uint32_t)(S * 4));
+      // the lane's byte offset of (co0 + 4 kh, x0 + wave, y0, z = j); row q of block mb: + (mb * 32 + rowq) * S * 4; y = nb: + nb * R * 4
+      const uint32_t yoff = (uint32_t)((co0 + 4 * khe) * S + (cur.x0 + wave) * RR + cur.y0 * R + je) * 4u;
+#pragma unroll
+      for (int mb = 0; mb < MBW; ++mb)
+#pragma unroll
+        for (int h8 = 0; h8 < 2; ++h8) {
+          float bv[8], unscale[8], ss[8], qq[8];
+#pragma unroll
+          for (int qi = 0; qi < 8; ++qi) {
+            const int q = h8 * 8 + qi, co = co0 + mb * 32 + (q & 3) + 8 * (q >> 2) + 4 * khe;
+            bv[qi] = (bias != nullptr && co < Co) ? bias[co] : 0.0f;
+            unscale[qi] = exp2_int(-wexp[co]);                  // wexp covers the padded rows of the tile
+            ss[qi] = qq[qi] = 0.0f;
+          }
+#pragma unroll
+          for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+            for (int qi = 0; qi < 8; ++qi) {
+              const int q = h8 * 8 + qi;
+              float v = acc[mb][nb][q] * unscale[qi] * x_unscale;          // powers of two: exact
+              if (want_stats) {                                 // statistics of (y - bias), see bn_finalize_kernel
+                ss[qi] += v;
+                qq[qi] += v * v;
+              }
+              v += bv[qi];
+              // (rows >= Co of the last channel block: beyond the descriptor, dropped)
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yrsrc,
+                                                    yoff + (uint32_t)((mb * 32 + (q & 3) + 8 * (q >> 2)) * (S * 4)) + (uint32_t)(nb * R * 4), 0, 0);
+            }
+          if (want_stats) {
+            const float st2 = half_wave_sum8(ss, je), qt = half_wave_sum8(qq, je);
+            const int q = h8 * 8 + ((je >> 2) & 7);
+            if ((je & 3) == 0) stat_lds[wave * kCoTileB + mb * 32 + (q & 3) + 8 * (q >> 2) + 4 * khe] = make_float2(st2, qt);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      if (want_stats) {
+        lds_barrier();
+        if (tid_e < kCoTileB && co0 + tid_e < Co) {
+          float2 t = stat_lds[tid_e];
+#pragma unroll
+          for (int w = 1; w < 4; ++w) { t.x += stat_lds[w * kCoTileB + tid_e].x; t.y += stat_lds[w * kCoTileB + tid_e].y; }
+          // stats_parts = the slots per channel the caller allocated (pvcnn_conv3d_fwd_split_stats_parts: the two-workgroup
+          // kernel's tile count -- twice n_tiles where a small batch takes its 256-voxel tile): the surplus slots are zeros
+          stats_part[(size_t)(co0 + tid_e) * stats_parts + cur.stat_slot] = t;
+          if (stats_parts > n_tiles) stats_part[(size_t)(co0 + tid_e) * stats_parts + n_tiles + cur.stat_slot] = make_float2(0.0f, 0.0f);
+        }
+      }
+    }
+    cur = nxt;
+    nxt = item_at(r + 2);
+  }
+}
+
 // Workgroup tile and staging path.  Vector staging (whole z rows as 16-byte loads) needs R % 4 == 0 and a tile that spans z:
 // tz = 8 / 16 / 32 for R <= 8 / 16 / 32.  At 16 < R <= 32 a 512-voxel tile (a wave owns 64 channels x 128 voxels: every weight
 // fragment feeds four MFMA column blocks, the halo overhead drops from 3.0x to 2.25x) when that still leaves two workgroups for
@@ -1090,6 +1437,38 @@ static int conv3d_fwd_split_impl(const float *x, const void *wts, const float *b
   // the pipelined 128-voxel kernel (f16x2 only).  Round 3, 64 -> 64 at 16^3 x 16: see profiles/ab/r03u_convbench.jsonl
   if (t.tz == 16 && t.tx == 2 && nsplit == 2 && Ci % kKc == 0) return launch_igemm_f16_pipe<2, 4>(x, w16, bias, y, B, Ci, Co, R, s, sp, am, wexp, amax_seg);
   if (t.tz == 16) return t.tx == 2 ? PVCNN_IGEMM_NS(2, 4, 16, true) : PVCNN_IGEMM_NS(4, 4, 16, true);
+  // round 6: R = 32, whole 16-channel chunks: the persistent one-workgroup-per-CU kernel (conv3d_igemm_f16_wide_kernel)
+  static const bool wide_on = [] { const char *e = getenv("PVCNN_CONV_WIDE"); return !(e && e[0] == '0'); }();
+  if (wide_on && nsplit == 2 && R == 32 && Co > 32 && Ci % kKc == 0 && Ci >= 2 * kKc && (long)B * std::max(Ci, Co) * R * R * R * 4 < 0xffffffffL) {
+    const int cotiles = ceil_div(Co, kCoTileB), n_tiles = B * (R / 4) * (R / 4);
+    const long per_xcd = (long)((n_tiles + 7) / 8) * cotiles;
+    const unsigned grid = 8u * (unsigned)std::min<long>(kNumCU / 8, per_xcd);
+    const unsigned xb = (unsigned)((size_t)B * Ci * R * R * R * 4), wb = (unsigned)weight_image_bytes(Ci, Co, 2);
+#define PVCNN_CW_LAUNCH(ABV)                                                                                                         \
+    do {                                                                                                                               \
+      auto kw = conv3d_igemm_f16_wide_kernel<ABV>;                                                                                     \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kw), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCwLds); \
+      if (e != hipSuccess) { set_error("conv3d(wide): LDS attribute: %s", hipGetErrorString(e)); return (int)e; }                      \
+      hipLaunchKernelGGL(kw, dim3(grid), dim3(256), kCwLds, s, x, w16, bias, y, Ci, Co, B, sp, am, wexp, amax_seg, xb, wb,              \
+                         (int)pvcnn_conv3d_fwd_split_stats_parts(B, Co, R, nsplit));                                                   \
+    } while (0)
+#ifdef PVCNN_ABLATE
+    const char *ab_env = getenv("PVCNN_CONV_ABLATE");
+    switch (ab_env ? atoi(ab_env) : 0) {
+      case 1: PVCNN_CW_LAUNCH(1); break;
+      case 2: PVCNN_CW_LAUNCH(2); break;
+      case 4: PVCNN_CW_LAUNCH(4); break;
+      case 8: PVCNN_CW_LAUNCH(8); break;
+      case 16: PVCNN_CW_LAUNCH(16); break;
+      case 31: PVCNN_CW_LAUNCH(31); break;
+      default: PVCNN_CW_LAUNCH(0);
+    }
+#else
+    PVCNN_CW_LAUNCH(0);
+#endif
+#undef PVCNN_CW_LAUNCH
+    return check_launch("conv3d_igemm_f16_wide");
+  }
   if (Co <= 32 && nsplit == 2)     // a 32-row weight tile: no MFMAs on the padded half (f16x2, the default arithmetic, only)
     return t.tx == 4 ? launch_igemm_bf16<2, 4, 4, 32, true, true>(x, w16, bias, y, B, Ci, Co, R, s, sp, am, wexp, amax_seg)
                      : launch_igemm_bf16<2, 2, 4, 32, true, true>(x, w16, bias, y, B, Ci, Co, R, s, sp, am, wexp, amax_seg);

@@ -1,0 +1,84 @@
+"""The persistent R = 32 Conv3d kernel (csrc/conv3d_bf16.hip, conv3d_igemm_f16_wide_kernel: round 6, the default for f16x2 at R = 32 with
+Ci % 16 == 0, Ci >= 32, Co > 32) is BIT-IDENTICAL to the two-workgroup kernel it replaces (PVCNN_CONV_WIDE=0, read once per process:
+two child processes) -- outputs AND the BatchNorm partial sums --, forward and backward-data: several tiles per workgroup (persistence),
+a batch that does not fill the chip, a channel count with a padded last block (Co = 96), per-row scales decades apart (every tile
+must be converted with ITS item's scale while the request streams run a chunk ahead) and a voxelised-cloud input (zero tiles)."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+_CHILD = r'''
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from pvcnn_amd.modules.functional.backend import HipBackend
+be = HipBackend()
+cases = torch.load(sys.argv[2])
+out = []
+for x, w, bias, gy in cases:
+    x, w, bias, gy = x.cuda(), w.cuda(), bias.cuda(), gy.cuda()
+    y, part = be.conv3d_forward_split(x, w, bias, 2, want_stats=True)
+    gx = be.conv3d_backward_data_split(gy, w, 2)
+    out.append([y.cpu(), part.cpu(), gx.cpu()])
+torch.save(out, sys.argv[3])
+'''
+
+SHAPES = [(16, 64, 64), (3, 32, 96), (1, 48, 64), (20, 64, 128)]          # (B, Ci, Co) at R = 32
+
+
+def test_the_wide_conv3d_kernel_is_bit_identical_to_the_two_workgroup_kernel(tmp_path):
+    g = torch.Generator().manual_seed(23)
+    r = 32
+    cases = []
+    for k, (b, ci, co) in enumerate(SHAPES):
+        x = torch.randn(b, ci, r, r, r, generator=g)
+        x = x * torch.pow(10.0, torch.randint(-5, 6, (b, 1, r, r, 1), generator=g).float())       # every z row at a scale of its own
+        if k == 1:                                                                                 # a voxelised cloud: most z rows empty
+            keep = torch.zeros(b, 1, r, r, 1)
+            keep[:, :, 9:23, 9:23] = 1.0
+            x = x * keep
+        gy = torch.randn(b, co, r, r, r, generator=g) * torch.pow(10.0, torch.randint(-8, 2, (b, 1, r, r, 1), generator=g).float())
+        cases.append((x, torch.randn(co, ci, 3, 3, 3, generator=g) * 0.05, torch.randn(co, generator=g), gy))
+    torch.save(cases, tmp_path / 'cases.pt')
+    script = tmp_path / 'child.py'
+    script.write_text(_CHILD)
+    outs = {}
+    for tag, flag in (('narrow', '0'), ('wide', '1')):
+        env = dict(os.environ, PVCNN_CONV_WIDE=flag)
+        subprocess.run([sys.executable, str(script), ROOT, str(tmp_path / 'cases.pt'), str(tmp_path / f'{tag}.pt')], check=True, env=env, timeout=900)
+        outs[tag] = torch.load(tmp_path / f'{tag}.pt')
+    for case, (a, b_) in enumerate(zip(outs['narrow'], outs['wide'])):
+        b, ci, co = SHAPES[case]
+        # the two-workgroup kernel takes the same 512-voxel tile (same scale tile, same products in the same order) once the batch
+        # fills the chip; a small batch takes its 256-voxel tile, whose halo -- and with it the tile's power-of-two scale -- is
+        # another one: the same fp32-class result, not the same bits
+        same_tile = b * 64 * ((co + 63) // 64) >= 512
+        for k, (p, q) in enumerate(zip(a, b_)):
+            what = ['y', 'stats_part', 'grad_x'][k]
+            if same_tile:
+                assert torch.equal(p, q), (SHAPES[case], what, (p - q).abs().max().item(), (p != q).float().mean().item())
+            elif what != 'stats_part':
+                scale = p.abs().amax(dim=(1, 4), keepdim=True).clamp_min(1e-30)       # per z row of the output
+                assert ((p - q).abs() / scale).max().item() < 2e-5, (SHAPES[case], what)
+    # ... and with the truth: per z row, relative to the row's own largest output (the range contract)
+    for case in range(len(SHAPES)):
+        x, w, bias, gy = cases[case]
+        ref = torch.nn.functional.conv3d(x.double(), w.double(), bias.double(), padding=1)
+        err = (outs['wide'][case][0].double() - ref).abs().amax(dim=(1, 4)) / ref.abs().amax(dim=(1, 4)).clamp_min(1e-300)
+        assert err.max().item() < 1e-5, (SHAPES[case], err.max().item())
+        centred = (outs['wide'][case][0].double() - bias.double().view(1, -1, 1, 1, 1)).transpose(0, 1).reshape(w.shape[0], -1)
+        sums = outs['wide'][case][1].double().sum(dim=1)
+        assert ((sums[:, 0] - centred.sum(dim=1)).abs().max() / centred.abs().sum(dim=1).max()).item() < 1e-5
+        assert ((sums[:, 1] - (centred * centred).sum(dim=1)).abs().max() / (centred * centred).sum(dim=1).max()).item() < 1e-5
+        gref = torch.nn.grad.conv3d_input(x.shape, w.double(), gy.double(), padding=1)
+        # (grad_y's rows are up to ten decades apart INSIDE a tile: the contract is relative to the tile's largest input, so the
+        #  error is judged per 4 x 4 x 32 output tile, against the largest output of the tile and its eight neighbours)
+        tile_max = lambda t: torch.nn.functional.max_pool2d(t.abs().amax(dim=(1, 4)).view(t.shape[0], 1, 8, 4, 8, 4).amax(dim=(3, 5)), 3, 1, 1)
+        gerr = (outs['wide'][case][2].double() - gref).abs().amax(dim=(1, 4)).view(x.shape[0], 1, 8, 4, 8, 4).amax(dim=(3, 5)) / tile_max(gref).clamp_min(1e-300)
+        assert gerr.max().item() < 1e-5, (SHAPES[case], gerr.max().item())
