@@ -873,19 +873,29 @@ __global__ __launch_bounds__(256, 2) void conv3d_igemm_f16_pipe_kernel(const flo
 //     on into the next tile, whose first chunk is staged while this tile's last one is multiplied; an item's first MFMAs start from
 //     C = 0; the epilogue's stores drain behind the next tile's MFMAs.
 // Needs R == 32, Ci % 16 == 0, Ci >= 32, tensors below 4 GiB.  PVCNN_CONV_WIDE=0 keeps the two-workgroup kernel.
-constexpr int kCwHX = 6, kCwHY = 6, kCwHZ = 34, kCwHS = kCwHX * kCwHY * kCwHZ;      // halo of the 4 x 4 x 32 tile
-constexpr int kCwHalfB = kCwHS * 16, kCwTileB = 4 * kCwHalfB;                      // bytes of one (plane, half) slab / of one buffer
-constexpr size_t kCwLds = (size_t)2 * kCwTileB + (size_t)4 * kCoTileB * sizeof(float2);
+// TZ = 16 (the R = 16 grids; round 6, second step): the same kernel on a 4 x 4 x 16 tile -- a wave still owns one x plane of the tile,
+// 64 channels x 64 voxels: two 32-voxel column blocks of two z rows each (lanes mapped to voxels by the hardware's ds_read_b128
+// service groups, as in conv3d_igemm_f16_pipe_kernel), 12 MFMAs per tap.  The tile (and with it the scale tile) is not the
+// 128-voxel tile of conv3d_igemm_f16_pipe_kernel: the same fp32-class result, not the same bits.
+template <int TZ> struct CwGeom {
+  static constexpr int HX = 6, HY = 6, HZ = TZ + 2, HS = HX * HY * HZ;             // halo of the 4 x 4 x TZ tile
+  static constexpr int HALFB = HS * 16, TILEB = 4 * HALFB;                         // bytes of one (plane, half) slab / of one buffer
+  static constexpr size_t LDS = (size_t)2 * TILEB + (size_t)4 * kCoTileB * sizeof(float2);
+};
 
-template <int AB = 0>
+template <int TZ, int AB = 0>
 __global__ __launch_bounds__(256, 1) void conv3d_igemm_f16_wide_kernel(const float *__restrict__ x, const uint16_t *__restrict__ wts,
                                                                        const float *__restrict__ bias, float *__restrict__ y, int Ci, int Co,
                                                                        int B, float2 *__restrict__ stats_part,
                                                                        const uint32_t *__restrict__ x_absmax, const int *__restrict__ wexp,
                                                                        int amax_seg, unsigned x_bytes, unsigned w_bytes, int stats_parts) {
-  constexpr int NS = 2, R = 32, TX = 4, TY = 4, HX = kCwHX, HY = kCwHY, HZ = kCwHZ, HS = kCwHS, NBW = 4, MBW = 2;
-  constexpr int HALFB = kCwHalfB, TILEB = kCwTileB, WBLK = 3 * NS * kCoTileB * kKc;
+  static_assert(TZ == 32 || TZ == 16, "the tile spans z: R = 32 or 16");
+  using G = CwGeom<TZ>;
+  constexpr int NS = 2, R = TZ, TX = 4, TY = 4, HX = G::HX, HY = G::HY, HZ = G::HZ, HS = G::HS, NBW = TZ / 8, MBW = 2;
+  constexpr int HALFB = G::HALFB, TILEB = G::TILEB, WBLK = 3 * NS * kCoTileB * kKc;
   constexpr int RR = R * R, S = RR * R, tiles_x = R / TX, tiles_y = R / TY;
+  constexpr int QZ = TZ / 4, NITEMS = 2 * HX * HY * QZ, NIT = (NITEMS + 255) / 256;       // staging items: 576 (3 per thread) / 288 (2)
+  constexpr int MPT = 6 * NBW;                                  // MFMAs (= slots) per tap: 24 / 12
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   extern __shared__ __attribute__((aligned(16))) uint32_t cw_lds[];
   unsigned char *xs8 = reinterpret_cast<unsigned char *>(cw_lds);
@@ -893,6 +903,11 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_f16_wide_kernel(const flo
 
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, kh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                     // = the x plane of the tile this wave owns
+  // lane -> voxel of a 32-voxel column block.  TZ = 32: one z row, lane j = z.  TZ = 16: two z rows (y, y + 1); the two ds_read_b128
+  // service groups of a half wave ({0-3, 12-15, 20-27} / {4-11, 16-19, 28-31}) read one whole row each
+  const int jj = TZ == 32 ? j : (j < 4 ? j : j < 12 ? 16 + (j - 4) : j < 16 ? j - 8 : j < 20 ? 24 + (j - 16) : j < 28 ? 8 + (j - 20) : 28 + (j - 28));
+  const int vrow = TZ == 32 ? 0 : jj >> 4, vz = TZ == 32 ? jj : jj & 15;          // row inside the block, z
+  constexpr int RPB = TZ == 32 ? 1 : 2;                                           // y rows per column block
   const int cotiles = ceil_div(Co, kCoTileB), chunks = Ci / kKc;
   const int n_tiles = B * tiles_x * tiles_y;
   // this workgroup's tiles: XCD x owns a contiguous range of the tile list (xcd_tile_order's), its workgroups take it round by round
@@ -911,14 +926,15 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_f16_wide_kernel(const flo
   const __amdgpu_buffer_rsrc_t xrsrc = descriptor(x, x_bytes), wrsrc = descriptor(wts, w_bytes);
 
   // ---- an item = (tile, 64-channel block); what the request streams need of it ----
-  // staging items of a thread: e = tid + 256 i, i < 3 (576 = 2 channel octets x 36 halo rows x 8 z quads; i = 2 exists for tid < 64:
-  // the other threads stage their item 0 twice -- the same bytes to the same place -- so that the chunk stays straight-line code)
+  // staging items of a thread: e = tid + 256 i, i < NIT (NITEMS = 2 channel octets x 36 halo rows x QZ z quads = 576 / 288; the last i
+  // exists for tid < 64 / 32 only: the other threads stage their item 0 twice -- the same bytes to the same place -- so that the
+  // chunk stays straight-line code)
   struct Item {
     int b, x0, y0, cot, stat_slot, shift;
     uint32_t x_base, a_base;         // bytes: x -> (cloud b, channel 0); image -> (chunk 0, dxy 0, cotile)
     float scale;
-    uint32_t xoff[3];                // per thread: byte offset of (octet, clamped halo row, z quad) inside the cloud's chunk
-    float sc[3];                     // per thread: the scale, or 0 for a row outside the grid / an item that does not exist
+    uint32_t xoff[NIT];              // per thread: byte offset of (octet, clamped halo row, z quad) inside the cloud's chunk
+    float sc[NIT];                   // per thread: the scale, or 0 for a row outside the grid
   };
   auto item_at = [&](int r) {
     Item it;
@@ -944,9 +960,9 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_f16_wide_kernel(const flo
     it.x_base = __builtin_amdgcn_readfirstlane((uint32_t)it.b * (uint32_t)Ci * (uint32_t)(S * 4));
     it.a_base = __builtin_amdgcn_readfirstlane((uint32_t)it.cot * (uint32_t)(WBLK * 2));
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int e = tid + 256 * i, ec = e < 576 ? e : tid;
-      const int q = ec & 7, row = (ec >> 3) % (HX * HY), cg = (ec >> 3) / (HX * HY), hy = row % HY, hx = row / HY;
+    for (int i = 0; i < NIT; ++i) {
+      const int e = tid + 256 * i, ec = e < NITEMS ? e : tid;
+      const int q = ec % QZ, row = (ec / QZ) % (HX * HY), cg = (ec / QZ) / (HX * HY), hy = row % HY, hx = row / HY;
       const int gx = it.x0 + hx - 1, gy = it.y0 + hy - 1;
       const bool in = (unsigned)gx < (unsigned)R && (unsigned)gy < (unsigned)R;
       it.sc[i] = in ? it.scale : 0.0f;
@@ -955,15 +971,15 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_f16_wide_kernel(const flo
     return it;
   };
   // LDS byte offset of staging item i's quad (plane 0, buffer 0), the same for every item
-  uint32_t st_off[3];
+  uint32_t st_off[NIT];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int e = tid + 256 * i, ec = e < 576 ? e : tid;
-    const int q = ec & 7, row = (ec >> 3) % (HX * HY), cg = (ec >> 3) / (HX * HY);
+  for (int i = 0; i < NIT; ++i) {
+    const int e = tid + 256 * i, ec = e < NITEMS ? e : tid;
+    const int q = ec % QZ, row = (ec / QZ) % (HX * HY), cg = (ec / QZ) / (HX * HY);
     st_off[i] = (uint32_t)(cg * HS + row * HZ + 1 + 4 * q) * 16u;
   }
-  // B fragment: lane j = voxel z of row (x plane = wave, y = nb) of the tile; tap (dx, dy, dz) and nb are immediates
-  const uint32_t b_off = (uint32_t)(kh * HS + (wave * HY) * HZ + j) * 16u;
+  // B fragment: the lane's voxel (row vrow of column block nb, z) of x plane `wave` of the tile; tap (dx, dy, dz) and nb are immediates
+  const uint32_t b_off = (uint32_t)(kh * HS + (wave * HY + vrow) * HZ + vz) * 16u;
   // A fragment: row mb * 32 + j of the 64-row slab (bytes); the swizzle bit is bit 3 of the row
   const uint32_t a_off = (uint32_t)(j * 8 + ((kh ^ ((j >> 3) & 1)) * 4)) * 4u;
   const uint32_t a_chunk = (uint32_t)(9 * cotiles) * (uint32_t)(WBLK * 2);      // bytes from a chunk's block to the next chunk's
@@ -975,7 +991,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_f16_wide_kernel(const flo
   };
   auto load_b1 = [&](int buf, int tap, int plane, int nb) {
     const int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
-    return *reinterpret_cast<const u32x4 *>(xs8 + buf * TILEB + plane * 2 * HALFB + b_off + ((dx * HY + nb + dy) * HZ + dz) * 16);
+    return *reinterpret_cast<const u32x4 *>(xs8 + buf * TILEB + plane * 2 * HALFB + b_off + ((dx * HY + RPB * nb + dy) * HZ + dz) * 16);
   };
   auto load_x1 = [&](uint32_t voff, uint32_t soff, int k) {               // channel k of the item's octet
     const u32x4 r4 = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff, soff + (uint32_t)k * (uint32_t)(S * 4), 0);
@@ -1023,13 +1039,13 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_f16_wide_kernel(const flo
     cw_lds[(slab * HS + row * HZ + side * (HZ - 1)) * 4 + w] = 0u;
   }
   Item cur = item_at(0), nxt = item_at(1);
-  float4 xv[3][8];                                              // the rows of the next chunk to convert
+  float4 xv[NIT][8];                                            // the rows of the next chunk to convert
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
+  for (int i = 0; i < NIT; ++i)
 #pragma unroll
     for (int k = 0; k < 8; ++k) xv[i][k] = load_x1(cur.xoff[i], cur.x_base, k);
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
+  for (int i = 0; i < NIT; ++i)
 #pragma unroll
     for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
@@ -1038,7 +1054,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_f16_wide_kernel(const flo
     const bool n1 = 1 >= chunks;                                // (chunks >= 2: never; kept for the form of the stream)
     const uint32_t soff = (n1 ? nxt.x_base : cur.x_base) + (uint32_t)(n1 ? 0 : 1) * (uint32_t)(kKc * S * 4);
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < NIT; ++i)
 #pragma unroll
       for (int k = 0; k < 8; ++k) xv[i][k] = load_x1(n1 ? nxt.xoff[i] : cur.xoff[i], soff, k);
   }
@@ -1067,21 +1083,41 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_f16_wide_kernel(const flo
     const uint32_t a_cur = cur.a_base + (uint32_t)chunk * a_chunk;
     const uint32_t a_nxt = n1 ? nxt.a_base : a_cur + a_chunk;
     const uint32_t x_soff = (n2 ? nxt.x_base : cur.x_base) + (uint32_t)(chunk + 2 - (n2 ? chunks : 0)) * (uint32_t)(kKc * S * 4);
-    float csc[3];
-    uint32_t cxo[3];
+    float csc[NIT];
+    uint32_t cxo[NIT];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { csc[i] = n1 ? nxt.sc[i] : cur.sc[i]; cxo[i] = n2 ? nxt.xoff[i] : cur.xoff[i]; }
+    for (int i = 0; i < NIT; ++i) { csc[i] = n1 ? nxt.sc[i] : cur.sc[i]; cxo[i] = n2 ? nxt.xoff[i] : cur.xoff[i]; }
     // B fragments of tap 0: behind the barrier that published this chunk's tile
 #pragma unroll
     for (int s2 = 0; s2 < NS; ++s2)
 #pragma unroll
       for (int nb = 0; nb < NBW; ++nb) bf[0][s2][nb] = load_b1(buf, 0, s2, nb);
     __builtin_amdgcn_sched_barrier(0);
+    constexpr int GS = 2 * NBW;                                 // MFMAs (= slots) per product group: 8 / 4
+    constexpr int PPT = TZ == 32 ? 6 : 4;                       // conversion pieces per tap (taps 1 .. 12: NIT x 2 units x 12 pieces)
+    constexpr int ROW_TAPS = NIT * 8 / 2;                       // taps 13 .. : two row requests each
+    // one conversion piece: index l of the tap's PPT
+    auto tap_piece = [&](int tap, int l) {
+      if constexpr (!(AB & 4)) {
+        if (tap >= 1 && tap <= 12) {
+          const int pidx = (tap - 1) * PPT + l, u = pidx / 12, piece = pidx % 12;
+          conv_piece(xv[u >> 1], csc[u >> 1], buf ^ 1, st_off[u >> 1], u & 1, piece);
+        }
+      }
+    };
+    auto tap_row = [&](int tap, int l2) {                       // one row request: index l2 of the tap's two
+      if constexpr (!(AB & 2)) {
+        if (tap >= 13 && tap < 13 + ROW_TAPS) {
+          const int l = (tap - 13) * 2 + l2, it3 = l >> 3, k = l & 7;
+          xv[it3][k] = load_x1(cxo[it3], x_soff, k);
+        }
+      }
+    };
 #pragma unroll
     for (int tap = 0; tap < 27; ++tap) {
       const int ac = tap % 3, an = (tap + 2) % 3, bc = tap & 1, bn = bc ^ 1;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {                             // ---- lo x hi
+      for (int i = 0; i < GS; ++i) {                            // ---- lo x hi  + the B fragments of tap + 1
         const int nb = i >> 1, mb = i & 1;
         if constexpr (FIRST) {
           if (tap == 0) acc[mb][nb] = mma(af[ac][1][mb], bf[bc][0][nb], f32x16{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f});
@@ -1089,11 +1125,11 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_f16_wide_kernel(const flo
         } else {
           acc[mb][nb] = mma(af[ac][1][mb], bf[bc][0][nb], acc[mb][nb]);
         }
-        if constexpr (!(AB & 8)) { if (tap + 1 < 27) bf[bn][i >> 2][i & 3] = load_b1(buf, tap + 1 < 27 ? tap + 1 : 0, i >> 2, i & 3); }
+        if constexpr (!(AB & 8)) { if (tap + 1 < 27) bf[bn][i / NBW][i % NBW] = load_b1(buf, tap + 1 < 27 ? tap + 1 : 0, i / NBW, i % NBW); }
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {                             // ---- hi x lo
+      for (int i = 0; i < GS; ++i) {                            // ---- hi x lo  + the A fragments of tap + 2
         const int nb = i >> 1, mb = i & 1;
         acc[mb][nb] = mma(af[ac][0][mb], bf[bc][1][nb], acc[mb][nb]);
         if constexpr (!(AB & 1)) {
@@ -1102,30 +1138,21 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_f16_wide_kernel(const flo
             else af[an][i >> 1][i & 1] = load_a1(a_nxt, tap + 2 - 27 >= 0 ? tap + 2 - 27 : 0, i >> 1, i & 1);
           }
         }
-        if constexpr (!(AB & 4)) {
-          // taps 1 .. 12: unit (tap - 1) / 2 = (item, z pair), 6 of its 12 pieces per tap: here pieces 0, 1 (slots 4, 5)
-          if ((i == 4 || i == 5) && tap >= 1 && tap <= 12) {
-            const int u = (tap - 1) >> 1, piece = ((tap - 1) & 1) * 6 + (i - 4);
-            conv_piece(xv[u >> 1], csc[u >> 1], buf ^ 1, st_off[u >> 1], u & 1, piece);
-          }
-        }
-        if constexpr (!(AB & 2)) {
-          if (i >= 6 && tap >= 13 && tap <= 24) {               // 2 row requests per tap: (item, channel) = (tap - 13) * 2 + (i - 6)
-            const int l = (tap - 13) * 2 + (i - 6), it3 = l >> 3, k = l & 7;
-            xv[it3][k] = load_x1(cxo[it3], x_soff, k);
-          }
+        if constexpr (TZ == 32) {
+          if (i == 4 || i == 5) tap_piece(tap, i - 4);
+          if (i >= 6) tap_row(tap, i - 6);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {                             // ---- hi x hi
+      for (int i = 0; i < GS; ++i) {                            // ---- hi x hi
         const int nb = i >> 1, mb = i & 1;
         acc[mb][nb] = mma(af[ac][0][mb], bf[bc][0][nb], acc[mb][nb]);
-        if constexpr (!(AB & 4)) {
-          if ((i & 1) == 0 && tap >= 1 && tap <= 12) {          // ... pieces 2 .. 5 of the tap (slots 0, 2, 4, 6)
-            const int u = (tap - 1) >> 1, piece = ((tap - 1) & 1) * 6 + 2 + (i >> 1);
-            conv_piece(xv[u >> 1], csc[u >> 1], buf ^ 1, st_off[u >> 1], u & 1, piece);
-          }
+        if constexpr (TZ == 32) {
+          if ((i & 1) == 0) tap_piece(tap, 2 + (i >> 1));
+        } else {
+          tap_piece(tap, i);
+          if (i < 2) tap_row(tap, i);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -1142,12 +1169,15 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_f16_wide_kernel(const flo
       int tid_e = tid;
       asm volatile("" : "+v"(tid_e));                           // (re-derived here: see pw_gemm_f16_wide_kernel)
       const int je = tid_e & 31, khe = (tid_e >> 5) & 1;
+      const int jje = TZ == 32 ? je : (je < 4 ? je : je < 12 ? 16 + (je - 4) : je < 16 ? je - 8 : je < 20 ? 24 + (je - 16) : je < 28 ? 8 + (je - 20) : 28 + (je - 28));
+      const int vrow_e = TZ == 32 ? 0 : jje >> 4, vz_e = TZ == 32 ? jje : jje & 15;
       const int co0 = cur.cot * kCoTileB;
       const bool want_stats = stats_part != nullptr;
       const float x_unscale = exp2_int(-cur.shift);
       const __amdgpu_buffer_rsrc_t yrsrc = descriptor(y + (size_t)cur.b * Co * S, (uint32_t)Co * (uint32_t)(S * 4));
-      // the lane's byte offset of (co0 + 4 kh, x0 + wave, y0, z = j); row q of block mb: + (mb * 32 + rowq) * S * 4; y = nb: + nb * R * 4
-      const uint32_t yoff = (uint32_t)((co0 + 4 * khe) * S + (cur.x0 + wave) * RR + cur.y0 * R + je) * 4u;
+      // the lane's byte offset of (co0 + 4 kh, x0 + wave, y0 + its row in the block, its z); row q of block mb: + (mb * 32 + rowq) * S * 4;
+      // column block nb: + RPB * nb * R * 4
+      const uint32_t yoff = (uint32_t)((co0 + 4 * khe) * S + (cur.x0 + wave) * RR + (cur.y0 + vrow_e) * R + vz_e) * 4u;
 #pragma unroll
       for (int mb = 0; mb < MBW; ++mb)
 #pragma unroll
@@ -1173,7 +1203,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_f16_wide_kernel(const flo
               v += bv[qi];
               // (rows >= Co of the last channel block: beyond the descriptor, dropped)
               __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yrsrc,
-                                                    yoff + (uint32_t)((mb * 32 + (q & 3) + 8 * (q >> 2)) * (S * 4)) + (uint32_t)(nb * R * 4), 0, 0);
+                                                    yoff + (uint32_t)((mb * 32 + (q & 3) + 8 * (q >> 2)) * (S * 4)) + (uint32_t)(RPB * nb * R * 4), 0, 0);
             }
           if (want_stats) {
             const float st2 = half_wave_sum8(ss, je), qt = half_wave_sum8(qq, je);
@@ -1430,6 +1460,52 @@ static int conv3d_fwd_split_impl(const float *x, const void *wts, const float *b
 #define PVCNN_IGEMM(NS, TX, TY, TZ, VEC) launch_igemm_bf16<NS, TX, TY, TZ, VEC>(x, w16, bias, y, B, Ci, Co, R, s, sp, am, wexp, amax_seg)
 #define PVCNN_IGEMM_NS(TX, TY, TZ, VEC) (nsplit == 3 ? PVCNN_IGEMM(3, TX, TY, TZ, VEC) : nsplit == 2 ? PVCNN_IGEMM(2, TX, TY, TZ, VEC) : PVCNN_IGEMM(1, TX, TY, TZ, VEC))
 #define PVCNN_IGEMM_BIG(TX, TY, TZ) (nsplit == 2 ? PVCNN_IGEMM(2, TX, TY, TZ, true) : PVCNN_IGEMM(1, TX, TY, TZ, true))
+  // round 6: R = 32 / 16, whole 16-channel chunks: the persistent one-workgroup-per-CU kernel (conv3d_igemm_f16_wide_kernel)
+  static const bool wide_on = [] { const char *e = getenv("PVCNN_CONV_WIDE"); return !(e && e[0] == '0'); }();
+  // (R = 16: measured -- tools/calls_r06/r06_call10: 6 .. 9 % faster per launch than conv3d_igemm_f16_pipe_kernel, 44.8 / 80.2 / 144.0 us
+  //  against 47.6 / 87.5 / 156.3 at 64 -> 64 / 64 -> 128 / 128 -> 128, but nothing in the step: 6.076 / 6.083 ms with, 6.066 / 6.060
+  //  without -- one item per workgroup at Co = 64, nothing for the persistence to hide.  Opt-in: PVCNN_CONV_WIDE16=1; tested either way)
+  static const bool wide16_on = [] { const char *e = getenv("PVCNN_CONV_WIDE16"); return e && e[0] == '1'; }();
+  if (wide_on && nsplit == 2 && (R == 32 || (R == 16 && wide16_on)) && Co > 32 && Ci % kKc == 0 && Ci >= 2 * kKc &&
+      (long)B * std::max(Ci, Co) * R * R * R * 4 < 0xffffffffL) {
+    const int cotiles = ceil_div(Co, kCoTileB), n_tiles = B * (R / 4) * (R / 4);
+    const long per_xcd = (long)((n_tiles + 7) / 8) * cotiles;
+    const unsigned grid = 8u * (unsigned)std::min<long>(kNumCU / 8, per_xcd);
+    const unsigned xb = (unsigned)((size_t)B * Ci * R * R * R * 4), wb = (unsigned)weight_image_bytes(Ci, Co, 2);
+    const int parts = (int)pvcnn_conv3d_fwd_split_stats_parts(B, Co, R, nsplit);
+#define PVCNN_CW_LAUNCH(TZV, ABV)                                                                                                    \
+    do {                                                                                                                               \
+      auto kw = conv3d_igemm_f16_wide_kernel<TZV, ABV>;                                                                                \
+      const int lds_bytes = (int)CwGeom<TZV>::LDS;                                                                                     \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kw), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);   \
+      if (e != hipSuccess) { set_error("conv3d(wide): LDS attribute: %s", hipGetErrorString(e)); return (int)e; }                      \
+      hipLaunchKernelGGL(kw, dim3(grid), dim3(256), lds_bytes, s, x, w16, bias, y, Ci, Co, B, sp, am, wexp, amax_seg, xb, wb, parts);   \
+    } while (0)
+#ifdef PVCNN_ABLATE
+    const char *ab_env = getenv("PVCNN_CONV_ABLATE");
+    const int ab = ab_env ? atoi(ab_env) : 0;
+    if (R == 32) {
+      switch (ab) {
+        case 1: PVCNN_CW_LAUNCH(32, 1); break;
+        case 2: PVCNN_CW_LAUNCH(32, 2); break;
+        case 4: PVCNN_CW_LAUNCH(32, 4); break;
+        case 8: PVCNN_CW_LAUNCH(32, 8); break;
+        case 16: PVCNN_CW_LAUNCH(32, 16); break;
+        case 31: PVCNN_CW_LAUNCH(32, 31); break;
+        default: PVCNN_CW_LAUNCH(32, 0);
+      }
+    } else {
+      switch (ab) {
+        case 31: PVCNN_CW_LAUNCH(16, 31); break;
+        default: PVCNN_CW_LAUNCH(16, 0);
+      }
+    }
+#else
+    if (R == 32) PVCNN_CW_LAUNCH(32, 0); else PVCNN_CW_LAUNCH(16, 0);
+#endif
+#undef PVCNN_CW_LAUNCH
+    return check_launch("conv3d_igemm_f16_wide");
+  }
   if (t.tz == 8 && t.tx == 1) return t.vec ? PVCNN_IGEMM_NS(1, 8, 8, true) : PVCNN_IGEMM_NS(1, 8, 8, false);
   if (t.tz == 8 && t.tx == 2) return t.vec ? PVCNN_IGEMM_NS(2, 8, 8, true) : PVCNN_IGEMM_NS(2, 8, 8, false);
   if (t.tz == 8) return t.vec ? PVCNN_IGEMM_NS(4, 8, 8, true) : PVCNN_IGEMM_NS(4, 8, 8, false);
@@ -1437,38 +1513,6 @@ static int conv3d_fwd_split_impl(const float *x, const void *wts, const float *b
   // the pipelined 128-voxel kernel (f16x2 only).  Round 3, 64 -> 64 at 16^3 x 16: see profiles/ab/r03u_convbench.jsonl
   if (t.tz == 16 && t.tx == 2 && nsplit == 2 && Ci % kKc == 0) return launch_igemm_f16_pipe<2, 4>(x, w16, bias, y, B, Ci, Co, R, s, sp, am, wexp, amax_seg);
   if (t.tz == 16) return t.tx == 2 ? PVCNN_IGEMM_NS(2, 4, 16, true) : PVCNN_IGEMM_NS(4, 4, 16, true);
-  // round 6: R = 32, whole 16-channel chunks: the persistent one-workgroup-per-CU kernel (conv3d_igemm_f16_wide_kernel)
-  static const bool wide_on = [] { const char *e = getenv("PVCNN_CONV_WIDE"); return !(e && e[0] == '0'); }();
-  if (wide_on && nsplit == 2 && R == 32 && Co > 32 && Ci % kKc == 0 && Ci >= 2 * kKc && (long)B * std::max(Ci, Co) * R * R * R * 4 < 0xffffffffL) {
-    const int cotiles = ceil_div(Co, kCoTileB), n_tiles = B * (R / 4) * (R / 4);
-    const long per_xcd = (long)((n_tiles + 7) / 8) * cotiles;
-    const unsigned grid = 8u * (unsigned)std::min<long>(kNumCU / 8, per_xcd);
-    const unsigned xb = (unsigned)((size_t)B * Ci * R * R * R * 4), wb = (unsigned)weight_image_bytes(Ci, Co, 2);
-#define PVCNN_CW_LAUNCH(ABV)                                                                                                         \
-    do {                                                                                                                               \
-      auto kw = conv3d_igemm_f16_wide_kernel<ABV>;                                                                                     \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kw), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCwLds); \
-      if (e != hipSuccess) { set_error("conv3d(wide): LDS attribute: %s", hipGetErrorString(e)); return (int)e; }                      \
-      hipLaunchKernelGGL(kw, dim3(grid), dim3(256), kCwLds, s, x, w16, bias, y, Ci, Co, B, sp, am, wexp, amax_seg, xb, wb,              \
-                         (int)pvcnn_conv3d_fwd_split_stats_parts(B, Co, R, nsplit));                                                   \
-    } while (0)
-#ifdef PVCNN_ABLATE
-    const char *ab_env = getenv("PVCNN_CONV_ABLATE");
-    switch (ab_env ? atoi(ab_env) : 0) {
-      case 1: PVCNN_CW_LAUNCH(1); break;
-      case 2: PVCNN_CW_LAUNCH(2); break;
-      case 4: PVCNN_CW_LAUNCH(4); break;
-      case 8: PVCNN_CW_LAUNCH(8); break;
-      case 16: PVCNN_CW_LAUNCH(16); break;
-      case 31: PVCNN_CW_LAUNCH(31); break;
-      default: PVCNN_CW_LAUNCH(0);
-    }
-#else
-    PVCNN_CW_LAUNCH(0);
-#endif
-#undef PVCNN_CW_LAUNCH
-    return check_launch("conv3d_igemm_f16_wide");
-  }
   if (Co <= 32 && nsplit == 2)     // a 32-row weight tile: no MFMAs on the padded half (f16x2, the default arithmetic, only)
     return t.tx == 4 ? launch_igemm_bf16<2, 4, 4, 32, true, true>(x, w16, bias, y, B, Ci, Co, R, s, sp, am, wexp, amax_seg)
                      : launch_igemm_bf16<2, 2, 4, 32, true, true>(x, w16, bias, y, B, Ci, Co, R, s, sp, am, wexp, amax_seg);

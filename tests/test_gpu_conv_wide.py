@@ -29,19 +29,19 @@ for x, w, bias, gy in cases:
 torch.save(out, sys.argv[3])
 '''
 
-SHAPES = [(16, 64, 64), (3, 32, 96), (1, 48, 64), (20, 64, 128)]          # (B, Ci, Co) at R = 32
+SHAPES = [(16, 64, 64, 32), (3, 32, 96, 32), (1, 48, 64, 32), (20, 64, 128, 32),       # (B, Ci, Co, R)
+          (16, 64, 64, 16), (16, 128, 128, 16), (5, 64, 128, 16), (1, 32, 96, 16)]   # R = 16: the same kernel on a 4 x 4 x 16 tile
 
 
 def test_the_wide_conv3d_kernel_is_bit_identical_to_the_two_workgroup_kernel(tmp_path):
     g = torch.Generator().manual_seed(23)
-    r = 32
     cases = []
-    for k, (b, ci, co) in enumerate(SHAPES):
+    for k, (b, ci, co, r) in enumerate(SHAPES):
         x = torch.randn(b, ci, r, r, r, generator=g)
         x = x * torch.pow(10.0, torch.randint(-5, 6, (b, 1, r, r, 1), generator=g).float())       # every z row at a scale of its own
         if k == 1:                                                                                 # a voxelised cloud: most z rows empty
             keep = torch.zeros(b, 1, r, r, 1)
-            keep[:, :, 9:23, 9:23] = 1.0
+            keep[:, :, 9 * r // 32:23 * r // 32, 9 * r // 32:23 * r // 32] = 1.0
             x = x * keep
         gy = torch.randn(b, co, r, r, r, generator=g) * torch.pow(10.0, torch.randint(-8, 2, (b, 1, r, r, 1), generator=g).float())
         cases.append((x, torch.randn(co, ci, 3, 3, 3, generator=g) * 0.05, torch.randn(co, generator=g), gy))
@@ -50,15 +50,15 @@ def test_the_wide_conv3d_kernel_is_bit_identical_to_the_two_workgroup_kernel(tmp
     script.write_text(_CHILD)
     outs = {}
     for tag, flag in (('narrow', '0'), ('wide', '1')):
-        env = dict(os.environ, PVCNN_CONV_WIDE=flag)
+        env = dict(os.environ, PVCNN_CONV_WIDE=flag, PVCNN_CONV_WIDE16=flag)       # (the R = 16 tile is opt-in: measured, no gain in the step)
         subprocess.run([sys.executable, str(script), ROOT, str(tmp_path / 'cases.pt'), str(tmp_path / f'{tag}.pt')], check=True, env=env, timeout=900)
         outs[tag] = torch.load(tmp_path / f'{tag}.pt')
     for case, (a, b_) in enumerate(zip(outs['narrow'], outs['wide'])):
-        b, ci, co = SHAPES[case]
+        b, ci, co, r = SHAPES[case]
         # the two-workgroup kernel takes the same 512-voxel tile (same scale tile, same products in the same order) once the batch
-        # fills the chip; a small batch takes its 256-voxel tile, whose halo -- and with it the tile's power-of-two scale -- is
-        # another one: the same fp32-class result, not the same bits
-        same_tile = b * 64 * ((co + 63) // 64) >= 512
+        # fills the chip; a small batch takes its 256-voxel tile -- and every R = 16 layer a 128-voxel one --, whose halo -- and with
+        # it the tile's power-of-two scale -- is another one: the same fp32-class result, not the same bits
+        same_tile = r == 32 and b * 64 * ((co + 63) // 64) >= 512
         for k, (p, q) in enumerate(zip(a, b_)):
             what = ['y', 'stats_part', 'grad_x'][k]
             if same_tile:
@@ -79,6 +79,7 @@ def test_the_wide_conv3d_kernel_is_bit_identical_to_the_two_workgroup_kernel(tmp
         gref = torch.nn.grad.conv3d_input(x.shape, w.double(), gy.double(), padding=1)
         # (grad_y's rows are up to ten decades apart INSIDE a tile: the contract is relative to the tile's largest input, so the
         #  error is judged per 4 x 4 x 32 output tile, against the largest output of the tile and its eight neighbours)
-        tile_max = lambda t: torch.nn.functional.max_pool2d(t.abs().amax(dim=(1, 4)).view(t.shape[0], 1, 8, 4, 8, 4).amax(dim=(3, 5)), 3, 1, 1)
-        gerr = (outs['wide'][case][2].double() - gref).abs().amax(dim=(1, 4)).view(x.shape[0], 1, 8, 4, 8, 4).amax(dim=(3, 5)) / tile_max(gref).clamp_min(1e-300)
+        nt = x.shape[2] // 4
+        tile_max = lambda t: torch.nn.functional.max_pool2d(t.abs().amax(dim=(1, 4)).view(t.shape[0], 1, nt, 4, nt, 4).amax(dim=(3, 5)), 3, 1, 1)
+        gerr = (outs['wide'][case][2].double() - gref).abs().amax(dim=(1, 4)).view(x.shape[0], 1, nt, 4, nt, 4).amax(dim=(3, 5)) / tile_max(gref).clamp_min(1e-300)
         assert gerr.max().item() < 1e-5, (SHAPES[case], gerr.max().item())

@@ -32,5 +32,5 @@ def t(fn, n=10):
 
 f = t(lambda: be.conv3d_igemm_split(x, wf, bias, co, 2, True, ax))
 d = t(lambda: be.conv3d_igemm_split(gy, wb, None, ci, 2, False, ag))
-print(json.dumps({'BCiCoR': [b, ci, co, r], 'wide': os.environ.get('PVCNN_CONV_WIDE', '1'), 'ablate': os.environ.get('PVCNN_CONV_ABLATE', '0'),
+print(json.dumps({"BCiCoR": [b, ci, co, r], "wide": os.environ.get("PVCNN_CONV_WIDE", "1") + "/" + os.environ.get("PVCNN_CONV_WIDE16", "1"), 'ablate': os.environ.get('PVCNN_CONV_ABLATE', '0'),
                   'fwd_us': round(f, 1), 'bwd_data_us': round(d, 1)}))

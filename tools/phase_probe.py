@@ -91,6 +91,35 @@ def probe_pw(shape, bwd_data):
         print(f"    slot {r['slot']:2d}  {100 * r['share']:5.1f} %  {r['cycles_per_wave']:>10d} cycles/wave   {r['what']}", file=sys.stderr)
 
 
+def ablate_conv(shape, bwd_data):
+    """The R = 32 Conv3d launch from the ablation build (tools/probe/libablate_conv3d_bf16.so, PVCNN_CONV_ABLATE=<bits>: 1 no A requests,
+    2 no row requests, 4 no conversion / tile store, 8 no B reads, 16 no chunk barrier, 31 MFMAs only) next to the product's."""
+    be = HipBackend()
+    lib = ctypes.CDLL(os.path.join(ROOT, 'tools', 'probe', 'libablate_conv3d_bf16.so'))
+    b, ci, co, r = shape
+    dev = 'cuda:0'
+    g = torch.Generator(device=dev).manual_seed(3)
+    w = torch.randn(co, ci, 3, 3, 3, device=dev, generator=g) * 0.05
+    x = torch.randn(b, co if bwd_data else ci, r, r, r, device=dev, generator=g)
+    k, m = (co, ci) if bwd_data else (ci, co)
+    bias = None if bwd_data else torch.randn(co, device=dev, generator=g)
+    wts = be._conv_wsplit(w, bwd_data, 2)
+    amax = be.conv_amax(x)
+    y = torch.empty(b, m, r, r, r, device=dev)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ablate = int(os.environ.get('PVCNN_CONV_ABLATE', '0'))
+
+    def launch():
+        rc = lib.pvcnn_conv3d_fwd_split(_p(x), _p(wts), _p(bias) if bias is not None else None, b, k, m, r, 2, _p(amax), r, _p(y), None, stream)
+        assert rc == 0, rc
+    launch()
+    torch.cuda.synchronize()
+    ref = be.conv3d_igemm_split(x, wts, bias, m, 2, False, amax)
+    assert ablate or torch.equal(ref, y), 'the ablation build with nothing left out computes something else'
+    print(json.dumps({'ablate': ablate, 'BCiCoR': list(shape), 'direction': 'backward-data' if bwd_data else 'forward',
+                      'launch_us': round(_time(launch, 20), 1), 'launch_us_product': round(_time(lambda: be.conv3d_igemm_split(x, wts, bias, m, 2, False, amax), 20), 1)}))
+
+
 if __name__ == '__main__':
     what = sys.argv[1] if len(sys.argv) > 1 else 'pw'
     shape = (16, 1472, 512, 4096)
@@ -98,5 +127,7 @@ if __name__ == '__main__':
         shape = tuple(int(v) for v in sys.argv[sys.argv.index('--shape') + 1].split('x'))
     if what == 'pw':
         probe_pw(shape, '--bwd-data' in sys.argv)
+    elif what == 'conv':
+        ablate_conv(shape if '--shape' in sys.argv else (16, 64, 64, 32), '--bwd-data' in sys.argv)
     else:
         raise SystemExit(__doc__)
