@@ -47,7 +47,8 @@ static_assert(sizeof(SplitEntry) == 80, "ten 8-byte words");
 // drain while the next phase runs.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// "Last workgroup done" WITHOUT fences.  A workgroup PUBLISHES the few words the finalize step needs with returning device-scope
+// "Last workgroup done" WITHOUT fences.  VALIDATED ON gfx950 ONLY: what orders a published word before the ticket is that returning
+// device-scope atomics are performed where all XCDs meet -- an observed property of this chip, not the HIP memory model's wording.  A workgroup PUBLISHES the few words the finalize step needs with returning device-scope
 // atomics (publish32 / publish64: an exchange executes at the level where all XCDs meet and its return says it has), then takes a
 // ticket; the workgroup that takes the last of `total` tickets reads the published words with device-scope atomic loads (peek32 /
 // peek64: they do not hit in this XCD's L2) and finishes the job.  No __threadfence(): on gfx950 an agent-scope release fence writes

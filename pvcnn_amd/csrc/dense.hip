@@ -167,6 +167,8 @@ static int dense_big_lds(K kernel, size_t bytes) {
 using namespace pvcnn;
 
 // 1 when the pair of launches below serves (rows, Cin, Cout): 2 <= rows <= 64 (train-mode BatchNorm1d needs two rows) and x fits the LDS
+// (kDenseLdsMax is gfx950's 160 KiB minus headroom: this library is built for gfx950 only -- common.h: kLdsBytesPerCU -- and the
+//  Makefile's ARCH is not a supported knob for this file)
 extern "C" int pvcnn_dense_bn_relu_supported(int rows, int Cin, int Cout) {
   return rows >= 2 && rows <= kDenseRowsMax && Cin > 0 && Cout > 0 && (size_t)rows * Cin * sizeof(float) <= kDenseLdsMax;
 }

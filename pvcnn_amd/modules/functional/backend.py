@@ -124,7 +124,9 @@ class HipBackend:
     # profiles/ab/r05d_fold_without_fences.md): the published atomics + tickets of ~100 k workgroups per step cost what the 26 launches
     # cost (PVCNN 6.636 vs 6.605 ms, Frustum-PVCNN 6.19 vs 6.07 ms); with fences, twice the step.  PVCNN_FOLD_FINALIZE=1 (read once per
     # process) switches it on; the tests pin both paths against each other.  One persistent pool per device (a captured graph keeps the
-    # addresses); slices are handed out round robin -- launches on one stream never overlap
+    # addresses); slices are handed out round robin PER (device, stream) -- launches on one stream never overlap, launches on two
+    # streams (a side stream, a parallel branch of a captured step) draw from pools of their own (a word shared by two
+    # concurrent launches would fool the "last workgroup" decision)
     fold_finalize = os.environ.get('PVCNN_FOLD_FINALIZE', '0') == '1'
     _TICKET_POOL = 1 << 16
 
@@ -133,7 +135,7 @@ class HipBackend:
         if not self.fold_finalize or n > self._TICKET_POOL:
             return None
         pools = self.__dict__.setdefault('_ticket_pools', {})
-        key = (device.type, device.index)
+        key = (device.type, device.index, int(torch.cuda.current_stream(device).cuda_stream) if device.type == 'cuda' else 0)
         ent = pools.get(key)
         if ent is None:
             ent = pools[key] = [torch.zeros((self._TICKET_POOL,), dtype=torch.int32, device=device), 0]

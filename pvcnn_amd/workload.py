@@ -119,14 +119,18 @@ class _Slot:
         return (tap.data_ptr() == v.data_ptr() and tuple(tap.shape) == tuple(v.shape) and tuple(tap.stride()) == tuple(v.stride()))
 
 
-def concat_slot(taps_so_far, stage_channels, total_channels, like):
+def concat_slot(taps_so_far, stage_channels, total_channels, like, training=True):
     """-> _Slot for the stage that comes next (its output: (B, stage_channels, N)) inside a fresh (B, total_channels, N) buffer, or None
-    where the GPU path with row maxima is not available."""
+    where the GPU path with row maxima is not available -- the same conditions under which the BatchNorm pass takes the row-maximum
+    route (train mode, f16x2 products: emit_row_max / batch_norm_act), so that the 386 MB buffer is not allocated for nothing
+    (eval mode with grad enabled, fp32 math)."""
     from .modules.functional._autograd import native
-    if not (_SLOT_ENABLED and like.is_cuda and like.dtype == torch.float32 and torch.is_grad_enabled()):
+    if not (_SLOT_ENABLED and training and like.is_cuda and like.dtype == torch.float32 and torch.is_grad_enabled()):
         return None
     be = native()
     if not (getattr(be, 'has_concat_points', False) and getattr(be, 'has_bnact_rowmax', False)) or like.shape[-1] % 256:
+        return None
+    if getattr(be, 'pw_math', '') != 'f16x2':
         return None
     c0 = sum(int(t.shape[1]) for t in taps_so_far)
     if c0 + stage_channels > total_channels:
@@ -300,7 +304,7 @@ class PVCNN(nn.Module):
             # (the last stage's BatchNorm + ReLU pass also emits the row maxima the global max-pool needs: no read of that tensor --
             #  and writes its output straight into its slice of the classifier's concatenation: no copy of that tensor either)
             if i == last:
-                slot = concat_slot(taps, _out_channels(stage), _in_channels(self.classifier), feats)
+                slot = concat_slot(taps, _out_channels(stage), _in_channels(self.classifier), feats, self.training)
             with (emit_row_max(_last_norm(stage), out=slot.view if slot is not None else None) if i == last else contextlib.nullcontext()):
                 feats, _ = stage((feats, coords))
             taps.append(feats)
@@ -489,7 +493,7 @@ class PVCNNShapeNet(nn.Module):
             # (the last stage's BatchNorm + ReLU pass also emits the row maxima the global max-pool needs and writes its output into its
             #  slice of the classifier's concatenation: see PVCNN.forward)
             if i == last:
-                slot = concat_slot(taps, _out_channels(stage), _in_channels(self.classifier), feats)
+                slot = concat_slot(taps, _out_channels(stage), _in_channels(self.classifier), feats, self.training)
             with (emit_row_max(_last_norm(stage), out=slot.view if slot is not None else None) if i == last else contextlib.nullcontext()):
                 feats, _ = stage((feats, coords))
             taps.append(feats)
@@ -537,7 +541,7 @@ class _FrustumSegmentation(nn.Module):
         coords, x, slot, slot_amax = feats[:, :3, :], feats, None, None
         for i, stage in enumerate(stages):
             if i + 1 == len(stages):
-                slot = concat_slot([one_hot], _out_channels(stage), _in_channels(self.classifier), x)
+                slot = concat_slot([one_hot], _out_channels(stage), _in_channels(self.classifier), x, self.training)
             with (emit_row_max(_last_norm(stage), out=slot.view if slot is not None else None) if i + 1 == len(stages)
                   else contextlib.nullcontext()):
                 x, coords = stage((x, coords))

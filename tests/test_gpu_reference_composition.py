@@ -199,6 +199,7 @@ def test_adopt_of_the_reference_composed_frustum_net_is_the_benched_composition(
         state = {k: v.clone() for k, v in adopted.state_dict().items()}
         out_r, loss_r, g_r = _frustum_step(adopted, inputs, targets, crit, autocast)     # the reference composition as it is
         adopted.load_state_dict(state)                                                   # (running statistics back to the start)
+        adopted.zero_grad(set_to_none=True)                                              # (... and no gradient left to accumulate into)
         dist = {k: ((out_b[k] - out_r[k]).abs().max() / out_b[k].abs().max().clamp_min(1e-30)).item() for k in out_b}
         print(f'[reference composition] cfg5 fp32: loss benched {loss_b:.7f} composed {loss_r:.7f}; heads differ (of the largest) by '
               + ', '.join(f'{k} {v:.1e}' for k, v in dist.items()))
