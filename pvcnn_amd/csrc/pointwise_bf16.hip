@@ -559,47 +559,63 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_f16_pipe_kernel(const float *_
 // block).  Per output element the same products in the same order as pw_gemm_f16_pipe_kernel: bit-identical results, BatchNorm partial
 // sums included (tests/test_gpu_pw_wide.py).  PVCNN_PW_WIDE=0 keeps the 128-row kernel.
 constexpr int kWideBufs = 3;
-constexpr int kWideTile = 2 * 8 * kPbN;                         // words of one staged 16-channel tile (two planes)
-constexpr size_t kWideLds = (size_t)kWideBufs * kWideTile * sizeof(uint32_t) + (size_t)(2 + 2) * 256 * sizeof(float2);
+// WMW = waves along the output channels.  2: the 256 x 256 item above.  4 (an image with a multiple of FOUR 128-row blocks: M = 512,
+// 1024, 1472): an item is 512 output channels x 128 points -- the four waves own a 128-row block each and share the B fragments --,
+// so that a staged and converted element feeds 512 channels: half the conversion, half the row requests per MFMA (the ablation builds
+// price the conversion at a quarter of the 256 x 256 kernel), and a layer with M = 512 streams x ONCE, without counting on a second
+// workgroup next to it.  The two 128-point halves of a 256-point tile are consecutive items of one workgroup: they take the tile's
+// scale, and their BatchNorm partial sums meet in LDS in the order of the 128-row kernel's two point groups (same bits).
+template <int WMW> struct WideGeom {
+  static constexpr int WNW = 4 / WMW, TP = 128 * WNW, ROWS = 128 * WMW;            // point groups; points / rows of an item
+  static constexpr int TILE = 2 * 2 * TP * 4;                                      // words of one staged 16-channel tile (two planes)
+  static constexpr size_t LDS = (size_t)kWideBufs * TILE * sizeof(uint32_t) + (size_t)(2 + 2) * ROWS * sizeof(float2);
+};
 
 // AB (ablation bits, tools/probe builds only; the library instantiates 0): 1 = no A requests in the step loop, 2 = no row requests,
 // 4 = no conversion / tile store, 8 = no B reads, 16 = no step barrier -- the step then multiplies stale fragments: wrong results, the
 // MFMAs and everything else stay, and the difference in time is what the removed part costs (phase clocks perturb too much here).
-template <int AB = 0>
+template <int WMW, int AB = 0>
 __global__ __launch_bounds__(256, 1) void pw_gemm_f16_wide_kernel(const float *__restrict__ x, const uint16_t *__restrict__ wts,
                                                                   const float *__restrict__ bias, float *__restrict__ y, int K, int M,
                                                                   int N, int tiles_n, int tiles_total, float2 *__restrict__ stats_part,
                                                                   const uint32_t *__restrict__ x_absmax, const int *__restrict__ wexp,
                                                                   int amax_seg, unsigned x_bytes, unsigned w_bytes) {
-  constexpr int NS = 2, MBW = 4, NBW = 4, TMI = 128, WBLK = NS * TMI * kPbK, TILE = kWideTile, XR = 2;
+  static_assert(WMW == 2 || WMW == 4, "2 x 2 or 4 x 1 waves");
+  using G = WideGeom<WMW>;
+  constexpr int NS = 2, MBW = 4, NBW = 4, TMI = 128, WBLK = NS * TMI * kPbK, TILE = G::TILE, TP = G::TP, ROWS = G::ROWS, XR = 2;
+  constexpr int HALVES = WMW == 4 ? 2 : 1;                      // 128-point halves of a 256-point tile = consecutive items
+  constexpr int NROW = WMW == 4 ? 2 : 4, NPAIR = NROW / 2;      // rows / channel pairs a thread stages per step
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
   extern __shared__ __attribute__((aligned(16))) uint32_t wide_lds[];
-  // staged tiles: [buffer][plane][kh][256 points][4 words]; word w of (kh, point) = channel pair 4 kh + w: a lane's B fragment (the 8
+  // staged tiles: [buffer][plane][kh][TP points][4 words]; word w of (kh, point) = channel pair 4 kh + w: a lane's B fragment (the 8
   // channels 8 kh .. 8 kh + 7 of its point) is ONE 16-byte read, 32 consecutive points = 512 contiguous bytes (conflict-free)
   uint32_t *xs = wide_lds;
-  float2 *stat_lds = reinterpret_cast<float2 *>(wide_lds + kWideBufs * TILE);     // [2 point groups][256 rows]
-  float2 *row_lds = stat_lds + 2 * 256;                         // [item parity][256 rows] (bias, 2^-wexp) of the item's rows
-  const int mtiles = ceil_div(M, TMI), mpairs = mtiles >> 1;
+  float2 *stat_lds = reinterpret_cast<float2 *>(wide_lds + kWideBufs * TILE);     // [2 point groups / halves][ROWS]
+  float2 *row_lds = stat_lds + 2 * ROWS;                        // [item parity][ROWS] (bias, 2^-wexp) of the item's rows
+  const int mtiles = ceil_div(M, TMI), mgroups = mtiles / WMW;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
-  const int items_local = ((tiles_total + 7) >> 3) * mpairs;   // items of this XCD: (its point tiles) x (channel-block pairs)
-  if (slot >= items_local) return;
-  const int rounds = (items_local - slot + nslots - 1) / nslots, chunks = K / kPbK;
+  const int items_local = ((tiles_total + 7) >> 3) * mgroups * HALVES;   // items of this XCD: (its point tiles) x (row groups) x halves
+  if (slot * HALVES >= items_local) return;
+  // a workgroup takes HALVES consecutive items per turn (the two halves of one tile), its turns are nslots apart
+  const int turns = (items_local / HALVES - slot + nslots - 1) / nslots, rounds = turns * HALVES, chunks = K / kPbK;
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, kh = lane >> 5;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave & 1, wn = wave >> 1;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = WMW == 4 ? wave : (wave & 1), wn = WMW == 4 ? 0 : (wave >> 1);
   const uint32_t row_bytes = (uint32_t)N * 4u;
 
   // ---- the items of this workgroup and what the request streams need of an item: three scalars ----
-  struct Item { int tile, mp; uint32_t x_base, a_base; float scale; };
+  struct Item { int tile, mg, half; uint32_t x_base, a_base; float scale; };
   auto item_at = [&](int r) {                                   // (clamped: past the last item the streams re-read it; nothing of that is used)
     Item it;
-    const int jdx = slot + min(r, rounds - 1) * nslots, tl = jdx / mpairs;
-    it.mp = jdx - tl * mpairs;
+    const int rc = min(r, rounds - 1), turn = rc / HALVES;
+    it.half = rc - turn * HALVES;
+    const int jdx = slot + turn * nslots, tl = jdx / mgroups;
+    it.mg = jdx - tl * mgroups;
     it.tile = tl * 8 + xcd;                                     // may be >= tiles_total in the padded tail: never stored
-    const int tc = min(it.tile, tiles_total - 1), b = tc / tiles_n, n0 = (tc - b * tiles_n) * kPbN;
+    const int tc = min(it.tile, tiles_total - 1), b = tc / tiles_n, n0 = (tc - b * tiles_n) * kPbN + it.half * 128;
     it.x_base = (uint32_t)b * (uint32_t)K * row_bytes + (uint32_t)n0 * 4u;              // bytes from x to (cloud, row 0, point n0)
-    it.a_base = (uint32_t)(2 * it.mp + wm) * (uint32_t)(WBLK * 2);                      // bytes from the image to this wave's row block, chunk 0
-    it.scale = exp2_int(scale_shift(amax_seg > 0 ? x_absmax[1 + tc] : *x_absmax));
+    it.a_base = (uint32_t)(WMW * it.mg + wm) * (uint32_t)(WBLK * 2);                    // bytes from the image to this wave's row block, chunk 0
+    it.scale = exp2_int(scale_shift(amax_seg > 0 ? x_absmax[1 + tc] : *x_absmax));     // (the 256-point tile's, also for a half)
     // (wave-uniform, all of it: say so -- a scale that the compiler keeps in a vector register is one more register across the step loop)
     it.x_base = __builtin_amdgcn_readfirstlane(it.x_base);
     it.a_base = __builtin_amdgcn_readfirstlane(it.a_base);
@@ -617,21 +633,24 @@ __global__ __launch_bounds__(256, 1) void pw_gemm_f16_wide_kernel(const float *_
   // per-lane offsets (bytes), the same in every step
   // A fragment: row mb * 32 + j of the 128-row block (the swizzle bit is bit 3 of the row, which a multiple of 32 does not touch)
   const uint32_t a_off = (uint32_t)(j * 8 + ((kh ^ ((j >> 3) & 1)) * 4)) * 4u;
-  // staging item: channel pairs 2 * wave, 2 * wave + 1 (= words 2 (wave & 1) + {0, 1} of half kh' = wave >> 1) of point quad `lane`
-  const uint32_t x_off = (uint32_t)lane * 16u + (uint32_t)(4 * wave) * row_bytes;
-  const uint32_t st_off = (uint32_t)((((wave >> 1) * 256 + 4 * lane) * 4 + 2 * (wave & 1)) * 4);
-  const uint32_t b_off = (uint32_t)((kh * 256 + wn * 128 + j) * 16);
+  // staging item of a thread.  WMW = 2: channel pairs 2 wave, 2 wave + 1 (words 2 (wave & 1) + {0, 1} of half kh' = wave >> 1) of
+  // point quad `lane` (64 quads).  WMW = 4: channel pair p = lane & 7 (word p & 3 of half p >> 2) of point quad 8 wave + (lane >> 3)
+  // (32 quads): a wave instruction reads 128-byte runs of 8 rows
+  const int sp = lane & 7, sq = WMW == 4 ? 8 * wave + (lane >> 3) : lane;
+  const uint32_t x_off = WMW == 4 ? (uint32_t)sq * 16u + (uint32_t)(2 * sp) * row_bytes : (uint32_t)lane * 16u + (uint32_t)(4 * wave) * row_bytes;
+  const uint32_t st_off = WMW == 4 ? (uint32_t)((((sp >> 2) * TP + 4 * sq) * 4 + (sp & 3)) * 4)
+                                   : (uint32_t)((((wave >> 1) * TP + 4 * lane) * 4 + 2 * (wave & 1)) * 4);
+  const uint32_t b_off = (uint32_t)((kh * TP + wn * 128 + j) * 16);
   unsigned char *xs8 = reinterpret_cast<unsigned char *>(xs);
 
-  // conversion of channel pair u (rows 2u, 2u + 1 of the thread's four), points 2 h2 and 2 h2 + 1, in two halves that are issued
+  // conversion of channel pair u (rows 2u, 2u + 1 of the thread's), points 2 h2 and 2 h2 + 1, in two halves that are issued
   // between different MFMAs: (1) scale + round to the hi fp16 pairs, (2) the residuals' fp16 pairs.  split_pair's arithmetic with the
   // packed vector ALU running ALONG THE POINTS (two neighbouring points of one row sit in neighbouring registers of the 16-byte load;
-  // the two rows of a pair do not): 2 packed multiplies + 2 packs, then 4 conversions back + 2 packed fused multiply-subtracts
-  // (a * scale - hi in ONE rounding = the exact residual, like the product minus hi) + 2 packs: 6 instructions per (pair, point)
-  // instead of ~10 (the ablation builds of tools/probe price the first form of this conversion at a quarter of the kernel).
-  f16x2 th[2][4];                                               // hi pairs, kept from half 1 to half 2
-  uint32_t tw[NS][2][4];                                        // [plane][pair u][point q]: the converted tile of this thread
-  auto conv_hi = [&](const float4 (&v)[4], float scale, int u, int h2) {
+  // the two rows of a pair do not): packed multiplies + packs, then conversions back + packed fused multiply-subtracts
+  // (a * scale - hi in ONE rounding = the exact residual, like the product minus hi) + packs
+  f16x2 th[NPAIR][4];                                           // hi pairs, kept from half 1 to half 2
+  uint32_t tw[NS][NPAIR][4];                                    // [plane][pair u][point q]: the converted tile of this thread
+  auto conv_hi = [&](const float4 (&v)[NROW], float scale, int u, int h2) {
     const f32x2 a = h2 == 0 ? f32x2{v[2 * u].x, v[2 * u].y} : f32x2{v[2 * u].z, v[2 * u].w};
     const f32x2 c = h2 == 0 ? f32x2{v[2 * u + 1].x, v[2 * u + 1].y} : f32x2{v[2 * u + 1].z, v[2 * u + 1].w};
     const f32x2 sa = a * scale, sc = c * scale;
@@ -641,7 +660,7 @@ __global__ __launch_bounds__(256, 1) void pw_gemm_f16_wide_kernel(const float *_
       tw[0][u][2 * h2 + e] = __builtin_bit_cast(uint32_t, th[u][2 * h2 + e]);
     }
   };
-  auto conv_lo = [&](const float4 (&v)[4], float scale, int u, int h2) {
+  auto conv_lo = [&](const float4 (&v)[NROW], float scale, int u, int h2) {
     const f32x2 a = h2 == 0 ? f32x2{v[2 * u].x, v[2 * u].y} : f32x2{v[2 * u].z, v[2 * u].w};
     const f32x2 c = h2 == 0 ? f32x2{v[2 * u + 1].x, v[2 * u + 1].y} : f32x2{v[2 * u + 1].z, v[2 * u + 1].w};
     const f32x2 ha = {(float)th[u][2 * h2][0], (float)th[u][2 * h2 + 1][0]}, hc = {(float)th[u][2 * h2][1], (float)th[u][2 * h2 + 1][1]};
@@ -650,15 +669,17 @@ __global__ __launch_bounds__(256, 1) void pw_gemm_f16_wide_kernel(const float *_
 #pragma unroll
     for (int e = 0; e < 2; ++e) tw[1][u][2 * h2 + e] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{ra[e], rc[e]}, f16x2));
   };
-  auto store_pt = [&](int buf, int s2, int q) {                 // 8 bytes: the thread's two words of (plane s2, point q)
-    *reinterpret_cast<u32x2 *>(xs8 + (buf * TILE + s2 * 8 * kPbN) * 4 + st_off + q * 16) = u32x2{tw[s2][0][q], tw[s2][1][q]};
+  auto store_pt = [&](int buf, int s2, int q) {                 // the thread's word(s) of (plane s2, point q): 8 / 4 bytes
+    unsigned char *dst = xs8 + (buf * TILE + s2 * 2 * TP * 4) * 4 + st_off + q * 16;
+    if constexpr (WMW == 4) *reinterpret_cast<uint32_t *>(dst) = tw[s2][0][q];
+    else *reinterpret_cast<u32x2 *>(dst) = u32x2{tw[s2][0][q], tw[s2][NPAIR - 1][q]};
   };
   // plane 0 = hi, plane 1 = lo (split_pair)
   auto load_a1 = [&](uint32_t soff, int plane, int mb) {
     return __builtin_amdgcn_raw_buffer_load_b128(wrsrc, a_off + (uint32_t)(plane * (TMI * kPbK * 2) + mb * 1024), soff, 0);
   };
   auto load_b1 = [&](int buf, int plane, int nb) {
-    return *reinterpret_cast<const u32x4 *>(xs8 + (buf * TILE + plane * 8 * kPbN) * 4 + b_off + nb * 512);
+    return *reinterpret_cast<const u32x4 *>(xs8 + (buf * TILE + plane * 2 * TP * 4) * 4 + b_off + nb * 512);
   };
   auto load_x1 = [&](uint32_t soff, int k) {
     const u32x4 r4 = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, x_off + (uint32_t)k * row_bytes, soff, 0);
@@ -671,19 +692,19 @@ __global__ __launch_bounds__(256, 1) void pw_gemm_f16_wide_kernel(const float *_
   // ---- prologue (item 0): tiles 0 and 1 published, rows of tiles 2 and 3 in flight, fragments of step 0 in registers ----
   PVCNN_PROBE_BEGIN();
   Item cur = item_at(0), nxt = item_at(1);
-  float4 xv[XR][4];
+  float4 xv[XR][NROW];
   u32x4 a_hi[2][MBW], a_lo[2][MBW], b_hi[2][NBW], b_lo[2][NBW];
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) xv[t][k] = load_x1(cur.x_base + (uint32_t)t * x_chunk, k);
+    for (int k = 0; k < NROW; ++k) xv[t][k] = load_x1(cur.x_base + (uint32_t)t * x_chunk, k);
   }
 #pragma unroll
   for (int mb = 0; mb < MBW; ++mb) { a_hi[0][mb] = load_a1(cur.a_base, 0, mb); a_lo[0][mb] = load_a1(cur.a_base, 1, mb); }
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < NPAIR; ++u)
 #pragma unroll
       for (int h2 = 0; h2 < 2; ++h2) { conv_hi(xv[t], cur.scale, u, h2); conv_lo(xv[t], cur.scale, u, h2); }
 #pragma unroll
@@ -691,7 +712,7 @@ __global__ __launch_bounds__(256, 1) void pw_gemm_f16_wide_kernel(const float *_
 #pragma unroll
       for (int q = 0; q < 4; ++q) store_pt(t, s2, q);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) xv[t][k] = load_x1(cur.x_base + (uint32_t)(2 + t) * x_chunk, k);
+    for (int k = 0; k < NROW; ++k) xv[t][k] = load_x1(cur.x_base + (uint32_t)(2 + t) * x_chunk, k);
   }
   lds_barrier();
 #pragma unroll
@@ -708,7 +729,7 @@ __global__ __launch_bounds__(256, 1) void pw_gemm_f16_wide_kernel(const float *_
   // to back, then 40 instructions with the matrix pipe idle: the second version of this kernel, phase clocks 2300 cycles per step
   // for 1536 of MFMA).  In-order issue lets ~7 other instructions go between two MFMAs for free; no slot has more.
   //     slots  0 .. 15  lo x hi   + the fragments of step s + 1: B hi, B lo (LDS), A hi, A lo (image) -- second register sets
-  //     slots 16 .. 31  hi x lo   + the conversion of the rows of step s + 2 (16 half-conversions)
+  //     slots 16 .. 31  hi x lo   + the conversion of the rows of step s + 2 (8 / 4 half-conversions)
   //     slots 32 .. 47  hi x hi   + the converted tile's 8 stores, the row requests of step s + 2 + XR
   auto group = [&](auto first_tag, int c0) {
     constexpr bool FIRST = decltype(first_tag)::value;
@@ -721,7 +742,7 @@ __global__ __launch_bounds__(256, 1) void pw_gemm_f16_wide_kernel(const float *_
       const uint32_t a_soff = (na ? nxt.a_base : cur.a_base) + (uint32_t)(c + 1 - (na ? chunks : 0)) * a_chunk;
       const uint32_t x_soff = (nx ? nxt.x_base : cur.x_base) + (uint32_t)(c + 2 + XR - (nx ? chunks : 0)) * x_chunk;
       const float vscale = nv ? nxt.scale : cur.scale;
-      float4 (&v)[4] = xv[d % XR];                              // rows of step s + 2
+      float4 (&v)[NROW] = xv[d % XR];                           // rows of step s + 2
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {                            // ---- lo x hi
@@ -743,8 +764,12 @@ __global__ __launch_bounds__(256, 1) void pw_gemm_f16_wide_kernel(const float *_
         const int nb = i >> 2, mb = i & 3;
         acc[mb][nb] = mma(a_hi[cs][mb], b_lo[cs][nb], acc[mb][nb]);
         if constexpr (!(AB & 4)) {
-          // (8 half-conversions of two points each over the 16 slots: one every other slot)
-          if ((i & 1) == 0) { if (i < 8) conv_hi(v, vscale, (i >> 2) & 1, (i >> 1) & 1); else conv_lo(v, vscale, ((i - 8) >> 2) & 1, (i >> 1) & 1); }
+          // NPAIR x 2 half-conversions of two points each (hi), then the same (lo): every other slot / every fourth
+          constexpr int NH = NPAIR * 2, STRIDE = 8 / NH;        // 4 -> every 2nd slot of a half; 2 -> every 4th
+          if (i % STRIDE == 0) {
+            const int l = (i & 7) / STRIDE;
+            if (i < 8) conv_hi(v, vscale, l >> 1, l & 1); else conv_lo(v, vscale, l >> 1, l & 1);
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -753,7 +778,7 @@ __global__ __launch_bounds__(256, 1) void pw_gemm_f16_wide_kernel(const float *_
         const int nb = i >> 2, mb = i & 3;
         acc[mb][nb] = mma(a_hi[cs][mb], b_hi[cs][nb], acc[mb][nb]);
         if (i < 8) { if constexpr (!(AB & 4)) store_pt(b_st, i >> 2, i & 3); }
-        else if (i < 12) { if constexpr (!(AB & 2)) v[i - 8] = load_x1(x_soff, i - 8); }
+        else if (i < 8 + NROW) { if constexpr (!(AB & 2)) v[i - 8] = load_x1(x_soff, i - 8); }
         __builtin_amdgcn_sched_barrier(0);
       }
       PVCNN_PROBE(3);                                           // slot 3: the step's 48 MFMAs and everything between them
@@ -765,13 +790,15 @@ __global__ __launch_bounds__(256, 1) void pw_gemm_f16_wide_kernel(const float *_
   for (int r = 0; r < rounds; ++r) {
     // the epilogue's per-row constants: requested now, parked in LDS behind the first group of steps (one read per row there instead
     // of 128 predicated loads that the compiler hoists to the top of the epilogue: seen in the ISA, 90 spilled registers)
-    float2 row_const;
-    {
-      const int m = cur.mp * 256 + tid;
-      row_const = make_float2((bias != nullptr && m < M) ? bias[m] : 0.0f, exp2_int(-wexp[m]));   // wexp covers the padded rows of the image
+    float2 row_const[ROWS / 256];
+#pragma unroll
+    for (int e = 0; e < ROWS / 256; ++e) {
+      const int m = cur.mg * ROWS + e * 256 + tid;
+      row_const[e] = make_float2((bias != nullptr && m < M) ? bias[m] : 0.0f, exp2_int(-wexp[m]));   // wexp covers the padded rows of the image
     }
     group(std::true_type{}, 0);
-    row_lds[(r & 1) * 256 + tid] = row_const;                   // (published by the barriers of the steps that follow, or the epilogue's)
+#pragma unroll
+    for (int e = 0; e < ROWS / 256; ++e) row_lds[(r & 1) * ROWS + e * 256 + tid] = row_const[e];    // (published by the barriers that follow)
     for (int c0 = 4; c0 < chunks; c0 += 4) group(std::false_type{}, c0);
     // ---- the item's epilogue: D[i = m][j = point]; lanes = consecutive points (128-byte rows); bias; BatchNorm partial sums ----
     if (chunks == 4) lds_barrier();                             // (K = 64: no step barrier between the row constants' store and their readers)
@@ -781,13 +808,15 @@ __global__ __launch_bounds__(256, 1) void pw_gemm_f16_wide_kernel(const float *_
       int tid_e = tid;
       asm volatile("" : "+v"(tid_e));
       const int j = tid_e & 31, kh = (tid_e >> 5) & 1;
-      const int b = cur.tile / tiles_n, n0 = (cur.tile - b * tiles_n) * kPbN, m0 = cur.mp * 256 + wm * TMI;
+      const int b = cur.tile / tiles_n, n0 = (cur.tile - b * tiles_n) * kPbN + cur.half * 128, m0 = cur.mg * ROWS + wm * TMI;
       const float x_unscale = 1.0f / cur.scale;                 // (a power of two: exact)
       const bool want_stats = stats_part != nullptr;
       // stores through a descriptor of the cloud's M x N outputs: rows >= M (the padded rows of the last channel block) are dropped by
       // the bounds check; the lane's offset is ONE register, the row a scalar multiple of the row pitch, the column block an immediate
       const __amdgpu_buffer_rsrc_t yrsrc = descriptor(y + (size_t)b * M * N, (uint32_t)M * row_bytes);
       const uint32_t yoff = (uint32_t)(m0 + 4 * kh) * row_bytes + (uint32_t)(n0 + wn * 128 + j) * 4u;
+      // the point group of this wave's partial sums: its 128-point column group (WMW = 2) / the item's half (WMW = 4)
+      const int sg = WMW == 4 ? cur.half : wn;
       // (eight rows at a time: the request streams of the NEXT item hold ~130 registers across this epilogue)
 #pragma unroll
       for (int mb = 0; mb < MBW; ++mb)
@@ -797,7 +826,7 @@ __global__ __launch_bounds__(256, 1) void pw_gemm_f16_wide_kernel(const float *_
 #pragma unroll
           for (int qi = 0; qi < 8; ++qi) {
             const int q = h8 * 8 + qi;
-            const float2 rc = row_lds[(r & 1) * 256 + wm * TMI + mb * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh];
+            const float2 rc = row_lds[(r & 1) * ROWS + wm * TMI + mb * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh];
             bv[qi] = rc.x;
             unscale[qi] = rc.y;
             ss[qi] = qq[qi] = 0.0f;
@@ -819,16 +848,19 @@ __global__ __launch_bounds__(256, 1) void pw_gemm_f16_wide_kernel(const float *_
           if (want_stats) {
             const float st2 = half_wave_sum8(ss, j), qt = half_wave_sum8(qq, j);
             const int q = h8 * 8 + ((j >> 2) & 7);
-            if ((j & 3) == 0) stat_lds[wn * 256 + wm * TMI + mb * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh] = make_float2(st2, qt);
+            if ((j & 3) == 0) stat_lds[sg * ROWS + wm * TMI + mb * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh] = make_float2(st2, qt);
           }
           __builtin_amdgcn_sched_barrier(0);                    // eight rows at a time, really
         }
-      if (want_stats) {                                         // (uniform over the workgroup: every wave has the same item)
+      if (want_stats && (WMW == 2 || cur.half == 1)) {          // (uniform over the workgroup: every wave has the same item)
         lds_barrier();
-        const int m = cur.mp * 256 + tid_e;
-        if (m < M) {
-          const float2 s0 = stat_lds[tid_e], s1 = stat_lds[256 + tid_e];
-          stats_part[(size_t)m * tiles_total + cur.tile] = make_float2(s0.x + s1.x, s0.y + s1.y);
+#pragma unroll
+        for (int e = 0; e < ROWS / 256; ++e) {
+          const int rr = e * 256 + tid_e, m = cur.mg * ROWS + rr;
+          if (m < M) {
+            const float2 s0 = stat_lds[rr], s1 = stat_lds[ROWS + rr];
+            stats_part[(size_t)m * tiles_total + cur.tile] = make_float2(s0.x + s1.x, s0.y + s1.y);
+          }
         }
       }
     }
@@ -987,11 +1019,24 @@ extern "C" int pvcnn_pwconv_fwd_split(const float *x, const void *wts, const flo
     const int mtiles128 = ceil_div(M, 128);
     if (wide_on && MB == 4 && vec && K % 64 == 0 && N % kPbN == 0 && M >= 256 && mtiles128 % 2 == 0 &&
         (long)B * std::max(K, M) * N * 4 < 0xffffffffL) {        // (buffer descriptors: 32-bit byte offsets inside a tensor)
-      const long items_local = ((tiles_total + 7) / 8) * (mtiles128 / 2);
-      const unsigned wide_grid = 8u * (unsigned)std::min<long>(kNumCU / 8, items_local);
+      // 512 x 128 items (4 x 1 waves) where the image has a multiple of four 128-row blocks (PVCNN_PW_WIDE=2: the 256 x 256 items only)
+      static const bool wide4_on = [] { const char *e = getenv("PVCNN_PW_WIDE"); return !(e && e[0] == '2'); }();
+      // (K >= 256: with a handful of steps per item -- 128 -> 1024: eight -- the launch is its epilogues and stores, and the 256 x 256
+      //  items are faster: 79 vs 94 us, tools/calls_r06/r06_call13)
+      const int wmw = (wide4_on && mtiles128 % 4 == 0 && K >= 256) ? 4 : 2;
+      const long turns_local = ((tiles_total + 7) / 8) * (mtiles128 / wmw);      // (a turn = one 256-point tile x one row group)
+      const unsigned wide_grid = 8u * (unsigned)std::min<long>(kNumCU / 8, turns_local);
 #define PVCNN_WIDE_LAUNCH(ABV)                                                                                                      \
-      hipLaunchKernelGGL(pw_gemm_f16_wide_kernel<ABV>, dim3(wide_grid), dim3(256), kWideLds, s, x, w16, bias, y, K, M, N, tiles_n,        \
-                         (int)tiles_total, sp, am, wexp, amax_seg, (unsigned)((size_t)B * K * N * 4), (unsigned)pb_image_bytes(K, M, 2))
+      do {                                                                                                                              \
+        if (wmw == 4)                                                                                                                   \
+          hipLaunchKernelGGL((pw_gemm_f16_wide_kernel<4, ABV>), dim3(wide_grid), dim3(256), WideGeom<4>::LDS, s, x, w16, bias, y, K, M, N,  \
+                             tiles_n, (int)tiles_total, sp, am, wexp, amax_seg, (unsigned)((size_t)B * K * N * 4),                      \
+                             (unsigned)pb_image_bytes(K, M, 2));                                                                        \
+        else                                                                                                                            \
+          hipLaunchKernelGGL((pw_gemm_f16_wide_kernel<2, ABV>), dim3(wide_grid), dim3(256), WideGeom<2>::LDS, s, x, w16, bias, y, K, M, N,  \
+                             tiles_n, (int)tiles_total, sp, am, wexp, amax_seg, (unsigned)((size_t)B * K * N * 4),                      \
+                             (unsigned)pb_image_bytes(K, M, 2));                                                                        \
+      } while (0)
 #ifdef PVCNN_ABLATE
       const char *ab_env = getenv("PVCNN_PW_ABLATE");
       switch (ab_env ? atoi(ab_env) : 0) {
@@ -1000,8 +1045,6 @@ extern "C" int pvcnn_pwconv_fwd_split(const float *x, const void *wts, const flo
         case 4: PVCNN_WIDE_LAUNCH(4); break;
         case 8: PVCNN_WIDE_LAUNCH(8); break;
         case 16: PVCNN_WIDE_LAUNCH(16); break;
-        case 6: PVCNN_WIDE_LAUNCH(6); break;
-        case 15: PVCNN_WIDE_LAUNCH(15); break;
         case 31: PVCNN_WIDE_LAUNCH(31); break;
         default: PVCNN_WIDE_LAUNCH(0);
       }

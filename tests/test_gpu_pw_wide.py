@@ -48,13 +48,15 @@ def test_the_wide_persistent_gemm_is_bit_identical_to_the_128_row_kernel(tmp_pat
     script = tmp_path / 'child.py'
     script.write_text(_CHILD)
     outs = {}
-    for tag, flag in (('narrow', '0'), ('wide', '1')):
+    # '1': the default (512 x 128 items where the image has a multiple of four 128-row blocks, 256 x 256 items else); '2': 256 x 256 items only
+    for tag, flag in (('narrow', '0'), ('wide', '1'), ('wide256', '2')):
         env = dict(os.environ, PVCNN_PW_WIDE=flag)
         subprocess.run([sys.executable, str(script), ROOT, str(tmp_path / 'cases.pt'), str(tmp_path / f'{tag}.pt')], check=True, env=env, timeout=600)
         outs[tag] = torch.load(tmp_path / f'{tag}.pt')
-    for case, (a, b_) in enumerate(zip(outs['narrow'], outs['wide'])):
-        for k, (p, q) in enumerate(zip(a, b_)):
-            assert torch.equal(p, q), (SHAPES[case], ['y', 'stats_part', 'y without bias', 'grad_x'][k], (p - q).abs().max().item())
+    for tag in ('wide', 'wide256'):
+        for case, (a, b_) in enumerate(zip(outs['narrow'], outs[tag])):
+            for k, (p, q) in enumerate(zip(a, b_)):
+                assert torch.equal(p, q), (tag, SHAPES[case], ['y', 'stats_part', 'y without bias', 'grad_x'][k], (p - q).abs().max().item())
     # and against fp64 on the first case (the kernels agree with each other AND with the truth)
     x, w, bias, _ = cases[0]
     ref = torch.einsum('oc,bcn->bon', w.double(), x.double()) + bias.double().view(1, -1, 1)
