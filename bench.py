@@ -732,8 +732,12 @@ def main():
             roofline.update(pmc_traffic('trilinear_devoxelize_fwd', head['shape_BCNR']))
         # the 64->64 forward at 32^3 is the SECOND launch of its template in a step (behind the 9->64 one, same grid): priced like the
         # HBM roofline on the slower of live events and the committed in-graph rocprofv3 average
-        mfma_graph_us = (in_graph_us(('conv3d_igemm_bf16_kernel<2, 4, 4, 32',), nth=1)[0]
-                         if mfma is not None and args.config == 'cfg2' and mfma['shape_BCiCoR'] == [16, 64, 64, 32] else None)
+        # (round 6: the 64 -> 64 forward at 32^3 is the FIRST launch of conv3d_igemm_f16_wide_kernel<32> in a step, its backward-data the
+        #  second; under PVCNN_CONV_WIDE=0 it is the second launch of the two-workgroup template, behind the 9 -> 64 one)
+        mfma_graph_us = None
+        if mfma is not None and args.config == 'cfg2' and mfma['shape_BCiCoR'] == [16, 64, 64, 32]:
+            mfma_graph_us = (in_graph_us(('conv3d_igemm_f16_wide_kernel<32',), nth=0)[0]
+                             or in_graph_us(('conv3d_igemm_bf16_kernel<2, 4, 4, 32',), nth=1)[0])
         mfma_price = 1.0 if not (mfma and mfma_graph_us) else mfma['avg_us'] / max(mfma['avg_us'], mfma_graph_us)
         timed = 'hipGraph replay' if graphed is not None else 'eager'
         line = {
@@ -767,16 +771,16 @@ def main():
             # the step's largest MFMA-bound launch (Conv3d forward of the R=32 stage), same event timing
             'roofline_mfma': None if mfma is None else {
                 'bound': 'mfma', 'kernel': mfma['kernel'] + ' (Conv3d 3x3x3 forward / backward-data of the largest stage)',
-                # the 64->64 forward at 32^3 is the SECOND launch of its template in a step (behind the 9->64 one, same grid)
                 'in_graph_us': mfma_graph_us, 'live_frac': mfma['frac_of_peak'],
                 'shape_BCiCoR': mfma['shape_BCiCoR'], 'achieved': round(mfma['executed_mfma_TFLOPs'] * mfma_price, 1), 'peak': mfma['peak_TFLOPs'],
                 'unit': 'TFLOP/s', 'frac': round(mfma['frac_of_peak'] * mfma_price, 4), 'avg_us': mfma['avg_us'], 'algorithmic_GFLOP': mfma['GFLOP'],
                 'effective_fp32_TFLOPs': mfma['effective_TFLOPs'], 'x_fp32_mfma_peak_157TF': mfma['x_fp32_mfma_peak'],
                 'note': 'achieved = MFMA flops actually executed (f16x2: 3 fp16 partial products per fp32 product; bf16x3: 6) / launch time; '
                         'effective = algorithmic 2*B*R^3*27*Ci*Co / launch time; frac is priced on the slower of live events and the '
-                        'committed in-graph rocprofv3 average (in_graph_us).  By the counters (profiles/r05_pmc_mfma_bench_table.md, '
-                        'r05_pmc_mfma_fill_probe.jsonl) the matrix pipes are busy in 0.41-0.53 of the shader cycles and the chip clocks '
-                        '2.0-2.1 GHz under these kernels on real operands (2.4 GHz on constant ones): frac = busy x clock / 2.4'},
+                        'committed in-graph rocprofv3 average (in_graph_us).  frac = pipe busy x clock / 2.4 GHz: the counters of the '
+                        'matrix kernels inside this step are profiles/r06_pmc_mfma_bench_table.md (busy share of the cycles, effective '
+                        'clock), the same binaries on random and on constant operands profiles/r06_pmc_mfma_fill_probe.jsonl, and what '
+                        'the parts of this kernel cost next to its bare MFMA stream profiles/r06_ablate_conv_fwd.jsonl (DESIGN 4)'},
             'kernels': kernels,
             'kernels_note': 'per-launch HIP event pairs inside the eager steps behind the timed region (median per launch shape, minus the '
                             'empty-pair time): host-paced, i.e. an upper bound per kernel; the in-graph durations are profiles/kernel_durations*.json',
