@@ -21,6 +21,7 @@
 // R = 8, 12, 16 and 32 are instantiated (a z row shorter than the 16-deep k-step is padded with zeros IN LDS: R = 12, the Frustum
 // grids, wastes a quarter of the MFMA work, R = 8 half of it); anything else stays on the fp32-MFMA kernel of conv3d.hip.
 #include <algorithm>
+#include <stdlib.h>
 
 #include "common.h"
 #include "split16.h"
@@ -43,7 +44,9 @@ struct WgradLds {
 // instead of 32 input channels of which Ci exist, so a workgroup has 6 units (dy; 32-row co block) instead of 18: a third of the
 // MFMAs (the unpacked kernel took 0.18 ms at Ci = 9 against 0.35 ms at Ci = 64, for a seventh of the work).  Waves 0..5 take one
 // unit each; all eight waves stage.
-template <int R, bool PACK = false>
+// AB (tools/probe, -DPVCNN_ABLATE only; the product instantiates AB = 0): 1 no global loads, 2 no conversion / LDS stores, 4 no MFMAs,
+// 8 no partial store, 16 no row barrier -- wrong results, honest time.
+template <int R, bool PACK = false, int AB = 0>
 __global__ __launch_bounds__(512, 2) void conv3d_wgrad_f16_kernel(const float *__restrict__ x, const float *__restrict__ gy,
                                                                   const uint32_t *__restrict__ x_absmax,
                                                                   const uint32_t *__restrict__ gy_absmax, int B, int Ci, int Co, int P,
@@ -122,14 +125,14 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_f16_kernel(const float *_
       const int y2 = t + 2, y1 = t + 1;
       const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       float4 vx0 = zero4, vx1 = zero4, vg = zero4;
-      if (y2 < R) {
+      if (!(AB & 1) && y2 < R) {
         const int gx0 = xo + xdx0 - 1, gx1 = xo + xdx1 - 1;
         if (has_x0 && (unsigned)gx0 < (unsigned)R && ci0 + xci0 < Ci)
           vx0 = *reinterpret_cast<const float4 *>(xb + (size_t)(ci0 + xci0) * S + (size_t)gx0 * RR + (size_t)y2 * R + 4 * xq0);
         if (has_x1 && (unsigned)gx1 < (unsigned)R && ci0 + xci1 < Ci)
           vx1 = *reinterpret_cast<const float4 *>(xb + (size_t)(ci0 + xci1) * S + (size_t)gx1 * RR + (size_t)y2 * R + 4 * xq1);
       }
-      if (y1 >= 0 && y1 < R && has_g && co0 + gco < Co)
+      if (!(AB & 1) && y1 >= 0 && y1 < R && has_g && co0 + gco < Co)
         vg = *reinterpret_cast<const float4 *>(gb_ + (size_t)(co0 + gco) * S + (size_t)xo * RR + (size_t)y1 * R + 4 * gq);
 
       // ---- multiply output row y = t (unless every x row it reads is zero) ----
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_f16_kernel(const float *_
           for (int dy = 0; dy < 3; ++dy) live |= rowmax[dx * (R + 2) + t + dy];
         live = __builtin_amdgcn_readfirstlane(live);
       }
-      if (live != 0) {
+      if (!(AB & 4) && live != 0) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           const int z8 = ks * 16 + kh * 8;
@@ -180,6 +183,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_f16_kernel(const float *_
       }
 
       // ---- convert and store the new rows (out-of-range rows are stored as zeros: they are the y / x halo) ----
+      if (!(AB & 2)) {
       if (t == -2) {                                            // row y = -1 of the new strip lives in slot 3
         if (has_x0) store_row(xl, L::XPL, ((3 * 3 + xdx0) * kWgCi + xci0) * ROWB, xq0, zero4, 1.0f);
         if (has_x1) store_row(xl, L::XPL, ((3 * 3 + xdx1) * kWgCi + xci1) * ROWB, xq1, zero4, 1.0f);
@@ -190,7 +194,8 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_f16_kernel(const float *_
         store_row(gl, L::GPL, ((y1 & 1) * kWgCo + gco) * ROWB, gq, vg, gy_scale);
         gsum += (vg.x + vg.y) + (vg.z + vg.w);
       }
-      __syncthreads();
+      }
+      if (!(AB & 16)) __syncthreads();
     }
   }
 
@@ -207,11 +212,302 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_f16_kernel(const float *_
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int co = co0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-          if (!PACK || j < 3 * Ci) pp[((size_t)tap * CoP + co) * CiP + ci0 + (PACK ? pci : j)] = acc[u][dz][r];
+          if (!(AB & 8) && (!PACK || j < 3 * Ci)) pp[((size_t)tap * CoP + co) * CiP + ci0 + (PACK ? pci : j)] = acc[u][dz][r];
         }
       }
     }
   }
+  if (gb_part != nullptr && cit == 0) {                         // grad_bias partial: the QZ quads of a channel, fixed order
+    __syncthreads();
+    float *red = reinterpret_cast<float *>(lds);
+    if (has_g) red[tid] = gsum;
+    __syncthreads();
+    if (tid < kWgCo) {
+      float s = 0.0f;
+#pragma unroll
+      for (int q = 0; q < QZ; ++q) s += red[tid * QZ + q];
+      gb_part[(size_t)p * CoP + co0 + tid] = s;
+    }
+  }
+}
+
+// ---- round 6: the same split-K block, two waves per SIMD in OPPOSITE phases ("ping-pong") ----------------------------------------------
+// The ablation builds of the kernel above (tools/wgrad_only.py, profiles/r06_ablate_conv_wgrad.jsonl) say its row step is serial:
+// at 128 -> 128 @ 16^3 the MFMAs alone cost 113 us and the staging (loads, conversion, LDS stores, barrier) alone 78 us, and a launch
+// takes their SUM (191 us).  Every wave loads, multiplies, converts, stores and meets the barrier in the same order, so the two waves
+// of a SIMD want the matrix pipe at the same time and the vector ALU at the same time.  This kernel keeps the block (64 co x 32 ci x
+// 27 taps = 54 accumulator tiles, the LDS ring, the partial layout, the per-tile order of the sums: its partials are BIT-IDENTICAL)
+// and changes three things:
+//   * the rows of step s + 1 are requested at the top of step s and converted DURING step s + 1 (a register set in flight): the
+//     conversion of a step no longer waits for its own loads, so it can stand anywhere in the step;
+//   * waves 0..3 multiply first and convert afterwards, waves 4..7 (the SIMDs' second waves) convert first and multiply afterwards
+//     -- what one wave of a SIMD spends on the vector ALU and the LDS stores, the other spends on the matrix pipe;
+//   * the 54 tiles are dealt 7, 7, 7, 7, 7, 7, 6, 6 (14, 14, 13, 13 per SIMD) instead of three-tile units 9, 9, 6, 6, 6, 6, 6, 6
+//     (15, 15, 12, 12): waves 0..5 hold two whole (dx, dy) units and ONE dz tile of units 12 / 13, waves 6, 7 two whole units.
+template <int R, bool PACK = false, int AB = 0>
+__global__ __launch_bounds__(512, 2) void conv3d_wgrad_f16_pp_kernel(const float *__restrict__ x, const float *__restrict__ gy,
+                                                                     const uint32_t *__restrict__ x_absmax,
+                                                                     const uint32_t *__restrict__ gy_absmax, int B, int Ci, int Co, int P,
+                                                                     int citiles, float *__restrict__ part, float *__restrict__ gb_part,
+                                                                     int x_seg) {
+  using L = WgradLds<R>;
+  constexpr int QZ = R / 4, KS = L::RP / 16, ROWB = L::ROWB;
+  constexpr int XITEMS = 3 * kWgCi * QZ, GITEMS = kWgCo * QZ;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  unsigned char *xl = lds, *gl = lds + 2 * L::XPL;
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, kh = lane >> 5;
+  int bid = blockIdx.x;
+  const int p = bid % P; bid /= P;
+  const int cit = bid % citiles, cot = bid / citiles;
+  const int ci0 = cit * kWgCi, co0 = cot * kWgCo;
+  const size_t RR = (size_t)R * R, S = RR * R;
+  const float x_scale = exp2_int(scale_shift(*x_absmax)), gy_scale = exp2_int(scale_shift(*gy_absmax));
+
+  for (int e = tid; e < L::BYTES / 4; e += 512) reinterpret_cast<uint32_t *>(lds)[e] = 0u;    // z halos stay zero for good
+  __syncthreads();
+
+  // tiles of this wave: waves 0..3 hold the 27 tiles of the first 32 grad_y rows (co block mb = 0), waves 4..7 those of the second -- a
+  // wave's tiles share ONE A fragment per k-step.  Within a block, wave q = w & 3 holds the whole units (three dz tiles of one (dx, dy))
+  // 2 q and 2 q + 1 and, q < 3, tile dz = q of unit 8: 7, 7, 7, 6 tiles; a SIMD's two waves (w, w + 4) 14, 14, 14, 12.
+  // PACK: unit = wave < 6 (dy = unit % 3, mb = unit / 3), as in the kernel above.
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int wq = wave_u & 3, wmb = PACK ? wave_u / 3 : wave_u >> 2;
+  const int nfull = PACK ? (wave_u < 6 ? 1 : 0) : 2;
+  const bool has_part = !PACK && wq < 3;
+  const int fu0 = PACK ? wave_u % 3 : 2 * wq;                   // (unit numbers within the co block: (dx, dy) = unit / 3, unit % 3)
+  const int pu = 8, pdz = wq;
+  const bool convert_first = (AB & 64) && wave_u >= 4;
+  const int pdx = PACK ? (j < 3 * Ci ? j / Ci : 0) : 0, pci = PACK ? (j < 3 * Ci ? j - (j / Ci) * Ci : kWgCi - 1) : 0;
+  f32x16 acc[2][3], accp;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    accp[r] = 0.0f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int dz = 0; dz < 3; ++dz) acc[u][dz][r] = 0.0f;
+  }
+
+  // staging roles: x item = (dx, ci, z quad), grad_y item = (co, z quad); a thread keeps its items for the whole kernel
+  const int xq0 = tid % QZ, xci0 = (tid / QZ) % kWgCi, xdx0 = tid / (QZ * kWgCi);
+  const int t1 = tid + 512;
+  const int xq1 = t1 % QZ, xci1 = (t1 / QZ) % kWgCi, xdx1 = t1 / (QZ * kWgCi);
+  const bool has_x0 = tid < XITEMS, has_x1 = t1 < XITEMS;
+  const int gq = tid % QZ, gco = tid / QZ;
+  const bool has_g = tid < GITEMS;
+  float gsum = 0.0f;
+
+  auto store_row = [&](unsigned char *plane0, int plane_bytes, int row_byte, int q, const float4 &v, float scale) {
+    uint32_t w0[2], w1[2];
+    split_pair<2>(v.x * scale, v.y * scale, w0);
+    split_pair<2>(v.z * scale, v.w * scale, w1);
+    const int off = row_byte + (8 + 4 * q) * 2;
+    *reinterpret_cast<uint2 *>(plane0 + off) = make_uint2(w0[0], w1[0]);                 // hi
+    *reinterpret_cast<uint2 *>(plane0 + plane_bytes + off) = make_uint2(w0[1], w1[1]);   // lo
+  };
+  const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  // the rows that ENTER the window at step (strip, t): x rows y = t + 2 of the strip's three x planes, grad_y row y = t + 1.  Buffer
+  // loads (one descriptor per cloud: Ci S floats) with the offset of a row that does not exist pushed out of range -- it arrives as
+  // zeros -- so that a request is three loads and NO branch: behind divergent branches the compiler cannot count the loads in
+  // flight and waits for all of them (vmcnt(0)) where it needs the previous step's.
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  auto descriptor = [](const void *base, uint32_t bytes) {
+    const uintptr_t q = reinterpret_cast<uintptr_t>(base);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)q), hi = __builtin_amdgcn_readfirstlane((uint32_t)(q >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((uintptr_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+  };
+  const uint32_t kOut = 0xfffffff0u;
+  const uint32_t xoff0 = has_x0 && ci0 + xci0 < Ci ? (uint32_t)(((size_t)(ci0 + xci0) * S + 4 * xq0) * 4) : kOut;
+  const uint32_t xoff1 = has_x1 && ci0 + xci1 < Ci ? (uint32_t)(((size_t)(ci0 + xci1) * S + 4 * xq1) * 4) : kOut;
+  const uint32_t goff = has_g && co0 + gco < Co ? (uint32_t)(((size_t)(co0 + gco) * S + 4 * gq) * 4) : kOut;
+  auto as_float4 = [](const u32x4 &r) { return make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w)); };
+  // What a request needs of its strip -- the two descriptors and the three row offsets at y = 0 -- is computed ONCE per strip (for the
+  // strip after the current one, at its first step) and kept: a step is ~1500 matrix-pipe cycles at R = 16, and the phase clocks put
+  // a quarter of it into ~150 scalar instructions that recomputed strip numbers (a modulo by P), 64-bit bases and descriptors.
+  struct StripRefs { __amdgpu_buffer_rsrc_t xr, gr; uint32_t o0, o1, og; };
+  auto refs_of = [&](int strip) {
+    StripRefs f;
+    const int st = max(strip, 0), b = st / R, xo = st - b * R;
+    f.xr = descriptor(x + (size_t)b * Ci * S, (uint32_t)((size_t)Ci * S * 4));
+    f.gr = descriptor(gy + (size_t)b * Co * S, (uint32_t)((size_t)Co * S * 4));
+    const int gx0 = xo + xdx0 - 1, gx1 = xo + xdx1 - 1;
+    f.o0 = strip >= 0 && (unsigned)gx0 < (unsigned)R && xoff0 != kOut ? xoff0 + (uint32_t)(gx0 * R * R * 4) : kOut;
+    f.o1 = strip >= 0 && (unsigned)gx1 < (unsigned)R && xoff1 != kOut ? xoff1 + (uint32_t)(gx1 * R * R * 4) : kOut;
+    f.og = strip >= 0 && goff != kOut ? goff + (uint32_t)(xo * R * R * 4) : kOut;
+    return f;
+  };
+  auto request = [&](const StripRefs &f, int t, float4 &vx0, float4 &vx1, float4 &vg) {       // the rows that enter at step t of f's strip
+    if (AB & 1) { vx0 = zero4; vx1 = zero4; vg = zero4; return; }
+    const int y2 = t + 2, y1 = t + 1;
+    const uint32_t o0 = y2 < R && f.o0 != kOut ? f.o0 + (uint32_t)(y2 * R * 4) : kOut;
+    const uint32_t o1 = y2 < R && f.o1 != kOut ? f.o1 + (uint32_t)(y2 * R * 4) : kOut;
+    const uint32_t og = y1 >= 0 && y1 < R && f.og != kOut ? f.og + (uint32_t)(y1 * R * 4) : kOut;
+    vx0 = as_float4(__builtin_amdgcn_raw_buffer_load_b128(f.xr, o0, 0, 0));
+    vx1 = as_float4(__builtin_amdgcn_raw_buffer_load_b128(f.xr, o1, 0, 0));
+    vg = as_float4(__builtin_amdgcn_raw_buffer_load_b128(f.gr, og, 0, 0));
+  };
+  // ... and their conversion into the ring (out-of-range rows arrive as zeros: they are the y / x halo)
+  auto convert = [&](int t, const float4 &vx0, const float4 &vx1, const float4 &vg) {
+    if (AB & 2) return;
+    const int y2 = t + 2, y1 = t + 1;
+    if (t == -2) {                                              // row y = -1 of the new strip lives in slot 3
+      if (has_x0) store_row(xl, L::XPL, ((3 * 3 + xdx0) * kWgCi + xci0) * ROWB, xq0, zero4, 1.0f);
+      if (has_x1) store_row(xl, L::XPL, ((3 * 3 + xdx1) * kWgCi + xci1) * ROWB, xq1, zero4, 1.0f);
+    }
+    if (has_x0) store_row(xl, L::XPL, (((y2 & 3) * 3 + xdx0) * kWgCi + xci0) * ROWB, xq0, vx0, x_scale);
+    if (has_x1) store_row(xl, L::XPL, (((y2 & 3) * 3 + xdx1) * kWgCi + xci1) * ROWB, xq1, vx1, x_scale);
+    if (has_g && y1 >= 0) {
+      store_row(gl, L::GPL, ((y1 & 1) * kWgCo + gco) * ROWB, gq, vg, gy_scale);
+      gsum += (vg.x + vg.y) + (vg.z + vg.w);
+    }
+  };
+  // The matrix phase of a step.  grad_w[tap dz] = sum_z grad_y[z] x[z + dz - 1] = sum_z' grad_y[z' - dz + 1] x[z']: the shift along z is
+  // applied to the A operand (grad_y: ONE fragment per k-step for all of a wave's tiles -- a 16-byte LDS read plus the dword on
+  // either side, two funnel shifts) instead of the B operand (x: one window per (dx, dy) unit, as the kernel above does it); a unit
+  // is then two aligned 16-byte reads and nine MFMAs with no vector-ALU work.  Why it matters: the phase clocks and the variants of
+  // tools/calls_r06 (fewer LDS reads, hand-prefetched fragments, opposite phases of a SIMD's two waves: all within +-5 %) say the
+  // step is bound by the NUMBER of vector-ALU instructions -- ~8 per MFMA, and a SIMD issues 8 per 32-cycle MFMA, the MFMA itself
+  // included.  The sums are the same products grouped into other 16-deep k-steps: same accuracy class, not the same bits as the
+  // kernel above.
+  auto a_shifts = [&](int t, int ks, uint4 (&as)[2][3]) {       // [hi, lo][dz]
+    const int z8 = ks * 16 + kh * 8;
+    const unsigned char *arow = gl + (((t & 1) * kWgCo + wmb * 32 + j) * ROWB) + (z8 + 6) * 2;
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+      const unsigned char *row = arow + pl * L::GPL;
+      const uint32_t d0 = *reinterpret_cast<const uint32_t *>(row);
+      const uint4 m = *reinterpret_cast<const uint4 *>(row + 4);
+      const uint32_t d5 = *reinterpret_cast<const uint32_t *>(row + 20);
+      as[pl][1] = m;                                                                                                    // dz = 1: gy[z']
+      as[pl][0] = make_uint4(__builtin_amdgcn_alignbit(m.y, m.x, 16), __builtin_amdgcn_alignbit(m.z, m.y, 16),
+                             __builtin_amdgcn_alignbit(m.w, m.z, 16), __builtin_amdgcn_alignbit(d5, m.w, 16));          // dz = 0: gy[z' + 1]
+      as[pl][2] = make_uint4(__builtin_amdgcn_alignbit(m.x, d0, 16), __builtin_amdgcn_alignbit(m.y, m.x, 16),
+                             __builtin_amdgcn_alignbit(m.z, m.y, 16), __builtin_amdgcn_alignbit(m.w, m.z, 16));         // dz = 2: gy[z' - 1]
+    }
+  };
+  auto b_fragment = [&](int t, int ks, int unit, uint4 &bh, uint4 &bl) {
+    const int z8 = ks * 16 + kh * 8;
+    const int dx = PACK ? pdx : unit / 3, dy = PACK ? unit : unit - (unit / 3) * 3;
+    const unsigned char *row = xl + ((((t + dy - 1) & 3) * 3 + dx) * kWgCi + (PACK ? pci : j)) * ROWB + (z8 + 8) * 2;
+    bh = *reinterpret_cast<const uint4 *>(row);
+    bl = *reinterpret_cast<const uint4 *>(row + L::XPL);
+  };
+  auto multiply = [&](int t) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      uint4 as[2][3];
+      a_shifts(t, ks, as);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (u < nfull) {
+          uint4 bh, bl;
+          b_fragment(t, ks, fu0 + u, bh, bl);
+#pragma unroll
+          for (int dz = 0; dz < 3; ++dz) acc[u][dz] = mfma16<2>(as[1][dz], bh, acc[u][dz]);     // lo x hi
+#pragma unroll
+          for (int dz = 0; dz < 3; ++dz) acc[u][dz] = mfma16<2>(as[0][dz], bl, acc[u][dz]);     // hi x lo
+#pragma unroll
+          for (int dz = 0; dz < 3; ++dz) acc[u][dz] = mfma16<2>(as[0][dz], bh, acc[u][dz]);     // hi x hi
+        }
+      }
+      if (has_part) {
+        uint4 bh, bl;
+        b_fragment(t, ks, pu, bh, bl);
+        const uint4 ah = pdz == 0 ? as[0][0] : pdz == 1 ? as[0][1] : as[0][2], al = pdz == 0 ? as[1][0] : pdz == 1 ? as[1][1] : as[1][2];
+        accp = mfma16<2>(al, bh, accp);
+        accp = mfma16<2>(ah, bl, accp);
+        accp = mfma16<2>(ah, bh, accp);
+      }
+    }
+  };
+
+  constexpr int kRot = R / 4 + 1;
+  const int nstrips = B * R;
+  auto strip_of = [&](int i0) { const int st = i0 * P + (p + i0 * kRot) % P; return (i0 * P < nstrips && st < nstrips) ? st : -1; };
+  // ONE flat loop over the steps (strip, t = -2 .. R - 1) of this partition's strips, two steps per trip with the two register sets
+  // exchanged (no copies; R + 2 is even): a loop whose first trips are special invites the compiler to peel them, and the peeled
+  // copies cost it the accumulators (spilled around them, reloaded -- with a vmcnt wait inside the matrix stream -- in the loop).
+  int npass = 0;
+  while (strip_of(npass) >= 0) ++npass;                        // (only the last pass can be without a strip)
+  float4 ax0, ax1, ag, bx0, bx1, bg;                           // the rows of this step (in registers since the last one) / of the next
+  int i0 = 0, t = -2, strip = strip_of(0);
+  StripRefs cur = refs_of(strip), nxt = cur;
+  request(cur, -2, ax0, ax1, ag);
+  unsigned long long live_rows = ~0ull;
+  PVCNN_PROBE_BEGIN();
+  const int pslot = convert_first ? 8 : 0;
+  (void)pslot;
+  auto step = [&](const float4 &cx0, const float4 &cx1, const float4 &cg, float4 &nx0, float4 &nx1, float4 &ng) {
+    if (t == -2) {
+      // ZERO ROWS (see the kernel above): which output rows y of this strip have a non-zero x row among their nine neighbours -- one
+      // bit per y, in a scalar register for the whole strip.  Lane y ORs its nine maxima straight from the amax buffer and the wave
+      // votes (every wave for itself: 9 loads per lane and strip).  (The kernel above keeps the strip's maxima in LDS and reads nine
+      // of them at the top of EVERY step: a handful of LDS reads that queue behind the other waves' fragment reads -- the phase
+      // clocks put a quarter of a step there.)
+      live_rows = ~0ull;
+      if (x_seg > 0) {
+        const int b = strip / R, xo = strip - b * R;
+        uint32_t m = 0;
+        if (lane < R) {
+#pragma unroll
+          for (int dx = -1; dx <= 1; ++dx)
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy) {
+              const int gx = xo + dx, yy = lane + dy;
+              if ((unsigned)gx < (unsigned)R && (unsigned)yy < (unsigned)R) m |= x_absmax[1 + ((size_t)b * R + gx) * R + yy];
+            }
+        }
+        live_rows = __ballot(m != 0);
+      }
+      nxt = refs_of(strip_of(i0 + 1));
+    }
+    const bool last = t + 1 == R;
+    if (last) request(nxt, -2, nx0, nx1, ng);
+    else request(cur, t + 1, nx0, nx1, ng);
+    const bool live = t >= 0 && ((live_rows >> t) & 1ull) != 0;
+    PVCNN_PROBE(0);
+    if (convert_first) convert(t, cx0, cx1, cg);
+    PVCNN_PROBE(1);
+    if (!(AB & 4) && live) multiply(t);
+    PVCNN_PROBE(2);
+    if (!convert_first) convert(t, cx0, cx1, cg);
+    PVCNN_PROBE(3);
+    if (!(AB & 16)) __syncthreads();
+    PVCNN_PROBE(4);
+    if (last) { ++i0; t = -2; strip = strip_of(i0); cur = nxt; } else ++t;
+  };
+#pragma nounroll
+  for (int q = 0; q < npass * (R + 2); q += 2) {
+    step(ax0, ax1, ag, bx0, bx1, bg);
+    step(bx0, bx1, bg, ax0, ax1, ag);
+  }
+#ifdef PVCNN_PHASE_PROBE
+  if (lane == 0 && phase_probe_buf != nullptr) {                // slots 0..4: waves 0-3, 8..12: waves 4-7
+    for (int k = 0; k < 5; ++k) atomicAdd(phase_probe_buf + pslot + k, (unsigned long long)probe_acc_[k]);
+    atomicAdd(phase_probe_buf + 31, 1ull);
+  }
+#endif
+
+  // ---- epilogue: part[p][tap][co][ci] (CoP x CiP padded block grid), lanes along ci ----
+  const int CoP = (int)gridDim.x / (P * citiles) * kWgCo, CiP = citiles * kWgCi;
+  float *pp = part + (size_t)p * 27 * CoP * CiP;
+  auto put = [&](const f32x16 &a, int tap, int mb) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+      if (!PACK || j < 3 * Ci) pp[((size_t)tap * CoP + co) * CiP + ci0 + (PACK ? pci : j)] = a[r];
+    }
+  };
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    if (u < nfull) {
+      const int unit = fu0 + u, dxy = PACK ? pdx * 3 + unit : unit;
+#pragma unroll
+      for (int dz = 0; dz < 3; ++dz) put(acc[u][dz], dxy * 3 + dz, wmb);
+    }
+  }
+  if (has_part) put(accp, pu * 3 + pdz, wmb);
   if (gb_part != nullptr && cit == 0) {                         // grad_bias partial: the QZ quads of a channel, fixed order
     __syncthreads();
     float *red = reinterpret_cast<float *>(lds);
@@ -300,7 +596,40 @@ static int launch_wgrad_f16(const float *x, const float *gy, const uint32_t *xa,
   const WgradPlan w = wgrad_f16_plan(B, Ci, Co, R);
   float *part = ws, *gb_part = ws + w.part_floats;
   const bool pack = 3 * Ci <= kWgCi && (R == 32 || R == 16);     // (instantiated for the grids a network's first layer has)
+  static const bool pingpong = [] { const char *e = getenv("PVCNN_WGRAD_PP"); return !(e && e[0] == '0'); }();
   auto k = pack ? conv3d_wgrad_f16_kernel<R, (R == 32 || R == 16)> : conv3d_wgrad_f16_kernel<R, false>;
+  const bool fits = (size_t)std::max(Ci, Co) * R * R * R * 4 < ((size_t)1 << 32) - 64;      // one buffer descriptor per cloud
+  if (pingpong && fits) k = pack ? conv3d_wgrad_f16_pp_kernel<R, (R == 32 || R == 16)> : conv3d_wgrad_f16_pp_kernel<R, false>;
+#ifdef PVCNN_ABLATE
+  if (const char *e = getenv("PVCNN_WGRAD_ABLATE")) {
+    switch (atoi(e)) {
+      case 1: k = conv3d_wgrad_f16_kernel<R, false, 1>; break;
+      case 2: k = conv3d_wgrad_f16_kernel<R, false, 2>; break;
+      case 3: k = conv3d_wgrad_f16_kernel<R, false, 3>; break;
+      case 4: k = conv3d_wgrad_f16_kernel<R, false, 4>; break;
+      case 8: k = conv3d_wgrad_f16_kernel<R, false, 8>; break;
+      case 16: k = conv3d_wgrad_f16_kernel<R, false, 16>; break;
+      case 27: k = conv3d_wgrad_f16_kernel<R, false, 27>; break;
+      case 31: k = conv3d_wgrad_f16_kernel<R, false, 31>; break;
+      default: break;
+    }
+    if (pingpong && fits) switch (atoi(e)) {
+      case 1: k = conv3d_wgrad_f16_pp_kernel<R, false, 1>; break;
+      case 2: k = conv3d_wgrad_f16_pp_kernel<R, false, 2>; break;
+      case 4: k = conv3d_wgrad_f16_pp_kernel<R, false, 4>; break;
+      case 16: k = conv3d_wgrad_f16_pp_kernel<R, false, 16>; break;
+      case 32: k = conv3d_wgrad_f16_pp_kernel<R, false, 32>; break;
+      case 64: k = conv3d_wgrad_f16_pp_kernel<R, false, 64>; break;
+      case 96: k = conv3d_wgrad_f16_pp_kernel<R, false, 96>; break;
+      case 100: k = conv3d_wgrad_f16_pp_kernel<R, false, 100>; break;
+      case 36: k = conv3d_wgrad_f16_pp_kernel<R, false, 36>; break;
+      case 192: k = conv3d_wgrad_f16_pp_kernel<R, false, 192>; break;
+      case 448: k = conv3d_wgrad_f16_pp_kernel<R, false, 448>; break;
+      case 480: k = conv3d_wgrad_f16_pp_kernel<R, false, 480>; break;
+      default: k = conv3d_wgrad_f16_pp_kernel<R, false, 0>; break;
+    }
+  }
+#endif
   const int lds = WgradLds<R>::BYTES + (3 * (R + 2) * 4 + 15) / 16 * 16;     // + the strip's row maxima
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e != hipSuccess) { set_error("conv3d_wgrad_f16: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }

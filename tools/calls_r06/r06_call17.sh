@@ -1,0 +1,14 @@
+#!/bin/bash
+# round 6, call 17: the ping-pong Conv3d backward-weight kernel: bit-identity, per-layer time next to the kernel it replaces, the step
+R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/r06q; mkdir -p $O
+cd $R
+timeout 900 python -m pytest tests/test_gpu_wgrad_pp.py -m gpu -q -x -p no:cacheprovider > $O/tests.log 2>&1; tail -5 $O/tests.log
+for pp in 0 1; do
+  PVCNN_WGRAD_PP=$pp timeout 300 python tools/wgrad_only.py > $O/wgrad_pp$pp.jsonl 2> $O/wgrad_pp$pp.err; echo "pp=$pp"; cat $O/wgrad_pp$pp.jsonl
+done
+for pp in 1 0 1 0; do
+  PVCNN_WGRAD_PP=$pp timeout 600 python bench.py --steps 30 --warmup 5 > $O/bench_pp$pp.json 2> $O/bench_pp$pp.err
+  python - <<PY
+import json; d=json.loads(open('$O/bench_pp$pp.json').read().strip().splitlines()[-1]); print('pp=$pp', d['value'], d['ms_per_step'])
+PY
+done

@@ -56,7 +56,7 @@ def absmax(x):
     """The amax buffer of a voxel grid (include/pvcnn_hip.h): [0] global, then one maximum per z row."""
     b, c, r = x.shape[0], x.shape[1], x.shape[2]
     out = torch.empty(lib.pvcnn_absmax_tiles_count(b, r ** 3, r), dtype=torch.int32, device=dev)
-    _lib.check(lib.pvcnn_absmax_tiles(P(x), b, c, r ** 3, r, P(out), S()), 'absmax_tiles')
+    _lib.check(lib.pvcnn_absmax_tiles(P(x), b, c, r ** 3, r, P(out), None, S()), 'absmax_tiles')
     return out
 
 
@@ -184,7 +184,7 @@ def main():
             wsb = torch.empty(nb, dtype=torch.uint8, device=dev)
             msw = graph_time(lambda: lib.pvcnn_conv3d_bwd_weight(P(x), P(gy), b, ci, co, r, P(gw), None, P(wsb), nb, S()))
             am = absmax(x)
-            msa = graph_time(lambda: lib.pvcnn_absmax_tiles(P(x), b, ci, r ** 3, r, P(am), S()))
+            msa = graph_time(lambda: lib.pvcnn_absmax_tiles(P(x), b, ci, r ** 3, r, P(am), None, S()))
             print(json.dumps({'absmax_tiles_BCR': [b, ci, r], 'ms': round(msa, 4), 'GBps': round(x.numel() * 4 / msa / 1e6, 0)}), flush=True)
             if r in (16, 32):
                 nb16 = lib.pvcnn_conv3d_bwd_weight_f16_workspace_bytes(b, ci, co, r)
