@@ -47,7 +47,7 @@ extern "C" {
 #define PVCNN_API
 #endif
 
-#define PVCNN_ABI_VERSION 11
+#define PVCNN_ABI_VERSION 12
 #define PVCNN_OK 0
 #define PVCNN_ERR_INVALID_ARGUMENT (-1)
 
@@ -279,6 +279,11 @@ PVCNN_API size_t pvcnn_absmax_tiles_count(int B, long L, int seg);      /* 1 + T
  * with a launch that can run concurrently (another stream); launches on one stream may reuse it.  The same convention: `tickets` of
  * pvcnn_bnact_bwd_strided (C words: the per-channel sums are finalised by the workgroup that writes a channel's last partial),
  * `ticket` of pvcnn_concat_points. */
+/* (ABI v12) ticket == PVCNN_TABLE_ONLY: the table out[1 ..] only -- word [0] is left UNWRITTEN and nothing is launched for it (~5 us
+ * of launch latency, eleven times per PVCNN step).  For buffers whose every consumer takes the maximum from the table: the f16x2
+ * convolutions / GEMMs with amax_seg > 0, and pvcnn_conv3d_bwd_weight_f16 / pvcnn_pwconv_bwd_weight_f16 with x_amax_seg / gy_amax_seg
+ * > 0 (their workgroups reduce the table themselves: <= 64 KiB from L2).  The same value of `ticket` in pvcnn_concat_points. */
+#define PVCNN_TABLE_ONLY ((void *)1)
 PVCNN_API int pvcnn_absmax_tiles(const float *x, int B, int C, long L, int seg, void *out, void *ticket, void *stream);
 PVCNN_API int pvcnn_conv3d_fwd_split(const float *x, const void *wts, const float *bias, int B, int Ci, int Co, int R, int nsplit,
                            const void *x_absmax, int amax_seg /* 0 | R */, float *y, float *stats_part, void *stream);
@@ -288,10 +293,13 @@ PVCNN_API int pvcnn_conv3d_fwd_split(const float *x, const void *wts, const floa
  * buffer).  (ABI v8) x_amax_seg = R says x_absmax IS an amax buffer with one maximum per z row (pvcnn_absmax_tiles(x, ..., seg = R),
  * or what pvcnn_bnact_fwd emitted): output rows whose nine neighbouring x rows are all zero -- the empty part of a voxelised
  * cloud -- skip their matrix work (exact: they would add zeros); x_amax_seg = 0: a 1-word buffer, nothing is skipped.
+ * (ABI v12) gy_amax_seg = R: gy_absmax IS an amax buffer with one maximum per z row, too; with x_amax_seg / gy_amax_seg = R the
+ * global maximum the kernel scales by is taken from the TABLE (word [0] is not read: its producer may have been asked for
+ * PVCNN_TABLE_ONLY); 0: from word [0] as before.
  * Deterministic (split-K partials summed in a fixed order), <= 1e-5 vs fp64 like pvcnn_conv3d_bwd_weight. */
 PVCNN_API size_t pvcnn_conv3d_bwd_weight_f16_workspace_bytes(int B, int Ci, int Co, int R);
 PVCNN_API int pvcnn_conv3d_bwd_weight_f16(const float *x, const float *grad_y, const void *x_absmax, int x_amax_seg, const void *gy_absmax,
-                                int B, int Ci, int Co, int R, float *grad_w, float *grad_bias, void *workspace,
+                                int gy_amax_seg, int B, int Ci, int Co, int R, float *grad_w, float *grad_bias, void *workspace,
                                 size_t workspace_bytes, void *stream);
 
 /* ---- 1x1 convolutions of SharedMLP (point branch, classifier) ------------------------------------
@@ -325,10 +333,13 @@ PVCNN_API int pvcnn_pwconv_fwd_split(const float *x, const void *wts, const floa
                            const void *x_absmax, int amax_seg /* 0 | 256 */, float *y, float *stats_part, void *stream);
 /* Backward-weight of the 1x1 convolution in f16x2 (csrc/pointwise_wgrad_f16.hip), N % 4 == 0 (workspace_bytes returns 0 otherwise:
  * use pvcnn_pwconv_bwd_weight).  x (B,K,N), grad_y (B,M,N) -> grad_w (M,K) [, grad_bias (M)]; *_absmax: pvcnn_absmax_bits of the two
- * tensors.  Deterministic split-K, <= 1e-5 vs fp64. */
+ * tensors (word [0] of an amax buffer).  (ABI v12) x_amax_seg / gy_amax_seg > 0: the buffer is an amax buffer with segments of that
+ * many points (pvcnn_absmax_tiles_count(B, N, seg) words) and the global maximum is taken from its TABLE, word [0] is not read (see
+ * PVCNN_TABLE_ONLY); 0: from word [0].  Deterministic split-K, <= 1e-5 vs fp64. */
 PVCNN_API size_t pvcnn_pwconv_bwd_weight_f16_workspace_bytes(int B, int K, int M, int N);
-PVCNN_API int pvcnn_pwconv_bwd_weight_f16(const float *x, const float *grad_y, const void *x_absmax, const void *gy_absmax, int B, int K,
-                                int M, int N, float *grad_w, float *grad_bias, void *workspace, size_t workspace_bytes, void *stream);
+PVCNN_API int pvcnn_pwconv_bwd_weight_f16(const float *x, const float *grad_y, const void *x_absmax, int x_amax_seg, const void *gy_absmax,
+                                int gy_amax_seg, int B, int K, int M, int N, float *grad_w, float *grad_bias, void *workspace,
+                                size_t workspace_bytes, void *stream);
 
 /* ---- BatchNorm fused with the following ReLU / LeakyReLU -----------------------------------------
  * replaces the (nn.BatchNorm{1,2,3}d, nn.ReLU | nn.LeakyReLU) module pairs of modules/pvconv.py:20-27

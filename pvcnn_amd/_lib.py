@@ -16,7 +16,7 @@ import torch  # noqa: F401  (must be imported before the dlopen, see above)
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 LIB_PATH = os.path.join(_CSRC, 'libpvcnn_hip.so')
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _vp, _i, _f, _sz, _l = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_long
 
@@ -67,7 +67,7 @@ SIGNATURES = {
     'pvcnn_absmax_tiles_count': (_sz, [_i, ctypes.c_long, _i]),
     'pvcnn_absmax_tiles': (_i, [_vp, _i, _i, ctypes.c_long, _i, _vp, _vp, _vp]),
     'pvcnn_conv3d_bwd_weight_f16_workspace_bytes': (_sz, [_i, _i, _i, _i]),
-    'pvcnn_conv3d_bwd_weight_f16': (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    'pvcnn_conv3d_bwd_weight_f16': (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     'pvcnn_conv3d_fwd_split': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
     'pvcnn_pwconv_transpose': (_i, [_vp, _i, _i, _vp, _vp]),
     'pvcnn_pwconv_fwd': (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
@@ -77,7 +77,7 @@ SIGNATURES = {
     'pvcnn_pwconv_fwd_split_stats_parts': (_sz, [_i, _i]),
     'pvcnn_pwconv_fwd_split': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
     'pvcnn_pwconv_bwd_weight_f16_workspace_bytes': (_sz, [_i, _i, _i, _i]),
-    'pvcnn_pwconv_bwd_weight_f16': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    'pvcnn_pwconv_bwd_weight_f16': (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     'pvcnn_pwconv_bwd_weight_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'pvcnn_pwconv_bwd_weight': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     'pvcnn_bnact_workspace_bytes': (_sz, [_i, _i, _i]),

@@ -869,11 +869,13 @@ extern "C" int pvcnn_concat_points(const float *const *srcs, const long *bstride
     hipError_t e = hipMemsetAsync(out_amax, 0, (1 + (size_t)B * blocks) * sizeof(uint32_t), s);
     if (e != hipSuccess) { set_error("concat_points: memset: %s", hipGetErrorString(e)); return (int)e; }
   }
+  const bool table_only = ticket == PVCNN_TABLE_ONLY;       // (ABI v12) see pvcnn_absmax_tiles
+  if (table_only) ticket = nullptr;
   PVCNN_REQUIRE(!ticket || (reinterpret_cast<uintptr_t>(ticket) & 3) == 0, "ticket must be 4-byte aligned");
   if ((long)B * blocks > kFoldTableMax) ticket = nullptr;    // a long table is read faster by the 1024 threads of the reduce launch
   hipLaunchKernelGGL(concat_points_kernel, dim3(blocks, B, groups), dim3(256), 0, s, cs, N, vec ? 1 : 0, out, static_cast<uint32_t *>(out_amax),
                      static_cast<unsigned *>(out_amax ? ticket : nullptr));
   if (int e = check_launch("concat_points")) return e;
-  if (out_amax != nullptr && ticket == nullptr) return launch_amax_reduce(static_cast<uint32_t *>(out_amax), (long)B * blocks, s);
+  if (out_amax != nullptr && ticket == nullptr && !table_only) return launch_amax_reduce(static_cast<uint32_t *>(out_amax), (long)B * blocks, s);
   return 0;
 }

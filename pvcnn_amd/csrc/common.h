@@ -117,6 +117,26 @@ __device__ __forceinline__ void amax_table_max(uint32_t *out, long T) {
   }
 }
 
+// (ABI v12) max |x| of the tensor behind an amax buffer, for every thread of the calling workgroup (all of them call; two barriers):
+// T > 0: the maximum of the table buf[1 .. T] -- word [0] is not read, its producer may have left it unwritten (PVCNN_TABLE_ONLY:
+// no one-workgroup launch behind the table pass); T == 0: buf[0] (a 1-word buffer, or an amax buffer with its word [0]).
+__device__ __forceinline__ uint32_t amax_table_value(const uint32_t *__restrict__ buf, long T) {
+  if (T <= 0) return buf[0];
+  __shared__ uint32_t s_amax_val[17];
+  uint32_t m = 0;
+  for (long i = threadIdx.x; i < T; i += blockDim.x) m = max(m, buf[1 + i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+  if ((threadIdx.x & 63) == 0) s_amax_val[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < (int)((blockDim.x + 63) >> 6); ++w) m = max(m, s_amax_val[w]);
+    s_amax_val[16] = m;
+  }
+  __syncthreads();
+  return s_amax_val[16];
+}
+
 // Sum each of 16 per-lane values over the 32 lanes of a half-wave (lanes that differ in bits 0..4) with a
 // transposing butterfly: every step halves the number of values a lane carries (the lane keeps one half and
 // ships the other), so it takes 8+4+2+1+1 = 16 shuffles instead of 16*5.  Returns, in lane j, the total of

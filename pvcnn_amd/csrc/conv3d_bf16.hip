@@ -895,7 +895,6 @@ __global__ __launch_bounds__(256, 1) void conv3d_igemm_f16_wide_kernel(const flo
   constexpr int HALFB = G::HALFB, TILEB = G::TILEB, WBLK = 3 * NS * kCoTileB * kKc;
   constexpr int RR = R * R, S = RR * R, tiles_x = R / TX, tiles_y = R / TY;
   constexpr int QZ = TZ / 4, NITEMS = 2 * HX * HY * QZ, NIT = (NITEMS + 255) / 256;       // staging items: 576 (3 per thread) / 288 (2)
-  constexpr int MPT = 6 * NBW;                                  // MFMAs (= slots) per tap: 24 / 12
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   extern __shared__ __attribute__((aligned(16))) uint32_t cw_lds[];
   unsigned char *xs8 = reinterpret_cast<unsigned char *>(cw_lds);
@@ -1333,12 +1332,14 @@ extern "C" int pvcnn_absmax_tiles(const float *x, int B, int C, long L, int seg,
   PVCNN_REQUIRE(nseg <= 0x7fffffffL && (long)B * nseg <= 0x7fffffffL, "too many segments");
   const int spb = amax_segs_per_block(seg);
   const int vec = (L % 4 == 0) && (seg % 4 == 0) && aligned16(x);
+  const bool table_only = ticket == PVCNN_TABLE_ONLY;       // (ABI v12) the consumers take the maximum from the table: no word [0], no launch for it
+  if (table_only) ticket = nullptr;
   PVCNN_REQUIRE(!ticket || (reinterpret_cast<uintptr_t>(ticket) & 3) == 0, "ticket must be 4-byte aligned");
   if ((long)B * nseg > kFoldTableMax || spb > 64) ticket = nullptr;   // a long table is read faster by the 1024 threads of the reduce launch
   hipLaunchKernelGGL(absmax_tiles_kernel, dim3((unsigned)((nseg + spb - 1) / spb), B), dim3(256), 0, s, x, C, L, seg, (int)nseg, vec, o,
                      static_cast<unsigned *>(ticket));
   if (int rc = check_launch("absmax_tiles")) return rc;
-  return ticket ? 0 : launch_amax_reduce(o, (long)B * nseg, s);
+  return ticket || table_only ? 0 : launch_amax_reduce(o, (long)B * nseg, s);
 }
 
 extern "C" int pvcnn_conv3d_weight_split(const float *w, int Co, int Ci, int for_bwd_data, int nsplit, void *wts, void *stream) {

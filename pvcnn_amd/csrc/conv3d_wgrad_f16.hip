@@ -51,7 +51,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_f16_kernel(const float *_
                                                                   const uint32_t *__restrict__ x_absmax,
                                                                   const uint32_t *__restrict__ gy_absmax, int B, int Ci, int Co, int P,
                                                                   int citiles, float *__restrict__ part, float *__restrict__ gb_part,
-                                                                  int x_seg) {
+                                                                  int x_seg, long x_words, long gy_words, uint32_t *__restrict__ maxima) {
   using L = WgradLds<R>;
   constexpr int QZ = R / 4, KS = L::RP / 16, ROWB = L::ROWB;
   constexpr int XITEMS = 3 * kWgCi * QZ, GITEMS = kWgCo * QZ;
@@ -69,7 +69,11 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_f16_kernel(const float *_
   const int cit = bid % citiles, cot = bid / citiles;
   const int ci0 = cit * kWgCi, co0 = cot * kWgCo;
   const size_t RR = (size_t)R * R, S = RR * R;
-  const float x_scale = exp2_int(scale_shift(*x_absmax)), gy_scale = exp2_int(scale_shift(*gy_absmax));
+  // the two global maxima (ABI v12): from the tables when the caller says they are amax buffers -- word [0] may be unwritten --, and
+  // handed to the reduce launch through `maxima` (the same two words for every workgroup)
+  const uint32_t x_max = amax_table_value(x_absmax, x_words), gy_max = amax_table_value(gy_absmax, gy_words);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { maxima[0] = x_max; maxima[1] = gy_max; }
+  const float x_scale = exp2_int(scale_shift(x_max)), gy_scale = exp2_int(scale_shift(gy_max));
 
   for (int e = tid; e < L::BYTES / 4; e += 512) reinterpret_cast<uint32_t *>(lds)[e] = 0u;    // z halos stay zero for good
   __syncthreads();
@@ -231,25 +235,34 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_f16_kernel(const float *_
   }
 }
 
-// ---- round 6: the same split-K block, two waves per SIMD in OPPOSITE phases ("ping-pong") ----------------------------------------------
-// The ablation builds of the kernel above (tools/wgrad_only.py, profiles/r06_ablate_conv_wgrad.jsonl) say its row step is serial:
-// at 128 -> 128 @ 16^3 the MFMAs alone cost 113 us and the staging (loads, conversion, LDS stores, barrier) alone 78 us, and a launch
-// takes their SUM (191 us).  Every wave loads, multiplies, converts, stores and meets the barrier in the same order, so the two waves
-// of a SIMD want the matrix pipe at the same time and the vector ALU at the same time.  This kernel keeps the block (64 co x 32 ci x
-// 27 taps = 54 accumulator tiles, the LDS ring, the partial layout, the per-tile order of the sums: its partials are BIT-IDENTICAL)
-// and changes three things:
-//   * the rows of step s + 1 are requested at the top of step s and converted DURING step s + 1 (a register set in flight): the
-//     conversion of a step no longer waits for its own loads, so it can stand anywhere in the step;
-//   * waves 0..3 multiply first and convert afterwards, waves 4..7 (the SIMDs' second waves) convert first and multiply afterwards
-//     -- what one wave of a SIMD spends on the vector ALU and the LDS stores, the other spends on the matrix pipe;
-//   * the 54 tiles are dealt 7, 7, 7, 7, 7, 7, 6, 6 (14, 14, 13, 13 per SIMD) instead of three-tile units 9, 9, 6, 6, 6, 6, 6, 6
-//     (15, 15, 12, 12): waves 0..5 hold two whole (dx, dy) units and ONE dz tile of units 12 / 13, waves 6, 7 two whole units.
+// ---- round 6: the same split-K block with "pinned pieces" (pp) -- what was measured, what was kept -------------------------------
+// The ablation builds of the kernel above (tools/wgrad_only.py, tools/calls_r06/README.md calls 16-24, profiles/r06_wgrad_*.jsonl):
+// at 128 -> 128 @ 16^3 a launch takes 190 us, without its MFMAs 78 us, without its loads / conversion 126 us -- close to the SUM of
+// the parts, and the matrix pipe is busy in 0.27-0.49 of the cycles.  This kernel keeps the block (64 co x 32 ci x 27 taps = 54
+// accumulator tiles per workgroup, the LDS ring, the partial layout, split-K over 256 workgroups, the reduce launch) and changes:
+//   * the rows of step s + 1 are requested during step s (a register set in flight, two steps per loop trip with the sets exchanged),
+//     by buffer loads whose offset is out of range for a row that does not exist -- a request has no branch, the compiler can count
+//     the loads in flight, and no vmcnt(0) stands in the matrix phase;
+//   * every thread stages the same number of items (the surplus ones stage another thread's item again): no divergent branch;
+//   * the zero-row test is ONE scalar bit mask per strip (a ballot over the amax table) instead of nine LDS reads per step;
+//   * what a request needs of its strip (descriptors, row offsets) is computed once per strip, not once per step;
+//   * the z shift of a tap is applied to the grad_y fragment -- once per k-step for all of a wave's tiles, which share one 32-row co
+//     block -- instead of the x fragment of every (dx, dy) unit: a third of the funnel shifts and LDS reads (the same products
+//     grouped into other k-steps: fp32-rounding-level differences to the kernel above, tests/test_gpu_wgrad_pp.py);
+//   * the 27 tiles of a co block are dealt 7, 7, 7, 6 to four waves (14, 14, 14, 12 per SIMD; before: 15, 15, 12, 12);
+//   * in a live step every MFMA is followed by one pinned piece of the step's other work (live_step below).
+// What it bought: 4-7 % per launch, 0.01-0.035 ms of the 6.2 ms step -- and the finding that NONE of the schedules tried (opposite
+// phases of a SIMD's two waves, hand-prefetched fragments, half the LDS reads, a third fewer vector-ALU instructions, the pinned
+// interleave) moves the launch time by more than +-5 %: with both operands converted in the kernel (x is staged 3 x cotiles times,
+// grad_y citiles times) the launch runs at ~2.0 GHz with the matrix pipe half busy -- the clock the chip grants for this mix of
+// MFMA, vector-ALU and LDS work -- and what is saved in one unit is granted to no other.  Fewer conversions per MFMA (a larger
+// block: 108 tiles need more registers than a workgroup has) or fewer MFMAs are what would help; neither is in this kernel.
 template <int R, bool PACK = false, int AB = 0>
 __global__ __launch_bounds__(512, 2) void conv3d_wgrad_f16_pp_kernel(const float *__restrict__ x, const float *__restrict__ gy,
                                                                      const uint32_t *__restrict__ x_absmax,
                                                                      const uint32_t *__restrict__ gy_absmax, int B, int Ci, int Co, int P,
                                                                      int citiles, float *__restrict__ part, float *__restrict__ gb_part,
-                                                                     int x_seg) {
+                                                                     int x_seg, long x_words, long gy_words, uint32_t *__restrict__ maxima) {
   using L = WgradLds<R>;
   constexpr int QZ = R / 4, KS = L::RP / 16, ROWB = L::ROWB;
   constexpr int XITEMS = 3 * kWgCi * QZ, GITEMS = kWgCo * QZ;
@@ -262,7 +275,11 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_f16_pp_kernel(const float
   const int cit = bid % citiles, cot = bid / citiles;
   const int ci0 = cit * kWgCi, co0 = cot * kWgCo;
   const size_t RR = (size_t)R * R, S = RR * R;
-  const float x_scale = exp2_int(scale_shift(*x_absmax)), gy_scale = exp2_int(scale_shift(*gy_absmax));
+  // the two global maxima (ABI v12): from the tables when the caller says they are amax buffers -- word [0] may be unwritten --, and
+  // handed to the reduce launch through `maxima` (the same two words for every workgroup)
+  const uint32_t x_max = amax_table_value(x_absmax, x_words), gy_max = amax_table_value(gy_absmax, gy_words);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { maxima[0] = x_max; maxima[1] = gy_max; }
+  const float x_scale = exp2_int(scale_shift(x_max)), gy_scale = exp2_int(scale_shift(gy_max));
 
   for (int e = tid; e < L::BYTES / 4; e += 512) reinterpret_cast<uint32_t *>(lds)[e] = 0u;    // z halos stay zero for good
   __syncthreads();
@@ -289,12 +306,15 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_f16_pp_kernel(const float
       for (int dz = 0; dz < 3; ++dz) acc[u][dz][r] = 0.0f;
   }
 
-  // staging roles: x item = (dx, ci, z quad), grad_y item = (co, z quad); a thread keeps its items for the whole kernel
-  const int xq0 = tid % QZ, xci0 = (tid / QZ) % kWgCi, xdx0 = tid / (QZ * kWgCi);
-  const int t1 = tid + 512;
-  const int xq1 = t1 % QZ, xci1 = (t1 / QZ) % kWgCi, xdx1 = t1 / (QZ * kWgCi);
-  const bool has_x0 = tid < XITEMS, has_x1 = t1 < XITEMS;
-  const int gq = tid % QZ, gco = tid / QZ;
+  // staging roles: x item = (dx, ci, z quad), grad_y item = (co, z quad); a thread keeps its items for the whole kernel.  EVERY thread
+  // has an x item, a grad_y item and (R = 32: 768 x items) a second x item: beyond the real ones a thread stages another thread's
+  // item again -- the same bytes to the same place -- so that the step has no divergent branch (behind one, the compiler sinks the
+  // conversion into the branch and the pinned pieces of the live step are gone); only grad_bias must count an item once (has_g).
+  const int e0 = tid % XITEMS, e1 = (tid + 512) % XITEMS, eg = tid % GITEMS;
+  const int xq0 = e0 % QZ, xci0 = (e0 / QZ) % kWgCi, xdx0 = e0 / (QZ * kWgCi);
+  const int xq1 = e1 % QZ, xci1 = (e1 / QZ) % kWgCi, xdx1 = e1 / (QZ * kWgCi);
+  constexpr bool has_x0 = true, has_x1 = XITEMS > 512;
+  const int gq = eg % QZ, gco = eg / QZ;
   const bool has_g = tid < GITEMS;
   float gsum = 0.0f;
 
@@ -318,9 +338,9 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_f16_pp_kernel(const float
     return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((uintptr_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
   };
   const uint32_t kOut = 0xfffffff0u;
-  const uint32_t xoff0 = has_x0 && ci0 + xci0 < Ci ? (uint32_t)(((size_t)(ci0 + xci0) * S + 4 * xq0) * 4) : kOut;
+  const uint32_t xoff0 = ci0 + xci0 < Ci ? (uint32_t)(((size_t)(ci0 + xci0) * S + 4 * xq0) * 4) : kOut;
   const uint32_t xoff1 = has_x1 && ci0 + xci1 < Ci ? (uint32_t)(((size_t)(ci0 + xci1) * S + 4 * xq1) * 4) : kOut;
-  const uint32_t goff = has_g && co0 + gco < Co ? (uint32_t)(((size_t)(co0 + gco) * S + 4 * gq) * 4) : kOut;
+  const uint32_t goff = co0 + gco < Co ? (uint32_t)(((size_t)(co0 + gco) * S + 4 * gq) * 4) : kOut;
   auto as_float4 = [](const u32x4 &r) { return make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w)); };
   // What a request needs of its strip -- the two descriptors and the three row offsets at y = 0 -- is computed ONCE per strip (for the
   // strip after the current one, at its first step) and kept: a step is ~1500 matrix-pipe cycles at R = 16, and the phase clocks put
@@ -357,9 +377,10 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_f16_pp_kernel(const float
     }
     if (has_x0) store_row(xl, L::XPL, (((y2 & 3) * 3 + xdx0) * kWgCi + xci0) * ROWB, xq0, vx0, x_scale);
     if (has_x1) store_row(xl, L::XPL, (((y2 & 3) * 3 + xdx1) * kWgCi + xci1) * ROWB, xq1, vx1, x_scale);
-    if (has_g && y1 >= 0) {
+    if (y1 >= 0) {
       store_row(gl, L::GPL, ((y1 & 1) * kWgCo + gco) * ROWB, gq, vg, gy_scale);
-      gsum += (vg.x + vg.y) + (vg.z + vg.w);
+      const float rs = (vg.x + vg.y) + (vg.z + vg.w);
+      gsum += has_g ? rs : 0.0f;
     }
   };
   // The matrix phase of a step.  grad_w[tap dz] = sum_z grad_y[z] x[z + dz - 1] = sum_z' grad_y[z' - dz + 1] x[z']: the shift along z is
@@ -422,6 +443,82 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_f16_pp_kernel(const float
     }
   };
 
+  // ---- the live step, interleaved by hand (not PACK) -------------------------------------------------------------------------------
+  // The phase clocks of the form above: matrix phase 0.61 us of a 1.24 us step at 128 -> 128 @ 16^3 (= the 42 MFMAs of the SIMD: the
+  // pipe is full while it lasts), request + conversion + barrier the other half, NOTHING of it under the MFMAs -- the compiler issues
+  // a unit's nine MFMAs back to back and the vector-ALU work around them; opposite phases of a SIMD's two waves do not help (a wave's
+  // vector-ALU work issues slowly against the other wave's back-to-back MFMAs).  What does overlap is vector-ALU work issued by
+  // the SAME wave right behind an MFMA (~7 issue slots before the pipe takes the next one): so every MFMA here is followed by one
+  // pinned PIECE of the step's other work -- a quarter of an item's conversion (scale + hi | back-conversion | residual + lo |
+  // address + two LDS stores), the request of the next step's rows, the LDS reads of the next fragments -- and a scheduling fence.
+  struct Conv { f32x2 a, b; uint32_t h0, h1, l0, l1; };
+  auto cpiece = [&](int k, Conv &c, const float4 &v, float scale, unsigned char *plane0, int plane_bytes, uint32_t off) {
+    if (k == 0) {
+      c.a = f32x2{v.x, v.y} * scale; c.b = f32x2{v.z, v.w} * scale;
+      c.h0 = __builtin_bit_cast(uint32_t, __builtin_convertvector(c.a, f16x2)); c.h1 = __builtin_bit_cast(uint32_t, __builtin_convertvector(c.b, f16x2));
+    } else if (k == 1) {
+      c.a = c.a - __builtin_convertvector(__builtin_bit_cast(f16x2, c.h0), f32x2);        // exact
+      c.b = c.b - __builtin_convertvector(__builtin_bit_cast(f16x2, c.h1), f32x2);
+    } else if (k == 2) {
+      c.l0 = __builtin_bit_cast(uint32_t, __builtin_convertvector(c.a, f16x2)); c.l1 = __builtin_bit_cast(uint32_t, __builtin_convertvector(c.b, f16x2));
+    } else {
+      *reinterpret_cast<uint2 *>(plane0 + off) = make_uint2(c.h0, c.h1);
+      *reinterpret_cast<uint2 *>(plane0 + plane_bytes + off) = make_uint2(c.l0, c.l1);
+    }
+  };
+  // per-thread LDS offsets of the staged items without the ring slot (added per step: one scalar)
+  const uint32_t xst0 = (uint32_t)((xdx0 * kWgCi + xci0) * ROWB + (8 + 4 * xq0) * 2), xst1 = (uint32_t)((xdx1 * kWgCi + xci1) * ROWB + (8 + 4 * xq1) * 2);
+  const uint32_t gst = (uint32_t)(gco * ROWB + (8 + 4 * gq) * 2);
+  constexpr bool HAS_X1 = XITEMS > 512;
+  auto live_step = [&](int t, const StripRefs &rf, int rt, const float4 &cx0, const float4 &cx1, const float4 &cg, float4 &nx0, float4 &nx1, float4 &ng) {
+    const uint32_t xslot = (uint32_t)(((t + 2) & 3) * 3 * kWgCi * ROWB), gslot = (uint32_t)(((t + 1) & 1) * kWgCo * ROWB);
+    Conv c0, c1, c2;
+    // pieces of a k-step's 18 whole-unit slots (the shared tile's three slots carry none: not every wave has them)
+    auto piece = [&](int ks, int slot) {
+      if (ks == 0) {
+        if (slot < 4) cpiece(slot, c0, cx0, x_scale, xl, L::XPL, xst0 + xslot);
+        else if (slot < 8) cpiece(slot - 4, c2, cg, gy_scale, gl, L::GPL, gst + gslot);
+        else if (slot == 8) { const float rs = (cg.x + cg.y) + (cg.z + cg.w); gsum += has_g ? rs : 0.0f; }
+        else if (HAS_X1 && slot < 13) cpiece(slot - 9, c1, cx1, x_scale, xl, L::XPL, xst1 + xslot);
+        else if (slot == 13) request(rf, rt, nx0, nx1, ng);
+      }
+    };
+    uint4 as[2][3], b0h, b0l, b1h, b1l, bph = make_uint4(0, 0, 0, 0), bpl = bph;
+    a_shifts(t, 0, as);
+    b_fragment(t, 0, fu0, b0h, b0l);
+    b_fragment(t, 0, fu0 + 1, b1h, b1l);
+    if (has_part) b_fragment(t, 0, pu, bph, bpl);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (ks > 0) {                                             // (the second k-step of an R = 32 row: its fragments, not overlapped)
+        a_shifts(t, ks, as);
+        b_fragment(t, ks, fu0, b0h, b0l);
+        b_fragment(t, ks, fu0 + 1, b1h, b1l);
+        if (has_part) b_fragment(t, ks, pu, bph, bpl);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const uint4 &bh = u == 0 ? b0h : b1h, &bl = u == 0 ? b0l : b1l;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+          const int dz = q % 3, prod = q / 3;
+          acc[u][dz] = mfma16<2>(prod == 0 ? as[1][dz] : as[0][dz], prod == 1 ? bl : bh, acc[u][dz]);      // lo x hi, hi x lo, hi x hi
+          piece(ks, u * 9 + q);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if (has_part) {
+        const uint4 ah = pdz == 0 ? as[0][0] : pdz == 1 ? as[0][1] : as[0][2], al = pdz == 0 ? as[1][0] : pdz == 1 ? as[1][1] : as[1][2];
+        accp = mfma16<2>(al, bph, accp);
+        accp = mfma16<2>(ah, bpl, accp);
+        accp = mfma16<2>(ah, bph, accp);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+
   constexpr int kRot = R / 4 + 1;
   const int nstrips = B * R;
   auto strip_of = [&](int i0) { const int st = i0 * P + (p + i0 * kRot) % P; return (i0 * P < nstrips && st < nstrips) ? st : -1; };
@@ -463,16 +560,24 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_f16_pp_kernel(const float
       nxt = refs_of(strip_of(i0 + 1));
     }
     const bool last = t + 1 == R;
-    if (last) request(nxt, -2, nx0, nx1, ng);
-    else request(cur, t + 1, nx0, nx1, ng);
     const bool live = t >= 0 && ((live_rows >> t) & 1ull) != 0;
-    PVCNN_PROBE(0);
-    if (convert_first) convert(t, cx0, cx1, cg);
-    PVCNN_PROBE(1);
-    if (!(AB & 4) && live) multiply(t);
-    PVCNN_PROBE(2);
-    if (!convert_first) convert(t, cx0, cx1, cg);
-    PVCNN_PROBE(3);
+    if (!PACK && !(AB & 128) && t >= 0 && ((live_rows >> t) & 1ull) != 0) {      // (= live; spelled out: with the one flag the compiler keeps two copies of the accumulators)
+      PVCNN_PROBE(0);
+      StripRefs rf = cur;
+      if (last) rf = nxt;
+      live_step(t, rf, last ? -2 : t + 1, cx0, cx1, cg, nx0, nx1, ng);
+      PVCNN_PROBE(2);
+    } else {
+      if (last) request(nxt, -2, nx0, nx1, ng);
+      else request(cur, t + 1, nx0, nx1, ng);
+      PVCNN_PROBE(0);
+      if (convert_first) convert(t, cx0, cx1, cg);
+      PVCNN_PROBE(1);
+      if (!(AB & 4) && live) multiply(t);                       // (not PACK: never -- a live step took the branch above)
+      PVCNN_PROBE(2);
+      if (!convert_first) convert(t, cx0, cx1, cg);
+      PVCNN_PROBE(3);
+    }
     if (!(AB & 16)) __syncthreads();
     PVCNN_PROBE(4);
     if (last) { ++i0; t = -2; strip = strip_of(i0); cur = nxt; } else ++t;
@@ -531,8 +636,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_f16_pp_kernel(const float
 constexpr int kRedSlices = 4, kRedCols = 27 * (kWgCi / 4);     // 216 float4 columns
 
 __global__ __launch_bounds__(1024) void conv3d_wgrad_f16_reduce_kernel(const float *__restrict__ part, const float *__restrict__ gb_part,
-                                                                       const uint32_t *__restrict__ x_absmax,
-                                                                       const uint32_t *__restrict__ gy_absmax, int P, int CoP, int CiP,
+                                                                       const uint32_t *__restrict__ maxima, int P, int CoP, int CiP,
                                                                        int Co, int Ci, float *__restrict__ gw, float *__restrict__ gb) {
   __shared__ __attribute__((aligned(16))) float red[kRedSlices][27 * kWgCi];
   const int citiles = CiP / kWgCi;
@@ -573,7 +677,7 @@ __global__ __launch_bounds__(1024) void conv3d_wgrad_f16_reduce_kernel(const flo
     const int e = tap * kWgCi + ci_l;
     const float s = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
     if (co < Co && ci0 + ci_l < Ci)
-      gw[((size_t)co * Ci + ci0 + ci_l) * 27 + tap] = s * exp2_int(-scale_shift(*x_absmax)) * exp2_int(-scale_shift(*gy_absmax));
+      gw[((size_t)co * Ci + ci0 + ci_l) * 27 + tap] = s * exp2_int(-scale_shift(maxima[0])) * exp2_int(-scale_shift(maxima[1]));
   }
 }
 
@@ -586,17 +690,19 @@ static WgradPlan wgrad_f16_plan(int B, int Ci, int Co, int R) {
   const int blocks = w.cotiles * w.citiles;
   w.P = std::max(1, std::min(B * R, 256 / blocks));             // one workgroup per CU (112 KiB of LDS each)
   w.part_floats = (size_t)w.P * 27 * w.cotiles * kWgCo * w.citiles * kWgCi;
-  w.gb_floats = (size_t)w.P * w.cotiles * kWgCo;
+  w.gb_floats = (size_t)w.P * w.cotiles * kWgCo + 4;            // + the two global maxima the main launch hands to the reduce launch
   return w;
 }
 
 template <int R>
 static int launch_wgrad_f16(const float *x, const float *gy, const uint32_t *xa, const uint32_t *ga, int B, int Ci, int Co, float *gw,
-                            float *gb, float *ws, hipStream_t s, int x_seg) {
+                            float *gb, float *ws, hipStream_t s, int x_seg, int gy_seg) {
   const WgradPlan w = wgrad_f16_plan(B, Ci, Co, R);
   float *part = ws, *gb_part = ws + w.part_floats;
+  uint32_t *maxima = reinterpret_cast<uint32_t *>(gb_part + w.gb_floats - 4);
+  const long x_words = x_seg > 0 ? (long)B * R * R : 0L, gy_words = gy_seg > 0 ? (long)B * R * R : 0L;
   const bool pack = 3 * Ci <= kWgCi && (R == 32 || R == 16);     // (instantiated for the grids a network's first layer has)
-  static const bool pingpong = [] { const char *e = getenv("PVCNN_WGRAD_PP"); return !(e && e[0] == '0'); }();
+  static const bool pingpong = [] { const char *e = getenv("PVCNN_WGRAD_PP"); return !(e && e[0] == '0'); }();   // 0: the kernel of rounds 3-5
   auto k = pack ? conv3d_wgrad_f16_kernel<R, (R == 32 || R == 16)> : conv3d_wgrad_f16_kernel<R, false>;
   const bool fits = (size_t)std::max(Ci, Co) * R * R * R * 4 < ((size_t)1 << 32) - 64;      // one buffer descriptor per cloud
   if (pingpong && fits) k = pack ? conv3d_wgrad_f16_pp_kernel<R, (R == 32 || R == 16)> : conv3d_wgrad_f16_pp_kernel<R, false>;
@@ -623,9 +729,7 @@ static int launch_wgrad_f16(const float *x, const float *gy, const uint32_t *xa,
       case 96: k = conv3d_wgrad_f16_pp_kernel<R, false, 96>; break;
       case 100: k = conv3d_wgrad_f16_pp_kernel<R, false, 100>; break;
       case 36: k = conv3d_wgrad_f16_pp_kernel<R, false, 36>; break;
-      case 192: k = conv3d_wgrad_f16_pp_kernel<R, false, 192>; break;
-      case 448: k = conv3d_wgrad_f16_pp_kernel<R, false, 448>; break;
-      case 480: k = conv3d_wgrad_f16_pp_kernel<R, false, 480>; break;
+      case 128: k = conv3d_wgrad_f16_pp_kernel<R, false, 128>; break;
       default: k = conv3d_wgrad_f16_pp_kernel<R, false, 0>; break;
     }
   }
@@ -634,10 +738,10 @@ static int launch_wgrad_f16(const float *x, const float *gy, const uint32_t *xa,
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e != hipSuccess) { set_error("conv3d_wgrad_f16: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
   hipLaunchKernelGGL(k, dim3((unsigned)(w.P * w.citiles * w.cotiles)), dim3(512), lds, s, x, gy, xa, ga, B, Ci, Co, w.P, w.citiles, part,
-                     gb ? gb_part : nullptr, x_seg);
+                     gb ? gb_part : nullptr, x_seg, x_words, gy_words, maxima);
   if (int rc = check_launch("conv3d_wgrad_f16")) return rc;
   const int CoP = w.cotiles * kWgCo, CiP = w.citiles * kWgCi;
-  hipLaunchKernelGGL(conv3d_wgrad_f16_reduce_kernel, dim3((unsigned)(CoP * w.citiles)), dim3(1024), 0, s, part, gb_part, xa, ga, w.P, CoP, CiP,
+  hipLaunchKernelGGL(conv3d_wgrad_f16_reduce_kernel, dim3((unsigned)(CoP * w.citiles)), dim3(1024), 0, s, part, gb_part, maxima, w.P, CoP, CiP,
                      Co, Ci, gw, gb);
   return check_launch("conv3d_wgrad_f16_reduce");
 }
@@ -656,10 +760,11 @@ extern "C" size_t pvcnn_conv3d_bwd_weight_f16_workspace_bytes(int B, int Ci, int
 }
 
 extern "C" int pvcnn_conv3d_bwd_weight_f16(const float *x, const float *grad_y, const void *x_absmax, int x_amax_seg, const void *gy_absmax,
-                                           int B, int Ci, int Co, int R, float *grad_w, float *grad_bias, void *workspace,
+                                           int gy_amax_seg, int B, int Ci, int Co, int R, float *grad_w, float *grad_bias, void *workspace,
                                            size_t workspace_bytes, void *stream) {
   PVCNN_REQUIRE(B > 0 && Ci > 0 && Co > 0 && wgrad_f16_serves(R), "bad size (R must be 8, 12, 16 or 32)");
   PVCNN_REQUIRE(x_amax_seg == 0 || x_amax_seg == R, "x_amax_seg must be 0 (1-word buffer) or R (amax buffer with one maximum per z row)");
+  PVCNN_REQUIRE(gy_amax_seg == 0 || gy_amax_seg == R, "gy_amax_seg must be 0 (word [0] holds the maximum) or R (amax buffer with one maximum per z row)");
   PVCNN_REQUIRE(x && grad_y && grad_w && x_absmax && gy_absmax, "null pointer");
   PVCNN_REQUIRE(aligned16(x) && aligned16(grad_y), "x and grad_y must be 16-byte aligned");
   PVCNN_REQUIRE(workspace && aligned16(workspace) && workspace_bytes >= pvcnn_conv3d_bwd_weight_f16_workspace_bytes(B, Ci, Co, R),
@@ -668,9 +773,9 @@ extern "C" int pvcnn_conv3d_bwd_weight_f16(const float *x, const float *grad_y, 
   const uint32_t *xa = static_cast<const uint32_t *>(x_absmax), *ga = static_cast<const uint32_t *>(gy_absmax);
   float *ws = static_cast<float *>(workspace);
   switch (R) {
-    case 32: return launch_wgrad_f16<32>(x, grad_y, xa, ga, B, Ci, Co, grad_w, grad_bias, ws, s, x_amax_seg);
-    case 16: return launch_wgrad_f16<16>(x, grad_y, xa, ga, B, Ci, Co, grad_w, grad_bias, ws, s, x_amax_seg);
-    case 12: return launch_wgrad_f16<12>(x, grad_y, xa, ga, B, Ci, Co, grad_w, grad_bias, ws, s, x_amax_seg);
-    default: return launch_wgrad_f16<8>(x, grad_y, xa, ga, B, Ci, Co, grad_w, grad_bias, ws, s, x_amax_seg);
+    case 32: return launch_wgrad_f16<32>(x, grad_y, xa, ga, B, Ci, Co, grad_w, grad_bias, ws, s, x_amax_seg, gy_amax_seg);
+    case 16: return launch_wgrad_f16<16>(x, grad_y, xa, ga, B, Ci, Co, grad_w, grad_bias, ws, s, x_amax_seg, gy_amax_seg);
+    case 12: return launch_wgrad_f16<12>(x, grad_y, xa, ga, B, Ci, Co, grad_w, grad_bias, ws, s, x_amax_seg, gy_amax_seg);
+    default: return launch_wgrad_f16<8>(x, grad_y, xa, ga, B, Ci, Co, grad_w, grad_bias, ws, s, x_amax_seg, gy_amax_seg);
   }
 }

@@ -36,7 +36,8 @@ constexpr int kGwBuf = 4 * kGwPlane;                // [grad_y hi, lo][x hi, lo]
 __global__ __launch_bounds__(256, 2) void pw_wgrad_f16_kernel(const float *__restrict__ x, const float *__restrict__ gy,
                                                               const uint32_t *__restrict__ x_absmax, const uint32_t *__restrict__ gy_absmax,
                                                               int K, int M, int N, int P, int mtiles, int ktiles, int cps,
-                                                              int total_chunks, float *__restrict__ part, float *__restrict__ gb_part) {
+                                                              int total_chunks, float *__restrict__ part, float *__restrict__ gb_part,
+                                                              long x_words, long gy_words, uint32_t *__restrict__ maxima) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kGwBuf];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, kh = lane >> 5;
   const int wm = wave >> 1, wk = wave & 1;
@@ -49,7 +50,11 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_f16_kernel(const float *__res
   if (p >= P) return;
   const int kt = tile % ktiles, mt = tile / ktiles;
   const int m0 = mt * kGwM, k0 = kt * kGwK;
-  const float x_scale = exp2_int(scale_shift(*x_absmax)), gy_scale = exp2_int(scale_shift(*gy_absmax));
+  // (ABI v12) the two global maxima from the tables when the buffers are amax buffers (word [0] may be unwritten), handed to the
+  // reduce launch through `maxima`
+  const uint32_t x_max = amax_table_value(x_absmax, x_words), gy_max = amax_table_value(gy_absmax, gy_words);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { maxima[0] = x_max; maxima[1] = gy_max; }
+  const float x_scale = exp2_int(scale_shift(x_max)), gy_scale = exp2_int(scale_shift(gy_max));
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -207,7 +212,8 @@ template <int WMB, int WNB, int WR, int WC>
 __global__ __launch_bounds__(512) void pw_wgrad_f16_wide_kernel(const float *__restrict__ x, const float *__restrict__ gy,
                                                                 const uint32_t *__restrict__ x_absmax, const uint32_t *__restrict__ gy_absmax,
                                                                 int K, int M, int N, int P, int mtiles, int ktiles, int cps, int total_chunks,
-                                                                float *__restrict__ part, float *__restrict__ gb_part) {
+                                                                float *__restrict__ part, float *__restrict__ gb_part, long x_words, long gy_words,
+                                                                uint32_t *__restrict__ maxima) {
   using T = GwWide<WMB, WNB, WR, WC>;
   static_assert(WR * WC == 8 && T::TM % 64 == 0 && T::TK % 64 == 0, "8 waves; 64-row staging items");
   constexpr int GI = T::GI, NI = T::NI;
@@ -220,7 +226,11 @@ __global__ __launch_bounds__(512) void pw_wgrad_f16_wide_kernel(const float *__r
   if (p >= P) return;
   const int kt = tile % ktiles, mt = tile / ktiles;
   const int m0 = mt * T::TM, k0 = kt * T::TK;
-  const float x_scale = exp2_int(scale_shift(*x_absmax)), gy_scale = exp2_int(scale_shift(*gy_absmax));
+  // (ABI v12) the two global maxima from the tables when the buffers are amax buffers (word [0] may be unwritten), handed to the
+  // reduce launch through `maxima`
+  const uint32_t x_max = amax_table_value(x_absmax, x_words), gy_max = amax_table_value(gy_absmax, gy_words);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { maxima[0] = x_max; maxima[1] = gy_max; }
+  const float x_scale = exp2_int(scale_shift(x_max)), gy_scale = exp2_int(scale_shift(gy_max));
 
   f32x16 acc[WMB][WNB];
 #pragma unroll
@@ -376,7 +386,7 @@ __global__ __launch_bounds__(512) void pw_wgrad_f16_wide_kernel(const float *__r
 }
 
 __global__ __launch_bounds__(256) void pw_wgrad_f16_reduce_kernel(const float *__restrict__ part, const float *__restrict__ gb_part,
-                                                                  const uint32_t *__restrict__ x_absmax, const uint32_t *__restrict__ gy_absmax,
+                                                                  const uint32_t *__restrict__ maxima,
                                                                   int P, int MP, int KP, int M, int K, float *__restrict__ gw,
                                                                   float *__restrict__ gb) {
   const size_t block = (size_t)MP * KP, e = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -392,7 +402,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_f16_reduce_kernel(const float *_
         s3 += part[(size_t)(i + 3) * block + e];
       }
       for (; i < P; ++i) s0 += part[(size_t)i * block + e];
-      gw[(size_t)m * K + k] = ((s0 + s1) + (s2 + s3)) * exp2_int(-scale_shift(*x_absmax)) * exp2_int(-scale_shift(*gy_absmax));
+      gw[(size_t)m * K + k] = ((s0 + s1) + (s2 + s3)) * exp2_int(-scale_shift(maxima[0])) * exp2_int(-scale_shift(maxima[1]));
     }
   }
   if (gb != nullptr && e < (size_t)M) {
@@ -431,7 +441,7 @@ static PwWgradPlan pw_wgrad_f16_plan(int B, int K, int M, int N) {
   w.ktiles = ceil_div(K, w.tk);
   w.P = partitions(w.mtiles * w.ktiles, w.wide ? 32 : 64);
   w.part_floats = (size_t)w.P * w.mtiles * w.tm * w.ktiles * w.tk;
-  w.gb_floats = (size_t)w.P * w.mtiles * w.tm;
+  w.gb_floats = (size_t)w.P * w.mtiles * w.tm + 4;             // + the two global maxima the main launch hands to the reduce launch
   return w;
 }
 
@@ -447,9 +457,10 @@ extern "C" size_t pvcnn_pwconv_bwd_weight_f16_workspace_bytes(int B, int K, int 
 }
 
 // grad_w (M, K) [, grad_bias (M)]:  x (B, K, N), grad_y (B, M, N);  *_absmax = pvcnn_absmax_bits of the two tensors
-extern "C" int pvcnn_pwconv_bwd_weight_f16(const float *x, const float *grad_y, const void *x_absmax, const void *gy_absmax, int B, int K,
-                                           int M, int N, float *grad_w, float *grad_bias, void *workspace, size_t workspace_bytes,
-                                           void *stream) {
+extern "C" int pvcnn_pwconv_bwd_weight_f16(const float *x, const float *grad_y, const void *x_absmax, int x_amax_seg, const void *gy_absmax,
+                                           int gy_amax_seg, int B, int K, int M, int N, float *grad_w, float *grad_bias, void *workspace,
+                                           size_t workspace_bytes, void *stream) {
+  PVCNN_REQUIRE(x_amax_seg >= 0 && gy_amax_seg >= 0, "amax_seg < 0");
   PVCNN_REQUIRE(B > 0 && K > 0 && M > 0 && N > 0 && N % 4 == 0, "bad size (N must be a multiple of 4)");
   PVCNN_REQUIRE(x && grad_y && grad_w && x_absmax && gy_absmax, "null pointer");
   PVCNN_REQUIRE(aligned16(x) && aligned16(grad_y), "x and grad_y must be 16-byte aligned");
@@ -460,6 +471,8 @@ extern "C" int pvcnn_pwconv_bwd_weight_f16(const float *x, const float *grad_y, 
   hipStream_t s = static_cast<hipStream_t>(stream);
   const uint32_t *xa = static_cast<const uint32_t *>(x_absmax), *ga = static_cast<const uint32_t *>(gy_absmax);
   float *part = static_cast<float *>(workspace), *gb_part = part + w.part_floats;
+  uint32_t *maxima = reinterpret_cast<uint32_t *>(gb_part + w.gb_floats - 4);
+  const long x_words = x_amax_seg > 0 ? (long)B * ceil_div(N, x_amax_seg) : 0L, gy_words = gy_amax_seg > 0 ? (long)B * ceil_div(N, gy_amax_seg) : 0L;
   const dim3 grid((unsigned)(8 * ceil_div(w.P, 8) * w.mtiles * w.ktiles));
   if (w.wide) {
     using WA = GwWide<4, 2, 2, 4>;
@@ -475,17 +488,17 @@ extern "C" int pvcnn_pwconv_bwd_weight_f16(const float *x, const float *grad_y, 
     }
     if (w.wide == 1)
       hipLaunchKernelGGL(ka, grid, dim3(512), 2 * WA::BUF, s, x, grad_y, xa, ga, K, M, N, w.P, w.mtiles, w.ktiles, w.cps, w.total_chunks, part,
-                         grad_bias ? gb_part : nullptr);
+                         grad_bias ? gb_part : nullptr, x_words, gy_words, maxima);
     else
       hipLaunchKernelGGL(kb, grid, dim3(512), 2 * WB::BUF, s, x, grad_y, xa, ga, K, M, N, w.P, w.mtiles, w.ktiles, w.cps, w.total_chunks, part,
-                         grad_bias ? gb_part : nullptr);
+                         grad_bias ? gb_part : nullptr, x_words, gy_words, maxima);
   } else {
     hipLaunchKernelGGL(pw_wgrad_f16_kernel, grid, dim3(256), 0, s, x, grad_y, xa, ga, K, M, N, w.P, w.mtiles, w.ktiles, w.cps, w.total_chunks,
-                       part, grad_bias ? gb_part : nullptr);
+                       part, grad_bias ? gb_part : nullptr, x_words, gy_words, maxima);
   }
   if (int rc = check_launch("pwconv_wgrad_f16")) return rc;
   const int MP = w.mtiles * w.tm, KP = w.ktiles * w.tk;
-  hipLaunchKernelGGL(pw_wgrad_f16_reduce_kernel, dim3((unsigned)ceil_div(MP * KP, 256)), dim3(256), 0, s, part, gb_part, xa, ga, w.P, MP, KP, M, K,
+  hipLaunchKernelGGL(pw_wgrad_f16_reduce_kernel, dim3((unsigned)ceil_div(MP * KP, 256)), dim3(256), 0, s, part, gb_part, maxima, w.P, MP, KP, M, K,
                      grad_w, grad_bias);
   return check_launch("pwconv_wgrad_f16_reduce");
 }

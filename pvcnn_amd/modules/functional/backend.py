@@ -589,28 +589,34 @@ class HipBackend:
 
     # "amax buffers" (include/pvcnn_hip.h): [0] = bits of max |x| over the tensor, [1 + t] = bits of the maximum over all channels of
     # position segment t.  The f16x2 forward / backward-data kernels scale each workgroup's tile of x by the maxima of the segments it
-    # touches (an outlier costs precision only inside its own tile); the backward-weight kernels use [0].
+    # touches (an outlier costs precision only inside its own tile); the backward-weight kernels scale by the global maximum, which
+    # they take from the table, too (ABI v12) -- so a buffer made with want_global=False has NO word [0] and costs no launch for it.
     PW_AMAX_SEG = 256          # the 1x1 GEMM's point tile
+    _TABLE_ONLY = ctypes.c_void_p(1)      # PVCNN_TABLE_ONLY (include/pvcnn_hip.h)
+    amax_global = os.environ.get('PVCNN_AMAX_GLOBAL', '0') == '1'      # A/B switch: every amax buffer with its word [0] (ABI v11 behaviour: 11 more launches per PVCNN step)
 
-    def absmax_tiles(self, x, seg):
-        """x (B, C, L) -> int32 (1 + B * ceil(L / seg),): the amax buffer of x with segments of `seg` positions (one read of x)."""
+    def absmax_tiles(self, x, seg, want_global=True):
+        """x (B, C, L) -> int32 (1 + B * ceil(L / seg),): the amax buffer of x with segments of `seg` positions (one read of x).
+        want_global=False: the table only, word [0] is left unwritten (for consumers that are handed the segment length)."""
         _f32(x, 'x')
         _shape(x.dim() == 3, 'absmax_tiles: x (B,C,L) expected')
         b, c, n = x.shape
         seg = int(seg)
         out = torch.empty((self.lib.pvcnn_absmax_tiles_count(b, n, seg),), dtype=torch.int32, device=x.device)
         ticket = self._tickets(1, x.device)
+        want_global = want_global or self.amax_global
+        tk = (_p(ticket) if ticket is not None else None) if want_global else self._TABLE_ONLY
         with _Launch(x) as s:
-            _lib.check(self.lib.pvcnn_absmax_tiles(_p(x), b, c, n, seg, _p(out), _p(ticket) if ticket is not None else None, s), 'absmax_tiles')
+            _lib.check(self.lib.pvcnn_absmax_tiles(_p(x), b, c, n, seg, _p(out), tk, s), 'absmax_tiles')
         return out
 
-    def conv_amax(self, x):
+    def conv_amax(self, x, want_global=True):
         """amax buffer of a voxel grid x (B,C,R,R,R) in the layout the Conv3d kernels take: one maximum per z row."""
-        return self.absmax_tiles(x.view(x.shape[0], x.shape[1], -1), x.shape[2])
+        return self.absmax_tiles(x.view(x.shape[0], x.shape[1], -1), x.shape[2], want_global)
 
-    def pw_amax(self, x):
+    def pw_amax(self, x, want_global=True):
         """amax buffer of point features x (B,C,N) in the layout the 1x1 GEMM takes: one maximum per 256-point tile."""
-        return self.absmax_tiles(x, self.PW_AMAX_SEG)
+        return self.absmax_tiles(x, self.PW_AMAX_SEG, want_global)
 
     @staticmethod
     def _amax_seg(amax, tiles, seg):
@@ -741,7 +747,8 @@ class HipBackend:
         gb = self._grad_out(out_b, (co,), x.device) if with_bias else None
         ws = self._scratch(self.lib.pvcnn_conv3d_bwd_weight_f16_workspace_bytes(b, ci, co, r), x.device)
         with _Launch(x) as s:
-            _lib.check(self.lib.pvcnn_conv3d_bwd_weight_f16(_p(x), _p(grad_y), _p(x_amax), self._amax_seg(x_amax, b * r * r, r), _p(gy_amax), b, ci, co, r, _p(gw),
+            _lib.check(self.lib.pvcnn_conv3d_bwd_weight_f16(_p(x), _p(grad_y), _p(x_amax), self._amax_seg(x_amax, b * r * r, r), _p(gy_amax),
+                                                            self._amax_seg(gy_amax, b * r * r, r), b, ci, co, r, _p(gw),
                                                             _p(gb) if with_bias else None, _p(ws), ws.numel(), s), 'conv3d_backward_weight_f16')
         return (gw, gb) if with_bias else gw
 
@@ -858,7 +865,9 @@ class HipBackend:
         gb = self._grad_out(out_b, (co,), x.device) if with_bias else None
         ws = self._scratch(self.lib.pvcnn_pwconv_bwd_weight_f16_workspace_bytes(b, ci, co, n), x.device)
         with _Launch(x) as s:
-            _lib.check(self.lib.pvcnn_pwconv_bwd_weight_f16(_p(x), _p(grad_y), _p(x_amax), _p(gy_amax), b, ci, co, n, _p(gw),
+            tiles = b * ((n + self.PW_AMAX_SEG - 1) // self.PW_AMAX_SEG)
+            _lib.check(self.lib.pvcnn_pwconv_bwd_weight_f16(_p(x), _p(grad_y), _p(x_amax), self._amax_seg(x_amax, tiles, self.PW_AMAX_SEG), _p(gy_amax),
+                                                            self._amax_seg(gy_amax, tiles, self.PW_AMAX_SEG), b, ci, co, n, _p(gw),
                                                             _p(gb) if with_bias else None, _p(ws), ws.numel(), s), 'pwconv_backward_weight_f16')
         return (gw, gb) if with_bias else gw
 
@@ -1031,11 +1040,12 @@ class HipBackend:
     # ---- torch.cat(features, dim=1) of the classifier input + the amax buffer of its output in one pass (csrc/bnact.hip) ----
     has_concat_points = True
 
-    def concat_points(self, tensors, want_amax=True, out=None, in_place=None):
+    def concat_points(self, tensors, want_amax=True, out=None, in_place=None, want_global=True):
         """tensors: (B, C_i, N) float32, each with contiguous rows inside a cloud (a channel slice is fine) or broadcast over the points
         (stride 0 along N, contiguous (B, C_i)) -> (out (B, sum C_i, N), its amax buffer with 256-point segments | None).
         out: the (B, sum C_i, N) buffer to fill; in_place = {i: amax buffer of tensors[i]}: those sources ALREADY ARE their channel slice
-        of `out` (the pass that produced them wrote them there: bnact_apply_rowmax(..., out=)): nothing is copied for them."""
+        of `out` (the pass that produced them wrote them there: bnact_apply_rowmax(..., out=)): nothing is copied for them.
+        want_global=False: the amax buffer's table only, no word [0] (see absmax_tiles)."""
         _shape(0 < len(tensors) <= 8, 'concat_points: 1..8 sources')
         b, n = tensors[0].shape[0], tensors[0].shape[2]
         ptrs, bstr, chans, pstr = [], [], [], []
@@ -1068,7 +1078,8 @@ class HipBackend:
             _lib.check(self.lib.pvcnn_concat_points((ctypes.c_void_p * k)(*ptrs), (ctypes.c_long * k)(*bstr), (ctypes.c_int * k)(*chans),
                                                     (ctypes.c_int * k)(*pstr), (ctypes.c_void_p * k)(*pre) if in_place else None, k, b, n,
                                                     _p(out), _p(amax) if want_amax else None,
-                                                    _p(ticket) if ticket is not None else None, s), 'concat_points')
+                                                    (_p(ticket) if ticket is not None else None) if want_global or self.amax_global or not want_amax else self._TABLE_ONLY,
+                                                    s), 'concat_points')
         return out, amax
 
     # ---- the two halves of bnact_backward on their own (PVConv's SE tail puts the excitation's backward between them) ----

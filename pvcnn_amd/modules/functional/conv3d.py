@@ -45,7 +45,7 @@ class VoxelConv3d(Function):
         if ctx.nsplit in (1, 2):
             ctx.x_amax = _cache.amax_of(given, x.shape[2])
             if ctx.x_amax is None and ctx.nsplit == 2:           # (bf16 mode: only backward-weight wants it, and measures it itself)
-                ctx.x_amax = be.conv_amax(x)
+                ctx.x_amax = be.conv_amax(x, want_global=False)      # (every consumer below takes the table)
         kw = {'amax': ctx.x_amax} if ctx.nsplit == 2 else {}
         # the pre-split weight images: when the input wants a gradient the backward-data image is made by the SAME launch as the
         # forward one and kept for backward (the values backward must use are the ones saved now, not a later state of the weight)
@@ -81,7 +81,7 @@ class VoxelConv3d(Function):
         if (f16 and (ctx.needs_input_grad[0] or wgrad_f16)) or (ctx.nsplit == 1 and wgrad_f16):
             g_amax = _cache.amax_of(received, grad_y.shape[2])
             if g_amax is None and f16:
-                g_amax = be.conv_amax(grad_y)
+                g_amax = be.conv_amax(grad_y, want_global=False)
         gx = None
         if ctx.needs_input_grad[0]:
             if ctx.nsplit and ctx.w_bwd_image is not None:     # a convolution with Ci and Co exchanged on the flipped weights (forward's image)

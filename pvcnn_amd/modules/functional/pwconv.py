@@ -48,7 +48,7 @@ class PointwiseConv(Function):
         if ctx.split in (1, 2):     # the input's amax buffer (one scale per 256-point tile): left on it by its producer, else one read
             ctx.x_amax = _cache.amax_of(x, be.PW_AMAX_SEG)
             if ctx.x_amax is None and ctx.split == 2:             # (bf16 mode: only backward-weight wants it, and measures it itself)
-                ctx.x_amax = be.pw_amax(x3)
+                ctx.x_amax = be.pw_amax(x3, want_global=False)        # (every consumer below takes the table)
         akw = {'amax': ctx.x_amax} if ctx.split == 2 else {}
         # forward + backward-data weight images from one launch when the input wants a gradient (see functional/conv3d.py)
         ctx.w_bwd_image = None
@@ -84,7 +84,7 @@ class PointwiseConv(Function):
         if (f16 and (ctx.needs_input_grad[0] or wgrad_f16)) or (ctx.split == 1 and wgrad_f16):
             g_amax = _cache.amax_of(grad_y, be.PW_AMAX_SEG)
             if g_amax is None and f16:
-                g_amax = be.pw_amax(g3)
+                g_amax = be.pw_amax(g3, want_global=False)
         gx = None
         if ctx.needs_input_grad[0]:
             if ctx.split and ctx.w_bwd_image is not None:

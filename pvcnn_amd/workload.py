@@ -81,9 +81,9 @@ class _ConcatPoints(torch.autograd.Function):
         be = native()
         ctx.splits = [t.shape[1] for t in taps]
         if spec is None:
-            out, amax = be.concat_points([t.detach() for t in taps])
+            out, amax = be.concat_points([t.detach() for t in taps], want_global=False)      # (its consumers -- the classifier's GEMMs -- take the table)
         else:
-            out, amax = be.concat_points([t.detach() for t in taps], out=spec[0], in_place=spec[1])
+            out, amax = be.concat_points([t.detach() for t in taps], out=spec[0], in_place=spec[1], want_global=False)
         ctx.mark_non_differentiable(amax)
         ctx.set_materialize_grads(False)
         return out, amax

@@ -36,7 +36,9 @@ def test_concat_points_autograd_and_tag(hip):
     (ref * w).sum().backward()
     assert torch.equal(out, ref) and torch.equal(a.grad, a2.grad) and torch.allclose(c.grad, c2.grad, rtol=1e-5, atol=1e-5)
     tag = _cache.amax_of(out, 256)
-    assert tag is not None and torch.equal(tag, hip.absmax_tiles(ref.detach().contiguous(), 256))
+    # (ABI v12: the workload's concatenation asks for the TABLE only -- its consumers, the classifier's GEMMs, are handed the segment
+    # length and never read word [0]: tests/test_gpu_amax_table_only.py)
+    assert tag is not None and torch.equal(tag[1:], hip.absmax_tiles(ref.detach().contiguous(), 256)[1:])
 
 
 @pytest.mark.parametrize('b', [8, 1])

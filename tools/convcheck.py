@@ -84,7 +84,7 @@ def wgrad_f16(x, gy, with_bias=False):
     nb = lib.pvcnn_conv3d_bwd_weight_f16_workspace_bytes(b, ci, co, r)
     ws = torch.empty(nb, dtype=torch.uint8, device=dev)
     ax, ag = absmax(x), absmax(gy)      # both alive until the launch is enqueued (a freed temporary would be reused by the second)
-    _lib.check(lib.pvcnn_conv3d_bwd_weight_f16(P(x), P(gy), P(ax), 0, P(ag), b, ci, co, r, P(gw), P(gb), P(ws), nb, S()), 'wgrad_f16')
+    _lib.check(lib.pvcnn_conv3d_bwd_weight_f16(P(x), P(gy), P(ax), 0, P(ag), 0, b, ci, co, r, P(gw), P(gb), P(ws), nb, S()), 'wgrad_f16')
     return (gw, gb) if with_bias else gw
 
 
@@ -190,7 +190,7 @@ def main():
                 nb16 = lib.pvcnn_conv3d_bwd_weight_f16_workspace_bytes(b, ci, co, r)
                 ws16 = torch.empty(nb16, dtype=torch.uint8, device=dev)
                 ax, ag = absmax(x), absmax(gy)
-                ms16 = graph_time(lambda: lib.pvcnn_conv3d_bwd_weight_f16(P(x), P(gy), P(ax), 0, P(ag), b, ci, co, r, P(gw), None, P(ws16), nb16, S()))
+                ms16 = graph_time(lambda: lib.pvcnn_conv3d_bwd_weight_f16(P(x), P(gy), P(ax), 0, P(ag), 0, b, ci, co, r, P(gw), None, P(ws16), nb16, S()))
                 print(json.dumps({'time_wgrad_f16_BCiCoR': [b, ci, co, r], 'ms': round(ms16, 4), 'effective_TFLOPs': round(fl / ms16 / 1e9, 1),
                                   'fp32_mfma_kernel_ms': round(msw, 4), 'ws_MB': round(nb16 / 1e6, 1)}), flush=True)
             for ns, dbg in [(2, 0), (3, 0), (1, 0)]:

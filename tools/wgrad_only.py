@@ -32,7 +32,7 @@ def main():
     if probe:
         assert lib.pvcnn_probe_set_buffer(P(pbuf)) == 0
     lib.pvcnn_conv3d_bwd_weight_f16_workspace_bytes.restype = ctypes.c_size_t
-    lib.pvcnn_conv3d_bwd_weight_f16.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_void_p]
+    lib.pvcnn_conv3d_bwd_weight_f16.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_void_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_void_p]
     shapes = '16x64x64x16,16x64x128x16,16x128x128x16,16x64x64x32,16x9x64x32'
     if '--shapes' in sys.argv:
         shapes = sys.argv[sys.argv.index('--shapes') + 1]
@@ -52,7 +52,7 @@ def main():
         ws = torch.empty(nb, dtype=torch.uint8, device=dev)
 
         def launch():
-            rc = lib.pvcnn_conv3d_bwd_weight_f16(P(x), P(gy), P(ax), 0, P(ag), b, ci, co, r, P(gw), P(gb), P(ws), nb, s)
+            rc = lib.pvcnn_conv3d_bwd_weight_f16(P(x), P(gy), P(ax), 0, P(ag), 0, b, ci, co, r, P(gw), P(gb), P(ws), nb, s)
             assert rc == 0, rc
         for _ in range(3):
             launch()
